@@ -1,0 +1,277 @@
+"""Synthetic-but-structurally-faithful musculoskeletal models.
+
+The reference's real MJCF (``myosuite/simhive/myo_sim``) is an empty submodule in
+/root/reference, so the task XMLs that only ``<include>`` it
+(myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles.xml:10-13,
+.../hand/myohand_pose.xml:10-15) cannot be compiled.  These generators build
+models with the DIMENSIONS, joint names/order and muscle names that in-repo
+evidence pins (joint names myosuite/envs/myo/myobase/__init__.py:301-325;
+muscle names docs/source/suite.rst:75-80,99-119) and the same feature mix:
+hinge trees, spatial tendons with via-points and sphere/cylinder wrapping with
+side-sites, Hill-type muscles (MuJoCo muscle defaults), limited joints with
+damping/armature, timestep 0.002.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .spec import ModelSpec, CompiledModel
+
+QX90N = (math.cos(-math.pi / 4), math.sin(-math.pi / 4), 0.0, 0.0)  # local z -> world y
+
+
+def _cyl_inertia(m, r, L, axis="x"):
+    ia = 0.5 * m * r * r
+    it = m * (3 * r * r + L * L) / 12.0
+    return {"x": (ia, it, it), "y": (it, ia, it), "z": (it, it, ia)}[axis]
+
+
+# ----------------------------------------------------------------------------- elbow
+def make_elbow() -> ModelSpec:
+    """myoElbow: 1 DoF (r_elbow_flex), 6 muscles (TRIlong TRIlat TRImed BIClong BICshort BRA)."""
+    s = ModelSpec("myoelbow_1dof6muscles")
+    s.add_body("humerus", "world", pos=(0, 0, 1.2), mass=2.0, ipos=(0, 0, -0.15),
+               inertia=_cyl_inertia(2.0, 0.03, 0.30, "z"))
+    s.add_body("forearm", "humerus", pos=(0, 0, -0.30), mass=1.5, ipos=(0, 0, -0.14),
+               inertia=_cyl_inertia(1.5, 0.03, 0.30, "z"))
+    s.add_joint("r_elbow_flex", "forearm", "hinge", pos=(0, 0, 0), axis=(0, -1, 0), range=(0.0, 2.27),
+                damping=0.4, armature=0.01, stiffness=0.0)
+    # wrap cylinder on the elbow axis (humerus frame), axis along world y
+    s.add_geom("elbow_wrap", "humerus", "cylinder", size=(0.022, 0.05), pos=(0, 0, -0.30), quat=QX90N)
+    s.add_site("elbow_side_post", "humerus", (-0.06, 0, -0.30))
+    s.add_site("elbow_side_ant", "humerus", (0.06, 0, -0.30))
+    s.add_site("wrist", "forearm", (0, 0, -0.27))
+    s.add_site("wrist_target", "world", (0.001, 0.001, 0.001))
+
+    def tri(name, y, org, force):
+        s.add_site(f"{name}_o", "humerus", org)
+        s.add_site(f"{name}_v", "humerus", (-0.028, y, -0.24))
+        s.add_site(f"{name}_i", "forearm", (-0.022, y, 0.018))
+        s.add_tendon(f"{name}_tendon", [("site", f"{name}_o"), ("site", f"{name}_v"),
+                                        ("cylinder", "elbow_wrap", "elbow_side_post"), ("site", f"{name}_i")])
+        s.add_muscle(name, f"{name}_tendon", force=force)
+
+    def flex(name, y, org, via, ins, force, wrap=True):
+        s.add_site(f"{name}_o", "humerus", org)
+        s.add_site(f"{name}_v", "humerus", via)
+        s.add_site(f"{name}_i", "forearm", ins)
+        path = [("site", f"{name}_o"), ("site", f"{name}_v")]
+        if wrap:
+            path.append(("cylinder", "elbow_wrap", "elbow_side_ant"))
+        path.append(("site", f"{name}_i"))
+        s.add_tendon(f"{name}_tendon", path)
+        s.add_muscle(name, f"{name}_tendon", force=force)
+
+    tri("TRIlong", -0.006, (-0.025, -0.006, -0.02), 800.0)
+    tri("TRIlat", 0.008, (-0.02, 0.008, -0.09), 620.0)
+    tri("TRImed", 0.0, (-0.015, 0.0, -0.14), 620.0)
+    flex("BIClong", -0.004, (0.02, -0.004, -0.01), (0.032, -0.004, -0.22), (0.014, -0.004, -0.05), 620.0)
+    flex("BICshort", 0.006, (0.025, 0.006, -0.03), (0.03, 0.006, -0.21), (0.014, 0.006, -0.055), 430.0)
+    flex("BRA", 0.0, (0.012, 0.0, -0.18), (0.02, 0.0, -0.25), (0.022, 0.0, -0.20), 260.0, wrap=False)
+    return s
+
+
+# ----------------------------------------------------------------------------- hand
+HAND_JOINTS = ["pro_sup", "deviation", "flexion", "cmc_abduction", "cmc_flexion", "mp_flexion",
+               "ip_flexion", "mcp2_flexion", "mcp2_abduction", "pm2_flexion", "md2_flexion",
+               "mcp3_flexion", "mcp3_abduction", "pm3_flexion", "md3_flexion", "mcp4_flexion",
+               "mcp4_abduction", "pm4_flexion", "md4_flexion", "mcp5_flexion", "mcp5_abduction",
+               "pm5_flexion", "md5_flexion"]
+
+HAND_MUSCLES = ["ECRL", "ECRB", "ECU", "FCR", "FCU", "PL", "PT", "PQ", "EIP", "EPL", "EPB", "FPL", "APL",
+                "OP", "FDS2", "FDS3", "FDS4", "FDS5", "FDP2", "FDP3", "FDP4", "FDP5", "EDC2", "EDC3",
+                "EDC4", "EDC5", "EDM", "RI2", "RI3", "RI4", "RI5", "LU_RB2", "LU_RB3", "LU_RB4", "LU_RB5",
+                "UI_UB2", "UI_UB3", "UI_UB4", "UI_UB5"]
+
+
+def make_hand(with_object: bool = False) -> ModelSpec:
+    """myoHand: 23 DoF, 39 muscle-tendon units, 29 bones.  Frame: +x distal, +z dorsal, -y radial."""
+    s = ModelSpec("myohand")
+    WX = 0.25  # wrist centre
+    s.add_body("ulna", "world", pos=(0, 0, 1.0), mass=0.6, ipos=(0.12, 0.01, 0),
+               inertia=_cyl_inertia(0.6, 0.015, 0.25, "x"))
+    s.add_body("radius", "ulna", pos=(0, 0, 0), mass=0.5, ipos=(0.13, -0.01, 0),
+               inertia=_cyl_inertia(0.5, 0.015, 0.25, "x"))
+    s.add_joint("pro_sup", "radius", "hinge", pos=(0, 0, 0), axis=(1, 0, 0), range=(-1.57, 1.57),
+                damping=0.15, armature=0.002)
+    s.add_body("lunate", "radius", pos=(WX, 0, 0), mass=0.03, ipos=(0.004, 0, 0), inertia=(3e-6, 3e-6, 3e-6))
+    s.add_joint("deviation", "lunate", "hinge", axis=(0, 0, 1), range=(-0.175, 0.436), damping=0.12,
+                armature=0.002)
+    s.add_body("scaphoid", "lunate", pos=(0.002, -0.012, 0), mass=0.01, inertia=(1e-6, 1e-6, 1e-6))
+    s.add_body("triquetrum", "lunate", pos=(0.002, 0.014, 0), mass=0.01, inertia=(1e-6, 1e-6, 1e-6))
+    s.add_body("capitate", "lunate", pos=(0.012, 0, 0), mass=0.05, ipos=(0.01, 0, 0), inertia=(6e-6, 6e-6, 6e-6))
+    s.add_joint("flexion", "capitate", "hinge", axis=(0, 1, 0), range=(-1.22, 1.22), damping=0.12,
+                armature=0.002)
+    s.add_body("trapezium", "capitate", pos=(0.004, -0.022, -0.004), mass=0.01, inertia=(1e-6, 1e-6, 1e-6))
+    s.add_body("trapezoid", "capitate", pos=(0.006, -0.012, 0.002), mass=0.01, inertia=(1e-6, 1e-6, 1e-6))
+    s.add_body("hamate", "capitate", pos=(0.006, 0.014, 0), mass=0.01, inertia=(1e-6, 1e-6, 1e-6))
+
+    fj = dict(damping=0.05, armature=0.0015)
+    # ---- thumb: axes chosen so negative mp/ip flexion curls toward the palm
+    tdir = np.array([0.55, -0.70, -0.46]); tdir /= np.linalg.norm(tdir)
+    tflex = np.cross(tdir, np.array([0.0, 0.0, 1.0])); tflex /= np.linalg.norm(tflex)  # flexion axis
+    tabd = np.cross(tflex, tdir)
+    TL = (0.044, 0.032, 0.026)
+    s.add_body("firstmc1", "capitate", pos=(0.006, -0.026, -0.008), mass=0.004, inertia=(5e-7, 5e-7, 5e-7))
+    s.add_joint("cmc_abduction", "firstmc1", "hinge", axis=tuple(tabd), range=(-0.209, 0.698), **fj)
+    s.add_body("firstmc", "firstmc1", pos=(0, 0, 0), mass=0.012, ipos=tuple(0.5 * TL[0] * tdir),
+               inertia=(1.2e-6, 1.2e-6, 1.2e-6))
+    s.add_joint("cmc_flexion", "firstmc", "hinge", axis=tuple(-tflex), range=(-0.35, 0.70), **fj)
+    s.add_body("proximal_thumb", "firstmc", pos=tuple(TL[0] * tdir), mass=0.008,
+               ipos=tuple(0.5 * TL[1] * tdir), inertia=(6e-7, 6e-7, 6e-7))
+    s.add_joint("mp_flexion", "proximal_thumb", "hinge", axis=tuple(-tflex), range=(-0.785, 0.262), **fj)
+    s.add_body("distal_thumb", "proximal_thumb", pos=tuple(TL[1] * tdir), mass=0.005,
+               ipos=tuple(0.5 * TL[2] * tdir), inertia=(3e-7, 3e-7, 3e-7))
+    s.add_joint("ip_flexion", "distal_thumb", "hinge", axis=tuple(-tflex), range=(-1.31, 0.262), **fj)
+    s.add_site("THtip", "distal_thumb", tuple(TL[2] * tdir))
+
+    # ---- fingers 2..5
+    fy = {2: -0.026, 3: -0.006, 4: 0.012, 5: 0.029}
+    fmc = {2: 0.066, 3: 0.064, 4: 0.058, 5: 0.053}
+    flen = {2: (0.043, 0.025, 0.019), 3: (0.047, 0.029, 0.020), 4: (0.043, 0.027, 0.020), 5: (0.034, 0.020, 0.018)}
+    mcname = {2: "secondmc", 3: "thirdmc", 4: "fourthmc", 5: "fifthmc"}
+    tipname = {2: "IFtip", 3: "MFtip", 4: "RFtip", 5: "LFtip"}
+    MC0 = 0.018
+    for k in (2, 3, 4, 5):
+        L = flen[k]
+        s.add_body(mcname[k], "capitate", pos=(MC0, fy[k], 0), mass=0.02, ipos=(0.5 * fmc[k], 0, 0),
+                   inertia=_cyl_inertia(0.02, 0.006, fmc[k], "x"))
+        s.add_body(f"proxph{k}", mcname[k], pos=(fmc[k], 0, 0), mass=0.011, ipos=(0.5 * L[0], 0, 0),
+                   inertia=_cyl_inertia(0.011, 0.008, L[0], "x"))
+        s.add_joint(f"mcp{k}_flexion", f"proxph{k}", "hinge", axis=(0, 1, 0), range=(-0.785, 1.571), **fj)
+        s.add_joint(f"mcp{k}_abduction", f"proxph{k}", "hinge", axis=(0, 0, 1), range=(-0.262, 0.262), **fj)
+        s.add_body(f"midph{k}", f"proxph{k}", pos=(L[0], 0, 0), mass=0.006, ipos=(0.5 * L[1], 0, 0),
+                   inertia=_cyl_inertia(0.006, 0.007, L[1], "x"))
+        s.add_joint(f"pm{k}_flexion", f"midph{k}", "hinge", axis=(0, 1, 0), range=(0.0, 1.571), **fj)
+        s.add_body(f"distph{k}", f"midph{k}", pos=(L[1], 0, 0), mass=0.004, ipos=(0.5 * L[2], 0, 0),
+                   inertia=_cyl_inertia(0.004, 0.006, L[2], "x"))
+        s.add_joint(f"md{k}_flexion", f"distph{k}", "hinge", axis=(0, 1, 0), range=(0.0, 1.571), **fj)
+        s.add_site(tipname[k], f"distph{k}", (L[2], 0, 0))
+        # extensor wrap cylinders at MCP and PIP (axis = flexion axis y)
+        s.add_geom(f"mcp{k}_wrap", mcname[k], "cylinder", size=(0.0065, 0.01), pos=(fmc[k], 0, 0), quat=QX90N)
+        s.add_site(f"mcp{k}_side", mcname[k], (fmc[k], 0, 0.03))
+        s.add_geom(f"pip{k}_wrap", f"proxph{k}", "cylinder", size=(0.0045, 0.008), pos=(L[0], 0, 0), quat=QX90N)
+        s.add_site(f"pip{k}_side", f"proxph{k}", (L[0], 0, 0.03))
+    for n in ("THtip", "IFtip", "MFtip", "RFtip", "LFtip"):
+        s.add_site(n + "_target", "world", (0, 0, 0.002))
+
+    # wrist wrap obstacles: dorsal cylinder about the flexion axis, on the radius
+    s.add_geom("wrist_wrap", "radius", "cylinder", size=(0.013, 0.03), pos=(WX + 0.004, 0, 0), quat=QX90N)
+    s.add_site("wrist_side_dors", "radius", (WX, 0, 0.06))
+    s.add_site("wrist_side_palm", "radius", (WX, 0, -0.06))
+    # thumb MP wrap sphere for the long extensor
+    s.add_geom("thmp_wrap", "firstmc", "sphere", size=(0.006,), pos=tuple(TL[0] * tdir))
+    s.add_site("thmp_side", "firstmc", tuple(TL[0] * tdir + 0.03 * tabd + 0.0 * tflex))
+
+    cnt = [0]
+
+    def site(body, p):
+        cnt[0] += 1
+        n = f"p{cnt[0]}"
+        s.add_site(n, body, tuple(float(x) for x in p))
+        return ("site", n)
+
+    def finger_path(k, side, last):
+        """via points along finger k; side=-1 palmar (flexor) / +1 dorsal (extensor);
+        last: 1 -> insert on proximal, 2 -> middle, 3 -> distal phalanx."""
+        L = flen[k]
+        hm = {-1: (0.010, 0.0075, 0.005), 1: (0.0085, 0.0065, 0.0045)}[side]
+        z = lambda i: side * hm[i]
+        p = [site(mcname[k], (fmc[k] - 0.012, 0, z(0)))]
+        if side > 0:
+            p.append(("cylinder", f"mcp{k}_wrap", f"mcp{k}_side"))
+        p.append(site(f"proxph{k}", (0.010, 0, z(0))))
+        if last == 1:
+            return p
+        p.append(site(f"proxph{k}", (L[0] - 0.008, 0, z(1))))
+        if side > 0:
+            p.append(("cylinder", f"pip{k}_wrap", f"pip{k}_side"))
+        p.append(site(f"midph{k}", (0.007, 0, z(1))))
+        if last == 2:
+            return p
+        p.append(site(f"midph{k}", (L[1] - 0.006, 0, z(2))))
+        p.append(site(f"distph{k}", (0.006, 0, z(2))))
+        return p
+
+    def wrist_path(side, y, radial_body="radius"):
+        """forearm via, wrist obstacle, carpal via; side -1 palmar / +1 dorsal"""
+        p = [site(radial_body, (WX - 0.035, y, side * 0.016))]
+        p.append(("cylinder", "wrist_wrap", "wrist_side_dors" if side > 0 else "wrist_side_palm"))
+        p.append(site("capitate", (0.010, y, side * 0.014)))
+        return p
+
+    def muscle(name, path, force):
+        s.add_tendon(name + "_tendon", path)
+        # operating range wide enough that stretched antagonists produce passive force
+        s.add_muscle(name, name + "_tendon", force=force, range=(0.70, 1.25))
+
+    # --- wrist movers (insert on metacarpal bases) and forearm rotators
+    muscle("ECRL", [site("ulna", (0.02, -0.02, 0.01))] + wrist_path(+1, -0.022) + [site("secondmc", (0.004, 0, 0.008))], 300.0)
+    muscle("ECRB", [site("ulna", (0.03, -0.015, 0.012))] + wrist_path(+1, -0.008) + [site("thirdmc", (0.004, 0, 0.008))], 250.0)
+    muscle("ECU", [site("ulna", (0.04, 0.02, 0.01))] + wrist_path(+1, 0.026) + [site("fifthmc", (0.004, 0, 0.007))], 200.0)
+    muscle("FCR", [site("ulna", (0.02, -0.005, -0.015))] + wrist_path(-1, -0.016) + [site("secondmc", (0.004, 0, -0.008))], 250.0)
+    muscle("FCU", [site("ulna", (0.03, 0.02, -0.012))] + wrist_path(-1, 0.024) + [site("fifthmc", (0.004, 0, -0.008))], 300.0)
+    muscle("PL", [site("ulna", (0.02, 0.004, -0.016))] + wrist_path(-1, 0.0) + [site("thirdmc", (0.012, 0, -0.010))], 80.0)
+    # pronators / supinator-like: wrap around the forearm axis is approximated with via points
+    muscle("PT", [site("ulna", (0.03, 0.022, -0.004)), site("ulna", (0.07, 0.010, -0.020)), site("radius", (0.11, -0.018, -0.004))], 300.0)
+    muscle("PQ", [site("ulna", (0.21, 0.020, -0.006)), site("ulna", (0.213, 0.0, -0.019)), site("radius", (0.216, -0.020, -0.004))], 150.0)
+    muscle("EIP", [site("ulna", (0.15, 0.010, 0.012))] + wrist_path(+1, -0.016) + finger_path(2, +1, 3), 70.0)
+    # --- thumb
+    def th(body, along, off_abd, off_flex):
+        base = {"firstmc": 0.0, "proximal_thumb": 0.0, "distal_thumb": 0.0}[body]
+        return site(body, (base + along) * tdir + off_abd * tabd + off_flex * tflex)
+    dors = np.cross(tdir, tflex)  # thumb dorsal direction (== -tabd up to sign)
+    def thd(body, along, h):  # h>0 dorsal (extensor), h<0 palmar (flexor) w.r.t. flexion axis
+        return site(body, along * tdir + h * np.cross(-tflex, tdir))
+    muscle("EPL", [site("ulna", (0.10, 0.012, 0.012))] + wrist_path(+1, -0.014) +
+           [thd("firstmc", 0.012, 0.008), thd("firstmc", TL[0] - 0.008, 0.007),
+            ("sphere", "thmp_wrap", None), thd("proximal_thumb", 0.008, 0.006),
+            thd("proximal_thumb", TL[1] - 0.006, 0.005), thd("distal_thumb", 0.006, 0.004)], 90.0)
+    muscle("EPB", [site("radius", (0.16, -0.010, 0.012)), site("radius", (WX - 0.01, -0.024, 0.006)),
+                   thd("firstmc", 0.010, 0.008), thd("firstmc", TL[0] - 0.008, 0.007),
+                   thd("proximal_thumb", 0.008, 0.006)], 60.0)
+    muscle("FPL", [site("radius", (0.10, -0.008, -0.012))] + wrist_path(-1, -0.018) +
+           [thd("firstmc", 0.012, -0.009), thd("firstmc", TL[0] - 0.008, -0.008),
+            thd("proximal_thumb", 0.008, -0.007), thd("proximal_thumb", TL[1] - 0.006, -0.006),
+            thd("distal_thumb", 0.007, -0.005)], 120.0)
+    muscle("APL", [site("radius", (0.14, -0.006, 0.012)), site("radius", (WX - 0.008, -0.026, 0.0)),
+                   site("firstmc", 0.008 * tdir + 0.009 * tabd)], 100.0)
+    muscle("OP", [site("capitate", (0.004, -0.004, -0.012)), site("firstmc", 0.030 * tdir - 0.008 * tabd - 0.004 * np.cross(-tflex, tdir))], 80.0)
+    # --- extrinsic finger flexors / extensors
+    for k in (2, 3, 4, 5):
+        muscle(f"FDS{k}", [site("ulna", (0.04 + 0.01 * k, fy[k] * 0.5, -0.014))] + wrist_path(-1, fy[k] * 0.6) +
+               finger_path(k, -1, 2), {2: 75.0, 3: 85.0, 4: 65.0, 5: 45.0}[k])
+    for k in (2, 3, 4, 5):
+        muscle(f"FDP{k}", [site("ulna", (0.05 + 0.01 * k, fy[k] * 0.5, -0.010))] + wrist_path(-1, fy[k] * 0.5) +
+               finger_path(k, -1, 3), {2: 80.0, 3: 90.0, 4: 75.0, 5: 55.0}[k])
+    for k in (2, 3, 4, 5):
+        muscle(f"EDC{k}", [site("ulna", (0.06 + 0.01 * k, fy[k] * 0.5, 0.012))] + wrist_path(+1, fy[k] * 0.55) +
+               finger_path(k, +1, 3), {2: 150.0, 3: 165.0, 4: 140.0, 5: 100.0}[k])
+    muscle("EDM", [site("ulna", (0.12, 0.018, 0.011))] + wrist_path(+1, 0.020) + finger_path(5, +1, 3), 60.0)
+    # --- intrinsics: metacarpal -> proximal phalanx sides (ab/adduction + MCP flexion)
+    for k in (2, 3, 4, 5):
+        muscle(f"RI{k}", [site(mcname[k], (0.020, -0.007, 0.0)), site(mcname[k], (fmc[k] - 0.010, -0.008, -0.003)),
+                          site(f"proxph{k}", (0.010, -0.007, -0.002))], 60.0)
+    for k in (2, 3, 4, 5):
+        muscle(f"LU_RB{k}", [site(mcname[k], (0.030, -0.004, -0.008)), site(mcname[k], (fmc[k] - 0.010, -0.005, -0.009)),
+                             site(f"proxph{k}", (0.012, -0.004, -0.006)), site(f"proxph{k}", (flen[k][0] - 0.008, -0.003, 0.004)),
+                             site(f"midph{k}", (0.006, 0.0, 0.005))], 25.0)
+    for k in (2, 3, 4, 5):
+        muscle(f"UI_UB{k}", [site(mcname[k], (0.020, 0.007, 0.0)), site(mcname[k], (fmc[k] - 0.010, 0.008, -0.003)),
+                             site(f"proxph{k}", (0.010, 0.007, -0.002))], 50.0)
+    assert [a.name for a in s.actuators] == HAND_MUSCLES
+    assert [j.name for j in s.joints] == HAND_JOINTS
+    return s
+
+
+_CACHE = {}
+
+
+def get_model(name: str) -> CompiledModel:
+    """Compiled synthetic model by short name: 'elbow' | 'hand'."""
+    if name not in _CACHE:
+        spec = {"elbow": make_elbow, "hand": make_hand}[name]()
+        _CACHE[name] = spec.compile()
+    return _CACHE[name]

@@ -1,0 +1,173 @@
+"""ctypes binding of the fp64 CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (myosuite_amd/) never imports
+this module; its step path fails loudly when the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("mmo_engine.c", "mmo_collision.inc", "mmo_batch.c")]
+    srcs.append(os.path.join(_HERE, "..", "include", "myosim_model.h"))
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.mmo_model_load.restype = C.c_void_p
+        L.mmo_model_load.argtypes = [C.c_void_p, C.c_int]
+        L.mmo_model_free.argtypes = [C.c_void_p]
+        L.mmo_data_create.restype = C.c_void_p
+        L.mmo_data_create.argtypes = [C.c_void_p]
+        L.mmo_data_free.argtypes = [C.c_void_p]
+        for f in ("mmo_reset", "mmo_forward", "mmo_step", "mmo_fwd_position", "mmo_fwd_velocity"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.mmo_field.restype = C.POINTER(C.c_double)
+        L.mmo_field.argtypes = [C.c_void_p, C.c_char_p]
+        L.mmo_time.restype = C.c_double
+        L.mmo_time.argtypes = [C.c_void_p]
+        L.mmo_set_time.argtypes = [C.c_void_p, C.c_double]
+        for f in ("mmo_nefc", "mmo_ncon", "mmo_solver_niter", "mmo_warn"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        L.mmo_efc_type.restype = C.POINTER(C.c_int)
+        L.mmo_efc_type.argtypes = [C.c_void_p]
+        L.mmo_full_m.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mmo_batch_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+class OracleModel:
+    def __init__(self, compiled):
+        """compiled: myosuite_amd.model.spec.CompiledModel (or anything with .blob + dims)"""
+        self.cm = compiled
+        blob = np.ascontiguousarray(compiled.blob, dtype=np.uint32)
+        self._blob = blob
+        self.ptr = lib().mmo_model_load(blob.ctypes.data, int(blob.size))
+        if not self.ptr:
+            raise RuntimeError("oracle rejected the model blob")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().mmo_model_free(self.ptr)
+        except Exception:
+            pass
+
+
+_SHAPES = {
+    "qpos": lambda m: (m.nq,), "qvel": lambda m: (m.nv,), "act": lambda m: (m.na,), "ctrl": lambda m: (m.nu,),
+    "qacc_warmstart": lambda m: (m.nv,), "xpos": lambda m: (m.nbody, 3), "xquat": lambda m: (m.nbody, 4),
+    "xmat": lambda m: (m.nbody, 9), "xipos": lambda m: (m.nbody, 3), "ximat": lambda m: (m.nbody, 9),
+    "xanchor": lambda m: (m.njnt, 3), "xaxis": lambda m: (m.njnt, 3), "site_xpos": lambda m: (m.nsite, 3),
+    "geom_xpos": lambda m: (m.ngeom, 3), "geom_xmat": lambda m: (m.ngeom, 9),
+    "subtree_com": lambda m: (m.nbody, 3), "cinert": lambda m: (m.nbody, 10), "cdof": lambda m: (m.nv, 6),
+    "crb": lambda m: (m.nbody, 10), "ten_length": lambda m: (m.ntendon,), "ten_J": lambda m: (m.ntendon, m.nv),
+    "actuator_length": lambda m: (m.nu,), "actuator_moment": lambda m: (m.nu, m.nv), "qM": lambda m: (m.nM,),
+    "qLD": lambda m: (m.nM,), "qLDiagInv": lambda m: (m.nv,), "ten_velocity": lambda m: (m.ntendon,),
+    "actuator_velocity": lambda m: (m.nu,), "cvel": lambda m: (m.nbody, 6), "cdof_dot": lambda m: (m.nv, 6),
+    "qfrc_passive": lambda m: (m.nv,), "qfrc_bias": lambda m: (m.nv,), "act_dot": lambda m: (m.na,),
+    "actuator_force": lambda m: (m.nu,), "qfrc_actuator": lambda m: (m.nv,), "qfrc_smooth": lambda m: (m.nv,),
+    "qacc_smooth": lambda m: (m.nv,), "efc_J": lambda m: (max(m.njmax, 1), m.nv),
+    "efc_pos": lambda m: (max(m.njmax, 1),), "efc_margin": lambda m: (max(m.njmax, 1),),
+    "efc_R": lambda m: (max(m.njmax, 1),), "efc_D": lambda m: (max(m.njmax, 1),),
+    "efc_vel": lambda m: (max(m.njmax, 1),), "efc_aref": lambda m: (max(m.njmax, 1),),
+    "efc_force": lambda m: (max(m.njmax, 1),), "qfrc_constraint": lambda m: (m.nv,), "qacc": lambda m: (m.nv,),
+    "cfrc": lambda m: (m.nbody, 6), "cacc": lambda m: (m.nbody, 6),
+}
+
+
+class OracleData:
+    """One env's mjData-like state; attributes are numpy views into the C arrays."""
+
+    def __init__(self, model: OracleModel):
+        self.model = model
+        self.ptr = lib().mmo_data_create(model.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().mmo_data_free(self.ptr)
+        except Exception:
+            pass
+
+    def __getattr__(self, name):
+        if name in _SHAPES:
+            shape = _SHAPES[name](self.model.cm)
+            n = int(np.prod(shape))
+            p = lib().mmo_field(self.ptr, name.encode())
+            if n == 0:
+                return np.zeros(shape)
+            return np.ctypeslib.as_array(p, shape=(n,)).reshape(shape)
+        raise AttributeError(name)
+
+    @property
+    def time(self):
+        return lib().mmo_time(self.ptr)
+
+    @time.setter
+    def time(self, t):
+        lib().mmo_set_time(self.ptr, float(t))
+
+    @property
+    def nefc(self):
+        return lib().mmo_nefc(self.ptr)
+
+    @property
+    def ncon(self):
+        return lib().mmo_ncon(self.ptr)
+
+    @property
+    def solver_niter(self):
+        return lib().mmo_solver_niter(self.ptr)
+
+    @property
+    def warn(self):
+        return lib().mmo_warn(self.ptr)
+
+    def reset(self):
+        lib().mmo_reset(self.model.ptr, self.ptr)
+
+    def forward(self):
+        lib().mmo_forward(self.model.ptr, self.ptr)
+
+    def step(self, n: int = 1):
+        for _ in range(n):
+            lib().mmo_step(self.model.ptr, self.ptr)
+
+    def full_M(self):
+        nv = self.model.cm.nv
+        out = np.zeros((nv, nv))
+        lib().mmo_full_m(self.model.ptr, self.ptr, out.ctypes.data)
+        return out
+
+
+def batch_rollout(model: OracleModel, datas, actions: np.ndarray, nsub: int, nthreads: int = 1,
+                  normalize: bool = True, do_forward: bool = True):
+    """actions [nsteps, nenv, nu] float64; advances every env in `datas` in place."""
+    actions = np.ascontiguousarray(actions, dtype=np.float64)
+    nsteps, nenv, nu = actions.shape
+    assert nenv == len(datas)
+    arr = (C.c_void_p * nenv)(*[d.ptr for d in datas])
+    lib().mmo_batch_rollout(model.ptr, arr, nenv, nthreads, nsub, nsteps, actions.ctypes.data,
+                            int(normalize), int(do_forward))
