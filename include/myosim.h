@@ -1,0 +1,153 @@
+/* myosim.h -- C ABI of libmyosim_hip.so: the MI355X-native batched physics step.
+ *
+ * This is the drop-in boundary for the ONE hot path of MyoSuite (SURVEY.md 8b,
+ * boundary A): everything the reference does between `env.step(a)` entering
+ * BaseV0.step and the observation/reward leaving MujocoEnv.forward, for E
+ * independent environments resident in HBM.
+ *
+ * Reference interfaces each entry point replaces (paths under /root/reference):
+ *   mm_model_create   <- MjSpec.from_file(path).compile()      myosuite/envs/env_base.py:72,96-106
+ *   mm_env_step       <- BaseV0.step + Robot.step + mj_step loop + MujocoEnv.forward
+ *                        myosuite/envs/myo/base_v0.py:82-118, myosuite/robot/robot.py:856-933,
+ *                        myosuite/envs/env_base.py:409-459, task get_obs_dict/get_reward_dict
+ *                        (myosuite/envs/myo/myobase/pose_v0.py:100-140)
+ *   mm_forward        <- mujoco.mj_forward via Robot.sensor2sim  myosuite/robot/robot.py:595-607
+ *   mm_env_reset      <- PoseEnvV0.reset / MujocoEnv.reset / Robot.reset (mj_resetData)
+ *                        myosuite/envs/myo/myobase/pose_v0.py:174-257, myosuite/robot/robot.py:936-1021
+ *   mm_fatigue_*      <- CumulativeFatigue.compute_act/reset     myosuite/envs/myo/fatigue.py:38-99
+ *   mm_uniform        <- jax.random.uniform action sampling      benchmarks/mjx_benchmark.py:29
+ *
+ * Conventions
+ *  - plain C, no torch types: every buffer is a raw DEVICE pointer owned by the
+ *    caller (PyTorch-ROCm tensors via data_ptr(), or hipMalloc).
+ *  - per-env arrays are ENV-MAJOR, row-major [nenv][n] float32: the wave-cooperative
+ *    kernels give each env a group of G lanes that sweep the components of that
+ *    env, so component-contiguous rows are the coalesced layout.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  No call
+ *    synchronises the host; all work is enqueued on `stream`.
+ *  - every function returns 0 on success, a negative MM_E* code otherwise, never
+ *    throws, never falls back to a CPU path.
+ */
+#ifndef MYOSIM_H_
+#define MYOSIM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_OK            0
+#define MM_EBADBLOB     -1
+#define MM_EHIP         -2   /* a HIP runtime call failed: see mm_last_error()   */
+#define MM_EUNSUPPORTED -3   /* model uses a feature the engine does not implement */
+#define MM_ELDS         -4   /* per-env workspace does not fit in LDS             */
+#define MM_EARG         -5
+
+typedef struct mm_model mm_model;
+
+/* task ids for the fused obs/reward stage */
+enum { MM_TASK_NONE = 0, MM_TASK_POSE = 1, MM_TASK_REACH = 2, MM_TASK_REORIENT = 3, MM_TASK_WALK = 4 };
+
+/* mm_model_info selectors */
+enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INFO_NSITE, MM_INFO_NTENDON,
+       MM_INFO_LANES_PER_ENV, MM_INFO_LDS_BYTES_PER_ENV, MM_INFO_ENVS_PER_BLOCK, MM_INFO_NGEOM,
+       MM_INFO_WAVES_PER_BLOCK };
+
+/* Simulation state of a batch, all [nenv][n] float32 device arrays. */
+typedef struct {
+  int    nenv;
+  float* qpos;            /* [nenv][nq]                                   */
+  float* qvel;            /* [nenv][nv]                                   */
+  float* act;             /* [nenv][na]                                   */
+  float* qacc_warmstart;  /* [nenv][nv]                                   */
+  float* time;            /* [nenv]                                       */
+  int32_t* status;        /* [nenv] bit0: bad-state auto reset, bit1: constraint rows overflowed,
+                                    bit2: solver hit the iteration cap (sticky; cleared by reset) */
+} mm_state;
+
+/* Optional derived outputs of the final forward pass (NULL = not requested). */
+typedef struct {
+  float* xpos;              /* [nenv][nbody][3] body frame origins, world    */
+  float* xquat;             /* [nenv][nbody][4]                               */
+  float* xipos;             /* [nenv][nbody][3] body COMs                     */
+  float* site_xpos;         /* [nenv][nsite][3]                               */
+  float* geom_xpos;         /* [nenv][ngeom][3]                               */
+  float* cvel;              /* [nenv][nbody][6] com-frame velocities (rot:lin)*/
+  float* subtree_com;       /* [nenv][nbody][3] (only tree roots are filled)  */
+  float* actuator_length;   /* [nenv][nu]                                     */
+  float* actuator_velocity; /* [nenv][nu]                                     */
+  float* actuator_force;    /* [nenv][nu]                                     */
+  float* qacc;              /* [nenv][nv]                                     */
+  float* ten_length;        /* [nenv][ntendon]                                */
+  int32_t* nefc;            /* [nenv] active constraint rows                  */
+  int32_t* solver_niter;    /* [nenv] Newton iterations of the last solve     */
+} mm_derived;
+
+/* Per-call description of the env-level (MyoBase) work fused around the physics. */
+typedef struct {
+  int   task;               /* MM_TASK_*                                       */
+  int   nsubsteps;          /* frame_skip                                      */
+  int   normalize_act;      /* 1: muscle ctrl = 1/(1+exp(-5(a-0.5)))  (base_v0.py:86-90) */
+  int   do_forward;         /* 1: run the post-step forward pass (sensor2sim)  */
+  int   fatigue;            /* 1: 3CC-r fatigue remaps muscle ctrl (fatigue.py) */
+  int   max_episode_steps;  /* TimeLimit horizon; 0 = none                     */
+  /* POSE task */
+  float pose_thd;           /* pose_v0.py:57                                   */
+  float far_th;             /* 4*pi/2, pose_v0.py:118                          */
+  float w_pose, w_bonus, w_act_reg, w_penalty;   /* pose_v0.py:18-23           */
+  const float* target_jnt_value; /* [nenv][nq]                                 */
+  /* fatigue state, [nenv][na] each (NULL unless fatigue=1) */
+  float* fat_MA; float* fat_MR; float* fat_MF;
+  float fat_F, fat_R, fat_r; /* fatigue.py:9-11                                */
+  /* outputs */
+  float* obs;               /* [nenv][obs_dim] float32, key order of the task  */
+  int   obs_dim;
+  float* rwd;               /* [nenv][8]: task reward terms, see MM_RWD_*      */
+  uint8_t* done;            /* [nenv]                                          */
+  uint8_t* truncated;       /* [nenv] step_count >= max_episode_steps          */
+  int32_t* step_count;      /* [nenv] in/out                                   */
+  float* ctrl_out;          /* [nenv][nu] optional: ctrl actually applied      */
+} mm_task;
+
+/* columns of mm_task.rwd for MM_TASK_POSE (pose_v0.py:120-139) */
+enum { MM_RWD_POSE = 0, MM_RWD_BONUS, MM_RWD_PENALTY, MM_RWD_ACT_REG, MM_RWD_SPARSE, MM_RWD_SOLVED,
+       MM_RWD_DONE, MM_RWD_DENSE, MM_RWD_COUNT };
+
+/* ---- model ---------------------------------------------------------------- */
+int  mm_model_create(const uint32_t* blob_host, int nwords, mm_model** out);
+void mm_model_destroy(mm_model* m);
+int  mm_model_info(const mm_model* m, int which);
+/* lanes_per_env in {4,8,16,32,64}; 0 = engine default for the model size. */
+int  mm_model_set_lanes(mm_model* m, int lanes_per_env);
+
+/* ---- physics -------------------------------------------------------------- */
+/* `nsub` mj_step substeps with ctrl [nenv][nu] applied as-is (engine boundary). */
+int  mm_step(const mm_model* m, const mm_state* s, const float* ctrl, int nsub, void* stream);
+/* mj_forward on the current state; fills the requested derived arrays. */
+int  mm_forward(const mm_model* m, const mm_state* s, const float* ctrl, const mm_derived* out, void* stream);
+/* fused env.step: action [nenv][nu] -> state advanced, obs/reward/done written. */
+int  mm_env_step(const mm_model* m, const mm_state* s, const float* action, const mm_task* t,
+                 const mm_derived* out, void* stream);
+
+/* ---- reset / RNG ----------------------------------------------------------- */
+/* mj_resetData + (qpos,qvel) overwrite for envs with mask[e]!=0 (mask NULL = all).
+ * qpos_src/qvel_src may be NULL (=> qpos0 / 0) and are [nenv][nq] / [nenv][nv]. */
+int  mm_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* qpos_src,
+              const float* qvel_src, void* stream);
+/* Pose-task reset: for masked envs draw qpos ~ U(lo,hi)[nq] and target ~ U(tlo,thi)[nq]
+ * from Philox4x32-10 keyed by (seed, env, episode counter), then mj_resetData. */
+int  mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* qlo,
+                   const float* qhi, const float* tlo, const float* thi, float* target, int32_t* episode,
+                   int32_t* step_count, uint64_t seed, int random_qpos, void* stream);
+/* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
+int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+const char* mm_last_error(void);
+const char* mm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYOSIM_H_ */

@@ -1,0 +1,246 @@
+"""ctypes binding of libmyosim_hip.so (C ABI in include/myosim.h).
+
+PyTorch-ROCm is used only as plumbing: it owns the device buffers (tensors), the
+current HIP stream and (in dist.py) the process group.  All per-step arithmetic
+runs in the hand-written HIP kernels of myosuite_amd/csrc/myosim_engine.hip.
+There is NO CPU fallback: if the library is missing or a call fails the error is
+raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmyosim_hip.so")
+_SOURCES = ["myosim_engine.hip"]
+_lib = None
+
+MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK = 0, 1, 2, 3, 4
+RWD_KEYS_POSE = ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+(INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
+ INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK) = range(12)
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in _SOURCES]
+    deps = srcs + [os.path.join(_HERE, "..", "include", h) for h in ("myosim.h", "myosim_model.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class mm_state(C.Structure):
+    _fields_ = [("nenv", C.c_int), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("act", C.c_void_p),
+                ("qacc_warmstart", C.c_void_p), ("time", C.c_void_p), ("status", C.c_void_p)]
+
+
+_DERIVED_FIELDS = ["xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "cvel", "subtree_com", "actuator_length",
+                   "actuator_velocity", "actuator_force", "qacc", "ten_length", "nefc", "solver_niter"]
+
+
+class mm_derived(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _DERIVED_FIELDS]
+
+
+class mm_task(C.Structure):
+    _fields_ = [("task", C.c_int), ("nsubsteps", C.c_int), ("normalize_act", C.c_int), ("do_forward", C.c_int),
+                ("fatigue", C.c_int), ("max_episode_steps", C.c_int),
+                ("pose_thd", C.c_float), ("far_th", C.c_float),
+                ("w_pose", C.c_float), ("w_bonus", C.c_float), ("w_act_reg", C.c_float), ("w_penalty", C.c_float),
+                ("target_jnt_value", C.c_void_p),
+                ("fat_MA", C.c_void_p), ("fat_MR", C.c_void_p), ("fat_MF", C.c_void_p),
+                ("fat_F", C.c_float), ("fat_R", C.c_float), ("fat_r", C.c_float),
+                ("obs", C.c_void_p), ("obs_dim", C.c_int), ("rwd", C.c_void_p), ("done", C.c_void_p),
+                ("truncated", C.c_void_p), ("step_count", C.c_void_p), ("ctrl_out", C.c_void_p)]
+
+
+def lib():
+    """Load libmyosim_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                f"{LIB_PATH} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (needs hipcc). There is no CPU fallback for the physics step.")
+        L = C.CDLL(LIB_PATH)
+        L.mm_model_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.mm_model_destroy.argtypes = [C.c_void_p]
+        L.mm_model_info.argtypes = [C.c_void_p, C.c_int]
+        L.mm_model_set_lanes.argtypes = [C.c_void_p, C.c_int]
+        L.mm_step.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_int, C.c_void_p]
+        L.mm_forward.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.POINTER(mm_derived), C.c_void_p]
+        L.mm_env_step.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.POINTER(mm_task),
+                                  C.POINTER(mm_derived), C.c_void_p]
+        L.mm_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mm_pose_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                    C.c_int, C.c_void_p]
+        L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.mm_last_error.restype = C.c_char_p
+        L.mm_version.restype = C.c_char_p
+        L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
+        L.mm_debug_set_dump.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise EngineError(f"{what} failed (rc={rc}): {lib().mm_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "engine buffers must be contiguous device tensors"
+    return t.data_ptr()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipModel:
+    """Device-resident compiled model (mm_model)."""
+
+    def __init__(self, compiled, lanes_per_env: int = 0, device: Optional[torch.device] = None):
+        self.cm = compiled
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible: the physics step only runs on the GPU (no CPU fallback)")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        blob = np.ascontiguousarray(compiled.blob, dtype=np.uint32)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _chk(lib().mm_model_create(blob.ctypes.data, int(blob.size), C.byref(h)), "mm_model_create")
+        self.h = h
+        if lanes_per_env:
+            _chk(lib().mm_model_set_lanes(self.h, lanes_per_env), "mm_model_set_lanes")
+
+    def info(self, which: int) -> int:
+        return lib().mm_model_info(self.h, which)
+
+    def layout(self, name: str) -> int:
+        return lib().mm_debug_layout(self.h, name.encode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().mm_model_destroy(self.h)
+        except Exception:
+            pass
+
+
+class BatchState:
+    """Env-major state tensors of E environments (mm_state)."""
+
+    def __init__(self, model: HipModel, nenv: int):
+        cm = model.cm
+        dev = model.device
+        self.model = model
+        self.nenv = nenv
+        f = dict(dtype=torch.float32, device=dev)
+        self.qpos = torch.from_numpy(np.tile(cm.qpos0.astype(np.float32), (nenv, 1))).to(dev).contiguous()
+        self.qvel = torch.zeros(nenv, cm.nv, **f)
+        self.act = torch.zeros(nenv, max(cm.na, 1), **f)[:, :cm.na].contiguous() if cm.na == 0 else torch.zeros(nenv, cm.na, **f)
+        self.qacc_warmstart = torch.zeros(nenv, cm.nv, **f)
+        self.time = torch.zeros(nenv, **f)
+        self.status = torch.zeros(nenv, dtype=torch.int32, device=dev)
+        self._c = mm_state(nenv, _ptr(self.qpos), _ptr(self.qvel), self.act.data_ptr(), _ptr(self.qacc_warmstart),
+                           _ptr(self.time), _ptr(self.status))
+
+    @property
+    def c(self):
+        return C.byref(self._c)
+
+
+class Derived:
+    """Requested derived outputs of the final forward pass (mm_derived)."""
+
+    def __init__(self, model: HipModel, nenv: int, fields):
+        cm = model.cm
+        dev = model.device
+        shapes = {"xpos": (cm.nbody, 3), "xquat": (cm.nbody, 4), "xipos": (cm.nbody, 3), "site_xpos": (cm.nsite, 3),
+                  "geom_xpos": (cm.ngeom, 3), "cvel": (cm.nbody, 6), "subtree_com": (cm.nbody, 3),
+                  "actuator_length": (cm.nu,), "actuator_velocity": (cm.nu,), "actuator_force": (cm.nu,),
+                  "qacc": (cm.nv,), "ten_length": (cm.ntendon,), "nefc": (), "solver_niter": ()}
+        self.t: Dict[str, torch.Tensor] = {}
+        self._c = mm_derived()
+        for name in fields:
+            dt = torch.int32 if name in ("nefc", "solver_niter") else torch.float32
+            self.t[name] = torch.zeros((nenv,) + shapes[name], dtype=dt, device=dev)
+            setattr(self._c, name, self.t[name].data_ptr())
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+    @property
+    def c(self):
+        return C.byref(self._c)
+
+
+def step(model: HipModel, state: BatchState, ctrl: torch.Tensor, nsub: int = 1):
+    """`nsub` raw mj_step substeps with ctrl [E,nu] applied unchanged."""
+    assert ctrl.shape == (state.nenv, model.cm.nu) and ctrl.dtype == torch.float32
+    _chk(lib().mm_step(model.h, state.c, _ptr(ctrl.contiguous()), int(nsub), _stream()), "mm_step")
+
+
+def forward(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] = None, derived: Optional[Derived] = None):
+    _chk(lib().mm_forward(model.h, state.c, _ptr(ctrl) if ctrl is not None else None,
+                          derived.c if derived is not None else None, _stream()), "mm_forward")
+
+
+def env_step(model: HipModel, state: BatchState, action: torch.Tensor, task: mm_task, derived: Optional[Derived] = None):
+    assert action.shape == (state.nenv, model.cm.nu) and action.dtype == torch.float32 and action.is_contiguous()
+    _chk(lib().mm_env_step(model.h, state.c, _ptr(action), C.byref(task), derived.c if derived is not None else None,
+                           _stream()), "mm_env_step")
+
+
+def reset(model: HipModel, state: BatchState, mask: Optional[torch.Tensor] = None, qpos: Optional[torch.Tensor] = None,
+          qvel: Optional[torch.Tensor] = None):
+    if mask is not None:
+        assert mask.dtype == torch.uint8
+    _chk(lib().mm_reset(model.h, state.c, _ptr(mask), _ptr(qpos), _ptr(qvel), _stream()), "mm_reset")
+
+
+def pose_reset(model: HipModel, state: BatchState, mask, qlo, qhi, tlo, thi, target, episode, step_count, seed: int,
+               random_qpos: bool):
+    _chk(lib().mm_pose_reset(model.h, state.c, _ptr(mask), _ptr(qlo), _ptr(qhi), _ptr(tlo), _ptr(thi), _ptr(target),
+                             _ptr(episode), _ptr(step_count), C.c_uint64(seed), int(random_qpos), _stream()),
+         "mm_pose_reset")
+
+
+def uniform(out: torch.Tensor, seed: int, stream_id: int):
+    """out[...] = U[0,1) float32, Philox4x32-10, counter=(i/4, stream_id), key=seed."""
+    assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+    _chk(lib().mm_uniform(out.data_ptr(), out.numel(), C.c_uint64(seed), C.c_uint64(stream_id), _stream()), "mm_uniform")
+    return out
+
+
+def debug_dump(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Run mm_forward and return the raw LDS workspace of every env [E, words] (tests only)."""
+    total = model.layout("total")
+    buf = torch.zeros(state.nenv, total, dtype=torch.float32, device=model.device)
+    lib().mm_debug_set_dump(buf.data_ptr())
+    try:
+        forward(model, state, ctrl)
+        torch.cuda.synchronize()
+    finally:
+        lib().mm_debug_set_dump(None)
+    return buf
