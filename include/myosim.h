@@ -109,6 +109,11 @@ typedef struct {
   uint8_t* truncated;       /* [nenv] step_count >= max_episode_steps          */
   int32_t* step_count;      /* [nenv] in/out                                   */
   float* ctrl_out;          /* [nenv][nu] optional: ctrl actually applied      */
+  int   reaf_src, reaf_dst; /* tendon transfer: ctrl[dst]=ctrl[src]; ctrl[src]=0 (base_v0.py:104-108); -1 = off */
+  int   obs_layout;         /* 0: myobase pose  [qpos, qvel*dt, pose_err, act]        (pose_v0.py:17,100-111)
+                               1: MJX pose      [qpos, qvel*timestep, act, pose_err]  (playground_pose_v0.py:119-129) */
+  int   act_reg_mean;       /* 1: act_mag = ||act||/na (pose_v0.py:115-117); 0: ||act|| (playground_pose_v0.py:63) */
+  float obs_dt;             /* scale of the qvel observation: env.dt (pose_v0.py:104) or opt.timestep (MJX) */
 } mm_task;
 
 /* columns of mm_task.rwd for MM_TASK_POSE (pose_v0.py:120-139) */
@@ -140,7 +145,9 @@ int  mm_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const f
  * from Philox4x32-10 keyed by (seed, env, episode counter), then mj_resetData. */
 int  mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* qlo,
                    const float* qhi, const float* tlo, const float* thi, float* target, int32_t* episode,
-                   int32_t* step_count, uint64_t seed, int random_qpos, void* stream);
+                   int32_t* step_count, uint64_t seed, int random_qpos, float* obs, int obs_dim,
+                   int obs_layout, void* stream);
+/* (obs != NULL: the first observation of the new episode is written for the reset envs) */
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

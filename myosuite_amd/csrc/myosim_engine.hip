@@ -1199,9 +1199,15 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
       c = MA;
     }
     W[L.ctrl + u] = c;
-    if (a.mode == 2 && t.ctrl_out && !dup) t.ctrl_out[(size_t)e * d.nu + u] = c;
   }
   GSYNC();
+  if (a.mode == 2 && t.reaf_src >= 0 && t.reaf_dst >= 0 && g == 0) {  // base_v0.py:104-108
+    W[L.ctrl + t.reaf_dst] = W[L.ctrl + t.reaf_src];
+    W[L.ctrl + t.reaf_src] = 0.f;
+  }
+  GSYNC();
+  if (a.mode == 2 && t.ctrl_out && !dup)
+    for (int u = g; u < d.nu; u += G) t.ctrl_out[(size_t)e * d.nu + u] = W[L.ctrl + u];
 
   int nsub = a.mode == 1 ? 0 : t.nsubsteps;
   bool fwd = a.mode == 1 || (a.mode == 2 && t.do_forward);
@@ -1244,25 +1250,27 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
     int sc = 0;
     if (t.step_count) { sc = t.step_count[e] + 1; }
     if (t.task == MM_TASK_POSE) {
-      const float dt = d.timestep * (float)t.nsubsteps;
+      const float dt = t.obs_dt;
+      const int o_err = t.obs_layout == 1 ? d.nq + d.nv + d.na : d.nq + d.nv;
+      const int o_act = t.obs_layout == 1 ? d.nq + d.nv : 2 * d.nq + d.nv;
       float err2 = 0.f, act2 = 0.f;
       float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
       for (int i = g; i < d.nq; i += G) {
         float q = W[L.qpos + i];
         float pe = t.target_jnt_value[(size_t)e * d.nq + i] - q;
         err2 += pe * pe;
-        if (ob) { ob[i] = q; ob[d.nq + d.nv + i] = pe; }
+        if (ob) { ob[i] = q; ob[o_err + i] = pe; }
       }
       for (int i = g; i < d.nv; i += G) if (ob) ob[d.nq + i] = W[L.qvel + i] * dt;
       for (int i = g; i < d.na; i += G) {
         float x = W[L.act + i];
         act2 += x * x;
-        if (ob) ob[2 * d.nq + d.nv + i] = x;
+        if (ob) ob[o_act + i] = x;
       }
       err2 = gsum<G>(err2); act2 = gsum<G>(act2);
       if (g == 0) {
         float pose_dist = sqrtf(err2), act_mag = sqrtf(act2);
-        if (d.na != 0) act_mag = act_mag / (float)d.na;
+        if (d.na != 0 && t.act_reg_mean) act_mag = act_mag / (float)d.na;
         float r_pose = -pose_dist;
         float r_bonus = (pose_dist < t.pose_thd ? 1.f : 0.f) + (pose_dist < 1.5f * t.pose_thd ? 1.f : 0.f);
         float r_pen = pose_dist > t.far_th ? -1.f : 0.f;
@@ -1312,6 +1320,7 @@ struct ResetArgs {
   // pose reset
   const float *qlo, *qhi, *tlo, *thi; float* target; int32_t* episode; int32_t* step_count; uint64_t seed;
   int pose, random_qpos;
+  float* obs; int obs_dim, obs_layout;
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -1332,6 +1341,16 @@ __global__ void k_reset(ResetArgs r) {
       if (r.target) r.target[(size_t)e * r.nq + i] = r.tlo[i] + (r.thi[i] - r.tlo[i]) * ut;
     }
     r.s.qpos[(size_t)e * r.nq + i] = q;
+    if (r.pose && r.obs) {  // first observation of the new episode: qvel = act = 0
+      float* ob = r.obs + (size_t)e * r.obs_dim;
+      ob[i] = q;
+      ob[(r.obs_layout == 1 ? r.nq + r.nv + r.na : r.nq + r.nv) + i] = r.target[(size_t)e * r.nq + i] - q;
+    }
+  }
+  if (r.pose && r.obs) {
+    float* ob = r.obs + (size_t)e * r.obs_dim;
+    for (int i = 0; i < r.nv; i++) ob[r.nq + i] = 0.f;
+    for (int i = 0; i < r.na; i++) ob[(r.obs_layout == 1 ? r.nq + r.nv : 2 * r.nq + r.nv) + i] = 0.f;
   }
   for (int i = 0; i < r.nv; i++) {
     r.s.qvel[(size_t)e * r.nv + i] = r.qvel_src ? r.qvel_src[(size_t)e * r.nv + i] : 0.f;
@@ -1584,7 +1603,8 @@ extern "C" int mm_reset(const mm_model* m, const mm_state* s, const uint8_t* mas
 
 extern "C" int mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* qlo,
                              const float* qhi, const float* tlo, const float* thi, float* target, int32_t* episode,
-                             int32_t* step_count, uint64_t seed, int random_qpos, void* stream) {
+                             int32_t* step_count, uint64_t seed, int random_qpos, float* obs, int obs_dim,
+                             int obs_layout, void* stream) {
   if (!m || !s || !tlo || !thi || !target) return fail(MM_EARG, "mm_pose_reset: bad argument");
   if (random_qpos && (!qlo || !qhi)) return fail(MM_EARG, "mm_pose_reset: random_qpos needs qlo/qhi");
   ResetArgs r; memset(&r, 0, sizeof(r));
@@ -1592,6 +1612,7 @@ extern "C" int mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t
   r.nenv = s->nenv; r.s = *s; r.mask = mask;
   r.qlo = qlo; r.qhi = qhi; r.tlo = tlo; r.thi = thi; r.target = target; r.episode = episode;
   r.step_count = step_count; r.seed = seed; r.pose = 1; r.random_qpos = random_qpos;
+  r.obs = obs; r.obs_dim = obs_dim; r.obs_layout = obs_layout;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;

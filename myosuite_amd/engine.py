@@ -68,7 +68,8 @@ class mm_task(C.Structure):
                 ("fat_MA", C.c_void_p), ("fat_MR", C.c_void_p), ("fat_MF", C.c_void_p),
                 ("fat_F", C.c_float), ("fat_R", C.c_float), ("fat_r", C.c_float),
                 ("obs", C.c_void_p), ("obs_dim", C.c_int), ("rwd", C.c_void_p), ("done", C.c_void_p),
-                ("truncated", C.c_void_p), ("step_count", C.c_void_p), ("ctrl_out", C.c_void_p)]
+                ("truncated", C.c_void_p), ("step_count", C.c_void_p), ("ctrl_out", C.c_void_p),
+                ("reaf_src", C.c_int), ("reaf_dst", C.c_int), ("obs_layout", C.c_int), ("act_reg_mean", C.c_int), ("obs_dt", C.c_float)]
 
 
 def lib():
@@ -91,7 +92,7 @@ def lib():
         L.mm_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mm_pose_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                                    C.c_int, C.c_void_p]
+                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
@@ -220,9 +221,10 @@ def reset(model: HipModel, state: BatchState, mask: Optional[torch.Tensor] = Non
 
 
 def pose_reset(model: HipModel, state: BatchState, mask, qlo, qhi, tlo, thi, target, episode, step_count, seed: int,
-               random_qpos: bool):
+               random_qpos: bool, obs=None, obs_layout: int = 0):
     _chk(lib().mm_pose_reset(model.h, state.c, _ptr(mask), _ptr(qlo), _ptr(qhi), _ptr(tlo), _ptr(thi), _ptr(target),
-                             _ptr(episode), _ptr(step_count), C.c_uint64(seed), int(random_qpos), _stream()),
+                             _ptr(episode), _ptr(step_count), C.c_uint64(seed), int(random_qpos), _ptr(obs),
+                             0 if obs is None else int(obs.shape[1]), int(obs_layout), _stream()),
          "mm_pose_reset")
 
 

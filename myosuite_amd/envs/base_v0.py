@@ -1,0 +1,191 @@
+"""Batched counterpart of the reference's env runtime for musculoskeletal tasks.
+
+Mirrors, for E environments at once and with tensors resident on the GPU:
+  * ``MujocoEnv``   myosuite/envs/env_base.py:33   (step/forward/get_obs/reset, spaces, info dict,
+                                                    get_env_state/set_env_state)
+  * ``BaseV0``      myosuite/envs/myo/base_v0.py:14 (act appended to obs keys, muscle ctrl map,
+                                                    sarcopenia / fatigue / reafferentation)
+  * ``ObsVecDict``  myosuite/envs/obs_vec_dict.py:76-88 (ordered-key concat to float32)
+The per-step arithmetic (ctrl map, fatigue, frame_skip x mj_step, final mj_forward, obs_dict,
+reward_dict) is ONE fused HIP kernel launch (mm_env_step); this class only owns buffers and
+bookkeeping.  API differences from the single-env reference: every returned array has a leading
+[num_envs] dimension and is a torch tensor on the device.
+"""
+from __future__ import annotations
+
+import collections
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .. import engine as E
+from ..model import synth
+from .spaces import Box
+
+_MODEL_CACHE: Dict[tuple, object] = {}
+
+
+def _compiled_model(name: str, muscle_condition: str):
+    """Compiled model, with the sarcopenia edit applied before compilation
+    (base_v0.py:63-67: gainprm[:,2] *= 0.5; biasprm is left untouched)."""
+    key = (name, muscle_condition == "sarcopenia")
+    if key not in _MODEL_CACHE:
+        spec = {"elbow": synth.make_elbow, "hand": synth.make_hand}[name]()
+        if muscle_condition == "sarcopenia":
+            for a in spec.actuators:
+                g = list(a.gainprm)
+                g[2] = 0.5 * g[2]
+                a.gainprm = tuple(g)
+        _MODEL_CACHE[key] = spec.compile()
+    return _MODEL_CACHE[key]
+
+
+class BaseV0:
+    MYO_CREDIT = "MyoSuite: A contact-rich simulation suite for musculoskeletal motor control"
+
+    def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None,
+                 max_episode_steps: int = 0, lanes_per_env: int = 0, autoreset: bool = True):
+        self.env_id = env_id
+        self.model_name = model
+        self.num_envs = int(num_envs)
+        self.max_episode_steps = int(max_episode_steps)
+        self.autoreset = autoreset
+        self.input_seed = seed
+        self._lanes = lanes_per_env
+        self._device = device
+        self.np_random = np.random.default_rng(seed)
+        self.unwrapped = self
+
+    # ------------------------------------------------------------------ setup
+    def _setup(self, obs_keys, weighted_reward_keys, frame_skip=10, normalize_act=True, muscle_condition="",
+               fatigue_reset_vec=None, fatigue_reset_random=False, reward_mode="dense", obs_range=(-10, 10),
+               sites=None, **kwargs):
+        self.muscle_condition = muscle_condition
+        self.cm = _compiled_model(self.model_name, muscle_condition)
+        self.hm = E.HipModel(self.cm, lanes_per_env=self._lanes, device=self._device)
+        self.device = self.hm.device
+        cm = self.cm
+        if cm.na > 0 and "act" not in obs_keys:       # base_v0.py:33-37
+            obs_keys = list(obs_keys) + ["act"]
+        self.obs_keys = list(obs_keys)
+        self.rwd_keys_wt = dict(weighted_reward_keys)
+        self.rwd_mode = reward_mode
+        self.frame_skip = int(frame_skip)
+        self.normalize_act = bool(normalize_act)
+        self.fatigue_reset_vec = fatigue_reset_vec
+        self.fatigue_reset_random = fatigue_reset_random
+        self.tip_sids, self.target_sids = [], []
+        if sites:
+            for s in sites:
+                self.tip_sids.append(cm.site_id(s))
+                self.target_sids.append(cm.site_id(s + "_target"))
+        n = self.num_envs
+        dev = self.device
+        self.state = E.BatchState(self.hm, n)
+        self.step_count = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.episode = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.last_ctrl = torch.zeros(n, cm.nu, dtype=torch.float32, device=dev)
+        # action space (env_base.py:143-155)
+        if self.normalize_act:
+            lo, hi = -np.ones(cm.nu), np.ones(cm.nu)
+        else:
+            cr = cm.arrays["ACT_CTRLRANGE"].reshape(-1, 2)
+            lo, hi = cr[:, 0].copy(), cr[:, 1].copy()
+        self.action_space = Box(lo, hi, dtype=np.float32, seed=self.input_seed)
+        # muscle conditions (base_v0.py:60-79)
+        self.fat_MA = self.fat_MR = self.fat_MF = None
+        self.reaf = (-1, -1)
+        if muscle_condition == "fatigue":
+            f = dict(dtype=torch.float32, device=dev)
+            self.fat_MA = torch.zeros(n, cm.na, **f)
+            self.fat_MR = torch.ones(n, cm.na, **f)
+            self.fat_MF = torch.zeros(n, cm.na, **f)
+            self._fat_rng = np.random.default_rng(seed)
+        elif muscle_condition == "reafferentation":
+            self.reaf = (cm.names["actuator"]["EIP"], cm.names["actuator"]["EPL"])
+        self.init_qpos = cm.qpos0.astype(np.float32).copy()
+        self.init_qvel = np.zeros(cm.nv, np.float32)
+        self.obs_dict: Dict[str, torch.Tensor] = {}
+        self.rwd_dict: Dict[str, torch.Tensor] = {}
+        self._obs_range = obs_range
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def dt(self) -> float:                    # env_base.py:660-662
+        return self.cm.timestep * self.frame_skip
+
+    @property
+    def horizon(self) -> int:
+        return self.max_episode_steps
+
+    @property
+    def id(self) -> str:
+        return self.env_id
+
+    @property
+    def time(self) -> torch.Tensor:
+        return self.state.time
+
+    def seed(self, seed=None):
+        self.input_seed = seed
+        self.np_random = np.random.default_rng(seed)
+        return [seed]
+
+    def get_input_seed(self):
+        return self.input_seed
+
+    # ------------------------------------------------------------------ fatigue (fatigue.py:82-99)
+    def _fatigue_reset(self, mask: Optional[torch.Tensor]):
+        if self.muscle_condition != "fatigue":
+            return
+        n, na = self.num_envs, self.cm.na
+        if self.fatigue_reset_random:
+            assert self.fatigue_reset_vec is None
+            nf = torch.from_numpy(self._fat_rng.random((n, na)).astype(np.float32)).to(self.device)
+            ap = torch.from_numpy(self._fat_rng.random((n, na)).astype(np.float32)).to(self.device)
+            MA, MR, MF = nf * ap, nf * (1 - ap), 1 - nf
+        elif self.fatigue_reset_vec is not None:
+            v = torch.as_tensor(np.asarray(self.fatigue_reset_vec, np.float32), device=self.device).expand(n, na)
+            MA, MR, MF = torch.zeros_like(v), 1 - v, v.clone()
+        else:
+            MA = torch.zeros(n, na, device=self.device); MR = torch.ones_like(MA); MF = torch.zeros_like(MA)
+        if mask is None:
+            self.fat_MA.copy_(MA); self.fat_MR.copy_(MR); self.fat_MF.copy_(MF)
+        else:
+            m = mask.bool()[:, None]
+            self.fat_MA.copy_(torch.where(m, MA, self.fat_MA))
+            self.fat_MR.copy_(torch.where(m, MR, self.fat_MR))
+            self.fat_MF.copy_(torch.where(m, MF, self.fat_MF))
+
+    def set_fatigue_reset_random(self, fatigue_reset_random):
+        self.fatigue_reset_random = fatigue_reset_random
+
+    # ------------------------------------------------------------------ state get/set (env_base.py:688-759)
+    def get_env_state(self) -> dict:
+        s = self.state
+        return dict(time=s.time.clone(), qpos=s.qpos.clone(), qvel=s.qvel.clone(),
+                    act=s.act.clone() if self.cm.na > 0 else None, qacc_warmstart=s.qacc_warmstart.clone(),
+                    step_count=self.step_count.clone())
+
+    def set_env_state(self, state_dict: dict):
+        s = self.state
+        s.time.copy_(state_dict["time"]); s.qpos.copy_(state_dict["qpos"]); s.qvel.copy_(state_dict["qvel"])
+        if self.cm.na > 0 and state_dict.get("act") is not None:
+            s.act.copy_(state_dict["act"])
+        if "qacc_warmstart" in state_dict:
+            s.qacc_warmstart.copy_(state_dict["qacc_warmstart"])
+        if "step_count" in state_dict:
+            self.step_count.copy_(state_dict["step_count"])
+
+    # ------------------------------------------------------------------ info dict (env_base.py:585-616)
+    def get_env_infos(self) -> dict:
+        return collections.OrderedDict(
+            time=self.obs_dict["time"], rwd_dense=self.rwd_dict["dense"], rwd_sparse=self.rwd_dict["sparse"],
+            solved=self.rwd_dict["solved"], done=self.rwd_dict["done"], obs_dict=self.obs_dict, visual_dict={},
+            proprio_dict={}, rwd_dict=self.rwd_dict, state=None)
+
+    def close(self):
+        pass

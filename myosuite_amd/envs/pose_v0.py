@@ -1,0 +1,194 @@
+"""Batched PoseEnvV0 -- host-side mirror of myosuite/envs/myo/myobase/pose_v0.py:15-257.
+
+Same constructor kwargs, obs keys (``qpos, qvel, pose_err`` + ``act``), reward keys and
+weights, reset/target types.  One ``step()`` = one fused HIP launch (mm_env_step) for all
+``num_envs`` environments (+ one masked reset launch when auto-reset is on).
+"""
+from __future__ import annotations
+
+import collections
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import engine as E
+from .base_v0 import BaseV0
+from .spaces import Box
+
+
+class PoseEnvV0(BaseV0):
+    DEFAULT_OBS_KEYS = ["qpos", "qvel", "pose_err"]                        # pose_v0.py:17
+    DEFAULT_RWD_KEYS_AND_WEIGHTS = {"pose": 1.0, "bonus": 4.0, "act_reg": 1.0, "penalty": 50}   # pose_v0.py:18-23
+
+    def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=100,
+                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+        self._setup(**kwargs)
+
+    def _setup(self, viz_site_targets: tuple = None, target_jnt_range: dict = None, target_jnt_value=None,
+               reset_type="init", target_type="generate", obs_keys=DEFAULT_OBS_KEYS,
+               weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS, pose_thd=0.35, weight_bodyname=None,
+               weight_range=None, do_forward: bool = True, **kwargs):
+        self.reset_type = reset_type
+        self.target_type = target_type
+        self.pose_thd = float(pose_thd)
+        if weight_bodyname is not None:
+            raise NotImplementedError("weight randomisation (Exo variant, pose_v0.py:177-187) is not built yet")
+        super()._setup(obs_keys=list(obs_keys), weighted_reward_keys=weighted_reward_keys, sites=viz_site_targets,
+                       **kwargs)
+        cm, n, dev = self.cm, self.num_envs, self.device
+        f = dict(dtype=torch.float32, device=dev)
+        # resolve joint demands (pose_v0.py:63-75)
+        if target_jnt_range:
+            ids = [cm.joint_id(j) for j in target_jnt_range]
+            assert ids == list(range(cm.nq)), "target_jnt_range must list every joint in qpos order"
+            self.target_jnt_range = np.array([target_jnt_range[j] for j in target_jnt_range], np.float32)
+            tv = np.mean(self.target_jnt_range, axis=1)
+        else:
+            self.target_jnt_range = None
+            tv = np.asarray(target_jnt_value, np.float32)
+            assert tv.shape == (cm.nq,)
+        self.target_jnt_value = torch.from_numpy(np.tile(tv.astype(np.float32), (n, 1))).to(dev).contiguous()
+        trange = self.target_jnt_range if self.target_jnt_range is not None else np.stack([tv, tv], 1)
+        if self.target_type == "fixed":
+            trange = np.stack([tv, tv], 1) if self.target_jnt_range is None else self.target_jnt_range
+        self._tlo = torch.from_numpy(np.ascontiguousarray(trange[:, 0], np.float32)).to(dev)
+        self._thi = torch.from_numpy(np.ascontiguousarray(trange[:, 1], np.float32)).to(dev)
+        jr = cm.jnt_range.astype(np.float32)
+        self._qlo = torch.from_numpy(np.ascontiguousarray(jr[:, 0])).to(dev)
+        self._qhi = torch.from_numpy(np.ascontiguousarray(jr[:, 1])).to(dev)
+        # outputs
+        self.obs_dim = cm.nq + cm.nv + cm.nq + cm.na
+        self.obs = torch.zeros(n, self.obs_dim, **f)
+        self.rwd = torch.zeros(n, len(E.RWD_KEYS_POSE), **f)
+        self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
+                                     dtype=np.float32)
+        w = self.rwd_keys_wt
+        t = E.mm_task()
+        t.task = E.MM_TASK_POSE; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
+        t.do_forward = int(do_forward); t.fatigue = int(self.muscle_condition == "fatigue")
+        t.max_episode_steps = self.max_episode_steps
+        t.pose_thd = self.pose_thd; t.far_th = 4 * math.pi / 2
+        t.w_pose = float(w.get("pose", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
+        t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
+        t.target_jnt_value = self.target_jnt_value.data_ptr()
+        if self.fat_MA is not None:
+            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
+        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15          # fatigue.py:9-11
+        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
+        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
+        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
+        t.reaf_src, t.reaf_dst = self.reaf
+        t.obs_layout = 0; t.act_reg_mean = 1; t.obs_dt = self.dt
+        self._task = t
+        self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
+        self.reset()
+
+    # ------------------------------------------------------------------ obs / reward dicts
+    def _refresh_dicts(self):
+        cm = self.cm
+        nq, nv, na = cm.nq, cm.nv, cm.na
+        o = self.obs
+        self.obs_dict = collections.OrderedDict(
+            time=self.state.time, qpos=o[:, :nq], qvel=o[:, nq:nq + nv], pose_err=o[:, nq + nv:2 * nq + nv],
+            act=o[:, 2 * nq + nv:2 * nq + nv + na])
+        r = self.rwd
+        self.rwd_dict = collections.OrderedDict((k, r[:, i]) for i, k in enumerate(E.RWD_KEYS_POSE))
+        self.rwd_dict["solved"] = self.rwd_dict["solved"] > 0.5
+        self.rwd_dict["done"] = self.rwd_dict["done"] > 0.5
+
+    def get_obs_dict(self, state=None):
+        """pose_v0.py:100-111 on the current (or given) batched state, as torch ops."""
+        s = state if state is not None else self.state
+        d = collections.OrderedDict()
+        d["time"] = s.time
+        d["qpos"] = s.qpos.clone()
+        d["qvel"] = s.qvel * self.dt
+        d["act"] = s.act.clone() if self.cm.na > 0 else torch.zeros_like(s.qpos)
+        d["pose_err"] = self.target_jnt_value - d["qpos"]
+        return d
+
+    def get_reward_dict(self, obs_dict):
+        """pose_v0.py:113-140 (vectorised over the leading env dimension)."""
+        pose_dist = torch.linalg.norm(obs_dict["pose_err"], dim=-1)
+        act_mag = torch.linalg.norm(obs_dict["act"], dim=-1)
+        if self.cm.na != 0:
+            act_mag = act_mag / self.cm.na
+        far_th = 4 * math.pi / 2
+        rwd = collections.OrderedDict((
+            ("pose", -1.0 * pose_dist),
+            ("bonus", 1.0 * (pose_dist < self.pose_thd) + 1.0 * (pose_dist < 1.5 * self.pose_thd)),
+            ("penalty", -1.0 * (pose_dist > far_th)),
+            ("act_reg", -1.0 * act_mag),
+            ("sparse", -1.0 * pose_dist),
+            ("solved", pose_dist < self.pose_thd),
+            ("done", pose_dist > far_th)))
+        rwd["dense"] = sum(wt * rwd[k] for k, wt in self.rwd_keys_wt.items())
+        return rwd
+
+    def get_obs(self):
+        """Observation vector of the current state without stepping (mm_forward-free: Pose needs none)."""
+        d = self.get_obs_dict()
+        return torch.cat([d[k].reshape(self.num_envs, -1) for k in self.obs_keys], dim=1).to(torch.float32)
+
+    # ------------------------------------------------------------------ reset (pose_v0.py:174-257)
+    def reset(self, seed=None, mask: Optional[torch.Tensor] = None, reset_qpos=None, reset_qvel=None, **kwargs):
+        if seed is not None:
+            self.seed(seed)
+            self._seed_u64 = int(seed)
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
+        self._fatigue_reset(mask)
+        if self.reset_type in (None, "none"):
+            # no state reset; only targets (and counters) are refreshed
+            keep = self.get_env_state()
+        generate = self.target_type == "generate"
+        random_q = self.reset_type == "random" and reset_qpos is None
+        # targets ~ U(target range) and (optionally) qpos ~ U(joint range): Philox keyed by (seed, env, episode)
+        E.pose_reset(self.hm, self.state, mask, self._qlo, self._qhi,
+                     self._tlo if generate else self.target_jnt_value[0].contiguous(),
+                     self._thi if generate else self.target_jnt_value[0].contiguous(),
+                     self.target_jnt_value, self.episode, self.step_count, self._seed_u64, random_q,
+                     obs=self.obs, obs_layout=0)
+        simple = reset_qpos is None and self.reset_type not in (None, "none")
+        if reset_qpos is not None:
+            q = torch.as_tensor(reset_qpos, dtype=torch.float32, device=self.device).expand(self.num_envs, -1).contiguous()
+            v = None if reset_qvel is None else torch.as_tensor(reset_qvel, dtype=torch.float32, device=self.device).expand(self.num_envs, -1).contiguous()
+            E.reset(self.hm, self.state, mask, q, v)
+        if self.reset_type in (None, "none"):
+            m = None if mask is None else mask.bool()
+            for k in ("time", "qpos", "qvel", "act", "qacc_warmstart"):
+                if keep[k] is None:
+                    continue
+                dst = getattr(self.state, k)
+                dst.copy_(keep[k] if m is None else torch.where(m.view(-1, *([1] * (dst.dim() - 1))), keep[k], dst))
+        if not simple:   # state was overwritten after the kernel wrote its observation
+            self.obs.copy_(self.get_obs()) if mask is None else self.obs.copy_(
+                torch.where(mask.bool()[:, None], self.get_obs(), self.obs))
+        self._refresh_dicts()
+        return self.obs, {}
+
+    # ------------------------------------------------------------------ step (base_v0.py:82-118 + env_base.py:403-432)
+    def step(self, a, **kwargs):
+        a = torch.as_tensor(a, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.expand(self.num_envs, -1)
+        a = a.contiguous()
+        E.env_step(self.hm, self.state, a, self._task)
+        self._refresh_dicts()
+        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
+        terminated = self.done.bool()
+        truncated = self.truncated.bool() & ~terminated
+        info = self.get_env_infos()
+        obs = self.obs
+        if self.autoreset:
+            need = (self.done | self.truncated)
+            info["final_obs"] = None
+            # masked reset is always enqueued (no host sync); it is a no-op for envs that continue
+            final_obs = obs.clone()
+            self.reset(mask=need)
+            info["final_obs"] = final_obs
+            obs = self.obs
+        return obs, reward, terminated, truncated, info

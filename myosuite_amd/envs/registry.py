@@ -1,0 +1,117 @@
+"""Env-id registry mirroring ``myosuite/envs/myo/myobase/__init__.py``.
+
+Same ids, same kwargs (targets, thresholds, reset/target types, horizons) and the
+same muscle-condition variants (``myoSarc*``, ``myoFati*``, ``myoReaf*``;
+myobase/__init__.py:17-49).  ``model_path`` is replaced by the name of a
+synthetic model (the real MJCF is an empty submodule in the reference).
+
+    env = make("myoHandPoseRandom-v0", num_envs=4096)     # batched, tensors on the GPU
+"""
+from __future__ import annotations
+
+import copy
+from typing import Callable, Dict
+
+import numpy as np
+
+_SPECS: Dict[str, dict] = {}
+
+
+def register(id: str, entry_point: Callable, max_episode_steps: int, kwargs: dict):
+    _SPECS[id] = dict(id=id, entry_point=entry_point, max_episode_steps=max_episode_steps, kwargs=kwargs)
+
+
+def register_env_variant(env_id: str, variants: dict, variant_id: str):
+    """Deep-merge `variants` into a registered env's kwargs (env_variants.py:91-129)."""
+    assert env_id in _SPECS, f"ERROR: {env_id} not found in env registry"
+    spec = copy.deepcopy(_SPECS[env_id])
+    variants = dict(variants)
+    if "max_episode_steps" in variants:
+        spec["max_episode_steps"] = variants.pop("max_episode_steps")
+
+    def merge(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                merge(dst[k], v)
+            else:
+                dst[k] = v
+    merge(spec["kwargs"], variants)
+    spec["id"] = variant_id
+    _SPECS[variant_id] = spec
+    return variant_id
+
+
+def register_env_with_variants(id, entry_point, max_episode_steps, kwargs):
+    register(id, entry_point, max_episode_steps, kwargs)
+    if id[:3] == "myo":
+        register_env_variant(id, {"muscle_condition": "sarcopenia"}, id[:3] + "Sarc" + id[3:])
+        register_env_variant(id, {"muscle_condition": "fatigue"}, id[:3] + "Fati" + id[3:])
+    if id[:7] == "myoHand":
+        register_env_variant(id, {"muscle_condition": "reafferentation"}, id[:3] + "Reaf" + id[3:])
+
+
+def registry_specs():
+    return _SPECS
+
+
+def spec(id: str) -> dict:
+    return _SPECS[id]
+
+
+def make(id: str, num_envs: int = 1, device=None, seed=None, **overrides):
+    """gym.make() equivalent returning a batched env (see envs/pose_v0.py)."""
+    if id not in _SPECS:
+        raise KeyError(f"unknown env id {id!r}; known: {sorted(_SPECS)[:8]} ...")
+    s = _SPECS[id]
+    kw = copy.deepcopy(s["kwargs"])
+    kw.update(overrides)
+    return s["entry_point"](env_id=id, num_envs=num_envs, device=device, seed=seed,
+                            max_episode_steps=s["max_episode_steps"], **kw)
+
+
+# ------------------------------------------------------------------ registrations
+def _pose(**kw):
+    from .pose_v0 import PoseEnvV0
+    return PoseEnvV0(**kw)
+
+
+# Elbow posing (myobase/__init__.py:108-138)
+register_env_with_variants(
+    id="myoElbowPose1D6MFixed-v0", entry_point=_pose, max_episode_steps=100,
+    kwargs={"model": "elbow", "target_jnt_range": {"r_elbow_flex": (2, 2)}, "viz_site_targets": ("wrist",),
+            "normalize_act": True, "pose_thd": 0.175, "reset_type": "random"})
+register_env_with_variants(
+    id="myoElbowPose1D6MRandom-v0", entry_point=_pose, max_episode_steps=100,
+    kwargs={"model": "elbow", "target_jnt_range": {"r_elbow_flex": (0, 2.27)}, "viz_site_targets": ("wrist",),
+            "normalize_act": True, "pose_thd": 0.175, "reset_type": "random"})
+
+# Hand ASL posing (myobase/__init__.py:300-415)
+jnt_namesHand = ["pro_sup", "deviation", "flexion", "cmc_abduction", "cmc_flexion", "mp_flexion", "ip_flexion",
+                 "mcp2_flexion", "mcp2_abduction", "pm2_flexion", "md2_flexion", "mcp3_flexion", "mcp3_abduction",
+                 "pm3_flexion", "md3_flexion", "mcp4_flexion", "mcp4_abduction", "pm4_flexion", "md4_flexion",
+                 "mcp5_flexion", "mcp5_abduction", "pm5_flexion", "md5_flexion"]
+ASL_qpos = {
+    0: "0 0 0 0.5624 0.28272 -0.75573 -1.309 1.30045 -0.006982 1.45492 0.998897 1.26466 0 1.40604 0.227795 1.07614 -0.020944 1.46103 0.06284 0.83263 -0.14399 1.571 1.38248",
+    1: "0 0 0 0.0248 0.04536 -0.7854 -1.309 0.366605 0.010473 0.269258 0.111722 1.48459 0 1.45318 1.44532 1.44532 -0.204204 1.46103 1.44532 1.48459 -0.2618 1.47674 1.48459",
+    2: "0 0 0 0.0248 0.04536 -0.7854 -1.13447 0.514973 0.010473 0.128305 0.111722 0.510575 0 0.37704 0.117825 1.44532 -0.204204 1.46103 1.44532 1.48459 -0.2618 1.47674 1.48459",
+    3: "0 0 0 0.3384 0.25305 0.01569 -0.0262045 0.645885 0.010473 0.128305 0.111722 0.510575 0 0.37704 0.117825 1.571 -0.036652 1.52387 1.45318 1.40604 -0.068068 1.39033 1.571",
+    4: "0 0 0 0.6392 -0.147495 -0.7854 -1.309 0.637158 0.010473 0.128305 0.111722 0.510575 0 0.37704 0.117825 0.306345 -0.010472 0.400605 0.133535 0.21994 -0.068068 0.274925 0.01571",
+    5: "0 0 0 0.3384 0.25305 0.01569 -0.0262045 0.645885 0.010473 0.128305 0.111722 0.510575 0 0.37704 0.117825 0.306345 -0.010472 0.400605 0.133535 0.21994 -0.068068 0.274925 0.01571",
+    6: "0 0 0 0.6392 -0.147495 -0.7854 -1.309 0.637158 0.010473 0.128305 0.111722 0.510575 0 0.37704 0.117825 0.306345 -0.010472 0.400605 0.133535 1.1861 -0.2618 1.35891 1.48459",
+    7: "0 0 0 0.524 0.01569 -0.7854 -1.309 0.645885 -0.006982 0.128305 0.111722 0.510575 0 0.37704 0.117825 1.28036 -0.115192 1.52387 1.45318 0.432025 -0.068068 0.18852 0.149245",
+    8: "0 0 0 0.428 0.22338 -0.7854 -1.309 0.645885 -0.006982 0.128305 0.194636 1.39033 0 1.08399 0.573415 0.667675 -0.020944 0 0.06284 0.432025 -0.068068 0.18852 0.149245",
+    9: "0 0 0 0.5624 0.28272 -0.75573 -1.309 1.30045 -0.006982 1.45492 0.998897 0.39275 0 0.18852 0.227795 0.667675 -0.020944 0 0.06284 0.432025 -0.068068 0.18852 0.149245",
+}
+ASL_qpos = {k: np.array(v.split(" "), "float") for k, v in ASL_qpos.items()}
+_HAND_SITES = ("THtip", "IFtip", "MFtip", "RFtip", "LFtip")
+for k in ASL_qpos:
+    register_env_with_variants(
+        id="myoHandPose" + str(k) + "Fixed-v0", entry_point=_pose, max_episode_steps=100,
+        kwargs={"model": "hand", "viz_site_targets": _HAND_SITES, "target_jnt_value": ASL_qpos[k],
+                "normalize_act": True, "pose_thd": 0.7, "reset_type": "init", "target_type": "fixed"})
+_m = np.array([ASL_qpos[i] for i in range(10)]).astype(float)
+Rpos = {n: (float(np.min(_m[:, i])), float(np.max(_m[:, i]))) for i, n in enumerate(jnt_namesHand)}
+register_env_with_variants(
+    id="myoHandPoseRandom-v0", entry_point=_pose, max_episode_steps=100,
+    kwargs={"model": "hand", "viz_site_targets": _HAND_SITES, "target_jnt_range": Rpos, "normalize_act": True,
+            "pose_thd": 0.7, "reset_type": "random", "target_type": "generate"})

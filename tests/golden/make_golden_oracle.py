@@ -1,0 +1,42 @@
+"""Golden trajectories of OUR fp64 oracle on the synthetic models (regression pins; the reference
+itself holds no mj_step golden vectors).  Run:  python tests/golden/make_golden_oracle.py
+Inputs are fully determined by Philox streams: qpos0 ~ pose_reset_draws(env, episode 0, seed 0),
+actions = uniform_stream(seed 0, stream_id = env-step index)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from myosuite_amd.model import synth
+from oracle import oracle as O
+from oracle import env_oracle as EO
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+NENV, NSTEPS, NSUB = 8, 30, 10
+
+
+def rollout(name):
+    cm = synth.get_model(name)
+    om = O.OracleModel(cm)
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    qpos = np.zeros((NSTEPS + 1, NENV, cm.nq)); qvel = np.zeros((NSTEPS + 1, NENV, cm.nv)); act = np.zeros((NSTEPS + 1, NENV, cm.na))
+    ds = []
+    for e in range(NENV):
+        uq, _ = EO.pose_reset_draws(cm.nq, e, 0, 0)
+        d = O.OracleData(om)
+        d.qpos[:] = (lo + (hi - lo) * uq).astype(np.float32)
+        ds.append(d)
+        qpos[0, e] = d.qpos
+    for s in range(NSTEPS):
+        a = EO.uniform_stream(NENV * cm.nu, 0, s).reshape(NENV, cm.nu)
+        ctrl = (1.0 / (1.0 + np.exp(-5.0 * (a.astype(np.float64) - 0.5)))).astype(np.float32)
+        for e, d in enumerate(ds):
+            d.ctrl[:] = ctrl[e]
+            d.step(NSUB)
+            qpos[s + 1, e] = d.qpos; qvel[s + 1, e] = d.qvel; act[s + 1, e] = d.act
+    return dict(qpos=qpos, qvel=qvel, act=act, model_hash=np.array(cm.hash()))
+
+
+if __name__ == "__main__":
+    for name in ("elbow", "hand"):
+        r = rollout(name)
+        np.savez_compressed(os.path.join(OUT, f"oracle_traj_{name}.npz"), **r)
+        print(name, r["model_hash"], float(np.abs(r["qpos"][-1]).max()))

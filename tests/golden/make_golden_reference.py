@@ -1,0 +1,143 @@
+"""Generate golden vectors by EXECUTING the reference's own Python (importable parts only).
+
+Run in the authoring container (needs /root/reference; the GPU box does not have it):
+    python tests/golden/make_golden_reference.py
+Writes tests/golden/ref_*.npz, which are committed.
+
+What can be executed from /root/reference without `mujoco`/`gym` (both absent here):
+  * myosuite/envs/myo/fatigue.py            CumulativeFatigue (3CC-r)        -> ref_fatigue.npz
+  * myosuite/envs/myo/myobase/pose_v0.py    get_obs_dict / get_reward_dict    -> ref_pose_env.npz
+  * myosuite/envs/obs_vec_dict.py           obsdict2obsvec                    -> ref_pose_env.npz
+  * myosuite/utils/quat_math.py, vector_math.py                               -> ref_math.npz
+`mujoco` and `myosuite.utils.gym` are replaced by stubs that only provide the names those files
+touch at import time (mjtDyn.mjDYN_MUSCLE, gym.utils.seeding.np_random, EzPickle); no arithmetic
+is stubbed.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference/myosuite"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path, stubs):
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    try:
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def _stubs():
+    mj = types.ModuleType("mujoco")
+    mj.mjtDyn = types.SimpleNamespace(mjDYN_MUSCLE=4)
+    gym = types.SimpleNamespace(
+        utils=types.SimpleNamespace(
+            seeding=types.SimpleNamespace(np_random=lambda seed=None: (np.random.default_rng(seed), seed)),
+            EzPickle=type("EzPickle", (), {"__init__": lambda self, *a, **k: None})))
+    utils = types.ModuleType("myosuite.utils")
+    utils.gym = gym
+    pkg = types.ModuleType("myosuite")
+    base = types.ModuleType("myosuite.envs.myo.base_v0")
+    base.BaseV0 = object
+    return {"mujoco": mj, "myosuite": pkg, "myosuite.utils": utils, "myosuite.envs": types.ModuleType("myosuite.envs"),
+            "myosuite.envs.myo": types.ModuleType("myosuite.envs.myo"), "myosuite.envs.myo.base_v0": base}
+
+
+def gen_fatigue():
+    fat = _load("ref_fatigue", f"{REF}/envs/myo/fatigue.py", _stubs())
+    out = {}
+    # (a) the reference's own test sequence (tests/mjx/test_fatigue.py:173-214): 5 muscles, frame_skip 5.
+    #     myofinger's tau values live in the missing XML; MuJoCo muscle defaults (0.01, 0.04) are used.
+    for tag, na, fs, tau in (("seq5", 5, 5, (0.01, 0.04)), ("rand39", 39, 10, (0.01, 0.04))):
+        model = types.SimpleNamespace(
+            opt=types.SimpleNamespace(timestep=0.002),
+            actuator_dyntype=np.full(na, 4), actuator_dynprm=np.tile(np.array([tau[0], tau[1], 0.0]), (na, 1)))
+        f = fat.CumulativeFatigue(model, frame_skip=fs, seed=0)
+        if tag == "seq5":
+            acts = [np.zeros(5), np.ones(5), np.array([0.3, 0.5, 0.7, 0.2, 0.8]), np.array([0.5] * 5)]
+        else:
+            rng = np.random.default_rng(7)
+            acts = [rng.random(na) for _ in range(200)]
+        MA, MR, MF = [], [], []
+        for a in acts:
+            ma, mr, mf = f.compute_act(np.asarray(a, dtype=np.float64))
+            MA.append(ma.copy()); MR.append(mr.copy()); MF.append(mf.copy())
+        out[f"{tag}_acts"] = np.array(acts); out[f"{tag}_MA"] = np.array(MA)
+        out[f"{tag}_MR"] = np.array(MR); out[f"{tag}_MF"] = np.array(MF)
+        out[f"{tag}_dt"] = np.array(0.002 * fs); out[f"{tag}_tau"] = np.array(tau)
+    np.savez(os.path.join(OUT, "ref_fatigue.npz"), **out)
+
+
+def gen_pose_env():
+    pose = _load("ref_pose_v0", f"{REF}/envs/myo/myobase/pose_v0.py", _stubs())
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(11)
+    out = {}
+    for tag, nq, na, thd in (("elbow", 1, 6, 0.175), ("hand", 23, 39, 0.7)):
+        n = 64
+        qpos = rng.uniform(-1.5, 2.5, (n, nq)); qvel = rng.standard_normal((n, nq)) * 3
+        act = rng.random((n, na)); target = rng.uniform(-1.0, 2.0, (n, nq))
+        if tag == "elbow":          # include far / solved cases
+            target[:8] = qpos[:8] + 7.0; target[8:16] = qpos[8:16] + 0.1
+        else:
+            target[:8] = qpos[:8] + 2.0; target[8:16] = qpos[8:16] + 0.05
+        dt = 0.02
+        obs, rwd = [], {k: [] for k in ("pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense")}
+        for i in range(n):
+            self = types.SimpleNamespace(dt=dt, target_jnt_value=target[i], pose_thd=thd,
+                                         mj_model=types.SimpleNamespace(na=na),
+                                         rwd_keys_wt=pose.PoseEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS)
+            data = types.SimpleNamespace(time=0.02 * i, qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy())
+            od = pose.PoseEnvV0.get_obs_dict(self, self.mj_model, data)
+            self.obs_dict = od
+            ov = ovd.ObsVecDict()
+            _, vec = ov.obsdict2obsvec(od, ["qpos", "qvel", "pose_err", "act"])     # key order: pose_v0.py:17 + base_v0.py:33-37
+            # the reference expands dims to (1,1,d) before the reward (env_base.py:423-426)
+            od3 = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+            self.obs_dict = od3
+            rd = pose.PoseEnvV0.get_reward_dict(self, od3)
+            obs.append(vec)
+            for k in rwd:
+                rwd[k].append(np.squeeze(rd[k]))
+        out[f"{tag}_qpos"] = qpos; out[f"{tag}_qvel"] = qvel; out[f"{tag}_act"] = act; out[f"{tag}_target"] = target
+        out[f"{tag}_obs"] = np.array(obs)
+        for k in rwd:
+            out[f"{tag}_rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+        out[f"{tag}_pose_thd"] = np.array(thd); out[f"{tag}_dt"] = np.array(dt)
+    np.savez(os.path.join(OUT, "ref_pose_env.npz"), **out)
+
+
+def gen_math():
+    qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
+    vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
+    rng = np.random.default_rng(3)
+    eul = rng.uniform(-1.2, 1.2, (32, 3))
+    quat = np.array([qm.euler2quat(e) for e in eul])
+    mat = np.array([qm.quat2mat(q) for q in quat])
+    v1 = rng.standard_normal((32, 3)); v2 = rng.standard_normal((32, 3))
+    cosv = vm.calculate_cosine(v1, v2)
+    qa = rng.standard_normal((32, 4)); qa /= np.linalg.norm(qa, axis=1, keepdims=True)
+    qb = rng.standard_normal((32, 4)); qb /= np.linalg.norm(qb, axis=1, keepdims=True)
+    mul = np.array([qm.mulQuat(a, b) for a, b in zip(qa, qb)])
+    np.savez(os.path.join(OUT, "ref_math.npz"), euler=eul, euler2quat=quat, quat2mat=mat, v1=v1, v2=v2,
+             cosine=cosv, qa=qa, qb=qb, mulQuat=mul)
+
+
+if __name__ == "__main__":
+    gen_fatigue()
+    gen_pose_env()
+    gen_math()
+    print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))

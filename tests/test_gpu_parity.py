@@ -1,0 +1,275 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI) against the fp64 oracle, the committed
+golden fixtures, and size-independent properties at BASELINE.json's full batch size.
+
+Tolerances (fp32 GPU vs fp64 oracle; north_star asks <1e-4 rel over 1000 steps for the smooth configs):
+  * single forward pass, every pipeline stage ....... 2e-4 relative to the stage's max magnitude
+  * teacher-forced one env-step (10 substeps) ....... 5e-5 abs on qpos, 5e-3 abs on qvel
+  * free-running rollouts ........................... see test bodies (limit-contact switching grows error)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from myosuite_amd import engine as E
+from myosuite_amd.envs import registry
+from myosuite_amd.model import synth
+from oracle import env_oracle as EO
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-9, np.abs(b).max())) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a HIP device")
+    return {n: E.HipModel(synth.get_model(n)) for n in ("elbow", "hand")}
+
+
+def test_uniform_matches_philox_oracle():
+    out = torch.empty(1003, device="cuda")
+    E.uniform(out, seed=1234567890123, stream_id=77)
+    np.testing.assert_array_equal(out.cpu().numpy(), EO.uniform_stream(1003, 1234567890123, 77))
+    assert 0 <= float(out.min()) and float(out.max()) < 1
+
+
+@pytest.mark.parametrize("name", ["elbow", "hand"])
+@pytest.mark.parametrize("lanes", [0, 8, 64])
+def test_forward_stages_match_oracle(hip, models, oracle_lib, name, lanes):
+    cm = models[name]
+    hm = E.HipModel(cm, lanes_per_env=lanes) if lanes else hip[name]
+    om = O.OracleModel(cm)
+    nenv = 19
+    rng = np.random.default_rng(0)
+    lo, hi = cm.jnt_range[:, 0].astype(np.float64), cm.jnt_range[:, 1].astype(np.float64)
+    qpos = ((lo - 0.05 * (hi - lo)) + 1.1 * (hi - lo) * rng.random((nenv, cm.nq))).astype(np.float32)
+    qvel = (rng.standard_normal((nenv, cm.nv)) * 2).astype(np.float32)
+    act = rng.random((nenv, cm.na)).astype(np.float32); ctrl = rng.random((nenv, cm.nu)).astype(np.float32)
+    st = E.BatchState(hm, nenv)
+    st.qpos.copy_(torch.from_numpy(qpos)); st.qvel.copy_(torch.from_numpy(qvel)); st.act.copy_(torch.from_numpy(act))
+    dump = E.debug_dump(hm, st, torch.from_numpy(ctrl).cuda()).cpu().numpy()
+    omap = {"tenlen": "ten_length", "tenvel": "ten_velocity", "actfrc": "actuator_force", "actdot": "act_dot",
+            "dinv": "qLDiagInv", "bias": "qfrc_bias", "smooth": "qfrc_smooth", "qaccsm": "qacc_smooth",
+            "cdofdot": "cdof_dot", "qM": "qM", "qLD": "qLD"}
+    names = ["xpos", "xquat", "xipos", "xanchor", "xaxis", "cdof", "cdofdot", "cvel", "tenlen", "tenvel", "actfrc",
+             "actdot", "qM", "qLD", "dinv", "bias", "smooth", "qaccsm", "qacc"]
+    for e in range(nenv):
+        d = O.OracleData(om)
+        d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.act[:] = act[e]; d.ctrl[:] = ctrl[e]
+        d.forward()
+        for n in names:
+            ref = getattr(d, omap.get(n, n)).ravel()
+            got = dump[e, hm.layout(n):hm.layout(n) + ref.size]
+            assert _rel(got, ref) < 2e-4, (n, e, _rel(got, ref))
+        # constraint force: compare in units of the smooth force scale
+        got = dump[e, hm.layout("qfrccon"):hm.layout("qfrccon") + cm.nv]
+        assert np.abs(got - d.qfrc_constraint).max() < 2e-4 * max(1.0, np.abs(d.qfrc_smooth).max())
+
+
+@pytest.mark.parametrize("name", ["elbow", "hand"])
+def test_teacher_forced_env_step(hip, models, oracle_lib, name):
+    """One env-step (10 substeps) from identical states: the per-step error the free-running error grows from."""
+    cm = models[name]; hm = hip[name]
+    om = O.OracleModel(cm)
+    g = np.load(os.path.join(G, f"oracle_traj_{name}.npz"))
+    nsteps, nenv = g["qpos"].shape[0] - 1, g["qpos"].shape[1]
+    worst_q = worst_v = 0.0
+    for s in range(0, nsteps, 3):
+        st = E.BatchState(hm, nenv)
+        st.qpos.copy_(torch.from_numpy(g["qpos"][s].astype(np.float32)))
+        st.qvel.copy_(torch.from_numpy(g["qvel"][s].astype(np.float32)))
+        st.act.copy_(torch.from_numpy(g["act"][s].astype(np.float32)))
+        a = EO.uniform_stream(nenv * cm.nu, 0, s).reshape(nenv, cm.nu)
+        ctrl = (1.0 / (1.0 + np.exp(-5.0 * (a.astype(np.float64) - 0.5)))).astype(np.float32)
+        E.step(hm, st, torch.from_numpy(ctrl).cuda(), 10)
+        # oracle from the same float32-rounded state (warm start zero on both sides)
+        for e in range(nenv):
+            d = O.OracleData(om)
+            d.qpos[:] = g["qpos"][s, e].astype(np.float32); d.qvel[:] = g["qvel"][s, e].astype(np.float32)
+            d.act[:] = g["act"][s, e].astype(np.float32); d.ctrl[:] = ctrl[e]
+            d.step(10)
+            worst_q = max(worst_q, np.abs(st.qpos[e].cpu().numpy() - d.qpos).max())
+            worst_v = max(worst_v, np.abs(st.qvel[e].cpu().numpy() - d.qvel).max())
+    assert worst_q < 5e-5 and worst_v < 5e-3, (worst_q, worst_v)
+
+
+@pytest.mark.parametrize("name,tol", [("elbow", 2e-5), ("hand", 1e-3)])
+def test_free_running_rollout_vs_golden(hip, models, name, tol):
+    """30 env-steps free running against the committed oracle trajectory (same Philox action stream)."""
+    cm = models[name]; hm = hip[name]
+    g = np.load(os.path.join(G, f"oracle_traj_{name}.npz"))
+    assert str(g["model_hash"]) == cm.hash()
+    nsteps, nenv = g["qpos"].shape[0] - 1, g["qpos"].shape[1]
+    st = E.BatchState(hm, nenv)
+    st.qpos.copy_(torch.from_numpy(g["qpos"][0].astype(np.float32)))
+    a = torch.empty(nenv, cm.nu, device="cuda")
+    errs = []
+    for s in range(nsteps):
+        E.uniform(a, 0, s)
+        ctrl = 1.0 / (1.0 + torch.exp(-5.0 * (a - 0.5)))
+        E.step(hm, st, ctrl.contiguous(), 10)
+        errs.append(np.abs(st.qpos.cpu().numpy() - g["qpos"][s + 1]).max() / max(1.0, np.abs(g["qpos"][s + 1]).max()))
+    assert max(errs) < tol, errs
+    assert int(st.status.max()) == 0
+
+
+@pytest.mark.parametrize("tag,model,thd", [("elbow", "elbow", 0.175), ("hand", "hand", 0.7)])
+def test_obs_reward_stage_matches_reference_golden(hip, models, tag, model, thd):
+    """GPU obs_dict/reward_dict stage (nsubsteps=0) on the vectors produced by the reference's own
+    get_obs_dict / get_reward_dict / obsdict2obsvec (tests/golden/ref_pose_env.npz)."""
+    g = np.load(os.path.join(G, "ref_pose_env.npz"))
+    n = g[f"{tag}_qpos"].shape[0]
+    env = registry.make("myoElbowPose1D6MRandom-v0" if tag == "elbow" else "myoHandPoseRandom-v0", num_envs=n, autoreset=False)
+    env.state.qpos.copy_(torch.from_numpy(g[f"{tag}_qpos"].astype(np.float32)))
+    env.state.qvel.copy_(torch.from_numpy(g[f"{tag}_qvel"].astype(np.float32)))
+    env.state.act.copy_(torch.from_numpy(g[f"{tag}_act"].astype(np.float32)))
+    env.target_jnt_value.copy_(torch.from_numpy(g[f"{tag}_target"].astype(np.float32)))
+    env._task.nsubsteps = 0; env._task.do_forward = 0
+    obs, rwd, term, trunc, info = env.step(torch.zeros(n, env.cm.nu))
+    np.testing.assert_allclose(obs.cpu().numpy(), g[f"{tag}_obs"], rtol=2e-6, atol=2e-6)
+    for i, k in enumerate(E.RWD_KEYS_POSE):
+        np.testing.assert_allclose(env.rwd[:, i].cpu().numpy(), g[f"{tag}_rwd_{k}"], rtol=1e-5, atol=1e-5, err_msg=k)
+    np.testing.assert_array_equal(term.cpu().numpy(), g[f"{tag}_rwd_done"] > 0.5)
+    assert list(info["obs_dict"].keys()) == ["time", "qpos", "qvel", "pose_err", "act"]
+    assert list(info["rwd_dict"].keys()) == ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+    assert set(["time", "rwd_dense", "rwd_sparse", "solved", "done", "obs_dict", "rwd_dict", "state"]) <= set(info.keys())
+
+
+@pytest.mark.parametrize("env_id", ["myoElbowPose1D6MRandom-v0", "myoHandPoseRandom-v0"])
+def test_env_step_matches_env_oracle(models, oracle_lib, env_id):
+    """gym-level parity: reset draws, ctrl map, 10 substeps + forward, obs vector, reward terms."""
+    nenv, nsteps = 6, 12
+    env = registry.make(env_id, num_envs=nenv, seed=3, autoreset=False)
+    cm = env.cm
+    obs0, _ = env.reset(seed=3)
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    tr = env.target_jnt_range
+    oracles = []
+    for e in range(nenv):
+        uq, ut = EO.pose_reset_draws(cm.nq, e, 1, 3)     # episode 0 was consumed by the constructor's reset
+        q0 = (lo + (hi - lo) * uq).astype(np.float32); tg = (tr[:, 0] + (tr[:, 1] - tr[:, 0]) * ut).astype(np.float32)
+        o = EO.PoseEnvOracle(cm, pose_thd=env.pose_thd)
+        ob = o.reset(q0, tg)
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), ob, rtol=1e-6, atol=1e-6)
+        oracles.append(o)
+    rng = np.random.default_rng(0)
+    for s in range(nsteps):
+        a = rng.uniform(-1, 1, (nenv, cm.nu)).astype(np.float32)
+        obs, rwd, term, trunc, info = env.step(torch.from_numpy(a))
+        for e, o in enumerate(oracles):
+            ob, r, done, rd = o.step(a[e])
+            np.testing.assert_allclose(env.last_ctrl[e].cpu().numpy(), o.last_ctrl, rtol=1e-6, atol=1e-7)
+            tol = 5e-4 if cm.nq > 1 else 5e-5
+            np.testing.assert_allclose(obs[e].cpu().numpy(), ob, rtol=0, atol=tol)
+            assert abs(float(rwd[e]) - r) < 2e-3 * max(1.0, abs(r))
+            assert bool(term[e]) == done
+        assert not bool(trunc.any())
+    assert float(env.state.time[0]) == pytest.approx(nsteps * env.dt, rel=1e-4)
+
+
+def test_autoreset_and_timelimit():
+    env = registry.make("myoElbowPose1D6MRandom-v0", num_envs=16, seed=1)
+    ep0 = env.episode.clone()
+    for s in range(100):
+        obs, rwd, term, trunc, info = env.step(torch.rand(16, env.cm.nu, device="cuda"))
+        if s < 99:
+            assert not bool(trunc.any()) or bool(term.any())
+    assert bool((trunc | term).all())                      # horizon 100 (myobase/__init__.py:126)
+    assert int(env.step_count.max()) == 0 and bool((env.episode > ep0).all())
+    assert float(env.state.time.max()) == 0.0
+    # first obs of the new episode: qvel and act parts are zero
+    nq, nv = env.cm.nq, env.cm.nv
+    assert float(obs[:, nq:nq + nv].abs().max()) == 0.0 and float(obs[:, 2 * nq + nv:].abs().max()) == 0.0
+
+
+def test_determinism_and_batch_position_independence():
+    """Same seed => bit-identical results (reference test strategy: tests/test_envs.py:103-121), and an
+    env's trajectory does not depend on where it sits in the batch / wavefront."""
+    n = 200
+    outs = []
+    for trial in range(2):
+        env = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=5, autoreset=False)
+        a = torch.empty(n, env.cm.nu, device="cuda")
+        for s in range(5):
+            E.uniform(a, 9, s)
+            obs, *_ = env.step(a)
+        outs.append(obs.clone())
+    assert torch.equal(outs[0], outs[1])
+    perm = torch.randperm(n, device="cuda")
+    env = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=5, autoreset=False)
+    st0 = env.get_env_state()
+    env2 = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=5, autoreset=False)
+    env2.set_env_state({k: (v[perm] if v is not None else None) for k, v in st0.items()})
+    env2.target_jnt_value.copy_(env.target_jnt_value[perm])
+    a = torch.empty(n, env.cm.nu, device="cuda")
+    for s in range(3):
+        E.uniform(a, 9, s)
+        o1, *_ = env.step(a)
+        o2, *_ = env2.step(a[perm].contiguous())
+    assert torch.equal(o1[perm], o2)
+
+
+def test_fatigue_on_gpu_matches_reference_golden():
+    """3CC-r in the fused kernel vs vectors produced by the reference's fatigue.py (ref_fatigue.npz, rand39)."""
+    g = np.load(os.path.join(G, "ref_fatigue.npz"))
+    acts = g["rand39_acts"]
+    env = registry.make("myoFatiHandPoseRandom-v0", num_envs=4, seed=0, autoreset=False)
+    env._task.normalize_act = 0        # feed target loads directly (the golden drives compute_act directly)
+    assert abs(env.dt - float(g["rand39_dt"])) < 1e-8
+    for i in range(60):
+        a = torch.from_numpy(np.tile(acts[i].astype(np.float32), (4, 1))).cuda()
+        env.step(a)
+        np.testing.assert_allclose(env.fat_MA[0].cpu().numpy(), g["rand39_MA"][i], rtol=1e-4, atol=1e-6)   # reference test: rtol 1e-5 numpy-vs-jax(f32)
+        np.testing.assert_allclose(env.fat_MF[0].cpu().numpy(), g["rand39_MF"][i], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(env.last_ctrl[0].cpu().numpy(), g["rand39_MA"][i], rtol=1e-4, atol=1e-6)
+    s = env.fat_MA + env.fat_MR + env.fat_MF
+    assert float((s - 1).abs().max()) < 1e-5
+
+
+def test_variants_sarcopenia_reafferentation():
+    base = registry.make("myoHandPoseRandom-v0", num_envs=2, seed=0, autoreset=False)
+    sarc = registry.make("myoSarcHandPoseRandom-v0", num_envs=2, seed=0, autoreset=False)
+    gb = base.cm.arrays["ACT_GAINPRM"].reshape(-1, 9); gs = sarc.cm.arrays["ACT_GAINPRM"].reshape(-1, 9)
+    np.testing.assert_allclose(gs[:, 2], 0.5 * gb[:, 2])                                    # base_v0.py:63-67
+    np.testing.assert_allclose(sarc.cm.arrays["ACT_BIASPRM"], base.cm.arrays["ACT_BIASPRM"])
+    reaf = registry.make("myoReafHandPoseRandom-v0", num_envs=2, seed=0, autoreset=False)
+    a = torch.rand(2, 39, device="cuda")
+    reaf.step(a)
+    eip, epl = reaf.cm.names["actuator"]["EIP"], reaf.cm.names["actuator"]["EPL"]
+    sig = 1.0 / (1.0 + torch.exp(-5.0 * (a - 0.5)))
+    assert torch.allclose(reaf.last_ctrl[:, epl], sig[:, eip], atol=1e-6) and float(reaf.last_ctrl[:, eip].abs().max()) == 0.0
+
+
+def test_full_size_properties_hand_4096():
+    """BASELINE config 3 size (4096 envs): invariants that do not need the oracle."""
+    n = 4096
+    env = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=0)
+    a = torch.empty(n, env.cm.nu, device="cuda")
+    lo = torch.from_numpy(env.cm.jnt_range[:, 0].copy()).cuda(); hi = torch.from_numpy(env.cm.jnt_range[:, 1].copy()).cuda()
+    for s in range(25):
+        E.uniform(a, 0, s)
+        obs, rwd, term, trunc, info = env.step(a)
+    st = env.state
+    assert bool(torch.isfinite(st.qpos).all() and torch.isfinite(st.qvel).all() and torch.isfinite(obs).all())
+    assert float(st.act.min()) >= 0.0 and float(st.act.max()) <= 1.0
+    viol = torch.maximum(lo - st.qpos, st.qpos - hi).max()
+    assert float(viol) < 0.2                      # soft joint limits (solref 0.02): bounded penetration
+    assert int((st.status & 1).max()) == 0        # no bad-state auto-resets
+    assert float(st.time.min()) == pytest.approx(25 * env.dt, rel=1e-4)
+    # reward identity: dense == sum_k w_k * r_k  (pose_v0.py:137-139)
+    r = env.rwd
+    dense = 1.0 * r[:, 0] + 4.0 * r[:, 1] + 50 * r[:, 2] + 1.0 * r[:, 3]
+    assert torch.allclose(dense, r[:, 7], atol=1e-4)
+    # mm_forward is idempotent on state
+    q = st.qpos.clone(); v = st.qvel.clone()
+    E.forward(env.hm, st)
+    assert torch.equal(q, st.qpos) and torch.equal(v, st.qvel)

@@ -1,0 +1,100 @@
+"""Host logic: blob packing, model compiler, and that the C-ABI library loads and exports every
+symbol include/myosim.h declares (no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from myosuite_amd.model import blob, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_blob_roundtrip(models):
+    for cm in models.values():
+        un = blob.unpack(cm.blob)
+        for name, arr in cm.arrays.items():
+            got = un[name].reshape(-1)
+            ref = np.asarray(arr).reshape(-1)
+            assert got.size == ref.size, name
+            np.testing.assert_array_equal(got, ref.astype(got.dtype))
+        assert cm.blob[0] == blob.MAGIC and cm.blob[3] == cm.blob.size
+
+
+def test_dimensions_pinned_by_reference(models):
+    # elbow 1/1/6, hand 23/23/39 (NPG policy pickles n=9,m=6 / n=108,m=39)
+    e, h = models["elbow"], models["hand"]
+    assert (e.nq, e.nv, e.nu, e.na) == (1, 1, 6, 6)
+    assert (h.nq, h.nv, h.nu, h.na) == (23, 23, 39, 39)
+    assert h.nbody == 30  # 29 bones + world (docs/source/suite.rst:88)
+    assert list(h.names["joint"]) == synth.HAND_JOINTS
+    assert list(h.names["actuator"]) == synth.HAND_MUSCLES
+    assert abs(e.timestep - 0.002) < 1e-9 and abs(h.timestep - 0.002) < 1e-9
+
+
+def test_compile_constants_sane(models):
+    for cm in models.values():
+        A = cm.arrays
+        assert np.all(A["DOF_INVWEIGHT0"] > 0)
+        lr = A["ACT_LENGTHRANGE"].reshape(-1, 2)
+        assert np.all(lr[:, 1] > lr[:, 0])
+        # tree ordering: parent < child and depth-first contiguity of dof subtrees
+        par = A["BODY_PARENT"]
+        assert np.all(par[1:] < np.arange(1, cm.nbody))
+        dpar = A["DOF_PARENTID"]
+        assert np.all(dpar < np.arange(cm.nv))
+
+
+def test_hip_library_exports_header_symbols():
+    from myosuite_amd import engine as E
+    path = E.build()
+    lib = ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "myosim.h")).read()
+    names = sorted(set(re.findall(r"\b(mm_[a-z_]+)\s*\(", hdr)))
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/myosim.h but not exported"
+    lib.mm_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.mm_version()
+
+
+def test_ctypes_structs_match_header_field_order():
+    from myosuite_amd import engine as E
+    hdr = open(os.path.join(ROOT, "include", "myosim.h")).read()
+
+    def c_fields(struct_end):
+        body = hdr[:hdr.index(struct_end)]
+        body = body[body.rindex("typedef struct {") + len("typedef struct {"):]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if not stmt:
+                continue
+            for decl in stmt.split(","):
+                out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", decl)[-1])
+        return out
+
+    for cls, end in ((E.mm_state, "} mm_state;"), (E.mm_derived, "} mm_derived;"), (E.mm_task, "} mm_task;")):
+        assert [f[0] for f in cls._fields_] == c_fields(end), cls.__name__
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    from myosuite_amd import engine as E
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(E.EngineError):
+        E.HipModel(synth.get_model("elbow"))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "myosuite_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "liboracle" not in src, f

@@ -1,0 +1,190 @@
+"""The fp64 oracle against physics invariants and an independent numpy implementation
+(SURVEY.md section 7 step 2): since MuJoCo itself is absent, these pin the restatement."""
+import numpy as np
+import pytest
+
+from myosuite_amd.model import kin_np as K
+from myosuite_amd.model.spec import ModelSpec
+
+
+def _rand_state(cm, rng):
+    lo, hi = cm.jnt_range[:, 0].astype(float), cm.jnt_range[:, 1].astype(float)
+    return lo + (hi - lo) * rng.random(cm.nq), rng.standard_normal(cm.nv)
+
+
+@pytest.mark.parametrize("name", ["elbow", "hand"])
+def test_mass_matrix_tendon_and_gravity(oracle_lib, models, name):
+    O = oracle_lib
+    cm = models[name]
+    om = O.OracleModel(cm); d = O.OracleData(om)
+    km = K.KinModel(cm.arrays, cm.nq, cm.nv, cm.nbody)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        q, v = _rand_state(cm, rng)
+        d.qpos[:] = q; d.qvel[:] = 0; d.forward()
+        M = km.mass_matrix(q[None])[0] + np.diag(cm.arrays["DOF_ARMATURE"].astype(float))
+        np.testing.assert_allclose(d.full_M(), M, atol=1e-12)
+        np.testing.assert_allclose(d.ten_length, km.tendon_length(q[None])[0], atol=1e-12)
+        np.testing.assert_allclose(d.ten_J, km.tendon_jacobian_fd(q[None])[0], atol=2e-7)
+        # L'DL solve
+        np.testing.assert_allclose(d.full_M() @ d.qacc_smooth, d.qfrc_smooth, atol=1e-9)
+        # gravity part of the bias force = dV/dq
+        def pot(qq):
+            xpos, xquat, _, _ = km.fk(qq[None])
+            R = K.quat2mat(xquat[0]); xi = xpos[0] + np.einsum("bij,bj->bi", R, km.body_ipos)
+            return np.sum(km.body_mass * xi[:, 2]) * 9.81
+        g = np.array([(pot(q + e) - pot(q - e)) / 2e-6 for e in np.eye(cm.nq) * 1e-6])
+        np.testing.assert_allclose(d.qfrc_bias, g, atol=1e-6)
+
+
+def test_coriolis_via_energy_conservation(oracle_lib):
+    """Passive 3-link chain with no damping: total energy must be conserved to O(h)."""
+    O = oracle_lib
+    s = ModelSpec("chain", timestep=0.0005, eulerdamp=False)
+    prev = "world"
+    for i in range(3):
+        s.add_body(f"b{i}", prev, pos=(0, 0, 0.0 if i == 0 else -0.3), mass=1.0, ipos=(0.02, 0.01, -0.15),
+                   inertia=(0.01, 0.012, 0.002))
+        s.add_joint(f"j{i}", f"b{i}", "hinge", axis=(0.2 * i, 1, 0.3 * (i - 1)))
+        prev = f"b{i}"
+    cm = s.compile()
+    om = O.OracleModel(cm); d = O.OracleData(om)
+    km = K.KinModel(cm.arrays, cm.nq, cm.nv, cm.nbody)
+    d.qpos[:] = [0.4, -0.7, 1.1]; d.qvel[:] = [1.0, -2.0, 0.5]
+
+    def energy():
+        q = np.array(d.qpos)[None]
+        M = km.mass_matrix(q)[0]
+        xpos, xquat, _, _ = km.fk(q)
+        xi = xpos[0] + np.einsum("bij,bj->bi", K.quat2mat(xquat[0]), km.body_ipos)
+        return 0.5 * d.qvel @ M @ d.qvel + 9.81 * np.sum(km.body_mass * xi[:, 2])
+    e0 = energy()
+    d.step(2000)
+    assert abs(energy() - e0) < 2e-2 * max(1.0, abs(e0))
+    # refine the step: the drift must shrink roughly linearly (first-order integrator)
+    s2 = ModelSpec("chain2", timestep=0.000125, eulerdamp=False)
+    prev = "world"
+    for i in range(3):
+        s2.add_body(f"b{i}", prev, pos=(0, 0, 0.0 if i == 0 else -0.3), mass=1.0, ipos=(0.02, 0.01, -0.15),
+                    inertia=(0.01, 0.012, 0.002))
+        s2.add_joint(f"j{i}", f"b{i}", "hinge", axis=(0.2 * i, 1, 0.3 * (i - 1)))
+        prev = f"b{i}"
+    cm2 = s2.compile(); om2 = O.OracleModel(cm2); d2 = O.OracleData(om2)
+    d2.qpos[:] = [0.4, -0.7, 1.1]; d2.qvel[:] = [1.0, -2.0, 0.5]
+    drift1 = abs(energy() - e0)
+    d_saved = d
+    d = d2
+    d.step(8000)
+    drift2 = abs(energy() - e0)
+    assert drift2 < 0.5 * drift1 + 1e-9
+
+
+def test_pendulum_period(oracle_lib):
+    O = oracle_lib
+    s = ModelSpec("pend", timestep=0.0005, eulerdamp=False)
+    s.add_body("b", "world", mass=1.0, ipos=(0, 0, -0.5), inertia=(0, 0, 0))
+    s.add_joint("j", "b", "hinge", axis=(0, 1, 0))
+    cm = s.compile(); om = O.OracleModel(cm); d = O.OracleData(om)
+    d.qpos[0] = 0.05
+    zero_cross = []
+    last = d.qpos[0]
+    for k in range(6000):
+        d.step()
+        if last > 0 >= d.qpos[0]:
+            zero_cross.append(d.time)
+        last = d.qpos[0]
+    period = zero_cross[1] - zero_cross[0]
+    assert abs(period - 2 * np.pi * np.sqrt(0.5 / 9.81)) < 3e-3
+
+
+def test_wrap_cylinder_closed_form(oracle_lib):
+    """Tendon over a cylinder between two symmetric points: length = 2*sqrt(d^2-r^2) + r*theta."""
+    O = oracle_lib
+    r, dd = 0.05, 0.2
+    s = ModelSpec("wrap")
+    s.add_body("b", "world", mass=1.0, inertia=(0.01, 0.01, 0.01))
+    s.add_joint("j", "b", "hinge", axis=(0, 0, 1))
+    s.add_geom("cyl", "world", "cylinder", size=(r, 0.1))
+    s.add_site("s0", "world", (-dd, -0.01, 0.02)); s.add_site("s1", "b", (dd, -0.01, 0.02))
+    s.add_site("side", "world", (0, 0.3, 0))
+    s.add_tendon("t", [("site", "s0"), ("cylinder", "cyl", "side"), ("site", "s1")])
+    s.add_muscle("m", "t", force=10.0, lengthrange=(0.3, 0.6))
+    cm = s.compile(); om = O.OracleModel(cm); d = O.OracleData(om)
+    d.forward()
+    d0 = np.hypot(dd, 0.01)
+    ang_total = np.pi + 2 * np.arctan2(0.01, dd)          # angle between the two points seen from the axis (far side)
+    theta = ang_total - 2 * np.arccos(r / d0)
+    expect = 2 * np.sqrt(d0 ** 2 - r ** 2) + r * theta
+    assert abs(d.ten_length[0] - expect) < 1e-7           # model parameters are stored as float32
+    # without the side site the straight segment does not touch the cylinder -> no wrap
+    s2 = ModelSpec("nowrap")
+    s2.add_body("b", "world", mass=1.0, inertia=(0.01, 0.01, 0.01)); s2.add_joint("j", "b", "hinge", axis=(0, 0, 1))
+    s2.add_geom("cyl", "world", "cylinder", size=(r, 0.1))
+    s2.add_site("s0", "world", (-dd, -0.08, 0.02)); s2.add_site("s1", "b", (dd, -0.08, 0.02))
+    s2.add_tendon("t", [("site", "s0"), ("cylinder", "cyl"), ("site", "s1")])
+    s2.add_muscle("m", "t", force=10.0, lengthrange=(0.3, 0.6))
+    cm2 = s2.compile(); om2 = O.OracleModel(cm2); d2 = O.OracleData(om2); d2.forward()
+    assert abs(d2.ten_length[0] - 2 * dd) < 1e-7
+
+
+def test_muscle_curves_known_points(oracle_lib):
+    """FL/FV/FP curves at the published break points."""
+    O = oracle_lib
+    s = ModelSpec("mus")
+    s.add_body("b", "world", mass=1.0, inertia=(0.01, 0.01, 0.01)); s.add_joint("j", "b", "slide", axis=(1, 0, 0))
+    s.add_site("s0", "world", (-1.0, 0, 0)); s.add_site("s1", "b", (0, 0, 0))
+    s.add_tendon("t", [("site", "s0"), ("site", "s1")])
+    s.add_muscle("m", "t", force=100.0, lengthrange=(0.75, 1.05))     # L0 = 1: normalised length == tendon length
+    cm = s.compile(); om = O.OracleModel(cm); d = O.OracleData(om)
+
+    def force(L, V, act):
+        d.qpos[0] = L - 1.0; d.qvel[0] = V * 1.5; d.act[0] = act; d.ctrl[0] = act
+        d.forward()
+        return d.actuator_force[0]
+    # tolerances: model parameters (fvmax=1.2, lmax=1.6, ...) are stored as float32
+    assert abs(force(1.0, 0.0, 1.0) - (-100.0)) < 2e-5             # FL(1)=1, FV(0)=1, FP(1)=0
+    assert abs(force(1.0, -1.0, 1.0)) < 2e-5                       # FV(-1)=0
+    assert abs(force(1.0, 1.0, 1.0) - (-120.0)) < 2e-5             # FV saturates at fvmax=1.2
+    assert abs(force(0.5, 0.0, 1.0)) < 2e-5                        # FL(lmin)=0
+    assert abs(force(1.3, 0.0, 0.0) - (-100.0 * 1.3 * 0.5)) < 2e-5  # FP(b)=fpmax/2 at b=(1+lmax)/2=1.3
+    assert abs(force(0.75, 0.0, 1.0) - (-100.0 * 0.5)) < 2e-5      # FL(a)=0.5 at a=(lmin+1)/2
+    # activation dynamics (tutorials/6_Inverse_Dynamics.ipynb:231-237): act=0.5, ctrl=1 -> tau=0.01*(0.5+0.75)
+    d.act[0] = 0.5; d.ctrl[0] = 1.0; d.forward()
+    assert abs(d.act_dot[0] - 0.5 / (0.01 * 1.25)) < 1e-5
+    d.act[0] = 0.5; d.ctrl[0] = 0.0; d.forward()
+    assert abs(d.act_dot[0] - (-0.5) / (0.04 / 1.25)) < 1e-5
+
+
+def test_joint_limit_pushes_back(oracle_lib, models):
+    O = oracle_lib
+    cm = models["elbow"]
+    om = O.OracleModel(cm); d = O.OracleData(om)
+    d.qpos[0] = 2.27 + 0.05; d.forward()
+    assert d.nefc == 1 and d.efc_force[0] > 0 and d.qfrc_constraint[0] < 0
+    d.qpos[0] = -0.05; d.forward()
+    assert d.nefc == 1 and d.qfrc_constraint[0] > 0
+    # solver optimality: gradient of the constrained cost vanishes
+    M = d.full_M()
+    grad = M @ d.qacc - d.qfrc_smooth - d.qfrc_constraint
+    assert np.abs(grad).max() < 1e-6 * max(1.0, np.abs(d.qfrc_smooth).max())
+
+
+def test_solver_kkt_hand(oracle_lib, models):
+    O = oracle_lib
+    cm = models["hand"]
+    om = O.OracleModel(cm); d = O.OracleData(om)
+    rng = np.random.default_rng(5)
+    lo, hi = cm.jnt_range[:, 0].astype(float), cm.jnt_range[:, 1].astype(float)
+    for _ in range(5):
+        d.reset()
+        q = lo + (hi - lo) * rng.random(cm.nq)
+        viol = rng.random(cm.nq) < 0.4
+        q[viol] = np.where(rng.random(viol.sum()) < 0.5, lo[viol] - 0.02, hi[viol] + 0.02)
+        d.qpos[:] = q
+        d.qvel[:] = rng.standard_normal(cm.nv)
+        d.ctrl[:] = rng.random(cm.nu); d.act[:] = rng.random(cm.na)
+        d.forward()
+        assert d.nefc == viol.sum() > 0
+        grad = d.full_M() @ d.qacc - d.qfrc_smooth - d.qfrc_constraint
+        assert np.abs(grad).max() < 1e-5 * max(1.0, np.abs(d.qfrc_smooth).max())
+        assert np.all(d.efc_force[:d.nefc] >= 0)
