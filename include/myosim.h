@@ -126,6 +126,8 @@ void mm_model_destroy(mm_model* m);
 int  mm_model_info(const mm_model* m, int which);
 /* lanes_per_env in {4,8,16,32,64}; 0 = engine default for the model size. */
 int  mm_model_set_lanes(mm_model* m, int lanes_per_env);
+/* tuning knobs: "lds_model" (1: stage model tables in LDS), "waves_per_block" (0 = auto) */
+int  mm_model_set_option(mm_model* m, const char* name, int value);
 
 /* ---- physics -------------------------------------------------------------- */
 /* `nsub` mj_step substeps with ctrl [nenv][nu] applied as-is (engine boundary). */

@@ -1,20 +1,24 @@
-// myosim_engine.hip -- MI355X (gfx950 / CDNA4) batched musculoskeletal physics step.
+// myosim_engine.hip -- MI355X (gfx950 / CDNA4) batched musculoskeletal physics step, engine v2.
 //
-// Execution model ("wave-cooperative"): every environment is owned by a GROUP of G
-// adjacent lanes of one 64-wide wavefront (G in {4,8,16,32,64}, 64/G envs per wave).
-// The env's whole mjData-like workspace lives in LDS for the duration of the fused
-// env-step (frame_skip substeps + final forward + obs/reward); HBM is touched once
-// to load state/action and once to store state/obs/reward.  Inside a stage the G
-// lanes sweep the stage's natural index set (bodies of one tree level, tendons,
-// dofs, constraint rows ...); tree recursions advance level by level.  Lanes of a
-// group exchange data through LDS; a wavefront executes in lock-step and the LDS
-// services one wave's instructions in order, so stage boundaries need only a
-// compiler fence (GSYNC), never s_barrier.  Reductions use cross-lane shuffles.
+// Execution model ("lane = item"): every environment is owned by a GROUP of G adjacent lanes of one
+// 64-wide wavefront (G in {8,16,32,64}; 64/G envs per wave).  Inside the group each lane permanently
+// OWNS one item of every kind -- lane g is body g, dof g, joint-limit row g (lower) / g-G/2 (upper) --
+// and keeps that item's data in REGISTERS for the whole fused env-step (frame_skip substeps + final
+// forward + obs/reward).  Variable-length work (tendon paths, actuators) is swept with lane-strided
+// loops.  Only data that other lanes must gather lives in LDS (pose / cdof / composite-inertia tables,
+// sparse tendon Jacobian, a dense nv x nv scratch tile); HBM is touched once to load state+action and
+// once to store state+obs+reward.
 //
-// Pipeline restated (stage order of mj_step; reference call
-// site myosuite/robot/robot.py:856-861):  kinematics -> comPos -> tendon(+wrap) ->
-// comVel/RNE -> CRB -> L'DL -> passive/actuation -> constraint rows -> Newton ->
-// semi-implicit Euler (implicit joint damping).
+// Linear algebra is DENSE and register resident: lane i holds row i of M / H / L.  Cholesky, the two
+// triangular solves and M*x run as fully unrolled lane-parallel loops whose only communication is a
+// cross-lane broadcast (v_readlane for G = 64, ds_bpermute otherwise): no LDS round trips, no level
+// synchronisation.  The constraint Newton solver keeps one (potential) joint-limit row per lane, so no
+// compaction is needed.  A wavefront executes in lock-step and the LDS services one wave's
+// instructions in order, so stage boundaries need only a compiler fence (GSYNC), never s_barrier.
+//
+// Pipeline restated (stage order of mj_step; reference call site
+// myosuite/robot/robot.py:856-861): kinematics -> comPos -> tendon(+wrap) -> limit rows -> comVel/RNE
+// -> CRB -> Cholesky -> passive/actuation -> Newton -> semi-implicit Euler (implicit joint damping).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,6 +26,7 @@
 #include <math.h>
 #include <vector>
 #include <string>
+#include <algorithm>
 
 #include "../../include/myosim_model.h"
 #include "../../include/myosim.h"
@@ -30,28 +35,34 @@
 
 // ------------------------------------------------------------------ kernel args
 struct Dims {
-  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, ndoflevel, njmax, ntenJ;
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, njmax, ntenJ;
   int iterations, ls_iterations, eulerdamp, any_damping;
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
 };
 
-// LDS workspace layout (offsets in 32-bit words from the env's base)
+// per-env LDS tables (offsets in 32-bit words from the env's base)
 struct Layout {
-  int qpos, qvel, act, ctrl, warm;
-  int xpos, xquat, xmat, xipos, xanchor, xaxis, com;
-  int cinert, cdof, cdofdot, cvel, cacc;
-  int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc, actdot;
-  int qM, qLD, qH, dinv, hdinv;
-  int bias, passive, smooth, qaccsm, qacc, qfrccon, Ma, grad, search, Mv, tmp;
-  int efc_kind, efc_id, efc_pos, efc_D, efc_aref, efc_jar, efc_jv, efc_frc;
+  int qpos, qvel, act, ctrl, actdot;
+  int xpos, xmat, xanchor, xaxis, com, cdof;
+  int u1;   // union: xquat[4nb] during FK | cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
+  int crb;
+  int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
+  int vec;  // nv: joint-transmission actuator forces
   int total;
+};
+
+// debug dump layout (tests only): one record per env in global memory
+struct DbgLayout {
+  int xpos, xquat, xipos, cdof, cvel, tenlen, tenvel, tenj, actfrc, actdot, M, bias, smooth, qaccsm, qacc, qfrccon,
+      efc_active, efc_D, efc_aref, scal, total;
 };
 
 // engine-private tables appended behind the model blob on the device
 struct Aux {
-  int dof_ndesc, dof_depth;        // [nv]
-  int dofj_adr, dofj_entry, dofj_tendon;  // transpose of the sparse tendon Jacobian
-  int root_list, nroot;            // bodies that root a kinematic tree
+  int body_depth, body_rootslot, dof_rootslot;
+  int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
+  int root_list, nroot;
+  int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
 };
 
 struct KArgs {
@@ -59,16 +70,17 @@ struct KArgs {
   int sec[MM_NSEC];
   Dims d;
   Layout L;
+  DbgLayout D;
   Aux x;
   mm_state s;
-  const float* ctrl;     // [nenv][nu] action / control input
-  mm_task t;             // task.task == MM_TASK_NONE for plain mm_step / mm_forward
+  const float* ctrl;
+  mm_task t;
   mm_derived o;
   int has_derived;
   int mode;              // 0: step(s) only, 1: forward only, 2: env step
-  float* dbg;            // optional [nenv][L.total] workspace dump after the last forward
-  int blob_words;        // model + aux words (for staging into LDS)
-  unsigned long long* prof;  // optional [NPROF] per-stage cycle counters (first wave of block 0)
+  float* dbg;
+  int blob_words;
+  unsigned long long* prof;
 };
 enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_ACT, PF_SOLVE0, PF_NEWTON, PF_EULER,
        PF_IO, PF_TOTAL, NPROF };
@@ -77,8 +89,6 @@ enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_A
 #define MF_(S) (reinterpret_cast<const float*>(mb + a.sec[MM_SEC_##S]))
 #define AUXI(f) (reinterpret_cast<const int*>(mb + a.x.f))
 
-// stage boundary inside one wavefront: LDS traffic of a wave is serviced in program
-// order, so only the compiler must be kept from moving LDS accesses across.
 #define GSYNC()                                           \
   do {                                                    \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -125,7 +135,12 @@ __device__ __forceinline__ M3 q2m(Q4 q) {
   r.m[5] = 2.f * (y * z - w * x); r.m[7] = 2.f * (y * z + w * x);
   return r;
 }
-__device__ __forceinline__ M3 ldm(const float* p) { M3 r; for (int i = 0; i < 9; i++) r.m[i] = p[i]; return r; }
+__device__ __forceinline__ M3 ldm(const float* p) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.m[i] = p[i];
+  return r;
+}
 __device__ __forceinline__ V3 mv(const M3& m, V3 v) {
   return v3(m.m[0] * v.x + m.m[1] * v.y + m.m[2] * v.z, m.m[3] * v.x + m.m[4] * v.y + m.m[5] * v.z,
             m.m[6] * v.x + m.m[7] * v.y + m.m[8] * v.z);
@@ -135,6 +150,23 @@ __device__ __forceinline__ V3 mtv(const M3& m, V3 v) {
             m.m[2] * v.x + m.m[5] * v.y + m.m[8] * v.z);
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// sin/cos for |x| <= ~8 (joint half-angles): Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials
+// (max abs error ~1.5e-7: at the fp32 rounding level of the quaternion it feeds).
+__device__ __forceinline__ void sincos_small(float x, float* s, float* c) {
+  float k = rintf(x * 0.636619772367581f);
+  float r = fmaf(-k, 1.5707963705062866f, x);
+  r = fmaf(-k, -4.371138828673793e-8f, r);
+  float r2 = r * r;
+  float sp = fmaf(fmaf(fmaf(2.718311493989822e-6f, r2, -1.984090227e-4f), r2, 8.3333169e-3f), r2, -0.16666667f);
+  float sn = fmaf(sp * r2, r, r);
+  float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625e-3f), r2, 4.166664568e-2f), r2, -0.5f);
+  float cs = fmaf(cp, r2, 1.f);
+  int q = (int)k & 3;
+  float ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
 
 // spatial inertia (Ixx Iyy Izz Ixy Ixz Iyz, m*r[3], m) times motion vector [w; v]
 __device__ __forceinline__ void inert_mul(float* res, const float* I, const float* v) {
@@ -147,8 +179,7 @@ __device__ __forceinline__ void inert_mul(float* res, const float* I, const floa
 }
 __device__ __forceinline__ void cross_motion(float* res, const float* v, const float* s) {
   V3 w = ld3(v), l = ld3(v + 3), sa = ld3(s), sl = ld3(s + 3);
-  V3 a = cross(w, sa), b = cross(w, sl) + cross(l, sa);
-  st3(res, a); st3(res + 3, b);
+  st3(res, cross(w, sa)); st3(res + 3, cross(w, sl) + cross(l, sa));
 }
 __device__ __forceinline__ void cross_force(float* res, const float* v, const float* f) {
   V3 w = ld3(v), l = ld3(v + 3), fa = ld3(f), fl = ld3(f + 3);
@@ -169,57 +200,70 @@ __device__ __forceinline__ int gor(int v) {
   for (int m = G / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, G);
   return v;
 }
+// broadcast lane j (group-uniform index) of the group
+template <int G>
+__device__ __forceinline__ float bc(float v, int j) {
+  if constexpr (G == 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+  else return __shfl(v, j, G);
+}
+// gather from a lane-varying source inside the group
+template <int G>
+__device__ __forceinline__ float sh(float v, int src) { return __shfl(v, src, G); }
 
-// ------------------------------------------------------------- tendon wrapping
+// ------------------------------------------------------------- tendon wrapping (A2)
 __device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y,
                                                float p4x, float p4y) {
   float det = (p4y - p3y) * (p2x - p1x) - (p4x - p3x) * (p2y - p1y);
-  if (fabsf(det) < MINVALF) return false;
+  // (nearly) parallel segments never cross; the relative test keeps the decision out of fp32 rounding noise
+  // at wrap onset, where both tangent segments lie along the chord
+  float n12 = (p2x - p1x) * (p2x - p1x) + (p2y - p1y) * (p2y - p1y), n34 = (p4x - p3x) * (p4x - p3x) + (p4y - p3y) * (p4y - p3y);
+  if (fabsf(det) < MINVALF || det * det < 4e-6f * n12 * n34) return false;
   float a = ((p4x - p3x) * (p1y - p3y) - (p4y - p3y) * (p1x - p3x)) / det;
   float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) / det;
   return a >= 0.f && a <= 1.f && b >= 0.f && b <= 1.f;
 }
 
-// 2-D wrap around origin-centred circle; returns arc length or -1; pnt = tangent points
-__device__ __forceinline__ float wrap_circle(float pnt[4], float d0x, float d0y, float d1x, float d1y, bool has_side, float sdx,
-                             float sdy, float radius) {
+__device__ __forceinline__ float wrap_circle(float pnt[4], float d0x, float d0y, float d1x, float d1y, bool has_side,
+                                             float sdx, float sdy, float radius) {
   float sqlen0 = d0x * d0x + d0y * d0y, sqlen1 = d1x * d1x + d1y * d1y, sqrad = radius * radius;
   float difx = d1x - d0x, dify = d1y - d0y;
   float dd = difx * difx + dify * dify;
-  float aa = -(difx * d0x + dify * d0y) / fmaxf(dd, MINVALF);
-  aa = clampf(aa, 0.f, 1.f);
+  float aa = clampf(-(difx * d0x + dify * d0y) / fmaxf(dd, MINVALF), 0.f, 1.f);
   float tx = d0x + aa * difx, ty = d0y + aa * dify;
   if (tx * tx + ty * ty > sqrad && (!has_side || sdx * tx + sdy * ty >= 0.f)) return -1.f;
   if (sqlen0 < sqrad || sqlen1 < sqrad) return -1.f;
   float sqrt0 = sqrtf(sqlen0 - sqrad), sqrt1 = sqrtf(sqlen1 - sqrad);
-  float sol[2][4], good[2];
+  float s0[4], s1[4], good0, good1;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     float sgn = i == 0 ? 1.f : -1.f;
-    sol[i][0] = (d0x * sqrad + sgn * radius * d0y * sqrt0) / sqlen0;
-    sol[i][1] = (d0y * sqrad - sgn * radius * d0x * sqrt0) / sqlen0;
-    sol[i][2] = (d1x * sqrad - sgn * radius * d1y * sqrt1) / sqlen1;
-    sol[i][3] = (d1y * sqrad + sgn * radius * d1x * sqrt1) / sqlen1;
+    float* sol = i == 0 ? s0 : s1;
+    sol[0] = (d0x * sqrad + sgn * radius * d0y * sqrt0) / sqlen0;
+    sol[1] = (d0y * sqrad - sgn * radius * d0x * sqrt0) / sqlen0;
+    sol[2] = (d1x * sqrad - sgn * radius * d1y * sqrt1) / sqlen1;
+    sol[3] = (d1y * sqrad + sgn * radius * d1x * sqrt1) / sqlen1;
+    float good;
     if (has_side) {
-      float ux = sol[i][0] + sol[i][2], uy = sol[i][1] + sol[i][3];
+      float ux = sol[0] + sol[2], uy = sol[1] + sol[3];
       float n = fmaxf(sqrtf(ux * ux + uy * uy), MINVALF);
-      good[i] = (ux * sdx + uy * sdy) / n;
+      good = (ux * sdx + uy * sdy) / n;
     } else {
-      float ux = sol[i][0] - sol[i][2], uy = sol[i][1] - sol[i][3];
-      good[i] = -(ux * ux + uy * uy);
+      float ux = sol[0] - sol[2], uy = sol[1] - sol[3];
+      good = -(ux * ux + uy * uy);
     }
-    if (seg_intersect(d0x, d0y, sol[i][0], sol[i][1], d1x, d1y, sol[i][2], sol[i][3])) good[i] = -10000.f;
+    if (seg_intersect(d0x, d0y, sol[0], sol[1], d1x, d1y, sol[2], sol[3])) good = -10000.f;
+    if (i == 0) good0 = good; else good1 = good;
   }
-  int i = good[0] > good[1] ? 0 : 1;
-  pnt[0] = sol[i][0]; pnt[1] = sol[i][1]; pnt[2] = sol[i][2]; pnt[3] = sol[i][3];
+  bool pick0 = good0 > good1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) pnt[k] = pick0 ? s0[k] : s1[k];
   if (seg_intersect(d0x, d0y, pnt[0], pnt[1], d1x, d1y, pnt[2], pnt[3])) return -1.f;
   float c = clampf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqrad, -1.f, 1.f);
   return radius * acosf(c);
 }
 
-// 3-D wrap over sphere / cylinder; w0,w1 world surface points; returns arc length or -1
-__device__ __forceinline__ float wrap_geom(V3& w0, V3& w1, V3 x0, V3 x1, V3 gpos, const M3& gmat, float radius, bool is_cyl,
-                           bool has_side, V3 side) {
+__device__ __forceinline__ float wrap_geom(V3& w0, V3& w1, V3 x0, V3 x1, V3 gpos, const M3& gmat, float radius,
+                                           bool is_cyl, bool has_side, V3 side) {
   V3 p0 = mtv(gmat, x0 - gpos), p1 = mtv(gmat, x1 - gpos);
   float n0 = sqrtf(dot(p0, p0)), n1 = sqrtf(dot(p1, p1));
   if (n0 < MINVALF || n1 < MINVALF) return -1.f;
@@ -268,7 +312,7 @@ __device__ __forceinline__ float wrap_geom(V3& w0, V3& w1, V3 x0, V3 x1, V3 gpos
   return wlen;
 }
 
-// ------------------------------------------------------------------ muscle model
+// ------------------------------------------------------------------ muscle model (A6)
 __device__ __forceinline__ float muscle_fl(float L, float lmin, float lmax) {
   if (L < lmin || L > lmax) return 0.f;
   float a = 0.5f * (lmin + 1.f), b = 0.5f * (1.f + lmax), x;
@@ -319,42 +363,76 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 }
 
 // =========================================================================== engine
-// All member functions are collective over the G lanes of one env group.
-template <int G>
+// All member functions are collective over the G lanes of one env group.  NVP = padded nv (compile time).
+template <int G, int NVP>
 struct Engine {
   const KArgs& a;
   const uint32_t* mb;  // model words (LDS-resident copy or global)
   unsigned long long pf[NPROF];
-  float* W;   // LDS workspace of this env
-  int g;      // lane within group
-  int nefc;   // constraint rows of the current forward pass (group-uniform)
-  int niter;  // Newton iterations of the last solve (group-uniform)
-  int status; // sticky status bits (group-uniform)
+  float* W;     // LDS tables of this env
+  const int g;  // lane within group == owned body / dof index
+  int status;   // sticky status bits (group-uniform)
+  int nefc, niter;
+  // ---- body-lane registers (valid for g < nbody)
+  V3 b_xpos, b_xipos;
+  Q4 b_xquat;
+  float b_cinert[10];
+  float b_cvel[6];
+  int b_depth, b_parent;
+  // ---- dof-lane registers (valid for g < nv)
+  float d_cdof[6];
+  float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
+  float Mrow[NVP];   // row g of M (dense, symmetric)
+  float Lrow[NVP];   // row g of the current Cholesky factor  (L[g][k], k <= g)
+  float LTrow[NVP];  // row g of its transpose                (L[k][g], k >= g)
+  float d_dinv;      // 1 / L[g][g]
+  // ---- joint-limit row owned by this lane (lower side: lanes < G/2, upper side: lanes >= G/2)
+  bool r_active;
+  float r_D, r_aref, r_sign, r_jar;
+  int r_dof;
 
-  __device__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
-      : a(a_), mb(mb_), W(W_), g(g_), nefc(0), niter(0), status(0) {
+  __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
+      : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
+#pragma unroll
     for (int i = 0; i < NPROF; i++) pf[i] = 0;
+    d_warm = 0.f; d_qvel = 0.f;
+    b_depth = (g < a.d.nbody) ? AUXI(body_depth)[g] : -1;
+    b_parent = (g > 0 && g < a.d.nbody) ? MI_(BODY_PARENT)[g] : 0;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f;
+    // lanes that own no body / dof still take part in reductions with zero weights: their registers must
+    // hold finite values (0 * garbage could be NaN)
+    b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
+    Q4 qi = {1.f, 0.f, 0.f, 0.f};
+    b_xquat = qi;
+#pragma unroll
+    for (int k = 0; k < 10; k++) b_cinert[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { b_cvel[k] = 0.f; d_cdof[k] = 0.f; }
+    d_bias = d_smooth = d_qaccsm = d_qacc = d_qfrccon = 0.f; d_dinv = 1.f;
+#pragma unroll
+    for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; LTrow[k] = 0.f; }
   }
+
+  __device__ __forceinline__ float com_of_body(int b, int k) const { return W[a.L.com + 3 * AUXI(body_rootslot)[b] + k]; }
 
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
     const Layout& L = a.L;
     if (g == 0) {
-      st3(W + L.xpos, v3(0.f, 0.f, 0.f));
-      W[L.xquat] = 1.f; W[L.xquat + 1] = 0.f; W[L.xquat + 2] = 0.f; W[L.xquat + 3] = 0.f;
+      b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
+      Q4 q = {1.f, 0.f, 0.f, 0.f};
+      b_xquat = q;
+      st3(W + L.xpos, b_xpos);
+      W[L.u1] = 1.f; W[L.u1 + 1] = 0.f; W[L.u1 + 2] = 0.f; W[L.u1 + 3] = 0.f;
       for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
-      st3(W + L.xipos, v3(0.f, 0.f, 0.f));
     }
     GSYNC();
-    const int* lv_adr = MI_(LEVEL_ADR); const int* lv_body = MI_(LEVEL_BODY);
-    const int* parent = MI_(BODY_PARENT);
-    for (int lv = 0; lv < a.d.nlevel; lv++) {
-      int i0 = lv_adr[lv], i1 = lv_adr[lv + 1];
-      for (int idx = i0 + g; idx < i1; idx += G) {
-        int b = lv_body[idx], p = parent[b];
+    for (int lv = 1; lv <= a.d.nlevel; lv++) {
+      if (b_depth == lv) {
+        const int b = g, p = b_parent;
         M3 pm = ldm(W + L.xmat + 9 * p);
         V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, ld3(MF_(BODY_POS) + 3 * b));
-        Q4 quat = qmul(ldq(W + L.xquat + 4 * p), ldq(MF_(BODY_QUAT) + 4 * b));
+        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), ldq(MF_(BODY_QUAT) + 4 * b));
         int ja = MI_(BODY_JNTADR)[b], jn = MI_(BODY_JNTNUM)[b];
         for (int j = ja; j < ja + jn; j++) {
           int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j];
@@ -376,7 +454,7 @@ struct Engine {
           } else if (type == MM_JNT_HINGE) {
             float ang = W[L.qpos + qa] - MF_(QPOS0)[qa];
             float sn, cs;
-            sincosf(0.5f * ang, &sn, &cs);
+            sincos_small(0.5f * ang, &sn, &cs);
             Q4 ql = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
             quat = qmul(quat, ql);
             pos = anchor - mv(q2m(quat), jpos);
@@ -387,11 +465,11 @@ struct Engine {
         }
         quat = qnorm(quat);
         M3 m = q2m(quat);
+        b_xpos = pos; b_xquat = quat;
         st3(W + L.xpos + 3 * b, pos);
-        W[L.xquat + 4 * b] = quat.w; W[L.xquat + 4 * b + 1] = quat.x;
-        W[L.xquat + 4 * b + 2] = quat.y; W[L.xquat + 4 * b + 3] = quat.z;
+        W[L.u1 + 4 * b] = quat.w; W[L.u1 + 4 * b + 1] = quat.x; W[L.u1 + 4 * b + 2] = quat.y; W[L.u1 + 4 * b + 3] = quat.z;
         for (int k = 0; k < 9; k++) W[L.xmat + 9 * b + k] = m.m[k];
-        st3(W + L.xipos + 3 * b, pos + mv(m, ld3(MF_(BODY_IPOS) + 3 * b)));
+        b_xipos = pos + mv(m, ld3(MF_(BODY_IPOS) + 3 * b));
       }
       GSYNC();
     }
@@ -405,38 +483,40 @@ struct Engine {
     int b = MI_(GEOM_BODYID)[gi];
     return ld3(W + a.L.xpos + 3 * b) + mv(ldm(W + a.L.xmat + 9 * b), ld3(MF_(GEOM_POS) + 3 * gi));
   }
-  __device__ __forceinline__ M3 geom_mat(int gi) const {
+  __device__ __forceinline__ M3 geom_mat(int gi) const {  // xmat_body * R(geom_quat)
     int b = MI_(GEOM_BODYID)[gi];
-    return q2m(qmul(ldq(W + a.L.xquat + 4 * b), ldq(MF_(GEOM_QUAT) + 4 * gi)));
+    M3 A = ldm(W + a.L.xmat + 9 * b), B = q2m(ldq(MF_(GEOM_QUAT) + 4 * gi)), R;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) R.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return R;
   }
 
-  // subtree COM of each tree root, body inertias about it, dof motion axes
+  // subtree COM of each tree root, body inertias about it (registers), dof motion axes (LDS + registers)
   __device__ __forceinline__ void com_pos() {
     const Layout& L = a.L;
-    const int* rootid = MI_(BODY_ROOTID);
-    const int* roots = AUXI(root_list);
+    const int nb = a.d.nbody;
+    const bool isb = g > 0 && g < nb;
+    float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+    int myslot = isb ? AUXI(body_rootslot)[g] : -1;
     for (int r = 0; r < a.x.nroot; r++) {
-      int rb = roots[r];
-      float sm = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
-      for (int b = 1 + g; b < a.d.nbody; b += G)
-        if (rootid[b] == rb) {
-          float m = MF_(BODY_MASS)[b];
-          V3 p = ld3(W + L.xipos + 3 * b);
-          sm += m; sx += m * p.x; sy += m * p.y; sz += m * p.z;
-        }
-      sm = gsum<G>(sm); sx = gsum<G>(sx); sy = gsum<G>(sy); sz = gsum<G>(sz);
+      float w = (myslot == r) ? ms : 0.f;
+      float sm = gsum<G>(w), sx = gsum<G>(w * b_xipos.x), sy = gsum<G>(w * b_xipos.y), sz = gsum<G>(w * b_xipos.z);
       if (g == 0) {
-        V3 c = sm < MINVALF ? ld3(W + L.xipos + 3 * rb) : (1.f / sm) * v3(sx, sy, sz);
-        st3(W + L.com + 3 * rb, c);
+        int rb = AUXI(root_list)[r];
+        V3 c;
+        if (sm < MINVALF) c = ld3(W + L.xpos + 3 * rb);
+        else c = (1.f / sm) * v3(sx, sy, sz);
+        st3(W + L.com + 3 * r, c);
       }
     }
     GSYNC();
-    for (int b = 1 + g; b < a.d.nbody; b += G) {
-      V3 c = ld3(W + L.com + 3 * rootid[b]);
-      M3 R = q2m(qmul(ldq(W + L.xquat + 4 * b), ldq(MF_(BODY_IQUAT) + 4 * b)));
-      V3 I = ld3(MF_(BODY_INERTIA) + 3 * b);
-      float ms = MF_(BODY_MASS)[b];
-      V3 r = ld3(W + L.xipos + 3 * b) - c;
+    if (isb) {
+      V3 c = ld3(W + L.com + 3 * myslot);
+      M3 R = q2m(qmul(b_xquat, ldq(MF_(BODY_IQUAT) + 4 * g)));
+      V3 I = ld3(MF_(BODY_INERTIA) + 3 * g);
+      V3 r = b_xipos - c;
       float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, xz = 0.f, yz = 0.f;
       const float Iv[3] = {I.x, I.y, I.z};
 #pragma unroll
@@ -445,62 +525,49 @@ struct Engine {
         xy += R.m[k] * Iv[k] * R.m[3 + k]; xz += R.m[k] * Iv[k] * R.m[6 + k]; yz += R.m[3 + k] * Iv[k] * R.m[6 + k];
       }
       float r2 = dot(r, r);
-      float* ci = W + L.cinert + 10 * b;
-      ci[0] = xx + ms * (r2 - r.x * r.x); ci[1] = yy + ms * (r2 - r.y * r.y); ci[2] = zz + ms * (r2 - r.z * r.z);
-      ci[3] = xy - ms * r.x * r.y; ci[4] = xz - ms * r.x * r.z; ci[5] = yz - ms * r.y * r.z;
-      ci[6] = ms * r.x; ci[7] = ms * r.y; ci[8] = ms * r.z; ci[9] = ms;
+      b_cinert[0] = xx + ms * (r2 - r.x * r.x); b_cinert[1] = yy + ms * (r2 - r.y * r.y); b_cinert[2] = zz + ms * (r2 - r.z * r.z);
+      b_cinert[3] = xy - ms * r.x * r.y; b_cinert[4] = xz - ms * r.x * r.z; b_cinert[5] = yz - ms * r.y * r.z;
+      b_cinert[6] = ms * r.x; b_cinert[7] = ms * r.y; b_cinert[8] = ms * r.z; b_cinert[9] = ms;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 10; k++) b_cinert[k] = 0.f;
     }
-    if (g == 0) for (int k = 0; k < 10; k++) W[L.cinert + k] = 0.f;
-    for (int j = g; j < a.d.njnt; j += G) {
-      int b = MI_(JNT_BODYID)[j], da = MI_(JNT_DOFADR)[j], type = MI_(JNT_TYPE)[j];
-      V3 off = ld3(W + L.com + 3 * rootid[b]) - ld3(W + L.xanchor + 3 * j);
-      if (type == MM_JNT_HINGE) {
-        V3 ax = ld3(W + L.xaxis + 3 * j);
-        st3(W + L.cdof + 6 * da, ax); st3(W + L.cdof + 6 * da + 3, cross(ax, off));
-      } else if (type == MM_JNT_SLIDE) {
-        st3(W + L.cdof + 6 * da, v3(0.f, 0.f, 0.f)); st3(W + L.cdof + 6 * da + 3, ld3(W + L.xaxis + 3 * j));
-      } else {
-        int r0 = da;
-        if (type == MM_JNT_FREE) {
-          for (int k = 0; k < 3; k++) {
-            st3(W + L.cdof + 6 * (da + k), v3(0.f, 0.f, 0.f));
-            st3(W + L.cdof + 6 * (da + k) + 3, v3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f));
-          }
-          r0 = da + 3;
-        }
-        M3 R = ldm(W + L.xmat + 9 * b);
-        for (int k = 0; k < 3; k++) {
-          V3 ax = v3(R.m[k], R.m[3 + k], R.m[6 + k]);
-          st3(W + L.cdof + 6 * (r0 + k), ax); st3(W + L.cdof + 6 * (r0 + k) + 3, cross(ax, off));
+    // motion axes of the dof(s) owned by this lane (lane g == dof g)
+    if (g < a.d.nv) {
+      int j = MI_(DOF_JNTID)[g], b = MI_(JNT_BODYID)[j], type = MI_(JNT_TYPE)[j], da = MI_(JNT_DOFADR)[j];
+      V3 off = ld3(W + L.com + 3 * AUXI(dof_rootslot)[g]) - ld3(W + L.xanchor + 3 * j);
+      V3 ang, lin;
+      if (type == MM_JNT_HINGE) { ang = ld3(W + L.xaxis + 3 * j); lin = cross(ang, off); }
+      else if (type == MM_JNT_SLIDE) { ang = v3(0.f, 0.f, 0.f); lin = ld3(W + L.xaxis + 3 * j); }
+      else {
+        int k = g - da;
+        if (type == MM_JNT_FREE && k < 3) { ang = v3(0.f, 0.f, 0.f); lin = v3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f); }
+        else {
+          if (type == MM_JNT_FREE) k -= 3;
+          const float* R = W + L.xmat + 9 * b;
+          ang = v3(R[k], R[3 + k], R[6 + k]); lin = cross(ang, off);
         }
       }
+      d_cdof[0] = ang.x; d_cdof[1] = ang.y; d_cdof[2] = ang.z; d_cdof[3] = lin.x; d_cdof[4] = lin.y; d_cdof[5] = lin.z;
+#pragma unroll
+      for (int k = 0; k < 6; k++) W[L.cdof + 6 * g + k] = d_cdof[k];
     }
     GSYNC();
   }
 
   // ---------------------------------------------------------------- A2 tendons
-  // add +/- u . (translational Jacobian column) for all dofs of `body` (one body only)
-  __device__ __forceinline__ void tenj_add_body(int t, int body, V3 pnt, V3 u, float sgn) {
+  // add the contributions of one straight segment (point p0 -> p1, unit direction u) to the sparse J row
+  __device__ __forceinline__ void tenj_segment(int l0, int l1, V3 p0, V3 p1, V3 u) {
     const Layout& L = a.L;
-    int da = MI_(BODY_DOFADR)[body], dn = MI_(BODY_DOFNUM)[body];
-    if (dn <= 0) return;
-    V3 off = pnt - ld3(W + L.com + 3 * MI_(BODY_ROOTID)[body]);
-    int j0 = MI_(TENJ_ADR)[t], j1 = MI_(TENJ_ADR)[t + 1];
-    const int* tdof = MI_(TENJ_DOF);
-    for (int i = da; i < da + dn; i++) {
-      V3 ang = ld3(W + L.cdof + 6 * i), lin = ld3(W + L.cdof + 6 * i + 3);
-      float val = sgn * dot(u, lin + cross(ang, off));
-      for (int e = j0; e < j1; e++)
-        if (tdof[e] == i) { W[L.tenj + e] += val; break; }
-    }
-  }
-  // segment p0 (body b0) -> p1 (body b1), unit direction u, path divisor
-  __device__ __forceinline__ void tenj_segment(int t, int b0, V3 p0, int b1, V3 p1, V3 u, float inv_div) {
-    const int* parent = MI_(BODY_PARENT);
-    u = inv_div * u;
-    while (b0 != b1) {
-      if (b0 > b1) { tenj_add_body(t, b0, p0, u, -1.f); b0 = parent[b0]; }
-      else { tenj_add_body(t, b1, p1, u, 1.f); b1 = parent[b1]; }
+    const int* lst = AUXI(seg_list);
+    for (int e = l0; e < l1; e++) {
+      int w = lst[e];
+      int dof = w & 0xff, ep = (w >> 8) & 1, ent = w >> 9;
+      V3 p = ep ? p1 : p0;
+      V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[dof]);
+      V3 ang = ld3(W + L.cdof + 6 * dof), lin = ld3(W + L.cdof + 6 * dof + 3);
+      float val = dot(u, lin + cross(ang, off));
+      W[L.tenj + ent] += ep ? val : -val;
     }
   }
 
@@ -508,6 +575,7 @@ struct Engine {
     const Layout& L = a.L;
     const int *wt = MI_(WRAP_TYPE), *wo = MI_(WRAP_OBJID);
     const float* wp = MF_(WRAP_PRM);
+    const int *sa = AUXI(sega_adr), *sb = AUXI(segb_adr), *sc = AUXI(segc_adr);
     for (int e = g; e < a.d.ntenJ; e += G) W[L.tenj + e] = 0.f;
     GSYNC();
     for (int t = g; t < a.d.ntendon; t += G) {
@@ -530,26 +598,22 @@ struct Engine {
           j++;
           continue;
         }
-        int s0 = wo[adr + j];
-        V3 p0 = site_pos(s0);
-        int b0 = MI_(SITE_BODYID)[s0];
+        const int k0 = adr + j;
+        V3 p0 = site_pos(wo[k0]);
         if (t1 == MM_WRAP_SITE) {
-          int s1 = wo[adr + j + 1];
-          V3 p1 = site_pos(s1);
-          int b1 = MI_(SITE_BODYID)[s1];
+          V3 p1 = site_pos(wo[k0 + 1]);
           V3 dif = p1 - p0;
           float n = sqrtf(dot(dif, dif));
           len += n * inv_div;
-          if (b0 != b1) {
-            V3 u = n < MINVALF ? v3(1.f, 0.f, 0.f) : (1.f / n) * dif;
-            tenj_segment(t, b0, p0, b1, p1, u, inv_div);
+          if (sa[k0 + 1] > sa[k0]) {
+            V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
+            tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
           }
           j += 1;
         } else {
-          int gi = wo[adr + j + 1], s1 = wo[adr + j + 2];
-          V3 p1 = site_pos(s1);
-          int b1 = MI_(SITE_BODYID)[s1];
-          int sideid = (int)lrintf(wp[adr + j + 1]);
+          int gi = wo[k0 + 1];
+          V3 p1 = site_pos(wo[k0 + 2]);
+          int sideid = (int)lrintf(wp[k0 + 1]);
           V3 side = v3(0.f, 0.f, 0.f);
           if (sideid >= 0) side = site_pos(sideid);
           V3 w0, w1;
@@ -559,17 +623,18 @@ struct Engine {
             V3 dif = p1 - p0;
             float n = sqrtf(dot(dif, dif));
             len += n * inv_div;
-            if (b0 != b1) {
-              V3 u = n < MINVALF ? v3(1.f, 0.f, 0.f) : (1.f / n) * dif;
-              tenj_segment(t, b0, p0, b1, p1, u, inv_div);
+            if (sa[k0 + 1] > sa[k0]) {
+              V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
+              tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
             }
           } else {
-            int bg = MI_(GEOM_BODYID)[gi];
             V3 d0 = w0 - p0, d1 = p1 - w1;
             float n0 = sqrtf(dot(d0, d0)), n1 = sqrtf(dot(d1, d1));
             len += (n0 + wlen + n1) * inv_div;
-            if (b0 != bg) tenj_segment(t, b0, p0, bg, w0, n0 < MINVALF ? v3(1.f, 0.f, 0.f) : (1.f / n0) * d0, inv_div);
-            if (bg != b1) tenj_segment(t, bg, w1, b1, p1, n1 < MINVALF ? v3(1.f, 0.f, 0.f) : (1.f / n1) * d1, inv_div);
+            if (sb[k0 + 1] > sb[k0])
+              tenj_segment(sb[k0], sb[k0 + 1], p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
+            if (sc[k0 + 1] > sc[k0])
+              tenj_segment(sc[k0], sc[k0 + 1], w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
           }
           j += 2;
         }
@@ -579,35 +644,92 @@ struct Engine {
     GSYNC();
   }
 
-  // ----------------------------------------------------- A5 velocity stage + bias
+  // ------------------------------------------------------------- A7 joint-limit rows (one per lane)
+  __device__ __forceinline__ void impedance(const float* si, const float* sr, float x, float diagApprox, float vel,
+                                            float& D, float& aref) const {
+    float dmin = clampf(si[0], 0.0001f, 0.9999f), dmax = clampf(si[1], 0.0001f, 0.9999f);
+    float width = fmaxf(0.f, si[2]), mid = clampf(si[3], 0.0001f, 0.9999f), power = fmaxf(1.f, si[4]);
+    float imp;
+    if (width < MINVALF || dmin == dmax) imp = 0.5f * (dmin + dmax);
+    else {
+      float xa = fabsf(x) / width, y;
+      if (xa >= 1.f) imp = dmax;
+      else if (xa == 0.f) imp = dmin;
+      else {
+        if (power == 1.f) y = xa;
+        else if (power == 2.f) y = xa <= mid ? xa * xa / mid : 1.f - (1.f - xa) * (1.f - xa) / (1.f - mid);
+        else if (xa <= mid) y = powf(xa, power) / powf(mid, power - 1.f);
+        else y = 1.f - powf(1.f - xa, power) / powf(1.f - mid, power - 1.f);
+        imp = dmin + y * (dmax - dmin);
+      }
+    }
+    float R = fmaxf(MINVALF, (1.f - imp) * diagApprox / imp);
+    float K, B;
+    if (sr[0] > 0.f) {
+      float tc = fmaxf(sr[0], 2.f * a.d.timestep), dr = sr[1];
+      K = 1.f / fmaxf(MINVALF, dmax * dmax * tc * tc * dr * dr);
+      B = 2.f / fmaxf(MINVALF, dmax * tc);
+    } else { K = -sr[0] / fmaxf(MINVALF, dmax * dmax); B = -sr[1] / fmaxf(MINVALF, dmax); }
+    D = 1.f / R;
+    aref = -B * vel - K * imp * x;
+  }
+
+  __device__ __forceinline__ void make_constraint() {
+    const Layout& L = a.L;
+    const int side = g >= G / 2 ? 1 : 0;
+    const int j = side ? g - G / 2 : g;
+    r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = side ? -1.f : 1.f;
+    if (j < a.d.njnt) {
+      int type = MI_(JNT_TYPE)[j];
+      if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+        r_dof = MI_(JNT_DOFADR)[j];
+        float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
+        float margin = MF_(JNT_MARGIN)[j];
+        float dist = side == 0 ? q - MF_(JNT_RANGE)[2 * j] : MF_(JNT_RANGE)[2 * j + 1] - q;
+        if (dist < margin) {
+          r_active = true;
+          impedance(MF_(JNT_SOLIMP) + 5 * j, MF_(JNT_SOLREF) + 2 * j, dist - margin, MF_(DOF_INVWEIGHT0)[r_dof],
+                    r_sign * W[L.qvel + r_dof], r_D, r_aref);
+        }
+      }
+    }
+    nefc = (int)(gsum<G>(r_active ? 1.f : 0.f) + 0.5f);
+  }
+
+  // sum over the (up to two) limit rows of the joint that owns dof g of  sign^p * val  (p = 1 or 2)
+  __device__ __forceinline__ float rows_to_dof(float val) const {
+    int j = g < a.d.nv ? MI_(DOF_JNTID)[g] : 0;
+    float lo = sh<G>(val, j), hi = sh<G>(val, j + G / 2);
+    bool mine = g < a.d.nv && j < G / 2 && MI_(JNT_DOFADR)[j] == g;
+    return mine ? lo + hi : 0.f;
+  }
+
+  // ----------------------------------------------------- A5 velocity stage + bias forces
   __device__ __forceinline__ void velocity_bias() {
     const Layout& L = a.L;
-    // tendon and actuator velocities
+    const int nb = a.d.nbody;
     for (int t = g; t < a.d.ntendon; t += G) {
       float s = 0.f;
       for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) s += W[L.tenj + e] * W[L.qvel + MI_(TENJ_DOF)[e]];
       W[L.tenvel + t] = s;
     }
-    if (g == 0) {
-      for (int k = 0; k < 6; k++) W[L.cvel + k] = 0.f;
-      W[L.cacc] = 0.f; W[L.cacc + 1] = 0.f; W[L.cacc + 2] = 0.f;
-      W[L.cacc + 3] = -a.d.gx; W[L.cacc + 4] = -a.d.gy; W[L.cacc + 5] = -a.d.gz;
-    }
-    GSYNC();
-    const int* lv_adr = MI_(LEVEL_ADR); const int* lv_body = MI_(LEVEL_BODY);
-    const int* parent = MI_(BODY_PARENT);
-    // forward pass: cvel, cdof_dot, cacc, then cfrc_body (stored over cacc)
-    for (int lv = 0; lv < a.d.nlevel; lv++) {
-      for (int idx = lv_adr[lv] + g; idx < lv_adr[lv + 1]; idx += G) {
-        int b = lv_body[idx], p = parent[b];
-        float cv[6], ca[6];
-        for (int k = 0; k < 6; k++) { cv[k] = W[L.cvel + 6 * p + k]; ca[k] = W[L.cacc + 6 * p + k]; }
-        int ja = MI_(BODY_JNTADR)[b], jn = MI_(BODY_JNTNUM)[b];
+    // forward pass over tree levels; parent values come straight from the parent's lane
+    float cv[6], ca[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cv[k] = 0.f; ca[k] = 0.f; }
+    if (g == 0) { ca[3] = -a.d.gx; ca[4] = -a.d.gy; ca[5] = -a.d.gz; }
+    for (int lv = 1; lv <= a.d.nlevel; lv++) {
+      float pv[6], pa[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { pv[k] = sh<G>(cv[k], b_parent); pa[k] = sh<G>(ca[k], b_parent); }
+      if (b_depth == lv) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cv[k] = pv[k]; ca[k] = pa[k]; }
+        int ja = MI_(BODY_JNTADR)[g], jn = MI_(BODY_JNTNUM)[g];
         for (int j = ja; j < ja + jn; j++) {
           int type = MI_(JNT_TYPE)[j], da = MI_(JNT_DOFADR)[j];
           if (type == MM_JNT_FREE) {
             for (int d3 = 0; d3 < 3; d3++) {
-              for (int k = 0; k < 6; k++) W[L.cdofdot + 6 * (da + d3) + k] = 0.f;
               float qv = W[L.qvel + da + d3];
               for (int k = 0; k < 6; k++) cv[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
             }
@@ -615,163 +737,160 @@ struct Engine {
             type = MM_JNT_BALL;
           }
           int nd = type == MM_JNT_BALL ? 3 : 1;
-          float cd[3][6], cdd[3][6];
+          float base[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) base[k] = cv[k];
           for (int d3 = 0; d3 < nd; d3++) {
-            for (int k = 0; k < 6; k++) cd[d3][k] = W[L.cdof + 6 * (da + d3) + k];
-            cross_motion(cdd[d3], cv, cd[d3]);
-            for (int k = 0; k < 6; k++) W[L.cdofdot + 6 * (da + d3) + k] = cdd[d3][k];
-          }
-          for (int d3 = 0; d3 < nd; d3++) {
+            float cd[6], cdd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cd[k] = W[L.cdof + 6 * (da + d3) + k];
+            cross_motion(cdd, base, cd);
             float qv = W[L.qvel + da + d3];
-            for (int k = 0; k < 6; k++) { cv[k] += cd[d3][k] * qv; ca[k] += cdd[d3][k] * qv; }
+#pragma unroll
+            for (int k = 0; k < 6; k++) { cv[k] += cd[k] * qv; ca[k] += cdd[k] * qv; }
           }
         }
-        for (int k = 0; k < 6; k++) { W[L.cvel + 6 * b + k] = cv[k]; W[L.cacc + 6 * b + k] = ca[k]; }
       }
-      GSYNC();
     }
-    // cfrc_body = I*cacc + cvel x* (I*cvel), in place over cacc (children only read parents' cacc above)
-    for (int b = 1 + g; b < a.d.nbody; b += G) {
-      float I[10], cv[6], ca[6], Ia[6], Iv[6], x[6];
-      for (int k = 0; k < 10; k++) I[k] = W[L.cinert + 10 * b + k];
-      for (int k = 0; k < 6; k++) { cv[k] = W[L.cvel + 6 * b + k]; ca[k] = W[L.cacc + 6 * b + k]; }
-      inert_mul(Ia, I, ca); inert_mul(Iv, I, cv); cross_force(x, cv, Iv);
-      for (int k = 0; k < 6; k++) W[L.cacc + 6 * b + k] = Ia[k] + x[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) b_cvel[k] = cv[k];
+    // cfrc_body = I*cacc + cvel x* (I*cvel)
+    float cf[6];
+    {
+      float Ia[6], Iv[6], x[6];
+      inert_mul(Ia, b_cinert, ca); inert_mul(Iv, b_cinert, cv); cross_force(x, cv, Iv);
+#pragma unroll
+      for (int k = 0; k < 6; k++) cf[k] = (g > 0 && g < nb) ? Ia[k] + x[k] : 0.f;
     }
-    if (g == 0) for (int k = 0; k < 6; k++) W[L.cacc + k] = 0.f;
+    // backward accumulation through LDS (u1 region now holds cfrc[6*nbody]); deepest level first
     GSYNC();
-    // backward accumulation (children -> parent), level by level, gather form
-    for (int lv = a.d.nlevel - 1; lv >= 1; lv--) {
-      for (int idx = lv_adr[lv - 1] + g; idx < lv_adr[lv]; idx += G) {
-        int p = lv_body[idx];
-        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        bool any = false;
-        for (int c = lv_adr[lv]; c < lv_adr[lv + 1]; c++) {
-          int b = lv_body[c];
-          if (parent[b] == p) { any = true; for (int k = 0; k < 6; k++) acc[k] += W[L.cacc + 6 * b + k]; }
+    if (g < nb)
+#pragma unroll
+      for (int k = 0; k < 6; k++) W[L.u1 + 6 * g + k] = 0.f;
+    GSYNC();
+    for (int lv = a.d.nlevel; lv >= 1; lv--) {
+      if (b_depth == lv) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          float tot = cf[k] + W[L.u1 + 6 * g + k];
+          W[L.u1 + 6 * g + k] = tot;
+          if (b_parent > 0) atomicAdd(&W[L.u1 + 6 * b_parent + k], tot);
         }
-        if (any) for (int k = 0; k < 6; k++) W[L.cacc + 6 * p + k] += acc[k];
       }
       GSYNC();
     }
-    for (int i = g; i < a.d.nv; i += G) {
-      int b = MI_(DOF_BODYID)[i];
-      float s = 0.f;
-      for (int k = 0; k < 6; k++) s += W[L.cdof + 6 * i + k] * W[L.cacc + 6 * b + k];
-      W[L.bias + i] = s;
+    d_bias = 0.f;
+    if (g < a.d.nv) {
+      int b = MI_(DOF_BODYID)[g];
+#pragma unroll
+      for (int k = 0; k < 6; k++) d_bias += d_cdof[k] * W[L.u1 + 6 * b + k];
     }
     GSYNC();
   }
 
-  // ---------------------------------------------------------------- A4 CRB + factor
+  // ---------------------------------------------------------------- A4 CRB -> dense M rows
   __device__ __forceinline__ void crb() {
     const Layout& L = a.L;
-    const int* lv_adr = MI_(LEVEL_ADR); const int* lv_body = MI_(LEVEL_BODY);
-    const int* parent = MI_(BODY_PARENT);
-    // composite inertias accumulate IN PLACE over cinert (velocity stage already consumed it)
-    for (int lv = a.d.nlevel - 1; lv >= 1; lv--) {
-      for (int idx = lv_adr[lv - 1] + g; idx < lv_adr[lv]; idx += G) {
-        int p = lv_body[idx];
-        float acc[10];
-        for (int k = 0; k < 10; k++) acc[k] = 0.f;
-        bool any = false;
-        for (int c = lv_adr[lv]; c < lv_adr[lv + 1]; c++) {
-          int b = lv_body[c];
-          if (parent[b] == p) { any = true; for (int k = 0; k < 10; k++) acc[k] += W[L.cinert + 10 * b + k]; }
-        }
-        if (any) for (int k = 0; k < 10; k++) W[L.cinert + 10 * p + k] += acc[k];
-      }
+    const int nb = a.d.nbody, nv = a.d.nv;
+    if (g < nb)
+#pragma unroll
+      for (int k = 0; k < 10; k++) W[L.crb + 10 * g + k] = b_cinert[k];
+    // zero the dense tile (u1 region; cfrc is dead now) and put 1 on the padded diagonal
+    for (int e = g; e < NVP * NVP; e += G) W[L.u1 + e] = 0.f;
+    GSYNC();
+    for (int lv = a.d.nlevel; lv >= 2; lv--) {
+      if (b_depth == lv && b_parent > 0)
+#pragma unroll
+        for (int k = 0; k < 10; k++) atomicAdd(&W[L.crb + 10 * b_parent + k], W[L.crb + 10 * g + k]);
       GSYNC();
     }
-    const int *dpar = MI_(DOF_PARENTID), *madr = MI_(DOF_MADR);
-    for (int i = g; i < a.d.nv; i += G) {
-      float I[10], cd[6], buf[6];
-      int b = MI_(DOF_BODYID)[i];
-      for (int k = 0; k < 10; k++) I[k] = W[L.cinert + 10 * b + k];
-      for (int k = 0; k < 6; k++) cd[k] = W[L.cdof + 6 * i + k];
-      inert_mul(buf, I, cd);
-      int adr = madr[i], j = i;
-      bool first = true;
+    if (g < nv) {
+      float I[10], buf[6];
+      int b = MI_(DOF_BODYID)[g];
+#pragma unroll
+      for (int k = 0; k < 10; k++) I[k] = W[L.crb + 10 * b + k];
+      inert_mul(buf, I, d_cdof);
+      const int* dpar = MI_(DOF_PARENTID);
+      int j = g;
       while (j >= 0) {
         float s = 0.f;
+#pragma unroll
         for (int k = 0; k < 6; k++) s += W[L.cdof + 6 * j + k] * buf[k];
-        if (first) { s += MF_(DOF_ARMATURE)[i]; first = false; }
-        W[L.qM + adr] = s;
-        adr++;
+        if (j == g) s += MF_(DOF_ARMATURE)[g];
+        W[L.u1 + g * NVP + j] = s;
+        W[L.u1 + j * NVP + g] = s;
         j = dpar[j];
       }
+    } else if (g < NVP) {
+      W[L.u1 + g * NVP + g] = 1.f;
+    }
+    GSYNC();
+    if (g < NVP) {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) Mrow[k] = W[L.u1 + g * NVP + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) Mrow[k] = 0.f;
     }
     GSYNC();
   }
 
-  // in-place sparse L'DL of the matrix stored at W[off..] (M layout); dinv at W[doff..]
-  __device__ __forceinline__ void factor(int off, int doff) {
-    const int *madr = MI_(DOF_MADR), *ndesc = AUXI(dof_ndesc), *depth = AUXI(dof_depth);
-    const int *dl_adr = MI_(DOF_LEVEL_ADR), *dl_dof = MI_(DOF_LEVEL_DOF);
-    for (int lv = a.d.ndoflevel - 1; lv >= 0; lv--) {
-      for (int idx = dl_adr[lv] + g; idx < dl_adr[lv + 1]; idx += G) {
-        int i = dl_dof[idx], di = depth[i], ai = madr[i];
-        for (int k = i + 1; k <= i + ndesc[i]; k++) {
-          int ak = madr[k], dk = depth[k] - di;
-          float t = W[off + ak + dk] * W[off + ak];  // L(k,i) * D_k
-          for (int c = 0; c <= di; c++) W[off + ai + c] -= t * W[off + ak + dk + c];
-        }
-        float D = W[off + ai];
-        if (D < MINVALF) D = MINVALF;
-        float inv = 1.f / D;
-        W[doff + i] = inv;
-        for (int c = 1; c <= di; c++) W[off + ai + c] *= inv;
-      }
-      GSYNC();
-    }
-  }
-
-  // x <- (L'DL)^-1 x, x at W[xoff..]
-  __device__ __forceinline__ void solve(int off, int doff, int xoff) {
-    const int *madr = MI_(DOF_MADR), *ndesc = AUXI(dof_ndesc), *depth = AUXI(dof_depth), *dpar = MI_(DOF_PARENTID);
-    const int *dl_adr = MI_(DOF_LEVEL_ADR), *dl_dof = MI_(DOF_LEVEL_DOF);
-    for (int lv = a.d.ndoflevel - 2; lv >= 0; lv--) {
-      for (int idx = dl_adr[lv] + g; idx < dl_adr[lv + 1]; idx += G) {
-        int j = dl_dof[idx], dj = depth[j];
-        float s = W[xoff + j];
-        for (int k = j + 1; k <= j + ndesc[j]; k++) s -= W[off + madr[k] + depth[k] - dj] * W[xoff + k];
-        W[xoff + j] = s;
-      }
-      GSYNC();
-    }
-    for (int i = g; i < a.d.nv; i += G) W[xoff + i] *= W[doff + i];
-    GSYNC();
-    for (int lv = 1; lv < a.d.ndoflevel; lv++) {
-      for (int idx = dl_adr[lv] + g; idx < dl_adr[lv + 1]; idx += G) {
-        int i = dl_dof[idx];
-        float s = W[xoff + i];
-        int j = dpar[i], c = 1;
-        while (j >= 0) { s -= W[off + madr[i] + c] * W[xoff + j]; j = dpar[j]; c++; }
-        W[xoff + i] = s;
-      }
-      GSYNC();
-    }
-  }
-
-  // y = M x
-  __device__ __forceinline__ void mul_m(int yoff, int xoff) {
-    const int *madr = MI_(DOF_MADR), *ndesc = AUXI(dof_ndesc), *depth = AUXI(dof_depth), *dpar = MI_(DOF_PARENTID);
+  // dense Cholesky H = L L' with lane i holding row i; `dadd` is added to this lane's diagonal element.
+  // Leaves Lrow (L[g][k]), d_dinv (1/L[g][g]) and LTrow (L[k][g]) in registers.
+  __device__ __forceinline__ void factor(float dadd) {
     const Layout& L = a.L;
-    for (int i = g; i < a.d.nv; i += G) {
-      float s = 0.f;
-      int j = i, c = 0;
-      while (j >= 0) { s += W[L.qM + madr[i] + c] * W[xoff + j]; j = dpar[j]; c++; }
-      int di = depth[i];
-      for (int k = i + 1; k <= i + ndesc[i]; k++) s += W[L.qM + madr[k] + depth[k] - di] * W[xoff + k];
-      W[yoff + i] = s;
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      float s = Mrow[j] + (j == g ? dadd : 0.f);
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= Lrow[k] * bc<G>(Lrow[k], j);
+      float piv = bc<G>(s, j);
+      float inv = 1.f / sqrtf(fmaxf(piv, MINVALF));
+      Lrow[j] = (g >= j) ? s * inv : 0.f;
+      if (g == j) d_dinv = inv;
+    }
+    // transpose through the dense LDS tile
+    if (g < NVP)
+#pragma unroll
+      for (int k = 0; k < NVP; k++) W[L.u1 + g * NVP + k] = Lrow[k];
+    GSYNC();
+    if (g < NVP) {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) LTrow[k] = W[L.u1 + k * NVP + g];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) LTrow[k] = 0.f;
+      d_dinv = 1.f;
     }
     GSYNC();
+  }
+
+  // x <- (L L')^-1 x ; lane i holds x_i
+  __device__ __forceinline__ float solve(float x) const {
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      float yj = bc<G>(x * d_dinv, j);
+      x = (g == j) ? yj : (g > j ? x - Lrow[j] * yj : x);
+    }
+#pragma unroll
+    for (int i = NVP - 1; i >= 0; i--) {
+      float zi = bc<G>(x * d_dinv, i);
+      x = (g == i) ? zi : (g < i ? x - LTrow[i] * zi : x);
+    }
+    return x;
+  }
+
+  // y_i = sum_j M[i][j] x_j
+  __device__ __forceinline__ float mul_m(float x) const {
+    float y = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVP; j++) y += Mrow[j] * bc<G>(x, j);
+    return y;
   }
 
   // ------------------------------------------- A5/A6 passive + actuation -> qfrc_smooth
   __device__ __forceinline__ void passive_actuation() {
     const Layout& L = a.L;
-    // tendon-level forces: spring/damper + actuators on tendon transmissions
     for (int t = g; t < a.d.ntendon; t += G) {
       float k = MF_(TENDON_STIFFNESS)[t], bd = MF_(TENDON_DAMPING)[t], f = 0.f;
       if (k != 0.f || bd != 0.f) {
@@ -782,7 +901,7 @@ struct Engine {
       }
       W[L.tenfrc + t] = f;
     }
-    for (int i = g; i < a.d.nv; i += G) W[L.tmp + i] = 0.f;  // joint-transmission actuator forces
+    if (g < a.d.nv) W[L.vec + g] = 0.f;
     GSYNC();
     for (int u = g; u < a.d.nu; u += G) {
       float ctrl = W[L.ctrl + u];
@@ -806,249 +925,105 @@ struct Engine {
       if (MI_(ACT_FORCELIMITED)[u]) f = clampf(f, MF_(ACT_FORCERANGE)[2 * u], MF_(ACT_FORCERANGE)[2 * u + 1]);
       W[L.actfrc + u] = f; W[L.actlen + u] = len; W[L.actvel + u] = vel;
       if (ten) atomicAdd(&W[L.tenfrc + id], gear * f);
-      else atomicAdd(&W[L.tmp + MI_(JNT_DOFADR)[id]], gear * f);
+      else atomicAdd(&W[L.vec + MI_(JNT_DOFADR)[id]], gear * f);
     }
     GSYNC();
-    // qfrc_smooth = passive - bias + actuator  (tendon part gathered through the transposed J)
-    const int *ja = AUXI(dofj_adr), *je = AUXI(dofj_entry), *jt = AUXI(dofj_tendon);
-    for (int i = g; i < a.d.nv; i += G) {
-      float s = -MF_(DOF_DAMPING)[i] * W[L.qvel + i] - W[L.bias + i] + W[L.tmp + i];
-      int j = MI_(DOF_JNTID)[i];
+    d_smooth = 0.f;
+    if (g < a.d.nv) {
+      const int *ja = AUXI(dofj_adr), *je = AUXI(dofj_entry), *jt = AUXI(dofj_tendon);
+      float s = -MF_(DOF_DAMPING)[g] * d_qvel - d_bias + W[L.vec + g];
+      int j = MI_(DOF_JNTID)[g];
       float ks = MF_(JNT_STIFFNESS)[j];
       int type = MI_(JNT_TYPE)[j];
       if (ks != 0.f && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
         int qa = MI_(JNT_QPOSADR)[j];
         s -= ks * (W[L.qpos + qa] - MF_(QPOS_SPRING)[qa]);
       }
-      for (int e = ja[i]; e < ja[i + 1]; e++) s += W[L.tenj + je[e]] * W[L.tenfrc + jt[e]];
-      W[L.smooth + i] = s;
-      W[L.qaccsm + i] = s;
+      for (int e = ja[g]; e < ja[g + 1]; e++) s += W[L.tenj + je[e]] * W[L.tenfrc + jt[e]];
+      d_smooth = s;
     }
-    GSYNC();
   }
 
-  // ------------------------------------------------------------- A7 constraint rows
-  // row kinds: bits 0-7 type, bit 8 = upper side.  Only rows with a single non-zero of
-  // the Jacobian (joint limits) are supported by the sparse Newton path of this engine.
-  __device__ __forceinline__ void make_constraint() {
-    const Layout& L = a.L;
-    int n = 0;
-    int nitem = 2 * a.d.njnt;
-    for (int base = 0; base < nitem; base += G) {
-      int it = base + g;
-      bool on = false;
-      float dist = 0.f, margin = 0.f;
-      int j = it >> 1, side = it & 1;
-      if (it < nitem) {
-        int type = MI_(JNT_TYPE)[j];
-        if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
-          float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
-          margin = MF_(JNT_MARGIN)[j];
-          dist = side == 0 ? q - MF_(JNT_RANGE)[2 * j] : MF_(JNT_RANGE)[2 * j + 1] - q;
-          on = dist < margin;
-        }
-      }
-      unsigned long long m = __ballot(on);
-      int lane = threadIdx.x & 63;
-      int gbase = lane - g;
-      unsigned long long gm = (m >> gbase) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
-      int before = __popcll(gm & ((1ull << g) - 1ull));
-      int cnt = __popcll(gm);
-      if (on) {
-        int r = n + before;
-        if (r < a.d.njmax) {
-          // impedance / reference (solref, solimp) -- MuJoCo constraint model
-          const float* si = MF_(JNT_SOLIMP) + 5 * j; const float* sr = MF_(JNT_SOLREF) + 2 * j;
-          int dof = MI_(JNT_DOFADR)[j];
-          float x = dist - margin;
-          float D, aref;
-          float Jv = (side == 0 ? 1.f : -1.f) * W[L.qvel + dof];
-          impedance(si, sr, x, MF_(DOF_INVWEIGHT0)[dof], Jv, D, aref);
-          W[L.efc_kind + r] = __int_as_float(MM_CON_LIMIT_JOINT | (side << 8));
-          W[L.efc_id + r] = __int_as_float(dof);
-          W[L.efc_pos + r] = x;
-          W[L.efc_D + r] = D;
-          W[L.efc_aref + r] = aref;
-        }
-      }
-      n += cnt;
-    }
-    if (n > a.d.njmax) { n = a.d.njmax; status |= 2; }
-    nefc = n;
-    GSYNC();
+  // ---------------------------------------------------------------- Newton solver (A7)
+  // total cost of candidate x (dof lanes) given Ma = M x; also latches r_jar
+  __device__ __forceinline__ float cost_of(float x, float Ma) {
+    float c = 0.5f * (x - d_qaccsm) * (Ma - d_smooth);
+    float xr = sh<G>(x, r_dof);
+    r_jar = r_sign * xr - r_aref;
+    if (r_active && r_jar < 0.f) c += 0.5f * r_D * r_jar * r_jar;
+    return gsum<G>(c);
   }
 
-  __device__ __forceinline__ void impedance(const float* si, const float* sr, float x, float diagApprox, float vel,
-                                            float& D, float& aref) const {
-    float dmin = clampf(si[0], 0.0001f, 0.9999f), dmax = clampf(si[1], 0.0001f, 0.9999f);
-    float width = fmaxf(0.f, si[2]), mid = clampf(si[3], 0.0001f, 0.9999f), power = fmaxf(1.f, si[4]);
-    float imp;
-    if (width < MINVALF || dmin == dmax) imp = 0.5f * (dmin + dmax);
-    else {
-      float xa = fabsf(x) / width, y;
-      if (xa >= 1.f) imp = dmax;
-      else if (xa == 0.f) imp = dmin;
-      else {
-        if (power == 1.f) y = xa;
-        else if (xa <= mid) y = powf(xa, power) / powf(mid, power - 1.f);
-        else y = 1.f - powf(1.f - xa, power) / powf(1.f - mid, power - 1.f);
-        imp = dmin + y * (dmax - dmin);
-      }
-    }
-    float R = fmaxf(MINVALF, (1.f - imp) * diagApprox / imp);
-    float K, B;
-    if (sr[0] > 0.f) {
-      float tc = fmaxf(sr[0], 2.f * a.d.timestep), dr = sr[1];
-      K = 1.f / fmaxf(MINVALF, dmax * dmax * tc * tc * dr * dr);
-      B = 2.f / fmaxf(MINVALF, dmax * tc);
-    } else { K = -sr[0] / fmaxf(MINVALF, dmax * dmax); B = -sr[1] / fmaxf(MINVALF, dmax); }
-    D = 1.f / R;
-    aref = -B * vel - K * imp * x;
-  }
-
-  // J_r . x for the sparse row kinds
-  __device__ __forceinline__ float row_dot(int r, int xoff) const {
-    int kind = __float_as_int(W[a.L.efc_kind + r]), dof = __float_as_int(W[a.L.efc_id + r]);
-    float sgn = (kind >> 8) & 1 ? -1.f : 1.f;
-    return sgn * W[xoff + dof];
-  }
-
-  // constraint cost + jar for the vector at xoff (collective); returns total cost
-  __device__ __forceinline__ float eval_cost(int xoff, bool write_jar) {
-    const Layout& L = a.L;
-    mul_m(L.Ma, xoff);
-    float gs = 0.f;
-    for (int i = g; i < a.d.nv; i += G) gs += (W[xoff + i] - W[L.qaccsm + i]) * (W[L.Ma + i] - W[L.smooth + i]);
-    float c = 0.5f * gs;
-    for (int r = g; r < nefc; r += G) {
-      float jar = row_dot(r, xoff) - W[L.efc_aref + r];
-      if (write_jar) W[L.efc_jar + r] = jar;
-      if (jar < 0.f) c += 0.5f * W[L.efc_D + r] * jar * jar;
-    }
-    c = gsum<G>(c);
-    GSYNC();
-    return c;
-  }
-
-  struct LsP { float cost, d1, d2; };
-  __device__ __forceinline__ LsP ls_eval(float alpha, float q0, float q1, float q2) const {
-    const Layout& L = a.L;
-    float c = 0.f, d1 = 0.f, d2 = 0.f;
-    for (int r = g; r < nefc; r += G) {
-      float jv = W[L.efc_jv + r];
-      float x = W[L.efc_jar + r] + alpha * jv;
-      if (x < 0.f) {
-        float D = W[L.efc_D + r];
-        c += 0.5f * D * x * x; d1 += D * x * jv; d2 += D * jv * jv;
-      }
-    }
-    LsP p;
-    p.cost = gsum<G>(c) + q0 + alpha * (q1 + alpha * q2);
-    p.d1 = gsum<G>(d1) + q1 + 2.f * alpha * q2;
-    p.d2 = gsum<G>(d2) + 2.f * q2;
-    return p;
-  }
-
-  __device__ __forceinline__ void update_forces() {
-    const Layout& L = a.L;
-    for (int i = g; i < a.d.nv; i += G) W[L.qfrccon + i] = 0.f;
-    GSYNC();
-    for (int r = g; r < nefc; r += G) {
-      float jar = W[L.efc_jar + r];
-      float f = jar < 0.f ? -W[L.efc_D + r] * jar : 0.f;
-      W[L.efc_frc + r] = f;
-      if (f != 0.f) {
-        int kind = __float_as_int(W[L.efc_kind + r]), dof = __float_as_int(W[L.efc_id + r]);
-        atomicAdd(&W[L.qfrccon + dof], ((kind >> 8) & 1 ? -1.f : 1.f) * f);
-      }
-    }
-    GSYNC();
-  }
-
-  // Newton solver (primal) with exact line search; mirrors oracle/mmo_engine.c mmo_solve
   __device__ __forceinline__ void solve_constraints() {
-    const Layout& L = a.L;
     const int nv = a.d.nv;
     niter = 0;
-    if (nefc == 0) {
-      for (int i = g; i < nv; i += G) { W[L.qacc + i] = W[L.qaccsm + i]; W[L.qfrccon + i] = 0.f; }
-      GSYNC();
-      return;
-    }
-    float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
+    d_qfrccon = 0.f;
+    if (nefc == 0) { d_qacc = d_qaccsm; return; }
+    const float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
     // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
-    float cost = 0.f, cost_ws = 0.f;
-    for (int pass = 0; pass < 3; pass++) {
-      int xoff = pass == 0 ? L.warm : (pass == 1 ? L.qaccsm : L.qacc);
-      float c = eval_cost(xoff, pass == 2);
-      if (pass == 0) cost_ws = c;
-      else if (pass == 1) {
-        int src = cost_ws < c ? L.warm : L.qaccsm;
-        for (int i = g; i < nv; i += G) W[L.qacc + i] = W[src + i];
-        GSYNC();
-      } else cost = c;
-    }
-    const int* madr = MI_(DOF_MADR);
+    float Ma_ws = mul_m(d_warm);
+    float cost_ws = cost_of(d_warm, Ma_ws);
+    float cost_sm = cost_of(d_qaccsm, d_smooth);
+    float Ma;
+    if (cost_ws < cost_sm) { d_qacc = d_warm; Ma = Ma_ws; (void)cost_of(d_qacc, Ma); }
+    else { d_qacc = d_qaccsm; Ma = d_smooth; }
+    // Termination in fp32: the cost (hundreds) carries ~1e-5 of rounding noise, far above MuJoCo's scaled
+    // tolerance, so "improvement < tol" would stop with a residual gradient.  The cost is piecewise quadratic:
+    // a FULL Newton step (alpha = 1) that leaves the active set unchanged lands on the exact minimiser, which is
+    // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
+    float alpha_prev = 0.f;
+    unsigned long long set_prev = 0ull;
     for (int iter = 0; iter < a.d.iterations; iter++) {
-      update_forces();
-      float gn = 0.f;
-      for (int i = g; i < nv; i += G) {
-        float gr = W[L.Ma + i] - W[L.smooth + i] - W[L.qfrccon + i];
-        W[L.grad + i] = gr; W[L.search + i] = gr;
-        gn += gr * gr;
-      }
-      gn = sqrtf(gsum<G>(gn));
-      GSYNC();
+      const bool on = r_active && r_jar < 0.f;
+      const unsigned long long set_now = __ballot(on);
+      float f = on ? -r_D * r_jar : 0.f;
+      d_qfrccon = rows_to_dof(r_sign * f);
+      float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
+      float gn = sqrtf(gsum<G>(grad * grad));
       if (scale * gn < a.d.tolerance) break;
-      // H = M + sum_active D e_dof e_dof'   (tree sparsity preserved)
-      for (int k = g; k < a.d.nM; k += G) W[L.qH + k] = W[L.qM + k];
-      GSYNC();
-      for (int r = g; r < nefc; r += G)
-        if (W[L.efc_jar + r] < 0.f) atomicAdd(&W[L.qH + madr[__float_as_int(W[L.efc_id + r])]], W[L.efc_D + r]);
-      GSYNC();
-      factor(L.qH, L.hdinv);
-      solve(L.qH, L.hdinv, L.search);
-      float sn = 0.f;
-      for (int i = g; i < nv; i += G) { float s = -W[L.search + i]; W[L.search + i] = s; sn += s * s; }
-      sn = sqrtf(gsum<G>(sn));
-      GSYNC();
-      if (sn < MINVALF) break;
-      mul_m(L.Mv, L.search);
-      for (int r = g; r < nefc; r += G) W[L.efc_jv + r] = row_dot(r, L.search);
-      float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-      for (int i = g; i < nv; i += G) {
-        float dm = W[L.Ma + i] - W[L.smooth + i], s = W[L.search + i];
-        q0 += 0.5f * (W[L.qacc + i] - W[L.qaccsm + i]) * dm;
-        q1 += s * dm;
-        q2 += 0.5f * s * W[L.Mv + i];
+      if (iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
+        // compare the active sets of THIS group only
+        const int lane = threadIdx.x & 63;
+        const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
+        if (((set_now ^ set_prev) & gm) == 0ull) break;
       }
-      q0 = gsum<G>(q0); q1 = gsum<G>(q1); q2 = gsum<G>(q2);
-      GSYNC();
-      float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
-      float alpha = 0.f, lo = 0.f, hi = -1.f;
-      LsP p = ls_eval(0.f, q0, q1, q2);
-      float best_alpha = 0.f, best_cost = p.cost;
+      set_prev = set_now;
+      float dadd = rows_to_dof(on ? r_D : 0.f);
+      factor(dadd);
+      float search = -solve(grad);
+      if (g >= nv) search = 0.f;
+      float sn = sqrtf(gsum<G>(search * search));
+      if (sn < MINVALF) break;
+      float Mv = mul_m(search);
+      float jv = r_sign * sh<G>(search, r_dof);
+      float dm = Ma - d_smooth;
+      float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
+      const float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
+      // exact line search on the convex piecewise-quadratic phi(alpha): safeguarded Newton on phi'(alpha) = 0
+      float alpha = 1.f, lo = 0.f, hi = -1.f;
       for (int it = 0; it < a.d.ls_iterations; it++) {
-        if (fabsf(p.d1) < gtol) break;
-        if (p.d1 < 0.f) lo = alpha; else hi = alpha;
-        float next = alpha - p.d1 / fmaxf(p.d2, MINVALF);
+        float x = r_jar + alpha * jv;
+        float d1 = 0.f, d2 = 0.f;
+        if (r_active && x < 0.f) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
+        d1 = gsum<G>(d1) + q1 + 2.f * alpha * q2;
+        d2 = gsum<G>(d2) + 2.f * q2;
+        if (fabsf(d1) < fmaxf(gtol, 1e-6f * fabsf(q1))) break;
+        if (d1 < 0.f) lo = alpha; else hi = alpha;
+        float next = alpha - d1 / fmaxf(d2, MINVALF);
         if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
         else if (hi < 0.f && next <= lo) next = 2.f * lo + 1e-10f;
         if (next == alpha) break;
         alpha = next;
-        p = ls_eval(alpha, q0, q1, q2);
-        if (p.cost < best_cost) { best_cost = p.cost; best_alpha = alpha; }
       }
-      alpha = best_alpha;
-      if (alpha == 0.f) break;
-      for (int i = g; i < nv; i += G) { W[L.qacc + i] += alpha * W[L.search + i]; W[L.Ma + i] += alpha * W[L.Mv + i]; }
-      for (int r = g; r < nefc; r += G) W[L.efc_jar + r] += alpha * W[L.efc_jv + r];
-      GSYNC();
-      float old = cost;
-      cost = best_cost;
+      if (!(alpha > 0.f)) break;
+      d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
+      alpha_prev = alpha;
       niter = iter + 1;
-      if (scale * (old - cost) < a.d.tolerance) { update_forces(); break; }
-      if (iter == a.d.iterations - 1) { update_forces(); status |= 4; }
+      if (iter == a.d.iterations - 1) {
+        const bool on2 = r_active && r_jar < 0.f;
+        d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
+        status |= 4;
+      }
     }
   }
 
@@ -1066,13 +1041,9 @@ struct Engine {
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
-    unsigned long long t0 = a.prof ? clock64() : 0;
-    for (int k = g; k < a.d.nM; k += G) W[a.L.qLD + k] = W[a.L.qM + k];
-    GSYNC();
-    factor(a.L.qLD, a.L.dinv);
-    if (a.prof) pf[PF_FACTOR] += clock64() - t0;
+    PFT(PF_FACTOR, factor(0.f));
     PFT(PF_ACT, passive_actuation());
-    PFT(PF_SOLVE0, solve(a.L.qLD, a.L.dinv, a.L.qaccsm));
+    PFT(PF_SOLVE0, d_qaccsm = solve(d_smooth));
     PFT(PF_NEWTON, solve_constraints());
   }
 
@@ -1080,16 +1051,17 @@ struct Engine {
     const Layout& L = a.L;
     int bad = 0;
     for (int i = g; i < a.d.nq; i += G) bad |= !(fabsf(W[L.qpos + i]) < 1e10f);
-    for (int i = g; i < a.d.nv; i += G) {
-      bad |= !(fabsf(W[L.qvel + i]) < 1e10f);
-      if (check_acc) bad |= !(fabsf(W[L.qacc + i]) < 1e10f);
+    if (g < a.d.nv) {
+      bad |= !(fabsf(d_qvel) < 1e10f);
+      if (check_acc) bad |= !(fabsf(d_qacc) < 1e10f);
     }
     return gor<G>(bad) != 0;
   }
   __device__ __forceinline__ void reset_data() {
     const Layout& L = a.L;
     for (int i = g; i < a.d.nq; i += G) W[L.qpos + i] = MF_(QPOS0)[i];
-    for (int i = g; i < a.d.nv; i += G) { W[L.qvel + i] = 0.f; W[L.warm + i] = 0.f; }
+    d_qvel = 0.f; d_warm = 0.f;
+    if (g < a.d.nv) W[L.qvel + g] = 0.f;
     for (int i = g; i < a.d.na; i += G) W[L.act + i] = 0.f;
     GSYNC();
   }
@@ -1098,20 +1070,11 @@ struct Engine {
   __device__ __forceinline__ void euler(float& time) {
     const Layout& L = a.L;
     const float h = a.d.timestep;
-    const int* madr = MI_(DOF_MADR);
-    int src = L.qacc;
-    for (int i = g; i < a.d.nv; i += G) W[L.warm + i] = W[L.qacc + i];
+    d_warm = d_qacc;
+    float qa_ = d_qacc;
     if (a.d.any_damping && a.d.eulerdamp) {
-      for (int k = g; k < a.d.nM; k += G) W[L.qH + k] = W[L.qM + k];
-      GSYNC();
-      for (int i = g; i < a.d.nv; i += G) {
-        W[L.qH + madr[i]] += h * MF_(DOF_DAMPING)[i];
-        W[L.tmp + i] = W[L.smooth + i] + W[L.qfrccon + i];
-      }
-      GSYNC();
-      factor(L.qH, L.hdinv);
-      solve(L.qH, L.hdinv, L.tmp);
-      src = L.tmp;
+      factor(g < a.d.nv ? h * MF_(DOF_DAMPING)[g] : 0.f);
+      qa_ = solve(g < a.d.nv ? d_smooth + d_qfrccon : 0.f);
     }
     for (int u = g; u < a.d.nu; u += G) {
       int aa = MI_(ACT_ACTADR)[u];
@@ -1120,7 +1083,10 @@ struct Engine {
       if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
       W[L.act + aa] = x;
     }
-    for (int i = g; i < a.d.nv; i += G) W[L.qvel + i] += h * W[src + i];
+    if (g < a.d.nv) {
+      d_qvel += h * qa_;
+      W[L.qvel + g] = d_qvel;
+    }
     GSYNC();
     for (int j = g; j < a.d.njnt; j += G) {
       int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j], da = MI_(JNT_DOFADR)[j];
@@ -1133,7 +1099,7 @@ struct Engine {
       float nw = sqrtf(dot(w, w)), ang = h * nw;
       if (ang > MINVALF) {
         float sn, cs;
-        sincosf(0.5f * ang, &sn, &cs);
+        sincos_small(0.5f * ang, &sn, &cs);
         float is = sn / nw;
         Q4 dq = {cs, w.x * is, w.y * is, w.z * is};
         Q4 qn = qnorm(qmul(ldq(W + L.qpos + qa), dq));
@@ -1165,8 +1131,8 @@ struct Engine {
 };
 
 // =========================================================================== kernels
-template <int G, bool LM>
-__global__ void __launch_bounds__(256) k_engine(KArgs a) {
+template <int G, int NVP, bool LM>
+__global__ void __launch_bounds__(512) k_engine(KArgs a) {
   extern __shared__ float lds[];
   constexpr int EPW = 64 / G;  // envs per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1191,13 +1157,14 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * a.L.total;
   const Layout& L = a.L;
   const Dims& d = a.d;
-  Engine<G> E(a, mb, W, g);
+  Engine<G, NVP> E(a, mb, W, g);
 
-  // ---- load state (HBM -> LDS)
+  // ---- load state (HBM -> LDS tables / owner registers)
   for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
-  for (int i = g; i < d.nv; i += G) {
-    W[L.qvel + i] = a.s.qvel[(size_t)e * d.nv + i];
-    W[L.warm + i] = a.s.qacc_warmstart[(size_t)e * d.nv + i];
+  if (g < d.nv) {
+    E.d_qvel = a.s.qvel[(size_t)e * d.nv + g];
+    E.d_warm = a.s.qacc_warmstart[(size_t)e * d.nv + g];
+    W[L.qvel + g] = E.d_qvel;
   }
   for (int i = g; i < d.na; i += G) W[L.act + i] = a.s.act[(size_t)e * d.na + i];
   float time = a.s.time[e];
@@ -1206,8 +1173,9 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
   // ---- action -> ctrl (BaseV0.step: base_v0.py:82-108)
   for (int u = g; u < d.nu; u += G) {
     float c = a.ctrl ? a.ctrl[(size_t)e * d.nu + u] : 0.f;
-    if (a.mode == 2 && t.normalize_act && MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
-    if (a.mode == 2 && t.fatigue && MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) {
+    const bool mus = MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE;
+    if (a.mode == 2 && t.normalize_act && mus) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
+    if (a.mode == 2 && t.fatigue && mus) {
       // 3CC-r muscle fatigue (fatigue.py:38-76), dt = timestep * frame_skip
       int aa = MI_(ACT_ACTADR)[u];
       size_t k = (size_t)e * d.na + aa;
@@ -1244,9 +1212,9 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
   // ---- store state (surplus groups never write)
   if (dup) return;
   for (int i = g; i < d.nq; i += G) a.s.qpos[(size_t)e * d.nq + i] = W[L.qpos + i];
-  for (int i = g; i < d.nv; i += G) {
-    a.s.qvel[(size_t)e * d.nv + i] = W[L.qvel + i];
-    a.s.qacc_warmstart[(size_t)e * d.nv + i] = W[L.warm + i];
+  if (g < d.nv) {
+    a.s.qvel[(size_t)e * d.nv + g] = E.d_qvel;
+    a.s.qacc_warmstart[(size_t)e * d.nv + g] = E.d_warm;
   }
   for (int i = g; i < d.na; i += G) a.s.act[(size_t)e * d.na + i] = W[L.act + i];
   if (g == 0) { a.s.time[e] = time; if (a.s.status) a.s.status[e] = E.status; }
@@ -1254,11 +1222,12 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
   // ---- derived outputs of the final forward
   if (fwd && a.has_derived) {
     const mm_derived& o = a.o;
-    if (o.xpos) for (int i = g; i < 3 * d.nbody; i += G) o.xpos[(size_t)e * 3 * d.nbody + i] = W[L.xpos + i];
-    if (o.xquat) for (int i = g; i < 4 * d.nbody; i += G) o.xquat[(size_t)e * 4 * d.nbody + i] = W[L.xquat + i];
-    if (o.xipos) for (int i = g; i < 3 * d.nbody; i += G) o.xipos[(size_t)e * 3 * d.nbody + i] = W[L.xipos + i];
-    if (o.cvel) for (int i = g; i < 6 * d.nbody; i += G) o.cvel[(size_t)e * 6 * d.nbody + i] = W[L.cvel + i];
-    if (o.subtree_com) for (int i = g; i < 3 * d.nbody; i += G) o.subtree_com[(size_t)e * 3 * d.nbody + i] = W[L.com + i];
+    const bool isb = g < d.nbody;
+    if (o.xpos && isb) st3(o.xpos + ((size_t)e * d.nbody + g) * 3, E.b_xpos);
+    if (o.xquat && isb) { float* q = o.xquat + ((size_t)e * d.nbody + g) * 4; q[0] = E.b_xquat.w; q[1] = E.b_xquat.x; q[2] = E.b_xquat.y; q[3] = E.b_xquat.z; }
+    if (o.xipos && isb) st3(o.xipos + ((size_t)e * d.nbody + g) * 3, E.b_xipos);
+    if (o.cvel && isb) for (int k = 0; k < 6; k++) o.cvel[((size_t)e * d.nbody + g) * 6 + k] = E.b_cvel[k];
+    if (o.subtree_com && isb) st3(o.subtree_com + ((size_t)e * d.nbody + g) * 3, ld3(W + L.com + 3 * AUXI(body_rootslot)[g]));
     if (o.site_xpos)
       for (int s = g; s < d.nsite; s += G) st3(o.site_xpos + ((size_t)e * d.nsite + s) * 3, E.site_pos(s));
     if (o.geom_xpos)
@@ -1266,14 +1235,36 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
     if (o.actuator_length) for (int i = g; i < d.nu; i += G) o.actuator_length[(size_t)e * d.nu + i] = W[L.actlen + i];
     if (o.actuator_velocity) for (int i = g; i < d.nu; i += G) o.actuator_velocity[(size_t)e * d.nu + i] = W[L.actvel + i];
     if (o.actuator_force) for (int i = g; i < d.nu; i += G) o.actuator_force[(size_t)e * d.nu + i] = W[L.actfrc + i];
-    if (o.qacc) for (int i = g; i < d.nv; i += G) o.qacc[(size_t)e * d.nv + i] = W[L.qacc + i];
+    if (o.qacc && g < d.nv) o.qacc[(size_t)e * d.nv + g] = E.d_qacc;
     if (o.ten_length) for (int i = g; i < d.ntendon; i += G) o.ten_length[(size_t)e * d.ntendon + i] = W[L.tenlen + i];
     if (g == 0 && o.nefc) o.nefc[e] = E.nefc;
     if (g == 0 && o.solver_niter) o.solver_niter[e] = E.niter;
   }
-  if (a.dbg) for (int i = g; i < L.total; i += G) a.dbg[(size_t)e * L.total + i] = W[i];
+  if (a.dbg) {  // tests only: owner registers and tables in a flat record
+    float* D = a.dbg + (size_t)e * a.D.total;
+    if (g < d.nbody) {
+      st3(D + a.D.xpos + 3 * g, E.b_xpos); st3(D + a.D.xipos + 3 * g, E.b_xipos);
+      D[a.D.xquat + 4 * g] = E.b_xquat.w; D[a.D.xquat + 4 * g + 1] = E.b_xquat.x;
+      D[a.D.xquat + 4 * g + 2] = E.b_xquat.y; D[a.D.xquat + 4 * g + 3] = E.b_xquat.z;
+      for (int k = 0; k < 6; k++) D[a.D.cvel + 6 * g + k] = E.b_cvel[k];
+    }
+    if (g < d.nv) {
+      for (int k = 0; k < 6; k++) D[a.D.cdof + 6 * g + k] = E.d_cdof[k];
+#pragma unroll
+      for (int k = 0; k < NVP; k++) if (k < d.nv) D[a.D.M + g * d.nv + k] = E.Mrow[k];
+      D[a.D.bias + g] = E.d_bias; D[a.D.smooth + g] = E.d_smooth; D[a.D.qaccsm + g] = E.d_qaccsm;
+      D[a.D.qacc + g] = E.d_qacc; D[a.D.qfrccon + g] = E.d_qfrccon;
+    }
+    for (int i = g; i < d.ntendon; i += G) { D[a.D.tenlen + i] = W[L.tenlen + i]; D[a.D.tenvel + i] = W[L.tenvel + i]; }
+    for (int i = g; i < d.ntenJ; i += G) D[a.D.tenj + i] = W[L.tenj + i];
+    for (int i = g; i < d.nu; i += G) D[a.D.actfrc + i] = W[L.actfrc + i];
+    for (int i = g; i < d.na; i += G) D[a.D.actdot + i] = W[L.actdot + i];
+    D[a.D.efc_active + g] = E.r_active ? 1.f : 0.f; D[a.D.efc_D + g] = E.r_D; D[a.D.efc_aref + g] = E.r_aref;
+    if (g == 0) D[a.D.scal] = (float)E.niter;
+  }
   if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
     E.pf[PF_TOTAL] = clock64() - t_start;
+#pragma unroll
     for (int i = 0; i < NPROF; i++) a.prof[i] = E.pf[i];
   }
 
@@ -1293,7 +1284,7 @@ __global__ void __launch_bounds__(256) k_engine(KArgs a) {
         err2 += pe * pe;
         if (ob) { ob[i] = q; ob[o_err + i] = pe; }
       }
-      for (int i = g; i < d.nv; i += G) if (ob) ob[d.nq + i] = W[L.qvel + i] * dt;
+      if (ob && g < d.nv) ob[d.nq + g] = E.d_qvel * dt;
       for (int i = g; i < d.na; i += G) {
         float x = W[L.act + i];
         act2 += x * x;
@@ -1349,7 +1340,6 @@ __global__ void k_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
 struct ResetArgs {
   const uint32_t* blob; int qpos0_off; int nq, nv, na, nenv;
   mm_state s; const uint8_t* mask; const float* qpos_src; const float* qvel_src;
-  // pose reset
   const float *qlo, *qhi, *tlo, *thi; float* target; int32_t* episode; int32_t* step_count; uint64_t seed;
   int pose, random_qpos;
   float* obs; int obs_dim, obs_layout;
@@ -1365,7 +1355,7 @@ __global__ void k_reset(ResetArgs r) {
   for (int i = 0; i < r.nq; i++) {
     float q = r.qpos_src ? r.qpos_src[(size_t)e * r.nq + i] : qpos0[i];
     if (r.pose) {
-      // counter = (i/2, which, env, episode): lane 0/1 -> qpos draw for coordinate i (even/odd), lane 2/3 -> target
+      // counter = (i/2, 0, env, episode): words 0/1 -> qpos draw of coordinate i (even/odd), words 2/3 -> target
       uint32_t c[4] = {(uint32_t)(i >> 1), 0u, (uint32_t)e, (uint32_t)ep};
       philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
       float uq = u01(c[i & 1]), ut = u01(c[2 + (i & 1)]);
@@ -1401,8 +1391,10 @@ struct mm_model {
   int sec[MM_NSEC];
   Dims d;
   Layout L;
+  DbgLayout D;
   Aux x;
-  int lanes = 16;
+  int lanes = 64;
+  int nvp = 24;
   int waves_per_block = 0;   // 0 = auto
   int lds_model = 1;
   int blob_words = 0;
@@ -1419,31 +1411,43 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mm_version(void) { return "myosim-hip 0.1 (gfx950)"; }
+extern "C" const char* mm_version(void) { return "myosim-hip 0.2 (gfx950, lane=item engine)"; }
+
+static const int kNvpChoices[] = {4, 24, 32, 40};
 
 static void build_layout(mm_model* m) {
   const Dims& d = m->d;
   Layout& L = m->L;
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n > 0 ? n : 0); return r; };
-  L.qpos = take(d.nq); L.qvel = take(d.nv); L.act = take(d.na); L.ctrl = take(d.nu); L.warm = take(d.nv);
-  L.xpos = take(3 * d.nbody); L.xquat = take(4 * d.nbody); L.xmat = take(9 * d.nbody); L.xipos = take(3 * d.nbody);
-  L.xanchor = take(3 * d.njnt); L.xaxis = take(3 * d.njnt); L.com = take(3 * d.nbody);
-  L.cinert = take(10 * d.nbody); L.cdof = take(6 * d.nv); L.cdofdot = take(6 * d.nv);
-  L.cvel = take(6 * d.nbody); L.cacc = take(6 * d.nbody);
+  L.qpos = take(d.nq); L.qvel = take(d.nv); L.act = take(d.na); L.ctrl = take(d.nu); L.actdot = take(d.na);
+  L.xpos = take(3 * d.nbody); L.xmat = take(9 * d.nbody);
+  L.com = take(3 * m->x.nroot); L.cdof = take(6 * d.nv);
+  o = (o + 3) & ~3;
+  L.u1 = take(std::max(std::max(4 * d.nbody, 6 * d.nbody), m->nvp * m->nvp));
+  L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
+  L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
-  L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu); L.actdot = take(d.na);
-  L.qM = take(d.nM); L.qLD = take(d.nM); L.qH = take(d.nM); L.dinv = take(d.nv); L.hdinv = take(d.nv);
-  L.bias = take(d.nv); L.passive = take(0); L.smooth = take(d.nv); L.qaccsm = take(d.nv); L.qacc = take(d.nv);
-  L.qfrccon = take(d.nv); L.Ma = take(d.nv); L.grad = take(d.nv); L.search = take(d.nv); L.Mv = take(d.nv);
-  L.tmp = take(d.nv);
-  int nj = d.njmax > 0 ? d.njmax : 1;
-  L.efc_kind = take(nj); L.efc_id = take(nj); L.efc_pos = take(nj); L.efc_D = take(nj); L.efc_aref = take(nj);
-  L.efc_jar = take(nj); L.efc_jv = take(nj); L.efc_frc = take(nj);
-  // odd stride: neighbouring envs of a wave start on different LDS banks
-  if ((o & 1) == 0) o++;
+  L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
+  L.vec = take(d.nv);
+  if ((o & 1) == 0) o++;   // odd stride: neighbouring envs start on different LDS banks
   L.total = o;
   m->lds_per_env = (size_t)o * 4;
+  DbgLayout& D = m->D;
+  o = 0;
+  D.xpos = take(3 * d.nbody); D.xquat = take(4 * d.nbody); D.xipos = take(3 * d.nbody); D.cdof = take(6 * d.nv);
+  D.cvel = take(6 * d.nbody); D.tenlen = take(d.ntendon); D.tenvel = take(d.ntendon); D.tenj = take(d.ntenJ);
+  D.actfrc = take(d.nu); D.actdot = take(d.na); D.M = take(d.nv * d.nv); D.bias = take(d.nv); D.smooth = take(d.nv);
+  D.qaccsm = take(d.nv); D.qacc = take(d.nv); D.qfrccon = take(d.nv);
+  D.efc_active = take(64); D.efc_D = take(64); D.efc_aref = take(64); D.scal = take(32);
+  D.total = o;
+}
+
+static int check_lanes(const mm_model* m, int lanes) {
+  const Dims& d = m->d;
+  if (lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return 0;
+  if (d.nbody > lanes || d.nv > lanes || 2 * d.njnt > lanes) return 0;
+  return 1;
 }
 
 extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out) {
@@ -1454,6 +1458,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->h_blob.assign(blob, blob + nwords);
   int len[MM_NSEC];
   for (int s = 0; s < MM_NSEC; s++) { m->sec[s] = (int)blob[MM_HEADER_WORDS + 2 * s]; len[s] = (int)blob[MM_HEADER_WORDS + 2 * s + 1]; }
+  (void)len;
   const int32_t* oi = (const int32_t*)(blob + m->sec[MM_SEC_OPT_I]);
   const float* of = (const float*)(blob + m->sec[MM_SEC_OPT_F]);
   Dims& d = m->d;
@@ -1461,7 +1466,6 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.njnt = oi[MM_OI_NJNT]; d.ngeom = oi[MM_OI_NGEOM]; d.nsite = oi[MM_OI_NSITE]; d.ntendon = oi[MM_OI_NTENDON];
   d.nwrap = oi[MM_OI_NWRAP]; d.neq = oi[MM_OI_NEQ]; d.npair = oi[MM_OI_NPAIR]; d.nM = oi[MM_OI_NM];
   d.nlevel = oi[MM_OI_NLEVEL]; d.njmax = oi[MM_OI_NJMAX]; d.ntenJ = oi[MM_OI_NTENJ];
-  d.ndoflevel = len[MM_SEC_DOF_LEVEL_ADR] > 0 ? len[MM_SEC_DOF_LEVEL_ADR] - 1 : 0;
   d.iterations = oi[MM_OI_ITERATIONS]; d.ls_iterations = oi[MM_OI_LS_ITERATIONS]; d.eulerdamp = oi[MM_OI_EULERDAMP];
   d.timestep = of[MM_OF_TIMESTEP]; d.gx = of[MM_OF_GRAV_X]; d.gy = of[MM_OF_GRAV_Y]; d.gz = of[MM_OF_GRAV_Z];
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
@@ -1470,23 +1474,26 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   const int32_t* tlim = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_LIMITED]);
   for (int t = 0; t < d.ntendon; t++)
     if (tlim[t]) { delete m; return fail(MM_EUNSUPPORTED, "tendon limits not implemented in this build"); }
+  if (d.nv > 255) { delete m; return fail(MM_EUNSUPPORTED, "nv > 255"); }
   const float* damp = (const float*)(blob + m->sec[MM_SEC_DOF_DAMPING]);
   d.any_damping = 0;
   for (int i = 0; i < d.nv; i++) if (damp[i] > 0.f) d.any_damping = 1;
+  m->nvp = 0;
+  for (int c : kNvpChoices) if (d.nv <= c) { m->nvp = c; break; }
+  if (!m->nvp) { delete m; return fail(MM_EUNSUPPORTED, "nv larger than the largest compiled dense tile (40)"); }
 
   // ---- engine-private tables
-  const int32_t* dpar = (const int32_t*)(blob + m->sec[MM_SEC_DOF_PARENTID]);
   const int32_t* bpar = (const int32_t*)(blob + m->sec[MM_SEC_BODY_PARENT]);
-  std::vector<int32_t> ndesc(d.nv, 0), depth(d.nv, 0);
-  for (int i = 0; i < d.nv; i++) depth[i] = dpar[i] >= 0 ? depth[dpar[i]] + 1 : 0;
-  for (int i = d.nv - 1; i >= 0; i--) if (dpar[i] >= 0) ndesc[dpar[i]] += ndesc[i] + 1;
-  // descendants must be the contiguous range (i, i+ndesc]: true for depth-first dof numbering
-  for (int i = 0; i < d.nv; i++)
-    for (int k = i + 1; k <= i + ndesc[i]; k++) {
-      int j = k; bool ok = false;
-      while (j >= 0) { if (j == i) { ok = true; break; } j = dpar[j]; }
-      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "dofs are not numbered depth-first"); }
-    }
+  const int32_t* brootid = (const int32_t*)(blob + m->sec[MM_SEC_BODY_ROOTID]);
+  const int32_t* bdofadr = (const int32_t*)(blob + m->sec[MM_SEC_BODY_DOFADR]);
+  const int32_t* bdofnum = (const int32_t*)(blob + m->sec[MM_SEC_BODY_DOFNUM]);
+  const int32_t* dofbody = (const int32_t*)(blob + m->sec[MM_SEC_DOF_BODYID]);
+  std::vector<int32_t> depth(d.nbody, 0), roots, rootslot(d.nbody, 0), dofslot(d.nv, 0);
+  for (int b = 1; b < d.nbody; b++) depth[b] = depth[bpar[b]] + 1;
+  for (int b = 1; b < d.nbody; b++) if (bpar[b] == 0) roots.push_back(b);
+  for (int b = 1; b < d.nbody; b++)
+    for (size_t r = 0; r < roots.size(); r++) if (roots[r] == brootid[b]) rootslot[b] = (int)r;
+  for (int i = 0; i < d.nv; i++) dofslot[i] = rootslot[dofbody[i]];
   const int32_t* tj_adr = (const int32_t*)(blob + m->sec[MM_SEC_TENJ_ADR]);
   const int32_t* tj_dof = (const int32_t*)(blob + m->sec[MM_SEC_TENJ_DOF]);
   std::vector<int32_t> dj_adr(d.nv + 1, 0), dj_entry, dj_tendon;
@@ -1497,8 +1504,62 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
         if (tj_dof[e] == i) { dj_entry.push_back(e); dj_tendon.push_back(t); }
   }
   dj_adr[d.nv] = (int)dj_entry.size();
-  std::vector<int32_t> roots;
-  for (int b = 1; b < d.nbody; b++) if (bpar[b] == 0) roots.push_back(b);
+  // per path element: dof lists of the straight segments that can start there
+  const int32_t* wt = (const int32_t*)(blob + m->sec[MM_SEC_WRAP_TYPE]);
+  const int32_t* wo = (const int32_t*)(blob + m->sec[MM_SEC_WRAP_OBJID]);
+  const int32_t* tadr = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_ADR]);
+  const int32_t* tnum = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_NUM]);
+  const int32_t* sbody = (const int32_t*)(blob + m->sec[MM_SEC_SITE_BODYID]);
+  const int32_t* gbody = (const int32_t*)(blob + m->sec[MM_SEC_GEOM_BODYID]);
+  std::vector<int32_t> seg_list;
+  std::vector<int32_t> sega(d.nwrap + 1, 0), segb(d.nwrap + 1, 0), segc(d.nwrap + 1, 0);
+  auto elem_body = [&](int k) -> int {
+    if (wt[k] == MM_WRAP_SITE) return sbody[wo[k]];
+    if (wt[k] == MM_WRAP_SPHERE || wt[k] == MM_WRAP_CYLINDER) return gbody[wo[k]];
+    return -1;
+  };
+  bool seg_ok = true;
+  auto emit = [&](int t, int b0, int b1) {
+    // dofs in chain(b0) XOR chain(b1): endpoint 0 for the b0 side (sign -), endpoint 1 for the b1 side (+)
+    while (b0 != b1) {
+      int b, ep;
+      if (b0 > b1) { b = b0; ep = 0; b0 = bpar[b0]; } else { b = b1; ep = 1; b1 = bpar[b1]; }
+      for (int i = bdofadr[b]; i >= 0 && i < bdofadr[b] + bdofnum[b]; i++) {
+        int ent = -1;
+        for (int e = tj_adr[t]; e < tj_adr[t + 1]; e++) if (tj_dof[e] == i) ent = e;
+        if (ent < 0 || ent >= (1 << 22)) { seg_ok = false; continue; }
+        seg_list.push_back(i | (ep << 8) | (ent << 9));
+      }
+    }
+  };
+  {
+    std::vector<int> tendon_of(d.nwrap, -1);
+    for (int t = 0; t < d.ntendon; t++) for (int k = tadr[t]; k < tadr[t] + tnum[t]; k++) tendon_of[k] = t;
+    // three passes so that each list family is contiguous with its own adr array
+    for (int pass = 0; pass < 3; pass++) {
+      std::vector<int32_t>& adr = pass == 0 ? sega : (pass == 1 ? segb : segc);
+      for (int k = 0; k < d.nwrap; k++) {
+        adr[k] = (int)seg_list.size();
+        int t = tendon_of[k];
+        if (t < 0 || wt[k] != MM_WRAP_SITE) continue;
+        int last = tadr[t] + tnum[t] - 1;
+        if (k + 1 > last) continue;
+        bool next_site = wt[k + 1] == MM_WRAP_SITE;
+        bool next_geom = wt[k + 1] == MM_WRAP_SPHERE || wt[k + 1] == MM_WRAP_CYLINDER;
+        if (pass == 0) {
+          if (next_site) emit(t, elem_body(k), elem_body(k + 1));
+          else if (next_geom && k + 2 <= last) emit(t, elem_body(k), elem_body(k + 2));
+        } else if (pass == 1) {
+          if (next_geom) emit(t, elem_body(k), elem_body(k + 1));
+        } else {
+          if (next_geom && k + 2 <= last) emit(t, elem_body(k + 1), elem_body(k + 2));
+        }
+      }
+      adr[d.nwrap] = (int)seg_list.size();
+    }
+  }
+  if (!seg_ok) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian pattern in the blob does not cover a path segment"); }
+
   std::vector<uint32_t> dev(m->h_blob);
   auto append = [&](const std::vector<int32_t>& v) {
     int off = (int)dev.size();
@@ -1506,18 +1567,21 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     if (v.empty()) dev.push_back(0);
     return off;
   };
-  m->x.dof_ndesc = append(ndesc); m->x.dof_depth = append(depth);
+  m->x.body_depth = append(depth); m->x.body_rootslot = append(rootslot); m->x.dof_rootslot = append(dofslot);
   m->x.dofj_adr = append(dj_adr); m->x.dofj_entry = append(dj_entry); m->x.dofj_tendon = append(dj_tendon);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
+  m->x.sega_adr = append(sega); m->x.segb_adr = append(segb); m->x.segc_adr = append(segc);
+  m->x.seg_list = append(seg_list);
   m->blob_words = (int)dev.size();
 
   build_layout(m);
+  // default group width: the smallest that can own every body / dof / limit row
+  m->lanes = 0;
+  for (int c : {8, 16, 32, 64}) if (check_lanes(m, c)) { m->lanes = c; break; }
+  if (!m->lanes) { delete m; return fail(MM_EUNSUPPORTED, "model needs more than 64 lanes per env (nbody, nv or 2*njnt > 64)"); }
   HIPCHK(hipGetDevice(&m->device));
   HIPCHK(hipMalloc((void**)&m->d_blob, dev.size() * sizeof(uint32_t)));
   HIPCHK(hipMemcpy(m->d_blob, dev.data(), dev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  // default lanes per env by model size
-  int work = d.ntendon > d.nv ? d.ntendon : d.nv;
-  m->lanes = work <= 8 ? 8 : (work <= 24 ? 16 : 32);
   *out = m;
   return MM_OK;
 }
@@ -1531,75 +1595,8 @@ extern "C" void mm_model_destroy(mm_model* m) {
 extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
   if (!m) return MM_EARG;
   if (lanes == 0) return MM_OK;
-  if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return fail(MM_EARG, "lanes must be 4..64 pow2");
+  if (!check_lanes(m, lanes)) return fail(MM_EARG, "lanes_per_env must be 8/16/32/64 and >= nbody, nv, 2*njnt");
   m->lanes = lanes;
-  return MM_OK;
-}
-
-extern "C" int mm_model_info(const mm_model* m, int which) {
-  if (!m) return MM_EARG;
-  switch (which) {
-    case MM_INFO_NQ: return m->d.nq; case MM_INFO_NV: return m->d.nv; case MM_INFO_NU: return m->d.nu;
-    case MM_INFO_NA: return m->d.na; case MM_INFO_NBODY: return m->d.nbody; case MM_INFO_NSITE: return m->d.nsite;
-    case MM_INFO_NTENDON: return m->d.ntendon; case MM_INFO_LANES_PER_ENV: return m->lanes;
-    case MM_INFO_LDS_BYTES_PER_ENV: return (int)m->lds_per_env; case MM_INFO_ENVS_PER_BLOCK: return (64 / m->lanes) * (m->waves_per_block > 0 ? m->waves_per_block : 1);
-    case MM_INFO_NGEOM: return m->d.ngeom; case MM_INFO_WAVES_PER_BLOCK: return m->waves_per_block;
-  }
-  return MM_EARG;
-}
-
-// layout query for debugging / tests: returns offset of a named workspace buffer
-extern "C" int mm_debug_layout(const mm_model* m, const char* name) {
-  const Layout& L = m->L;
-#define LQ(n) if (!strcmp(name, #n)) return L.n;
-  LQ(qpos) LQ(qvel) LQ(act) LQ(ctrl) LQ(warm) LQ(xpos) LQ(xquat) LQ(xmat) LQ(xipos) LQ(xanchor) LQ(xaxis) LQ(com)
-  LQ(cinert) LQ(cdof) LQ(cdofdot) LQ(cvel) LQ(cacc) LQ(tenlen) LQ(tenvel) LQ(tenj) LQ(tenfrc) LQ(actlen) LQ(actvel)
-  LQ(actfrc) LQ(actdot) LQ(qM) LQ(qLD) LQ(qH) LQ(dinv) LQ(hdinv) LQ(bias) LQ(smooth) LQ(qaccsm) LQ(qacc) LQ(qfrccon)
-  LQ(Ma) LQ(grad) LQ(search) LQ(Mv) LQ(tmp) LQ(efc_kind) LQ(efc_id) LQ(efc_pos) LQ(efc_D) LQ(efc_aref) LQ(efc_jar)
-  LQ(efc_jv) LQ(efc_frc) LQ(total)
-#undef LQ
-  return -1;
-}
-
-static unsigned long long* g_prof = nullptr;
-extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_ptr; }
-
-static int launch(const mm_model* m, KArgs& a, void* stream) {
-  int G = m->lanes;
-  int epw = 64 / G;
-  const size_t kLds = 160 * 1024;
-  size_t model_bytes = m->lds_model ? (size_t)((m->blob_words + 3) & ~3) * 4 : 0;
-  // waves per block: as many as fit next to the (shared) model copy, capped at 4 and by the batch size
-  int wpb = m->waves_per_block;
-  if (wpb <= 0) {
-    wpb = 4;
-    while (wpb > 1 && model_bytes + (size_t)wpb * epw * m->lds_per_env > kLds) wpb--;
-    int waves_needed = (a.s.nenv + epw - 1) / epw;
-    // do not make blocks so fat that CUs stay empty
-    while (wpb > 1 && (waves_needed + wpb - 1) / wpb < 256) wpb--;
-  }
-  int epb = epw * wpb;
-  size_t lds = model_bytes + (size_t)epb * m->lds_per_env;
-  if (lds > kLds) return fail(MM_ELDS, "per-block LDS workspace exceeds 160 KiB");
-  int nblocks = (a.s.nenv + epb - 1) / epb;
-  dim3 grid(nblocks), block(64 * wpb);
-  hipStream_t st = (hipStream_t)stream;
-  a.blob_words = m->blob_words;
-  a.prof = g_prof;
-#define LAUNCH1(GG, LMV)                                                                                 \
-  {                                                                                                      \
-    static bool attr_done = false;                                                                       \
-    if (!attr_done) {                                                                                    \
-      HIPCHK(hipFuncSetAttribute((const void*)k_engine<GG, LMV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds)); \
-      attr_done = true;                                                                                  \
-    }                                                                                                    \
-    hipLaunchKernelGGL((k_engine<GG, LMV>), grid, block, lds, st, a);                                    \
-  }
-#define LAUNCH(GG) case GG: if (m->lds_model) LAUNCH1(GG, true) else LAUNCH1(GG, false) break;
-  switch (G) { LAUNCH(4) LAUNCH(8) LAUNCH(16) LAUNCH(32) LAUNCH(64) default: return fail(MM_EARG, "bad lanes"); }
-#undef LAUNCH
-#undef LAUNCH1
-  HIPCHK(hipGetLastError());
   return MM_OK;
 }
 
@@ -1610,15 +1607,86 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
   return fail(MM_EARG, "unknown option");
 }
 
-static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
-  memset(&a, 0, sizeof(a));
-  a.blob = m->d_blob;
-  memcpy(a.sec, m->sec, sizeof(a.sec));
-  a.d = m->d; a.L = m->L; a.x = m->x; a.s = *s;
+extern "C" int mm_model_info(const mm_model* m, int which) {
+  if (!m) return MM_EARG;
+  switch (which) {
+    case MM_INFO_NQ: return m->d.nq; case MM_INFO_NV: return m->d.nv; case MM_INFO_NU: return m->d.nu;
+    case MM_INFO_NA: return m->d.na; case MM_INFO_NBODY: return m->d.nbody; case MM_INFO_NSITE: return m->d.nsite;
+    case MM_INFO_NTENDON: return m->d.ntendon; case MM_INFO_LANES_PER_ENV: return m->lanes;
+    case MM_INFO_LDS_BYTES_PER_ENV: return (int)m->lds_per_env;
+    case MM_INFO_ENVS_PER_BLOCK: return (64 / m->lanes) * (m->waves_per_block > 0 ? m->waves_per_block : 1);
+    case MM_INFO_NGEOM: return m->d.ngeom; case MM_INFO_WAVES_PER_BLOCK: return m->waves_per_block;
+  }
+  return MM_EARG;
+}
+
+// debug-record layout query (tests): offset of a named field in the per-env dump record
+extern "C" int mm_debug_layout(const mm_model* m, const char* name) {
+  const DbgLayout& D = m->D;
+#define LQ(n) if (!strcmp(name, #n)) return D.n;
+  LQ(xpos) LQ(xquat) LQ(xipos) LQ(cdof) LQ(cvel) LQ(tenlen) LQ(tenvel) LQ(tenj) LQ(actfrc) LQ(actdot) LQ(M) LQ(bias)
+  LQ(smooth) LQ(qaccsm) LQ(qacc) LQ(qfrccon) LQ(efc_active) LQ(efc_D) LQ(efc_aref) LQ(scal) LQ(total)
+#undef LQ
+  return -1;
 }
 
 static float* g_dbg = nullptr;
 extern "C" void mm_debug_set_dump(float* dev_ptr) { g_dbg = dev_ptr; }
+static unsigned long long* g_prof = nullptr;
+extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_ptr; }
+
+template <int G, int NVP>
+static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  static bool attr_done[2] = {false, false};
+  const int lm = m->lds_model ? 1 : 0;
+  if (!attr_done[lm]) {
+    if (lm) HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[lm] = true;
+  }
+  if (lm) hipLaunchKernelGGL((k_engine<G, NVP, true>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((k_engine<G, NVP, false>), grid, block, lds, st, a);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+static int launch(const mm_model* m, KArgs& a, void* stream) {
+  const int G = m->lanes;
+  const int epw = 64 / G;
+  const size_t kLds = 160 * 1024;
+  const size_t model_bytes = m->lds_model ? (size_t)((m->blob_words + 3) & ~3) * 4 : 0;
+  const int waves_needed = (a.s.nenv + epw - 1) / epw;
+  int wpb = m->waves_per_block;
+  if (wpb <= 0) {
+    // one block per CU sharing one model copy: as many waves as fit in LDS (<= 16), but no fatter than
+    // needed to spread the batch over all 256 CUs
+    int fit = 8;   // __launch_bounds__(512): 8 waves per block
+    while (fit > 1 && model_bytes + (size_t)fit * epw * m->lds_per_env > kLds) fit--;
+    wpb = (waves_needed + 255) / 256;
+    if (wpb < 1) wpb = 1;
+    if (wpb > fit) wpb = fit;
+  }
+  const int epb = epw * wpb;
+  const size_t lds = model_bytes + (size_t)epb * m->lds_per_env;
+  if (lds > kLds) return fail(MM_ELDS, "per-block LDS tables exceed 160 KiB");
+  dim3 grid((a.s.nenv + epb - 1) / epb), block(64 * wpb);
+  hipStream_t st = (hipStream_t)stream;
+  a.blob_words = m->blob_words;
+  a.prof = g_prof;
+#define CASE(GG, NN) if (G == GG && m->nvp == NN) return launch_t<GG, NN>(m, a, grid, block, lds, st);
+  CASE(8, 4) CASE(16, 4) CASE(32, 4) CASE(64, 4)
+  CASE(32, 24) CASE(64, 24)
+  CASE(64, 32) CASE(64, 40)
+#undef CASE
+  return fail(MM_EUNSUPPORTED, "no compiled kernel for this (lanes_per_env, nv) combination");
+}
+
+static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
+  memset(&a, 0, sizeof(a));
+  a.blob = m->d_blob;
+  memcpy(a.sec, m->sec, sizeof(a.sec));
+  a.d = m->d; a.L = m->L; a.D = m->D; a.x = m->x; a.s = *s;
+}
 
 extern "C" int mm_step(const mm_model* m, const mm_state* s, const float* ctrl, int nsub, void* stream) {
   if (!m || !s || nsub < 0) return fail(MM_EARG, "mm_step: bad argument");

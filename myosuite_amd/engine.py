@@ -98,6 +98,8 @@ def lib():
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
         L.mm_debug_set_dump.argtypes = [C.c_void_p]
+        L.mm_debug_set_prof.argtypes = [C.c_void_p]
+        L.mm_model_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -136,6 +138,9 @@ class HipModel:
 
     def info(self, which: int) -> int:
         return lib().mm_model_info(self.h, which)
+
+    def set_option(self, name: str, value: int):
+        _chk(lib().mm_model_set_option(self.h, name.encode(), int(value)), "mm_model_set_option")
 
     def layout(self, name: str) -> int:
         return lib().mm_debug_layout(self.h, name.encode())
@@ -236,7 +241,7 @@ def uniform(out: torch.Tensor, seed: int, stream_id: int):
 
 
 def debug_dump(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Run mm_forward and return the raw LDS workspace of every env [E, words] (tests only)."""
+    """Run mm_forward and return the per-env debug record [E, words] (tests only; fields via model.layout())."""
     total = model.layout("total")
     buf = torch.zeros(state.nenv, total, dtype=torch.float32, device=model.device)
     lib().mm_debug_set_dump(buf.data_ptr())
@@ -246,3 +251,18 @@ def debug_dump(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] 
     finally:
         lib().mm_debug_set_dump(None)
     return buf
+
+
+PROF_STAGES = ["kin", "com", "tendon", "constr", "vel", "crb", "factor", "act", "solve0", "newton", "euler", "io", "total"]
+
+
+def profile_stages(fn):
+    """Run fn() with in-kernel stage timers on; returns {stage: cycles} of wave 0 / block 0 (tests/tools only)."""
+    buf = torch.zeros(len(PROF_STAGES), dtype=torch.int64, device="cuda")
+    lib().mm_debug_set_prof(buf.data_ptr())
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        lib().mm_debug_set_prof(None)
+    return dict(zip(PROF_STAGES, buf.cpu().tolist()))

@@ -103,7 +103,7 @@ class BaseV0:
             self.fat_MA = torch.zeros(n, cm.na, **f)
             self.fat_MR = torch.ones(n, cm.na, **f)
             self.fat_MF = torch.zeros(n, cm.na, **f)
-            self._fat_rng = np.random.default_rng(seed)
+            self._fat_rng = np.random.default_rng(self.input_seed)
         elif muscle_condition == "reafferentation":
             self.reaf = (cm.names["actuator"]["EIP"], cm.names["actuator"]["EPL"])
         self.init_qpos = cm.qpos0.astype(np.float32).copy()

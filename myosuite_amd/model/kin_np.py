@@ -263,7 +263,9 @@ class KinModel:
 # ---------------------------------------------------------------------- wrapping
 def _is_intersect(p1, p2, p3, p4):
     det = (p4[:, 1] - p3[:, 1]) * (p2[:, 0] - p1[:, 0]) - (p4[:, 0] - p3[:, 0]) * (p2[:, 1] - p1[:, 1])
-    ok = np.abs(det) >= MINVAL
+    n12 = (p2[:, 0] - p1[:, 0]) ** 2 + (p2[:, 1] - p1[:, 1]) ** 2
+    n34 = (p4[:, 0] - p3[:, 0]) ** 2 + (p4[:, 1] - p3[:, 1]) ** 2
+    ok = (np.abs(det) >= MINVAL) & (det * det >= 4e-6 * n12 * n34)   # (nearly) parallel segments never cross
     sd = np.where(ok, det, 1.0)
     a = ((p4[:, 0] - p3[:, 0]) * (p1[:, 1] - p3[:, 1]) - (p4[:, 1] - p3[:, 1]) * (p1[:, 0] - p3[:, 0])) / sd
     b = ((p2[:, 0] - p1[:, 0]) * (p1[:, 1] - p3[:, 1]) - (p2[:, 1] - p1[:, 1]) * (p1[:, 0] - p3[:, 0])) / sd

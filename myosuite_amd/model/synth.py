@@ -157,13 +157,15 @@ def make_hand(with_object: bool = False) -> ModelSpec:
     for n in ("THtip", "IFtip", "MFtip", "RFtip", "LFtip"):
         s.add_site(n + "_target", "world", (0, 0, 0.002))
 
-    # wrist wrap obstacles: dorsal cylinder about the flexion axis, on the radius
-    s.add_geom("wrist_wrap", "radius", "cylinder", size=(0.013, 0.03), pos=(WX + 0.004, 0, 0), quat=QX90N)
-    s.add_site("wrist_side_dors", "radius", (WX, 0, 0.06))
-    s.add_site("wrist_side_palm", "radius", (WX, 0, -0.06))
+    # wrist wrap obstacle: cylinder ON the flexion axis (capitate origin), carried by the lunate.  Via points sit
+    # outside the cylinder at every wrist angle and the wrap angle stays < ~80 deg over the (soft) joint range, so
+    # tendon lengths are continuous inside the reachable box (checked by tools/check_tendon_continuity.py).
+    s.add_geom("wrist_wrap", "lunate", "cylinder", size=(0.013, 0.03), pos=(0.012, 0, 0), quat=QX90N)
+    s.add_site("wrist_side_dors", "lunate", (0.012, 0, 0.06))
+    s.add_site("wrist_side_palm", "lunate", (0.012, 0, -0.06))
     # thumb MP wrap sphere for the long extensor
     s.add_geom("thmp_wrap", "firstmc", "sphere", size=(0.006,), pos=tuple(TL[0] * tdir))
-    s.add_site("thmp_side", "firstmc", tuple(TL[0] * tdir + 0.03 * tabd + 0.0 * tflex))
+    s.add_site("thmp_side", "firstmc", tuple(TL[0] * tdir + 0.03 * np.cross(-tflex, tdir)))
 
     cnt = [0]
 
@@ -197,9 +199,9 @@ def make_hand(with_object: bool = False) -> ModelSpec:
 
     def wrist_path(side, y, radial_body="radius"):
         """forearm via, wrist obstacle, carpal via; side -1 palmar / +1 dorsal"""
-        p = [site(radial_body, (WX - 0.035, y, side * 0.016))]
+        p = [site(radial_body, (WX + 0.012 - 0.040, y, side * 0.014))]
         p.append(("cylinder", "wrist_wrap", "wrist_side_dors" if side > 0 else "wrist_side_palm"))
-        p.append(site("capitate", (0.010, y, side * 0.014)))
+        p.append(site("capitate", (0.022, y, side * 0.014)))
         return p
 
     def muscle(name, path, force):
@@ -227,7 +229,7 @@ def make_hand(with_object: bool = False) -> ModelSpec:
         return site(body, along * tdir + h * np.cross(-tflex, tdir))
     muscle("EPL", [site("ulna", (0.10, 0.012, 0.012))] + wrist_path(+1, -0.014) +
            [thd("firstmc", 0.012, 0.008), thd("firstmc", TL[0] - 0.008, 0.007),
-            ("sphere", "thmp_wrap", None), thd("proximal_thumb", 0.008, 0.006),
+            ("sphere", "thmp_wrap", "thmp_side"), thd("proximal_thumb", 0.008, 0.006),
             thd("proximal_thumb", TL[1] - 0.006, 0.005), thd("distal_thumb", 0.006, 0.004)], 90.0)
     muscle("EPB", [site("radius", (0.16, -0.010, 0.012)), site("radius", (WX - 0.01, -0.024, 0.006)),
                    thd("firstmc", 0.010, 0.008), thd("firstmc", TL[0] - 0.008, 0.007),

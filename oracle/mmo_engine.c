@@ -449,7 +449,10 @@ static void mmo_jac(const mmo_model* m, const mmo_data* d, real* jacp, real* jac
 /* ------------------------------------------------- A2 tendon wrapping */
 static int seg_intersect(const real* p1, const real* p2, const real* p3, const real* p4) {
   real det = (p4[1] - p3[1]) * (p2[0] - p1[0]) - (p4[0] - p3[0]) * (p2[1] - p1[1]);
-  if (fabs(det) < MINVAL) return 0;
+  /* (nearly) parallel segments never cross: relative test, identical to the HIP engine's */
+  real n12 = (p2[0] - p1[0]) * (p2[0] - p1[0]) + (p2[1] - p1[1]) * (p2[1] - p1[1]);
+  real n34 = (p4[0] - p3[0]) * (p4[0] - p3[0]) + (p4[1] - p3[1]) * (p4[1] - p3[1]);
+  if (fabs(det) < MINVAL || det * det < 4e-6 * n12 * n34) return 0;
   real a = ((p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0])) / det;
   real b = ((p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0])) / det;
   return (a >= 0 && a <= 1 && b >= 0 && b <= 1);

@@ -43,7 +43,7 @@ def test_uniform_matches_philox_oracle():
 
 
 @pytest.mark.parametrize("name", ["elbow", "hand"])
-@pytest.mark.parametrize("lanes", [0, 8, 64])
+@pytest.mark.parametrize("lanes", [0, 64])
 def test_forward_stages_match_oracle(hip, models, oracle_lib, name, lanes):
     cm = models[name]
     hm = E.HipModel(cm, lanes_per_env=lanes) if lanes else hip[name]
@@ -58,10 +58,9 @@ def test_forward_stages_match_oracle(hip, models, oracle_lib, name, lanes):
     st.qpos.copy_(torch.from_numpy(qpos)); st.qvel.copy_(torch.from_numpy(qvel)); st.act.copy_(torch.from_numpy(act))
     dump = E.debug_dump(hm, st, torch.from_numpy(ctrl).cuda()).cpu().numpy()
     omap = {"tenlen": "ten_length", "tenvel": "ten_velocity", "actfrc": "actuator_force", "actdot": "act_dot",
-            "dinv": "qLDiagInv", "bias": "qfrc_bias", "smooth": "qfrc_smooth", "qaccsm": "qacc_smooth",
-            "cdofdot": "cdof_dot", "qM": "qM", "qLD": "qLD"}
-    names = ["xpos", "xquat", "xipos", "xanchor", "xaxis", "cdof", "cdofdot", "cvel", "tenlen", "tenvel", "actfrc",
-             "actdot", "qM", "qLD", "dinv", "bias", "smooth", "qaccsm", "qacc"]
+            "bias": "qfrc_bias", "smooth": "qfrc_smooth", "qaccsm": "qacc_smooth"}
+    names = ["xpos", "xquat", "xipos", "cdof", "cvel", "tenlen", "tenvel", "actfrc", "actdot", "bias", "smooth",
+             "qaccsm", "qacc"]
     for e in range(nenv):
         d = O.OracleData(om)
         d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.act[:] = act[e]; d.ctrl[:] = ctrl[e]
@@ -70,6 +69,8 @@ def test_forward_stages_match_oracle(hip, models, oracle_lib, name, lanes):
             ref = getattr(d, omap.get(n, n)).ravel()
             got = dump[e, hm.layout(n):hm.layout(n) + ref.size]
             assert _rel(got, ref) < 2e-4, (n, e, _rel(got, ref))
+        M = dump[e, hm.layout("M"):hm.layout("M") + cm.nv * cm.nv].reshape(cm.nv, cm.nv)
+        assert _rel(M, d.full_M()) < 2e-5
         # constraint force: compare in units of the smooth force scale
         got = dump[e, hm.layout("qfrccon"):hm.layout("qfrccon") + cm.nv]
         assert np.abs(got - d.qfrc_constraint).max() < 2e-4 * max(1.0, np.abs(d.qfrc_smooth).max())

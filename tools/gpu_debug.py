@@ -38,15 +38,12 @@ def main(name, lanes):
     st.act.copy_(torch.from_numpy(act.astype(np.float32)))
     tctrl = torch.from_numpy(ctrl.astype(np.float32)).cuda()
     dump = E.debug_dump(hm, st, tctrl).cpu().numpy()
-    names = ["xpos", "xquat", "xmat", "xipos", "xanchor", "xaxis", "cdof", "cdofdot", "cvel", "tenlen", "tenvel",
-             "actlen", "actvel", "actfrc", "actdot", "qM", "qLD", "dinv", "bias", "smooth", "qaccsm", "qacc",
-             "qfrccon"]
-    omap = {"tenlen": "ten_length", "tenvel": "ten_velocity", "actlen": "actuator_length", "actvel": "actuator_velocity",
-            "actfrc": "actuator_force", "actdot": "act_dot", "dinv": "qLDiagInv", "bias": "qfrc_bias",
-            "smooth": "qfrc_smooth", "qaccsm": "qacc_smooth", "qfrccon": "qfrc_constraint", "cdofdot": "cdof_dot"}
+    names = ["xpos", "xquat", "xipos", "cdof", "cvel", "tenlen", "tenvel", "actfrc", "actdot", "bias", "smooth",
+             "qaccsm", "qacc", "qfrccon"]
+    omap = {"tenlen": "ten_length", "tenvel": "ten_velocity", "actfrc": "actuator_force", "actdot": "act_dot",
+            "bias": "qfrc_bias", "smooth": "qfrc_smooth", "qaccsm": "qacc_smooth", "qfrccon": "qfrc_constraint"}
     worst = {n: (0.0, 0.0) for n in names}
-    worst["tenJ"] = (0.0, 0.0)
-    nefc_mismatch = 0
+    worst["tenJ"] = (0.0, 0.0); worst["M"] = (0.0, 0.0)
     for e in range(nenv):
         d = O.OracleData(om)
         d.qpos[:] = qpos[e].astype(np.float32); d.qvel[:] = qvel[e].astype(np.float32)
@@ -59,7 +56,10 @@ def main(name, lanes):
             a, r = rel(got, ref)
             if r > worst[n][1]:
                 worst[n] = (a, r)
-        # sparse tendon Jacobian
+        M = dump[e, hm.layout("M"):hm.layout("M") + cm.nv * cm.nv].reshape(cm.nv, cm.nv)
+        a, r = rel(M, d.full_M())
+        if r > worst["M"][1]:
+            worst["M"] = (a, r)
         tj = dump[e, hm.layout("tenj"):hm.layout("tenj") + cm.ntenJ]
         adr = cm.arrays["TENJ_ADR"]; dof = cm.arrays["TENJ_DOF"]
         dense = np.zeros((cm.ntendon, cm.nv))

@@ -1,25 +1,37 @@
-"""Throughput sweep over lanes-per-env (raw mm_step, 10 substeps). python tools/gpu_sweep.py"""
+"""Throughput + in-kernel stage profile. python tools/gpu_sweep.py [quick]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from myosuite_amd.model import synth
 from myosuite_amd import engine as E
-for name, lanes_list in (("elbow", (4, 8, 16)), ("hand", (8, 16, 32, 64))):
+
+def bench(hm, cm, nenv, nsub=10, n=8):
+    st = E.BatchState(hm, nenv)
+    a = torch.rand(nenv, cm.nu, device="cuda")
+    for _ in range(2):
+        E.step(hm, st, a, nsub)
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(n):
+        E.step(hm, st, a, nsub)
+    torch.cuda.synchronize()
+    return (time.time() - t) / n
+
+cfgs = {"elbow": [(8, 1), (8, 0), (4, 1), (16, 1)], "hand": [(32, 1), (32, 0), (16, 1), (64, 1)]}
+for name, lst in cfgs.items():
     cm = synth.get_model(name)
-    for lanes in lanes_list:
+    for lanes, lm in lst:
         try:
             hm = E.HipModel(cm, lanes_per_env=lanes)
-            for nenv in (4096, 16384):
-                st = E.BatchState(hm, nenv)
-                a = torch.rand(nenv, cm.nu, device="cuda")
-                for _ in range(2):
-                    E.step(hm, st, a, 10)
-                torch.cuda.synchronize()
-                t = time.time(); n = 10
-                for _ in range(n):
-                    E.step(hm, st, a, 10)
-                torch.cuda.synchronize()
-                dt = (time.time() - t) / n
-                print(f"{name} lanes={lanes} nenv={nenv}: {dt*1e3:.3f} ms/10sub -> {nenv/dt/1e6:.3f} M env-steps/s", flush=True)
+            hm.set_option("lds_model", lm)
+            for nenv in (4096, 32768):
+                dt = bench(hm, cm, nenv)
+                print(f"{name} lanes={lanes} ldsmodel={lm} nenv={nenv}: {dt*1e3:.3f} ms/10sub -> {nenv/dt/1e6:.3f} M env-steps/s", flush=True)
+            st = E.BatchState(hm, 4096)
+            a = torch.rand(4096, cm.nu, device="cuda")
+            E.step(hm, st, a, 30)
+            pr = E.profile_stages(lambda: E.step(hm, st, a, 10))
+            tot = pr["total"]
+            print("   stage cycles/substep:", {k: v // 10 for k, v in pr.items()}, flush=True)
         except Exception as ex:
-            print(name, lanes, "ERR", ex)
+            print(name, lanes, lm, "ERR", ex)
