@@ -188,10 +188,44 @@ __device__ __forceinline__ void cross_force(float* res, const float* v, const fl
 }
 
 // ---------------------------------------------------------------- group helpers
+// broadcast lane j (group-uniform index) of the group
+template <int G>
+__device__ __forceinline__ float bc(float v, int j) {
+  const int iv = __builtin_bit_cast(int, v);
+  if constexpr (G == 64) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, j));
+  } else if constexpr (G == 32) {
+    // one v_readlane per env of the wave + a select: no LDS crossbar round trip
+    int s0 = __builtin_amdgcn_readlane(iv, j), s1 = __builtin_amdgcn_readlane(iv, j + 32);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? s1 : s0);
+  } else if constexpr (G == 16) {
+    int s0 = __builtin_amdgcn_readlane(iv, j), s1 = __builtin_amdgcn_readlane(iv, j + 16);
+    int s2 = __builtin_amdgcn_readlane(iv, j + 32), s3 = __builtin_amdgcn_readlane(iv, j + 48);
+    const int q = (threadIdx.x >> 4) & 3;
+    return __builtin_bit_cast(float, q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3)));
+  } else {
+    return __shfl(v, j, G);
+  }
+}
+// gather from a lane-varying source inside the group
+template <int G>
+__device__ __forceinline__ float sh(float v, int src) { return __shfl(v, src, G); }
+
+// Group sum, BITWISE IDENTICAL in every lane of the group.  Two things make that true by construction:
+// (1) the butterfly adds are explicit (__fadd_rn), so the compiler cannot contract `a*b + shfl(..)` into an
+//     FMA -- contraction makes lane i compute fma(a_i,b_i,c_j) and lane j fma(a_j,b_j,c_i), which differ in the
+//     last bits and would let "group-uniform" decisions (line-search alpha, loop exits) diverge between lanes;
+// (2) lane 0's total is broadcast to the whole group.
 template <int G>
 __device__ __forceinline__ float gsum(float v) {
 #pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
+  for (int m = G / 2; m >= 1; m >>= 1) v = __fadd_rn(v, __shfl_xor(v, m, G));
+  return bc<G>(v, 0);
+}
+template <int G>
+__device__ __forceinline__ float gmax(float v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, G));
   return v;
 }
 template <int G>
@@ -200,15 +234,6 @@ __device__ __forceinline__ int gor(int v) {
   for (int m = G / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, G);
   return v;
 }
-// broadcast lane j (group-uniform index) of the group
-template <int G>
-__device__ __forceinline__ float bc(float v, int j) {
-  if constexpr (G == 64) return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-  else return __shfl(v, j, G);
-}
-// gather from a lane-varying source inside the group
-template <int G>
-__device__ __forceinline__ float sh(float v, int src) { return __shfl(v, src, G); }
 
 // ------------------------------------------------------------- tendon wrapping (A2)
 __device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y,
@@ -384,7 +409,6 @@ struct Engine {
   float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
   float Mrow[NVP];   // row g of M (dense, symmetric)
   float Lrow[NVP];   // row g of the current Cholesky factor  (L[g][k], k <= g)
-  float LTrow[NVP];  // row g of its transpose                (L[k][g], k >= g)
   float d_dinv;      // 1 / L[g][g]
   // ---- joint-limit row owned by this lane (lower side: lanes < G/2, upper side: lanes >= G/2)
   bool r_active;
@@ -410,7 +434,7 @@ struct Engine {
     for (int k = 0; k < 6; k++) { b_cvel[k] = 0.f; d_cdof[k] = 0.f; }
     d_bias = d_smooth = d_qaccsm = d_qacc = d_qfrccon = 0.f; d_dinv = 1.f;
 #pragma unroll
-    for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; LTrow[k] = 0.f; }
+    for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; }
   }
 
   __device__ __forceinline__ float com_of_body(int b, int k) const { return W[a.L.com + 3 * AUXI(body_rootslot)[b] + k]; }
@@ -674,18 +698,21 @@ struct Engine {
     aref = -B * vel - K * imp * x;
   }
 
+  // One potential limit row per JOINT, owned by lane j: a joint can violate only one side of its range at a
+  // time (mm_model_create rejects ranges narrower than 2*margin).
   __device__ __forceinline__ void make_constraint() {
     const Layout& L = a.L;
-    const int side = g >= G / 2 ? 1 : 0;
-    const int j = side ? g - G / 2 : g;
-    r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = side ? -1.f : 1.f;
+    const int j = g;
+    r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = 1.f;
     if (j < a.d.njnt) {
       int type = MI_(JNT_TYPE)[j];
       if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
         r_dof = MI_(JNT_DOFADR)[j];
         float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
         float margin = MF_(JNT_MARGIN)[j];
-        float dist = side == 0 ? q - MF_(JNT_RANGE)[2 * j] : MF_(JNT_RANGE)[2 * j + 1] - q;
+        float dlo = q - MF_(JNT_RANGE)[2 * j], dhi = MF_(JNT_RANGE)[2 * j + 1] - q;
+        float dist = dlo;
+        if (!(dlo < margin) && dhi < margin) { dist = dhi; r_sign = -1.f; }
         if (dist < margin) {
           r_active = true;
           impedance(MF_(JNT_SOLIMP) + 5 * j, MF_(JNT_SOLREF) + 2 * j, dist - margin, MF_(DOF_INVWEIGHT0)[r_dof],
@@ -696,12 +723,12 @@ struct Engine {
     nefc = (int)(gsum<G>(r_active ? 1.f : 0.f) + 0.5f);
   }
 
-  // sum over the (up to two) limit rows of the joint that owns dof g of  sign^p * val  (p = 1 or 2)
+  // value of the limit row of the joint that owns dof g (0 for dofs that are not a hinge/slide joint's dof)
   __device__ __forceinline__ float rows_to_dof(float val) const {
     int j = g < a.d.nv ? MI_(DOF_JNTID)[g] : 0;
-    float lo = sh<G>(val, j), hi = sh<G>(val, j + G / 2);
-    bool mine = g < a.d.nv && j < G / 2 && MI_(JNT_DOFADR)[j] == g;
-    return mine ? lo + hi : 0.f;
+    float v = sh<G>(val, j);
+    bool mine = g < a.d.nv && MI_(JNT_DOFADR)[j] == g;
+    return mine ? v : 0.f;
   }
 
   // ----------------------------------------------------- A5 velocity stage + bias forces
@@ -849,19 +876,11 @@ struct Engine {
       Lrow[j] = (g >= j) ? s * inv : 0.f;
       if (g == j) d_dinv = inv;
     }
-    // transpose through the dense LDS tile
+    // leave L in the dense LDS tile: the backward substitution reads its columns (= rows of L') from there
     if (g < NVP)
 #pragma unroll
       for (int k = 0; k < NVP; k++) W[L.u1 + g * NVP + k] = Lrow[k];
-    GSYNC();
-    if (g < NVP) {
-#pragma unroll
-      for (int k = 0; k < NVP; k++) LTrow[k] = W[L.u1 + k * NVP + g];
-    } else {
-#pragma unroll
-      for (int k = 0; k < NVP; k++) LTrow[k] = 0.f;
-      d_dinv = 1.f;
-    }
+    else d_dinv = 1.f;
     GSYNC();
   }
 
@@ -872,10 +891,11 @@ struct Engine {
       float yj = bc<G>(x * d_dinv, j);
       x = (g == j) ? yj : (g > j ? x - Lrow[j] * yj : x);
     }
+    const float* LT = W + a.L.u1 + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
 #pragma unroll
     for (int i = NVP - 1; i >= 0; i--) {
       float zi = bc<G>(x * d_dinv, i);
-      x = (g == i) ? zi : (g < i ? x - LTrow[i] * zi : x);
+      x = (g == i) ? zi : (g < i ? x - LT[i * NVP] * zi : x);
     }
     return x;
   }
@@ -1019,6 +1039,16 @@ struct Engine {
       d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
       alpha_prev = alpha;
       niter = iter + 1;
+      // a step below fp32 resolution of qacc cannot improve the solution (rows sitting at jar ~ 0 would
+      // otherwise toggle in and out of the active set for ever)
+      {
+        float stepmax = gmax<G>(fabsf(alpha * search)), qmax = gmax<G>(fabsf(d_qacc));
+        if (stepmax <= 2e-7f * fmaxf(qmax, 1.f)) {
+          const bool on2 = r_active && r_jar < 0.f;
+          d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
+          break;
+        }
+      }
       if (iter == a.d.iterations - 1) {
         const bool on2 = r_active && r_jar < 0.f;
         d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
@@ -1394,6 +1424,7 @@ struct mm_model {
   DbgLayout D;
   Aux x;
   int lanes = 64;
+  int lanes_auto = 1;        // pick the group width per launch from the batch size
   int nvp = 24;
   int waves_per_block = 0;   // 0 = auto
   int lds_model = 1;
@@ -1445,8 +1476,8 @@ static void build_layout(mm_model* m) {
 
 static int check_lanes(const mm_model* m, int lanes) {
   const Dims& d = m->d;
-  if (lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return 0;
-  if (d.nbody > lanes || d.nv > lanes || 2 * d.njnt > lanes) return 0;
+  if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return 0;
+  if (d.nbody > lanes || d.nv > lanes || d.njnt > lanes || m->nvp > lanes) return 0;
   return 1;
 }
 
@@ -1475,6 +1506,13 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   for (int t = 0; t < d.ntendon; t++)
     if (tlim[t]) { delete m; return fail(MM_EUNSUPPORTED, "tendon limits not implemented in this build"); }
   if (d.nv > 255) { delete m; return fail(MM_EUNSUPPORTED, "nv > 255"); }
+  {
+    const int32_t* jlim = (const int32_t*)(blob + m->sec[MM_SEC_JNT_LIMITED]);
+    const float* jr = (const float*)(blob + m->sec[MM_SEC_JNT_RANGE]);
+    const float* jm = (const float*)(blob + m->sec[MM_SEC_JNT_MARGIN]);
+    for (int j = 0; j < d.njnt; j++)
+      if (jlim[j] && jr[2 * j + 1] - jr[2 * j] < 2.f * jm[j]) { delete m; return fail(MM_EUNSUPPORTED, "joint range narrower than 2*margin"); }
+  }
   const float* damp = (const float*)(blob + m->sec[MM_SEC_DOF_DAMPING]);
   d.any_damping = 0;
   for (int i = 0; i < d.nv; i++) if (damp[i] > 0.f) d.any_damping = 1;
@@ -1577,8 +1615,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   build_layout(m);
   // default group width: the smallest that can own every body / dof / limit row
   m->lanes = 0;
-  for (int c : {8, 16, 32, 64}) if (check_lanes(m, c)) { m->lanes = c; break; }
-  if (!m->lanes) { delete m; return fail(MM_EUNSUPPORTED, "model needs more than 64 lanes per env (nbody, nv or 2*njnt > 64)"); }
+  for (int c : {4, 8, 16, 32, 64}) if (check_lanes(m, c)) { m->lanes = c; break; }
+  if (!m->lanes) { delete m; return fail(MM_EUNSUPPORTED, "model needs more than 64 lanes per env (nbody, nv or njnt > 64)"); }
   HIPCHK(hipGetDevice(&m->device));
   HIPCHK(hipMalloc((void**)&m->d_blob, dev.size() * sizeof(uint32_t)));
   HIPCHK(hipMemcpy(m->d_blob, dev.data(), dev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1595,8 +1633,9 @@ extern "C" void mm_model_destroy(mm_model* m) {
 extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
   if (!m) return MM_EARG;
   if (lanes == 0) return MM_OK;
-  if (!check_lanes(m, lanes)) return fail(MM_EARG, "lanes_per_env must be 8/16/32/64 and >= nbody, nv, 2*njnt");
+  if (!check_lanes(m, lanes)) return fail(MM_EARG, "lanes_per_env must be 4/8/16/32/64 and >= nbody, nv, njnt, padded nv");
   m->lanes = lanes;
+  m->lanes_auto = 0;
   return MM_OK;
 }
 
@@ -1650,8 +1689,26 @@ static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t l
   return MM_OK;
 }
 
+static bool have_kernel(int G, int nvp) {
+  if (nvp == 4) return G == 4 || G == 8 || G == 16 || G == 32 || G == 64;
+  if (nvp == 24) return G == 32 || G == 64;
+  if (nvp == 32) return G == 32 || G == 64;
+  if (nvp == 40) return G == 64;
+  return false;
+}
+
 static int launch(const mm_model* m, KArgs& a, void* stream) {
-  const int G = m->lanes;
+  int G = m->lanes;
+  if (m->lanes_auto) {
+    // narrowest group (most envs per wave) that still yields >= 2 waves per CU; else the widest available
+    int best = 0;
+    for (int c : {4, 8, 16, 32, 64}) {
+      if (!check_lanes(m, c) || !have_kernel(c, m->nvp)) continue;
+      best = c;
+      if ((a.s.nenv + (64 / c) - 1) / (64 / c) >= 512) break;
+    }
+    if (best) G = best;
+  }
   const int epw = 64 / G;
   const size_t kLds = 160 * 1024;
   const size_t model_bytes = m->lds_model ? (size_t)((m->blob_words + 3) & ~3) * 4 : 0;
@@ -1674,9 +1731,10 @@ static int launch(const mm_model* m, KArgs& a, void* stream) {
   a.blob_words = m->blob_words;
   a.prof = g_prof;
 #define CASE(GG, NN) if (G == GG && m->nvp == NN) return launch_t<GG, NN>(m, a, grid, block, lds, st);
-  CASE(8, 4) CASE(16, 4) CASE(32, 4) CASE(64, 4)
+  CASE(4, 4) CASE(8, 4) CASE(16, 4) CASE(32, 4) CASE(64, 4)
   CASE(32, 24) CASE(64, 24)
-  CASE(64, 32) CASE(64, 40)
+  CASE(32, 32) CASE(64, 32)
+  CASE(64, 40)
 #undef CASE
   return fail(MM_EUNSUPPORTED, "no compiled kernel for this (lanes_per_env, nv) combination");
 }

@@ -18,7 +18,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmyosim_hip.so")
+LIB_PATH = os.environ.get("MYOSIM_LIB", os.path.join(CSRC, "libmyosim_hip.so"))   # override only for A/B experiments
 _SOURCES = ["myosim_engine.hip"]
 _lib = None
 
