@@ -404,6 +404,13 @@ struct Engine {
   float b_cinert[10];
   float b_cvel[6];
   int b_depth, b_parent;
+  // model constants of the owned body and of its first two joints (loaded once per kernel)
+  V3 c_bpos, c_bipos;
+  Q4 c_bquat;
+  int c_jn, c_ja;
+  int c_jtype[2], c_jqadr[2], c_jdadr[2];
+  V3 c_jpos[2], c_jaxis[2];
+  float c_jq0[2];
   // ---- dof-lane registers (valid for g < nv)
   float d_cdof[6];
   float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
@@ -422,6 +429,26 @@ struct Engine {
     d_warm = 0.f; d_qvel = 0.f;
     b_depth = (g < a.d.nbody) ? AUXI(body_depth)[g] : -1;
     b_parent = (g > 0 && g < a.d.nbody) ? MI_(BODY_PARENT)[g] : 0;
+    {
+      const bool isb = g > 0 && g < a.d.nbody;
+      c_bpos = isb ? ld3(MF_(BODY_POS) + 3 * g) : v3(0.f, 0.f, 0.f);
+      c_bipos = isb ? ld3(MF_(BODY_IPOS) + 3 * g) : v3(0.f, 0.f, 0.f);
+      Q4 q1 = {1.f, 0.f, 0.f, 0.f};
+      c_bquat = isb ? ldq(MF_(BODY_QUAT) + 4 * g) : q1;
+      c_ja = isb ? MI_(BODY_JNTADR)[g] : 0;
+      c_jn = isb ? MI_(BODY_JNTNUM)[g] : 0;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const bool has = i < c_jn;
+        const int j = has ? c_ja + i : 0;
+        c_jtype[i] = has ? MI_(JNT_TYPE)[j] : -1;
+        c_jqadr[i] = has ? MI_(JNT_QPOSADR)[j] : 0;
+        c_jdadr[i] = has ? MI_(JNT_DOFADR)[j] : 0;
+        c_jpos[i] = has ? ld3(MF_(JNT_POS) + 3 * j) : v3(0.f, 0.f, 0.f);
+        c_jaxis[i] = has ? ld3(MF_(JNT_AXIS) + 3 * j) : v3(0.f, 0.f, 1.f);
+        c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
+      }
+    }
     r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
@@ -455,11 +482,14 @@ struct Engine {
       if (b_depth == lv) {
         const int b = g, p = b_parent;
         M3 pm = ldm(W + L.xmat + 9 * p);
-        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, ld3(MF_(BODY_POS) + 3 * b));
-        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), ldq(MF_(BODY_QUAT) + 4 * b));
-        int ja = MI_(BODY_JNTADR)[b], jn = MI_(BODY_JNTNUM)[b];
-        for (int j = ja; j < ja + jn; j++) {
-          int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j];
+        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, c_bpos);
+        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), c_bquat);
+        for (int i = 0; i < c_jn; i++) {
+          const int j = c_ja + i;
+          int type, qa; V3 jpos, jax; float q0;
+          if (i == 0) { type = c_jtype[0]; qa = c_jqadr[0]; jpos = c_jpos[0]; jax = c_jaxis[0]; q0 = c_jq0[0]; }
+          else if (i == 1) { type = c_jtype[1]; qa = c_jqadr[1]; jpos = c_jpos[1]; jax = c_jaxis[1]; q0 = c_jq0[1]; }
+          else { type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
           if (type == MM_JNT_FREE) {
             pos = ld3(W + L.qpos + qa);
             quat = qnorm(ldq(W + L.qpos + qa + 3));
@@ -469,14 +499,13 @@ struct Engine {
             continue;
           }
           M3 m = q2m(quat);
-          V3 jpos = ld3(MF_(JNT_POS) + 3 * j), jax = ld3(MF_(JNT_AXIS) + 3 * j);
           V3 anchor = pos + mv(m, jpos), axis = mv(m, jax);
           st3(W + L.xanchor + 3 * j, anchor);
           st3(W + L.xaxis + 3 * j, axis);
           if (type == MM_JNT_SLIDE) {
-            pos = pos + (W[L.qpos + qa] - MF_(QPOS0)[qa]) * axis;
+            pos = pos + (W[L.qpos + qa] - q0) * axis;
           } else if (type == MM_JNT_HINGE) {
-            float ang = W[L.qpos + qa] - MF_(QPOS0)[qa];
+            float ang = W[L.qpos + qa] - q0;
             float sn, cs;
             sincos_small(0.5f * ang, &sn, &cs);
             Q4 ql = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
@@ -493,7 +522,7 @@ struct Engine {
         st3(W + L.xpos + 3 * b, pos);
         W[L.u1 + 4 * b] = quat.w; W[L.u1 + 4 * b + 1] = quat.x; W[L.u1 + 4 * b + 2] = quat.y; W[L.u1 + 4 * b + 3] = quat.z;
         for (int k = 0; k < 9; k++) W[L.xmat + 9 * b + k] = m.m[k];
-        b_xipos = pos + mv(m, ld3(MF_(BODY_IPOS) + 3 * b));
+        b_xipos = pos + mv(m, c_bipos);
       }
       GSYNC();
     }
@@ -752,9 +781,11 @@ struct Engine {
       if (b_depth == lv) {
 #pragma unroll
         for (int k = 0; k < 6; k++) { cv[k] = pv[k]; ca[k] = pa[k]; }
-        int ja = MI_(BODY_JNTADR)[g], jn = MI_(BODY_JNTNUM)[g];
-        for (int j = ja; j < ja + jn; j++) {
-          int type = MI_(JNT_TYPE)[j], da = MI_(JNT_DOFADR)[j];
+        for (int i = 0; i < c_jn; i++) {
+          int type, da;
+          if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
+          else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
+          else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
           if (type == MM_JNT_FREE) {
             for (int d3 = 0; d3 < 3; d3++) {
               float qv = W[L.qvel + da + d3];
@@ -863,18 +894,23 @@ struct Engine {
   }
 
   // dense Cholesky H = L L' with lane i holding row i; `dadd` is added to this lane's diagonal element.
-  // Leaves Lrow (L[g][k]), d_dinv (1/L[g][g]) and LTrow (L[k][g]) in registers.
+  // Right-looking form: after column j is scaled, the updates of the trailing columns are independent FMAs
+  // (instruction-level parallelism) instead of one serial dot-product chain per column.
+  // Leaves Lrow (L[g][k]) and d_dinv (1/L[g][g]) in registers and L in the LDS tile (for the L' solve).
   __device__ __forceinline__ void factor(float dadd) {
     const Layout& L = a.L;
+    float A[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == g ? dadd : 0.f);
 #pragma unroll
     for (int j = 0; j < NVP; j++) {
-      float s = Mrow[j] + (j == g ? dadd : 0.f);
-#pragma unroll
-      for (int k = 0; k < j; k++) s -= Lrow[k] * bc<G>(Lrow[k], j);
-      float piv = bc<G>(s, j);
-      float inv = 1.f / sqrtf(fmaxf(piv, MINVALF));
-      Lrow[j] = (g >= j) ? s * inv : 0.f;
+      float piv = bc<G>(A[j], j);
+      float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
+      float lj = (g >= j) ? A[j] * inv : 0.f;
+      Lrow[j] = lj;
       if (g == j) d_dinv = inv;
+#pragma unroll
+      for (int k = j + 1; k < NVP; k++) A[k] -= lj * bc<G>(lj, k);
     }
     // leave L in the dense LDS tile: the backward substitution reads its columns (= rows of L') from there
     if (g < NVP)
@@ -948,9 +984,16 @@ struct Engine {
       else atomicAdd(&W[L.vec + MI_(JNT_DOFADR)[id]], gear * f);
     }
     GSYNC();
+    // J' f: every tendon lane scatters its (<= 8) Jacobian entries into the per-dof accumulator with LDS float
+    // atomics (one wave => deterministic lane order); shorter critical path than gathering ~25 entries per wrist dof
+    for (int t = g; t < a.d.ntendon; t += G) {
+      float f = W[L.tenfrc + t];
+      if (f != 0.f)
+        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) atomicAdd(&W[L.vec + MI_(TENJ_DOF)[e]], W[L.tenj + e] * f);
+    }
+    GSYNC();
     d_smooth = 0.f;
     if (g < a.d.nv) {
-      const int *ja = AUXI(dofj_adr), *je = AUXI(dofj_entry), *jt = AUXI(dofj_tendon);
       float s = -MF_(DOF_DAMPING)[g] * d_qvel - d_bias + W[L.vec + g];
       int j = MI_(DOF_JNTID)[g];
       float ks = MF_(JNT_STIFFNESS)[j];
@@ -959,7 +1002,6 @@ struct Engine {
         int qa = MI_(JNT_QPOSADR)[j];
         s -= ks * (W[L.qpos + qa] - MF_(QPOS_SPRING)[qa]);
       }
-      for (int e = ja[g]; e < ja[g + 1]; e++) s += W[L.tenj + je[e]] * W[L.tenfrc + jt[e]];
       d_smooth = s;
     }
   }
