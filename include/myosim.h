@@ -114,6 +114,12 @@ typedef struct {
                                1: MJX pose      [qpos, qvel*timestep, act, pose_err]  (playground_pose_v0.py:119-129) */
   int   act_reg_mean;       /* 1: act_mag = ||act||/na (pose_v0.py:115-117); 0: ||act|| (playground_pose_v0.py:63) */
   float obs_dt;             /* scale of the qvel observation: env.dt (pose_v0.py:104) or opt.timestep (MJX) */
+  /* REACH task (envs/myo/myobase/reach_v0.py:95-151): obs [qpos, qvel*dt, tip_pos, reach_err, act];
+     reward keys reuse the columns of MM_RWD_* with `pose` := `reach` (w_pose is the reach weight) */
+  const int32_t* tip_sites; /* [ntip] site ids (device)                        */
+  int   ntip;
+  const float* target_pos;  /* [nenv][3*ntip] world positions of the *_target sites */
+  float reach_far_th;       /* far_th (per tip), reach_v0.py:57,131-135         */
 } mm_task;
 
 /* columns of mm_task.rwd for MM_TASK_POSE (pose_v0.py:120-139) */
@@ -150,6 +156,11 @@ int  mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, co
                    int32_t* step_count, uint64_t seed, int random_qpos, float* obs, int obs_dim,
                    int obs_layout, void* stream);
 /* (obs != NULL: the first observation of the new episode is written for the reset envs) */
+/* Reach-task reset (reach_v0.py:153-172): targets ~ U(tlo,thi)[3*ntip] (Philox keyed by seed, env, episode),
+ * state = mj_resetData (qpos0); the first observation uses tip0 = tip positions at qpos0. */
+int  mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* tlo, const float* thi,
+                    float* target, const float* tip0, int ntip, int32_t* episode, int32_t* step_count,
+                    uint64_t seed, float* obs, int obs_dim, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

@@ -1381,6 +1381,44 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         if (t.done) t.done[e] = done ? 1 : 0;
       }
     }
+    if (t.task == MM_TASK_REACH) {
+      // obs [qpos, qvel*dt, tip_pos, reach_err, act]; reward dict of reach_v0.py:123-151
+      const int n3 = 3 * t.ntip;
+      float err2 = 0.f, act2 = 0.f;
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      for (int i = g; i < d.nq; i += G) if (ob) ob[i] = W[L.qpos + i];
+      if (ob && g < d.nv) ob[d.nq + g] = E.d_qvel * t.obs_dt;
+      for (int i = g; i < t.ntip; i += G) {
+        V3 tip = E.site_pos(t.tip_sites[i]);
+        V3 tgt = ld3(t.target_pos + (size_t)e * n3 + 3 * i);
+        V3 er = tgt - tip;
+        err2 += dot(er, er);
+        if (ob) { st3(ob + d.nq + d.nv + 3 * i, tip); st3(ob + d.nq + d.nv + n3 + 3 * i, er); }
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[d.nq + d.nv + 2 * n3 + i] = x;
+      }
+      err2 = gsum<G>(err2); act2 = gsum<G>(act2);
+      if (g == 0) {
+        float reach_dist = sqrtf(err2), act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        float far_th = time > 2.f * t.obs_dt ? t.reach_far_th * (float)t.ntip : INFINITY;
+        float near_th = (float)t.ntip * 0.0125f;
+        float r_reach = -reach_dist;
+        float r_bonus = (reach_dist < 2.f * near_th ? 1.f : 0.f) + (reach_dist < near_th ? 1.f : 0.f);
+        float r_pen = reach_dist > far_th ? -1.f : 0.f;
+        bool done = reach_dist > far_th;
+        if (t.rwd) {
+          float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
+          r[MM_RWD_POSE] = r_reach; r[MM_RWD_BONUS] = r_bonus; r[MM_RWD_PENALTY] = r_pen; r[MM_RWD_ACT_REG] = -act_mag;
+          r[MM_RWD_SPARSE] = -reach_dist; r[MM_RWD_SOLVED] = reach_dist < near_th ? 1.f : 0.f;
+          r[MM_RWD_DONE] = done ? 1.f : 0.f;
+          r[MM_RWD_DENSE] = t.w_pose * r_reach + t.w_bonus * r_bonus + t.w_act_reg * (-act_mag) + t.w_penalty * r_pen;
+        }
+        if (t.done) t.done[e] = done ? 1 : 0;
+      }
+    }
     if (g == 0) {
       if (t.step_count) t.step_count[e] = sc;
       if (t.truncated) t.truncated[e] = (t.max_episode_steps > 0 && sc >= t.max_episode_steps) ? 1 : 0;
@@ -1415,6 +1453,7 @@ struct ResetArgs {
   const float *qlo, *qhi, *tlo, *thi; float* target; int32_t* episode; int32_t* step_count; uint64_t seed;
   int pose, random_qpos;
   float* obs; int obs_dim, obs_layout;
+  int reach, ntip; const float* tip0;
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -1445,6 +1484,24 @@ __global__ void k_reset(ResetArgs r) {
     float* ob = r.obs + (size_t)e * r.obs_dim;
     for (int i = 0; i < r.nv; i++) ob[r.nq + i] = 0.f;
     for (int i = 0; i < r.na; i++) ob[(r.obs_layout == 1 ? r.nq + r.nv : 2 * r.nq + r.nv) + i] = 0.f;
+  }
+  if (r.reach) {
+    int ep = r.episode ? r.episode[e] : 0;
+    if (r.episode) r.episode[e] = ep + 1;
+    const int n3 = 3 * r.ntip;
+    float* ob = r.obs ? r.obs + (size_t)e * r.obs_dim : nullptr;
+    for (int i = 0; i < n3; i++) {
+      uint32_t c[4] = {(uint32_t)(i >> 2), 1u, (uint32_t)e, (uint32_t)ep};
+      philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+      float tg = r.tlo[i] + (r.thi[i] - r.tlo[i]) * u01(c[i & 3]);
+      r.target[(size_t)e * n3 + i] = tg;
+      if (ob) { ob[r.nq + r.nv + i] = r.tip0[i]; ob[r.nq + r.nv + n3 + i] = tg - r.tip0[i]; }
+    }
+    if (ob) {
+      for (int i = 0; i < r.nq; i++) ob[i] = qpos0[i];
+      for (int i = 0; i < r.nv; i++) ob[r.nq + i] = 0.f;
+      for (int i = 0; i < r.na; i++) ob[r.nq + r.nv + 2 * n3 + i] = 0.f;
+    }
   }
   for (int i = 0; i < r.nv; i++) {
     r.s.qvel[(size_t)e * r.nv + i] = r.qvel_src ? r.qvel_src[(size_t)e * r.nv + i] : 0.f;
@@ -1808,7 +1865,8 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
                            const mm_derived* out, void* stream) {
   if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
-  if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE) return fail(MM_EUNSUPPORTED, "task not implemented");
+  if (t->task == MM_TASK_REACH && (!t->tip_sites || !t->target_pos || t->ntip <= 0)) return fail(MM_EARG, "reach task needs tip_sites/target_pos");
+  if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH) return fail(MM_EUNSUPPORTED, "task not implemented");
   if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "fatigue needs MA/MR/MF");
   KArgs a; fill_common(m, a, s);
   a.ctrl = action; a.mode = 2; a.t = *t;
@@ -1849,6 +1907,20 @@ extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
   if (!out) return fail(MM_EARG, "mm_uniform: null output");
   size_t n4 = (n + 3) / 4;
   hipLaunchKernelGGL(k_uniform, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* tlo, const float* thi,
+                              float* target, const float* tip0, int ntip, int32_t* episode, int32_t* step_count,
+                              uint64_t seed, float* obs, int obs_dim, void* stream) {
+  if (!m || !s || !tlo || !thi || !target || !tip0 || ntip <= 0) return fail(MM_EARG, "mm_reach_reset: bad argument");
+  ResetArgs r; memset(&r, 0, sizeof(r));
+  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.nenv = s->nenv; r.s = *s; r.mask = mask;
+  r.tlo = tlo; r.thi = thi; r.target = target; r.episode = episode; r.step_count = step_count; r.seed = seed;
+  r.reach = 1; r.ntip = ntip; r.tip0 = tip0; r.obs = obs; r.obs_dim = obs_dim;
+  hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;
 }

@@ -24,6 +24,7 @@ _lib = None
 
 MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK = 0, 1, 2, 3, 4
 RWD_KEYS_POSE = ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+RWD_KEYS_REACH = ["reach", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
  INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK) = range(12)
 
@@ -69,7 +70,8 @@ class mm_task(C.Structure):
                 ("fat_F", C.c_float), ("fat_R", C.c_float), ("fat_r", C.c_float),
                 ("obs", C.c_void_p), ("obs_dim", C.c_int), ("rwd", C.c_void_p), ("done", C.c_void_p),
                 ("truncated", C.c_void_p), ("step_count", C.c_void_p), ("ctrl_out", C.c_void_p),
-                ("reaf_src", C.c_int), ("reaf_dst", C.c_int), ("obs_layout", C.c_int), ("act_reg_mean", C.c_int), ("obs_dt", C.c_float)]
+                ("reaf_src", C.c_int), ("reaf_dst", C.c_int), ("obs_layout", C.c_int), ("act_reg_mean", C.c_int), ("obs_dt", C.c_float),
+                ("tip_sites", C.c_void_p), ("ntip", C.c_int), ("target_pos", C.c_void_p), ("reach_far_th", C.c_float)]
 
 
 def lib():
@@ -94,6 +96,8 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.mm_reach_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
@@ -231,6 +235,13 @@ def pose_reset(model: HipModel, state: BatchState, mask, qlo, qhi, tlo, thi, tar
                              _ptr(episode), _ptr(step_count), C.c_uint64(seed), int(random_qpos), _ptr(obs),
                              0 if obs is None else int(obs.shape[1]), int(obs_layout), _stream()),
          "mm_pose_reset")
+
+
+def reach_reset(model: HipModel, state: BatchState, mask, tlo, thi, target, tip0, ntip: int, episode, step_count,
+                seed: int, obs=None):
+    _chk(lib().mm_reach_reset(model.h, state.c, _ptr(mask), _ptr(tlo), _ptr(thi), _ptr(target), _ptr(tip0), int(ntip),
+                              _ptr(episode), _ptr(step_count), C.c_uint64(seed), _ptr(obs),
+                              0 if obs is None else int(obs.shape[1]), _stream()), "mm_reach_reset")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

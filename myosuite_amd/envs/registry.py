@@ -75,6 +75,11 @@ def _pose(**kw):
     return PoseEnvV0(**kw)
 
 
+def _reach(**kw):
+    from .reach_v0 import ReachEnvV0
+    return ReachEnvV0(**kw)
+
+
 # Elbow posing (myobase/__init__.py:108-138)
 register_env_with_variants(
     id="myoElbowPose1D6MFixed-v0", entry_point=_pose, max_episode_steps=100,
@@ -115,3 +120,22 @@ register_env_with_variants(
     id="myoHandPoseRandom-v0", entry_point=_pose, max_episode_steps=100,
     kwargs={"model": "hand", "viz_site_targets": _HAND_SITES, "target_jnt_range": Rpos, "normalize_act": True,
             "pose_thd": 0.7, "reset_type": "random", "target_type": "generate"})
+
+
+# Hand-tip reaching (myobase/__init__.py:521-575).  `target_center` = the Fixed env's targets: the reference box centres,
+# used by the synthetic-model env to re-centre the boxes on the synthetic hand's tips (reach_v0.py docstring).
+_REACH_CENTER = {"THtip": (-0.165, -0.537, 1.495), "IFtip": (-0.151, -0.547, 1.455), "MFtip": (-0.146, -0.547, 1.447),
+                 "RFtip": (-0.148, -0.543, 1.445), "LFtip": (-0.148, -0.528, 1.434)}
+register_env_with_variants(
+    id="myoHandReachFixed-v0", entry_point=_reach, max_episode_steps=100,
+    kwargs={"model": "hand", "target_reach_range": {k: (v, v) for k, v in _REACH_CENTER.items()},
+            "target_center": _REACH_CENTER, "normalize_act": True, "far_th": 0.044})
+register_env_with_variants(
+    id="myoHandReachRandom-v0", entry_point=_reach, max_episode_steps=100,
+    kwargs={"model": "hand", "target_center": _REACH_CENTER, "normalize_act": True, "far_th": 0.034,
+            "target_reach_range": {
+                "THtip": ((-0.165 - 0.020, -0.537 - 0.040, 1.495 - 0.040), (-0.165 + 0.040, -0.537 + 0.020, 1.495 + 0.040)),
+                "IFtip": ((-0.151 - 0.040, -0.547 - 0.020, 1.455 - 0.010), (-0.151 + 0.040, -0.547 + 0.020, 1.455 + 0.010)),
+                "MFtip": ((-0.146 - 0.040, -0.547 - 0.020, 1.447 - 0.010), (-0.146 + 0.040, -0.547 + 0.020, 1.447 + 0.010)),
+                "RFtip": ((-0.148 - 0.040, -0.543 - 0.020, 1.445 - 0.010), (-0.148 + 0.040, -0.543 + 0.020, 1.445 + 0.010)),
+                "LFtip": ((-0.148 - 0.040, -0.528 - 0.020, 1.434 - 0.010), (-0.148 + 0.040, -0.528 + 0.020, 1.434 + 0.010))}})

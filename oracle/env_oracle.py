@@ -187,3 +187,66 @@ class PoseEnvOracle:
         rwd = self.get_reward_dict(self.obs_dict)
         self.rwd_dict = rwd
         return obs, float(rwd["dense"]), bool(rwd["done"]), rwd
+
+
+def reach_reset_draws(n3: int, env: int, episode: int, seed: int):
+    """u[n3] exactly as k_reset draws the reach targets (counter = (i/4, 1, env, episode), word i%4)."""
+    i = np.arange(n3)
+    c = philox4x32_10((i >> 2).astype(np.uint64), np.ones(n3, np.uint64), np.full(n3, env, np.uint64),
+                      np.full(n3, episode, np.uint64), seed & 0xFFFFFFFF, seed >> 32)
+    u = np.stack([u01(x) for x in c], axis=1)
+    return u[i, i & 3]
+
+
+class ReachEnvOracle(PoseEnvOracle):
+    """Single-env CPU restatement of ReachEnvV0 (myosuite/envs/myo/myobase/reach_v0.py:95-151)."""
+    RWD_KEYS_WT = {"reach": 1.0, "bonus": 4.0, "penalty": 50}
+
+    def __init__(self, compiled, tip_sids, far_th, frame_skip=10, normalize_act=True, muscle_condition="", reaf=None):
+        super().__init__(compiled, pose_thd=0.0, frame_skip=frame_skip, normalize_act=normalize_act,
+                         muscle_condition=muscle_condition, weighted_reward_keys=self.RWD_KEYS_WT, reaf=reaf)
+        self.tip_sids = list(tip_sids)
+        self.far_th = far_th
+        self.target_pos = np.zeros(3 * len(self.tip_sids))
+
+    def reset(self, target_pos):
+        self.d.reset()
+        self.target_pos = np.asarray(target_pos, np.float64).copy()
+        self.steps = 0
+        if self.muscle_condition == "fatigue":
+            self.fatigue.reset()
+        self.d.forward()
+        return self.get_obs()
+
+    def get_obs_dict(self):                                      # reach_v0.py:95-121
+        d = self.d
+        od = collections.OrderedDict()
+        od["time"] = np.array([d.time])
+        od["qpos"] = d.qpos.copy()
+        od["qvel"] = d.qvel.copy() * self.dt
+        od["act"] = d.act.copy()
+        od["tip_pos"] = np.concatenate([d.site_xpos[s] for s in self.tip_sids])
+        od["target_pos"] = self.target_pos.copy()
+        od["reach_err"] = od["target_pos"] - od["tip_pos"]
+        return od
+
+    def get_obs(self):
+        od = self.get_obs_dict()
+        self.obs_dict = od
+        return np.concatenate([od[k].ravel() for k in ("qpos", "qvel", "tip_pos", "reach_err", "act")]).astype(np.float32)
+
+    def get_reward_dict(self, od):                               # reach_v0.py:123-151
+        reach_dist = np.linalg.norm(od["reach_err"], axis=-1)
+        act_mag = np.linalg.norm(od["act"], axis=-1) / self.cm.na if self.cm.na != 0 else 0
+        far_th = self.far_th * len(self.tip_sids) if np.squeeze(od["time"]) > 2 * self.dt else np.inf
+        near_th = len(self.tip_sids) * 0.0125
+        rwd = collections.OrderedDict((
+            ("reach", -1.0 * reach_dist),
+            ("bonus", 1.0 * (reach_dist < 2 * near_th) + 1.0 * (reach_dist < near_th)),
+            ("act_reg", -1.0 * act_mag),
+            ("penalty", -1.0 * (reach_dist > far_th)),
+            ("sparse", -1.0 * reach_dist),
+            ("solved", reach_dist < near_th),
+            ("done", reach_dist > far_th)))
+        rwd["dense"] = np.sum([wt * rwd[k] for k, wt in self.rwd_keys_wt.items()], axis=0)
+        return rwd

@@ -120,6 +120,42 @@ def gen_pose_env():
     np.savez(os.path.join(OUT, "ref_pose_env.npz"), **out)
 
 
+def gen_reach_env():
+    """ReachEnvV0.get_obs_dict / get_reward_dict (reach_v0.py:95-151) executed on synthetic (qpos,qvel,act,site_xpos)."""
+    reach = _load("ref_reach_v0", f"{REF}/envs/myo/myobase/reach_v0.py", _stubs())
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(5)
+    n, nq, na, ntip = 48, 23, 39, 5
+    tip_sids = [3, 7, 11, 15, 19]; target_sids = [20, 21, 22, 23, 24]
+    qpos = rng.uniform(-1, 1.5, (n, nq)); qvel = rng.standard_normal((n, nq)) * 3; act = rng.random((n, na))
+    site = rng.uniform(-0.3, 0.3, (n, 25, 3))
+    site[:12, target_sids] = site[:12, tip_sids] + rng.uniform(-0.01, 0.01, (12, 5, 3))     # near: bonus / solved
+    site[12:24, target_sids] = site[12:24, tip_sids] + 0.3                                  # far: penalty / done
+    times = np.where(np.arange(n) % 3 == 0, 0.02, 0.5)                                      # far_th = inf while t <= 2 dt
+    dt, far_th = 0.02, 0.034
+    obs, rwd = [], {k: [] for k in ("reach", "bonus", "act_reg", "penalty", "sparse", "solved", "done", "dense")}
+    for i in range(n):
+        self = types.SimpleNamespace(dt=dt, far_th=far_th, tip_sids=tip_sids, target_sids=target_sids,
+                                     mj_model=types.SimpleNamespace(na=na),
+                                     rwd_keys_wt=reach.ReachEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS)
+        data = types.SimpleNamespace(time=times[i], qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(),
+                                     site_xpos=site[i].copy())
+        od = reach.ReachEnvV0.get_obs_dict(self, self.mj_model, data)
+        ov = ovd.ObsVecDict()
+        _, vec = ov.obsdict2obsvec(od, ["qpos", "qvel", "tip_pos", "reach_err", "act"])
+        od3 = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+        self.obs_dict = od3
+        rd = reach.ReachEnvV0.get_reward_dict(self, od3)
+        obs.append(vec)
+        for k in rwd:
+            rwd[k].append(np.squeeze(rd[k]))
+    out = dict(qpos=qpos, qvel=qvel, act=act, site_xpos=site, time=times, obs=np.array(obs), dt=np.array(dt),
+               far_th=np.array(far_th), tip_sids=np.array(tip_sids), target_sids=np.array(target_sids))
+    for k in rwd:
+        out[f"rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    np.savez(os.path.join(OUT, "ref_reach_env.npz"), **out)
+
+
 def gen_math():
     qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
     vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
@@ -139,5 +175,6 @@ def gen_math():
 if __name__ == "__main__":
     gen_fatigue()
     gen_pose_env()
+    gen_reach_env()
     gen_math()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))

@@ -94,3 +94,25 @@ def test_philox_known_answer():
     assert [int(x) for x in c] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     c = philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
     assert [int(x) for x in c] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_reach_oracle_obs_reward_match_reference_code(oracle_lib, models):
+    """ReachEnvOracle's dict arithmetic vs vectors produced by the reference's reach_v0.py (ref_reach_env.npz)."""
+    import collections
+    from oracle.env_oracle import ReachEnvOracle
+    g = np.load(os.path.join(G, "ref_reach_env.npz"))
+    tips, tgts = list(g["tip_sids"]), list(g["target_sids"])
+    env = ReachEnvOracle(models["hand"], tip_sids=tips, far_th=float(g["far_th"]))
+    env.dt = float(g["dt"])
+    for i in range(g["qpos"].shape[0]):
+        site = g["site_xpos"][i]
+        od = collections.OrderedDict()
+        od["time"] = np.array([g["time"][i]]); od["qpos"] = g["qpos"][i]; od["qvel"] = g["qvel"][i] * env.dt
+        od["act"] = g["act"][i]
+        od["tip_pos"] = np.concatenate([site[s] for s in tips]); od["target_pos"] = np.concatenate([site[s] for s in tgts])
+        od["reach_err"] = od["target_pos"] - od["tip_pos"]
+        vec = np.concatenate([od[k].ravel() for k in ("qpos", "qvel", "tip_pos", "reach_err", "act")]).astype(np.float32)
+        np.testing.assert_array_equal(vec, g["obs"][i])
+        rd = env.get_reward_dict(od)
+        for k in ("reach", "bonus", "act_reg", "penalty", "sparse", "solved", "done", "dense"):
+            np.testing.assert_allclose(float(rd[k]), g[f"rwd_{k}"][i], rtol=1e-12, atol=1e-12, err_msg=k)

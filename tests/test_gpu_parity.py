@@ -274,3 +274,35 @@ def test_full_size_properties_hand_4096():
     q = st.qpos.clone(); v = st.qvel.clone()
     E.forward(env.hm, st)
     assert torch.equal(q, st.qpos) and torch.equal(v, st.qvel)
+
+
+def test_reach_env_matches_env_oracle(models, oracle_lib):
+    """myoHandReachRandom-v0: target draws, first obs, 10 steps of obs / reward terms / done vs ReachEnvOracle
+    (whose dict arithmetic is pinned to the reference's reach_v0.py by tests/test_golden.py)."""
+    nenv, nsteps = 5, 10
+    env = registry.make("myoHandReachRandom-v0", num_envs=nenv, seed=11, autoreset=False)
+    cm = env.cm
+    obs0, _ = env.reset(seed=11)
+    tlo, thi = env._tlo.cpu().numpy(), env._thi.cpu().numpy()
+    oracles = []
+    for e in range(nenv):
+        u = EO.reach_reset_draws(3 * env.ntip, e, 1, 11)
+        tg = (tlo + (thi - tlo) * u).astype(np.float32)
+        np.testing.assert_allclose(env.target_pos[e].cpu().numpy(), tg, rtol=0, atol=1e-7)
+        o = EO.ReachEnvOracle(cm, tip_sids=env.tip_sids, far_th=env.far_th)
+        ob = o.reset(tg)
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), ob, rtol=0, atol=2e-6)
+        oracles.append(o)
+    assert obs0.shape == (nenv, 115)                      # NPG policy pickle n=115 (SURVEY.md 8f)
+    rng = np.random.default_rng(1)
+    for s in range(nsteps):
+        a = rng.uniform(-1, 1, (nenv, cm.nu)).astype(np.float32)
+        obs, rwd, term, trunc, info = env.step(torch.from_numpy(a))
+        for e, o in enumerate(oracles):
+            ob, r, done, rd = o.step(a[e])
+            np.testing.assert_allclose(obs[e].cpu().numpy(), ob, rtol=0, atol=5e-4)
+            for i, k in enumerate(E.RWD_KEYS_REACH):
+                assert abs(float(env.rwd[e, i]) - float(rd[k])) < 2e-3 * max(1.0, abs(float(rd[k]))), k
+            assert bool(term[e]) == done
+    assert list(info["obs_dict"].keys()) == ["time", "qpos", "qvel", "tip_pos", "target_pos", "reach_err", "act"]
+    assert list(info["rwd_dict"].keys()) == E.RWD_KEYS_REACH
