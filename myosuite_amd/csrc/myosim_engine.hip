@@ -1560,7 +1560,10 @@ static void build_layout(mm_model* m) {
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
-  if ((o & 1) == 0) o++;   // odd stride: neighbouring envs start on different LDS banks
+  // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
+  // envs of a wave do not start on the same LDS bank
+  o = (o + 3) & ~3;
+  if ((o & 31) == 0) o += 4;
   L.total = o;
   m->lds_per_env = (size_t)o * 4;
   DbgLayout& D = m->D;
