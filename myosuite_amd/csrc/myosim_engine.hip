@@ -37,6 +37,7 @@
 struct Dims {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, njmax, ntenJ;
   int iterations, ls_iterations, eulerdamp, any_damping;
+  int gen;   // model has equality / contact rows: general (dense-J) constraint path
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
 };
 
@@ -48,6 +49,7 @@ struct Layout {
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
   int vec;  // nv: joint-transmission actuator forces
+  int efcJ, rowtab;   // general constraint rows: J [G][NVP+1], row table [G][3] (GEN models only)
   int total;
 };
 
@@ -389,7 +391,7 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 
 // =========================================================================== engine
 // All member functions are collective over the G lanes of one env group.  NVP = padded nv (compile time).
-template <int G, int NVP>
+template <int G, int NVP, bool GEN>
 struct Engine {
   const KArgs& a;
   const uint32_t* mb;  // model words (LDS-resident copy or global)
@@ -421,6 +423,9 @@ struct Engine {
   bool r_active;
   float r_D, r_aref, r_sign, r_jar;
   int r_dof;
+  // ---- general rows (GEN): lane r owns row r of efc_J (LDS); equality rows are always active
+  bool r_eq;
+  int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
 
   __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
       : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
@@ -449,7 +454,7 @@ struct Engine {
         c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
       }
     }
-    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
     b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
@@ -730,6 +735,7 @@ struct Engine {
   // One potential limit row per JOINT, owned by lane j: a joint can violate only one side of its range at a
   // time (mm_model_create rejects ranges narrower than 2*margin).
   __device__ __forceinline__ void make_constraint() {
+    if constexpr (GEN) { make_constraint_gen(); return; }
     const Layout& L = a.L;
     const int j = g;
     r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = 1.f;
@@ -898,10 +904,13 @@ struct Engine {
   // (instruction-level parallelism) instead of one serial dot-product chain per column.
   // Leaves Lrow (L[g][k]) and d_dinv (1/L[g][g]) in registers and L in the LDS tile (for the L' solve).
   __device__ __forceinline__ void factor(float dadd) {
-    const Layout& L = a.L;
     float A[NVP];
 #pragma unroll
     for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == g ? dadd : 0.f);
+    factor_core(A);
+  }
+  __device__ __forceinline__ void factor_core(float (&A)[NVP]) {
+    const Layout& L = a.L;
 #pragma unroll
     for (int j = 0; j < NVP; j++) {
       float piv = bc<G>(A[j], j);
@@ -1017,6 +1026,7 @@ struct Engine {
   }
 
   __device__ __forceinline__ void solve_constraints() {
+    if constexpr (GEN) { solve_constraints_gen(); return; }
     const int nv = a.d.nv;
     niter = 0;
     d_qfrccon = 0.f;
@@ -1097,6 +1107,325 @@ struct Engine {
         status |= 4;
       }
     }
+  }
+
+
+  // ===================================================== general constraint rows (GEN models)
+  // Row r of efc_J lives in LDS (row stride NVP+1: odd, so both "lane = row" and "lane = column" sweeps are
+  // bank-conflict free); lane r owns the row's scalars (D, aref, jar).  Row order: equalities, active joint
+  // limits (compacted), contact pyramid edges (compacted).  Restates mmo_make_constraint / mmo_collision.inc.
+  static constexpr int RS = NVP + 1;
+  __device__ __forceinline__ float* Jrow(int r) const { return W + a.L.efcJ + r * RS; }
+  __device__ __forceinline__ int gscan_excl(int v) const {
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) { int t = __shfl_up(incl, d, G); if (g >= d) incl += t; }
+    return incl - v;
+  }
+  __device__ __forceinline__ int gsum_i(int v) const {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
+    return v;
+  }
+  __device__ __forceinline__ V3 geom_zaxis(int gi) const {
+    M3 R = geom_mat(gi);
+    return v3(R.m[2], R.m[5], R.m[8]);
+  }
+  // Jacobian entries of one contact: rows r0.. get  +-(edge . (J_b2 - J_b1))  over the two kinematic chains
+  __device__ __forceinline__ void contact_rows(int r0, int nrow, int b1, int b2, V3 pos, V3 n, V3 t1, V3 t2, float mu) {
+    const Layout& L = a.L;
+    for (int side = 0; side < 2; side++) {
+      int b = side ? b2 : b1;
+      const float sg = side ? 1.f : -1.f;
+      while (b > 0) {
+        const int da = MI_(BODY_DOFADR)[b], dn = MI_(BODY_DOFNUM)[b];
+        for (int i = da; i < da + dn; i++) {
+          V3 ang = ld3(W + L.cdof + 6 * i), lin = ld3(W + L.cdof + 6 * i + 3);
+          V3 off = pos - ld3(W + L.com + 3 * AUXI(dof_rootslot)[i]);
+          V3 v = lin + cross(ang, off);
+          float vn = sg * dot(n, v), v1 = sg * mu * dot(t1, v), v2 = sg * mu * dot(t2, v);
+          if (nrow == 1) Jrow(r0)[i] += vn;
+          else { Jrow(r0)[i] += vn + v1; Jrow(r0 + 1)[i] += vn - v1; Jrow(r0 + 2)[i] += vn + v2; Jrow(r0 + 3)[i] += vn - v2; }
+        }
+        b = MI_(BODY_PARENT)[b];
+      }
+    }
+  }
+  // sphere-sphere building block (mmo_collision.inc: sphere_sphere); returns false when dist >= margin
+  __device__ __forceinline__ bool sph_sph(V3 c1, float r1, V3 c2, float r2, float margin, float& dist, V3& pos, V3& n) const {
+    V3 d = c2 - c1;
+    float len = sqrtf(dot(d, d));
+    dist = len - r1 - r2;
+    if (!(dist < margin)) return false;
+    n = len < MINVALF ? v3(0.f, 0.f, 1.f) : (1.f / len) * d;
+    pos = c1 + (r1 + 0.5f * dist) * n;
+    return true;
+  }
+  __device__ __forceinline__ bool pln_sph(V3 pp, V3 pn, V3 c, float r, float margin, float& dist, V3& pos, V3& n) const {
+    dist = dot(c - pp, pn) - r;
+    if (!(dist < margin)) return false;
+    n = pn;
+    pos = c - (r + 0.5f * dist) * pn;
+    return true;
+  }
+  __device__ __forceinline__ V3 seg_closest(V3 a0, V3 u, float h, V3 p) const {
+    float t = clampf(dot(p - a0, u), -h, h);
+    return a0 + t * u;
+  }
+
+  __device__ __forceinline__ void make_constraint_gen() {
+    const Layout& L = a.L;
+    float* RT = W + L.rowtab;
+    for (int e = g; e < G * RS; e += G) W[L.efcJ + e] = 0.f;
+    GSYNC();
+    const int neq = a.d.neq;
+    // ---- equality rows: joint coupling q1 - q1_0 = poly(q2 - q2_0)
+    if (g < neq) {
+      const int e = g, j1 = MI_(EQ_OBJ1ID)[e], j2 = MI_(EQ_OBJ2ID)[e];
+      const float* c = MF_(EQ_DATA) + 5 * e;
+      const int q1 = MI_(JNT_QPOSADR)[j1], d1 = MI_(JNT_DOFADR)[j1];
+      float pos1 = W[L.qpos + q1] - MF_(QPOS0)[q1], res, deriv = 0.f;
+      float dA = MF_(DOF_INVWEIGHT0)[d1];
+      if (j2 >= 0) {
+        const int q2 = MI_(JNT_QPOSADR)[j2], d2 = MI_(JNT_DOFADR)[j2];
+        float x = W[L.qpos + q2] - MF_(QPOS0)[q2];
+        res = pos1 - (c[0] + x * (c[1] + x * (c[2] + x * (c[3] + x * c[4]))));
+        deriv = c[1] + x * (2.f * c[2] + x * (3.f * c[3] + x * 4.f * c[4]));
+        dA += MF_(DOF_INVWEIGHT0)[d2];
+        Jrow(e)[d2] = -deriv;
+      } else res = pos1 - c[0];
+      Jrow(e)[d1] = 1.f;
+      RT[3 * e] = __int_as_float(MM_CON_EQUALITY | (e << 2)); RT[3 * e + 1] = res; RT[3 * e + 2] = dA;
+    }
+    // ---- joint limits, compacted behind the equalities
+    int lim = 0, ldof = 0;
+    float ldist = 0.f, lsign = 1.f, lmargin = 0.f;
+    if (g < a.d.njnt) {
+      const int j = g, type = MI_(JNT_TYPE)[j];
+      if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+        ldof = MI_(JNT_DOFADR)[j];
+        float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
+        lmargin = MF_(JNT_MARGIN)[j];
+        float dlo = q - MF_(JNT_RANGE)[2 * j], dhi = MF_(JNT_RANGE)[2 * j + 1] - q;
+        ldist = dlo;
+        if (!(dlo < lmargin) && dhi < lmargin) { ldist = dhi; lsign = -1.f; }
+        lim = ldist < lmargin ? 1 : 0;
+      }
+    }
+    const int lrank = gscan_excl(lim), nlim = gsum_i(lim);
+    int over = 0;
+    if (lim) {
+      const int r = neq + lrank;
+      if (r < G) {
+        Jrow(r)[ldof] = lsign;
+        RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 2)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
+      } else over = 1;
+    }
+    // ---- contacts: lane p handles explicit pair p (up to two contacts for plane-capsule)
+    int nc = 0, rowsper = 0, b1 = 0, b2 = 0;
+    float cdist[2] = {0.f, 0.f}, mu = 0.f, incl = 0.f;
+    V3 cpos[2], cn[2];
+    cpos[0] = cpos[1] = cn[0] = cn[1] = v3(0.f, 0.f, 0.f);
+    if (g < a.d.npair) {
+      const int p = g, g1 = MI_(PAIR_GEOM1)[p], g2 = MI_(PAIR_GEOM2)[p];
+      const int t1 = MI_(GEOM_TYPE)[g1], t2 = MI_(GEOM_TYPE)[g2];
+      const float margin = MF_(PAIR_MARGIN)[p];
+      incl = margin - MF_(PAIR_GAP)[p];
+      mu = MF_(PAIR_FRICTION)[3 * p];
+      rowsper = MI_(PAIR_CONDIM)[p] == 1 ? 1 : 4;
+      b1 = MI_(GEOM_BODYID)[g1]; b2 = MI_(GEOM_BODYID)[g2];
+      V3 x1 = geom_pos(g1), x2 = geom_pos(g2);
+      const float r1 = MF_(GEOM_SIZE)[3 * g1], h1 = MF_(GEOM_SIZE)[3 * g1 + 1];
+      const float r2 = MF_(GEOM_SIZE)[3 * g2], h2 = MF_(GEOM_SIZE)[3 * g2 + 1];
+      if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_SPHERE) {
+        nc = pln_sph(x1, geom_zaxis(g1), x2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_CAPSULE) {
+        V3 pn = geom_zaxis(g1), u2 = geom_zaxis(g2);
+        for (int sgn = 0; sgn < 2; sgn++) {
+          V3 c = x2 + (sgn ? h2 : -h2) * u2;
+          float dd; V3 pp, nn;
+          if (pln_sph(x1, pn, c, r2, margin, dd, pp, nn)) { cdist[nc] = dd; cpos[nc] = pp; cn[nc] = nn; nc++; }
+        }
+      } else if (t1 == MM_GEOM_SPHERE && t2 == MM_GEOM_SPHERE) {
+        nc = sph_sph(x1, r1, x2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if (t1 == MM_GEOM_SPHERE && t2 == MM_GEOM_CAPSULE) {
+        V3 c = seg_closest(x2, geom_zaxis(g2), h2, x1);
+        nc = sph_sph(x1, r1, c, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if (t1 == MM_GEOM_CAPSULE && t2 == MM_GEOM_CAPSULE) {
+        V3 u1 = geom_zaxis(g1), u2 = geom_zaxis(g2), w = x1 - x2;
+        float bb = dot(u1, u2), dd = dot(u1, w), ee = dot(u2, w), den = 1.f - bb * bb;
+        float s1 = den < 1e-9f ? 0.f : (bb * ee - dd) / den;
+        s1 = clampf(s1, -h1, h1);
+        float s2 = ee + bb * s1;
+        if (s2 < -h2 || s2 > h2) { s2 = s2 < -h2 ? -h2 : h2; s1 = clampf(bb * s2 - dd, -h1, h1); }
+        nc = sph_sph(x1 + s1 * u1, r1, x2 + s2 * u2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      }
+    }
+    int myrows = 0;
+    for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
+    int base = neq + nlim + gscan_excl(myrows);
+    const int ncrows = gsum_i(myrows);
+    for (int c = 0; c < 2; c++) {
+      if (!(c < nc && cdist[c] < incl)) continue;
+      if (base + rowsper > G) { over = 1; continue; }
+      // contact frame (mmo_collision.inc: make_frame)
+      V3 n = cn[c];
+      V3 y = (n.y < 0.5f && n.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
+      y = y - dot(n, y) * n;
+      y = (1.f / fmaxf(sqrtf(dot(y, y)), MINVALF)) * y;
+      V3 z = cross(n, y);
+      contact_rows(base, rowsper, b1, b2, cpos[c], n, y, z, mu);
+      const float tran = MF_(BODY_INVWEIGHT0)[2 * b1] + MF_(BODY_INVWEIGHT0)[2 * b2];
+      for (int k = 0; k < rowsper; k++) {
+        RT[3 * (base + k)] = __int_as_float(MM_CON_CONTACT | (g << 2));
+        RT[3 * (base + k) + 1] = cdist[c] - incl;
+        RT[3 * (base + k) + 2] = rowsper == 1 ? tran : tran + mu * mu * tran;
+      }
+      base += rowsper;
+    }
+    if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
+    nefc = neq + nlim + ncrows;
+    if (nefc > G) nefc = G;
+    {
+      int w = nefc;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) w = max(w, __shfl_xor(w, m, 64));
+      nrows_wave = __builtin_amdgcn_readfirstlane(w);
+    }
+    GSYNC();
+    // ---- owner stage: impedance / reference acceleration of row g (mmo_reference_constraint + pyramid R)
+    r_active = g < nefc; r_eq = false; r_D = 0.f; r_aref = 0.f; r_jar = 0.f;
+    if (r_active) {
+      const int desc = __float_as_int(RT[3 * g]), kind = desc & 3, id = desc >> 2;
+      const float x = RT[3 * g + 1], dA = RT[3 * g + 2];
+      float vel = 0.f;
+      const float* J = Jrow(g);
+      for (int k = 0; k < a.d.nv; k++) vel += J[k] * W[L.qvel + k];
+      const float *si, *sr;
+      if (kind == MM_CON_EQUALITY) { si = MF_(EQ_SOLIMP) + 5 * id; sr = MF_(EQ_SOLREF) + 2 * id; }
+      else if (kind == MM_CON_LIMIT_JOINT) { si = MF_(JNT_SOLIMP) + 5 * id; sr = MF_(JNT_SOLREF) + 2 * id; }
+      else { si = MF_(PAIR_SOLIMP) + 5 * id; sr = MF_(PAIR_SOLREF) + 2 * id; }
+      impedance(si, sr, x, dA, vel, r_D, r_aref);
+      if (kind == MM_CON_CONTACT && MI_(PAIR_CONDIM)[id] > 1) {
+        const float m_ = MF_(PAIR_FRICTION)[3 * id];
+        r_D = 1.f / fmaxf(MINVALF, 2.f * m_ * m_ / r_D);
+      }
+      r_eq = kind == MM_CON_EQUALITY;
+    }
+  }
+
+  // (J x)_r for the row owned by this lane; x lives in the dof lanes
+  __device__ __forceinline__ float jac_mul(float x) const {
+    const float* J = Jrow(g);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVP; k++) s += J[k] * bc<G>(x, k);
+    return s;
+  }
+  // (J' f)_i for the dof owned by this lane; f lives in the row lanes
+  __device__ __forceinline__ float jacT_mul(float f) const {
+    const float* Jc = W + a.L.efcJ + (g < NVP ? g : 0);
+    float s = 0.f;
+    for (int r = 0; r < nrows_wave; r++) s += Jc[r * RS] * bc<G>(f, r);
+    return g < a.d.nv ? s : 0.f;
+  }
+  __device__ __forceinline__ float cost_gen(float x, float Ma) {
+    float c = 0.5f * (x - d_qaccsm) * (Ma - d_smooth);
+    r_jar = jac_mul(x) - r_aref;
+    if (r_active && (r_eq || r_jar < 0.f)) c += 0.5f * r_D * r_jar * r_jar;
+    return gsum<G>(c);
+  }
+
+  __device__ __forceinline__ void solve_constraints_gen() {
+    const int nv = a.d.nv;
+    niter = 0;
+    d_qfrccon = 0.f;
+    if (nrows_wave == 0) { d_qacc = d_qaccsm; return; }
+    const float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
+    float Ma_ws = mul_m(d_warm);
+    float cost_ws = cost_gen(d_warm, Ma_ws);
+    float cost_sm = cost_gen(d_qaccsm, d_smooth);
+    float Ma;
+    if (cost_ws < cost_sm) { d_qacc = d_warm; Ma = Ma_ws; (void)cost_gen(d_qacc, Ma); }
+    else { d_qacc = d_qaccsm; Ma = d_smooth; }
+    float alpha_prev = 0.f;
+    unsigned long long set_prev = 0ull;
+    bool done = nefc == 0;     // envs of the wave that have no rows idle through the loop (wave-collective code below)
+    for (int iter = 0; iter < a.d.iterations; iter++) {
+      const bool on = r_active && (r_eq || r_jar < 0.f);
+      const unsigned long long set_now = __ballot(on);
+      d_qfrccon = jacT_mul(on ? -r_D * r_jar : 0.f);
+      float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
+      float gn = sqrtf(gsum<G>(grad * grad));
+      if (scale * gn < a.d.tolerance) done = true;
+      if (!done && iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
+        if (((set_now ^ set_prev) & gm) == 0ull) done = true;
+      }
+      if (__ballot(!done) == 0ull) break;
+      set_prev = set_now;
+      // H = M + J_A' D J_A : lane i accumulates row i, the J row is an LDS broadcast
+      float A[NVP];
+#pragma unroll
+      for (int k = 0; k < NVP; k++) A[k] = Mrow[k];
+      {
+        const float dr = on ? r_D : 0.f;
+        const int col = g < NVP ? g : 0;
+        for (int r = 0; r < nrows_wave; r++) {
+          const float sD = bc<G>(dr, r);
+          if (__ballot(sD != 0.f) == 0ull) continue;
+          const float* Jr = W + a.L.efcJ + r * RS;
+          const float c = g < NVP ? sD * Jr[col] : 0.f;
+#pragma unroll
+          for (int k = 0; k < NVP; k++) A[k] += c * Jr[k];
+        }
+      }
+      factor_core(A);
+      float search = -solve(grad);
+      if (g >= nv || done) search = 0.f;
+      float sn = sqrtf(gsum<G>(search * search));
+      if (sn < MINVALF) done = true;
+      float Mv = mul_m(search);
+      float jv = jac_mul(search);
+      float dm = Ma - d_smooth;
+      float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
+      const float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
+      float alpha = 1.f, lo = 0.f, hi = -1.f;
+      bool lsdone = done;
+      for (int it = 0; it < a.d.ls_iterations; it++) {
+        float x = r_jar + alpha * jv;
+        float d1 = 0.f, d2 = 0.f;
+        if (r_active && (r_eq || x < 0.f)) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
+        d1 = gsum<G>(d1) + q1 + 2.f * alpha * q2;
+        d2 = gsum<G>(d2) + 2.f * q2;
+        if (!lsdone) {
+          if (fabsf(d1) < fmaxf(gtol, 1e-6f * fabsf(q1))) lsdone = true;
+          else {
+            if (d1 < 0.f) lo = alpha; else hi = alpha;
+            float next = alpha - d1 / fmaxf(d2, MINVALF);
+            if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
+            else if (hi < 0.f && next <= lo) next = 2.f * lo + 1e-10f;
+            if (next == alpha) lsdone = true;
+            alpha = next;
+          }
+        }
+        if (__ballot(!lsdone) == 0ull) break;
+      }
+      if (!(alpha > 0.f)) done = true;
+      if (!done) {
+        d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
+        alpha_prev = alpha;
+        niter = iter + 1;
+      }
+      {
+        float stepmax = gmax<G>(fabsf(alpha * search)), qmax = gmax<G>(fabsf(d_qacc));
+        if (!done && stepmax <= 2e-7f * fmaxf(qmax, 1.f)) done = true;
+      }
+      if (iter == a.d.iterations - 1 && !done) status |= 4;
+    }
+    const bool on2 = r_active && (r_eq || r_jar < 0.f);
+    d_qfrccon = jacT_mul(on2 ? -r_D * r_jar : 0.f);
   }
 
   // ------------------------------------------------------------------ pipeline
@@ -1203,7 +1532,7 @@ struct Engine {
 };
 
 // =========================================================================== kernels
-template <int G, int NVP, bool LM>
+template <int G, int NVP, bool LM, bool GEN>
 __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   extern __shared__ float lds[];
   constexpr int EPW = 64 / G;  // envs per wave
@@ -1229,7 +1558,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * a.L.total;
   const Layout& L = a.L;
   const Dims& d = a.d;
-  Engine<G, NVP> E(a, mb, W, g);
+  Engine<G, NVP, GEN> E(a, mb, W, g);
 
   // ---- load state (HBM -> LDS tables / owner registers)
   for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
@@ -1545,6 +1874,16 @@ extern "C" const char* mm_version(void) { return "myosim-hip 0.2 (gfx950, lane=i
 
 static const int kNvpChoices[] = {4, 24, 32, 40};
 
+// compiled (lanes_per_env, padded nv, general-rows) kernel instantiations -- keep in sync with the CASE table in launch()
+static bool have_kernel(int G, int nvp, int gen) {
+  if (gen) return (nvp == 4 && G == 16) || (nvp == 24 && G == 32) || (nvp == 40 && G == 64);
+  if (nvp == 4) return G == 4 || G == 8 || G == 16 || G == 32 || G == 64;
+  if (nvp == 24) return G == 32 || G == 64;
+  if (nvp == 32) return G == 32 || G == 64;
+  if (nvp == 40) return G == 64;
+  return false;
+}
+
 static void build_layout(mm_model* m) {
   const Dims& d = m->d;
   Layout& L = m->L;
@@ -1560,6 +1899,8 @@ static void build_layout(mm_model* m) {
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
+  L.efcJ = L.rowtab = 0;
+  if (d.gen) { L.efcJ = take(m->lanes * (m->nvp + 1)); L.rowtab = take(3 * m->lanes); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
   o = (o + 3) & ~3;
@@ -1580,6 +1921,7 @@ static int check_lanes(const mm_model* m, int lanes) {
   const Dims& d = m->d;
   if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return 0;
   if (d.nbody > lanes || d.nv > lanes || d.njnt > lanes || m->nvp > lanes) return 0;
+  if (d.gen && (d.njmax > lanes || d.npair > lanes || d.neq > lanes)) return 0;   // one constraint row / pair per lane
   return 1;
 }
 
@@ -1603,7 +1945,24 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.timestep = of[MM_OF_TIMESTEP]; d.gx = of[MM_OF_GRAV_X]; d.gy = of[MM_OF_GRAV_Y]; d.gz = of[MM_OF_GRAV_Z];
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
   if (oi[MM_OI_INTEGRATOR] != 0) { delete m; return fail(MM_EUNSUPPORTED, "only the Euler integrator is implemented"); }
-  if (d.neq > 0 || d.npair > 0) { delete m; return fail(MM_EUNSUPPORTED, "equality/contact rows not implemented in this build"); }
+  d.gen = (d.neq > 0 || d.npair > 0) ? 1 : 0;
+  {
+    const int32_t* et = (const int32_t*)(blob + m->sec[MM_SEC_EQ_TYPE]);
+    for (int e = 0; e < d.neq; e++)
+      if (et[e] != MM_EQ_JOINT) { delete m; return fail(MM_EUNSUPPORTED, "only joint equalities are implemented"); }
+    const int32_t* gt = (const int32_t*)(blob + m->sec[MM_SEC_GEOM_TYPE]);
+    const int32_t* p1 = (const int32_t*)(blob + m->sec[MM_SEC_PAIR_GEOM1]);
+    const int32_t* p2 = (const int32_t*)(blob + m->sec[MM_SEC_PAIR_GEOM2]);
+    const int32_t* pc = (const int32_t*)(blob + m->sec[MM_SEC_PAIR_CONDIM]);
+    for (int p = 0; p < d.npair; p++) {
+      const int t1 = gt[p1[p]], t2 = gt[p2[p]];
+      const bool ok = (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
+                      (t1 == MM_GEOM_SPHERE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
+                      (t1 == MM_GEOM_CAPSULE && t2 == MM_GEOM_CAPSULE);
+      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane/sphere/capsule only (geom1 type <= geom2 type)"); }
+      if (pc[p] != 1 && pc[p] != 3) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1 or 3"); }
+    }
+  }
   const int32_t* tlim = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_LIMITED]);
   for (int t = 0; t < d.ntendon; t++)
     if (tlim[t]) { delete m; return fail(MM_EUNSUPPORTED, "tendon limits not implemented in this build"); }
@@ -1714,11 +2073,12 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->x.seg_list = append(seg_list);
   m->blob_words = (int)dev.size();
 
-  build_layout(m);
-  // default group width: the smallest that can own every body / dof / limit row
+  // default group width: the smallest that can own every body / dof / constraint row and has a compiled kernel
   m->lanes = 0;
-  for (int c : {4, 8, 16, 32, 64}) if (check_lanes(m, c)) { m->lanes = c; break; }
-  if (!m->lanes) { delete m; return fail(MM_EUNSUPPORTED, "model needs more than 64 lanes per env (nbody, nv or njnt > 64)"); }
+  for (int c : {4, 8, 16, 32, 64}) if (check_lanes(m, c) && have_kernel(c, m->nvp, d.gen)) { m->lanes = c; break; }
+  if (!m->lanes) { delete m; return fail(MM_EUNSUPPORTED, "no compiled kernel owns this model (needs > 64 lanes per env: nbody, nv, njnt or constraint rows > 64)"); }
+  if (d.gen) m->lanes_auto = 0;   // the row tables are sized for one group width
+  build_layout(m);
   HIPCHK(hipGetDevice(&m->device));
   HIPCHK(hipMalloc((void**)&m->d_blob, dev.size() * sizeof(uint32_t)));
   HIPCHK(hipMemcpy(m->d_blob, dev.data(), dev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1735,9 +2095,11 @@ extern "C" void mm_model_destroy(mm_model* m) {
 extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
   if (!m) return MM_EARG;
   if (lanes == 0) return MM_OK;
-  if (!check_lanes(m, lanes)) return fail(MM_EARG, "lanes_per_env must be 4/8/16/32/64 and >= nbody, nv, njnt, padded nv");
+  if (!check_lanes(m, lanes) || !have_kernel(lanes, m->nvp, m->d.gen))
+    return fail(MM_EARG, "lanes_per_env must be 4/8/16/32/64, >= nbody, nv, njnt, padded nv (and constraint rows), with a compiled kernel");
   m->lanes = lanes;
   m->lanes_auto = 0;
+  build_layout(m);
   return MM_OK;
 }
 
@@ -1776,36 +2138,28 @@ extern "C" void mm_debug_set_dump(float* dev_ptr) { g_dbg = dev_ptr; }
 static unsigned long long* g_prof = nullptr;
 extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_ptr; }
 
-template <int G, int NVP>
+template <int G, int NVP, bool GEN>
 static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static bool attr_done[2] = {false, false};
   const int lm = m->lds_model ? 1 : 0;
   if (!attr_done[lm]) {
-    if (lm) HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    else HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lm) HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, true, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[lm] = true;
   }
-  if (lm) hipLaunchKernelGGL((k_engine<G, NVP, true>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((k_engine<G, NVP, false>), grid, block, lds, st, a);
+  if (lm) hipLaunchKernelGGL((k_engine<G, NVP, true, GEN>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((k_engine<G, NVP, false, GEN>), grid, block, lds, st, a);
   HIPCHK(hipGetLastError());
   return MM_OK;
 }
 
-static bool have_kernel(int G, int nvp) {
-  if (nvp == 4) return G == 4 || G == 8 || G == 16 || G == 32 || G == 64;
-  if (nvp == 24) return G == 32 || G == 64;
-  if (nvp == 32) return G == 32 || G == 64;
-  if (nvp == 40) return G == 64;
-  return false;
-}
-
 static int launch(const mm_model* m, KArgs& a, void* stream) {
   int G = m->lanes;
-  if (m->lanes_auto) {
+  if (m->lanes_auto && !m->d.gen) {
     // narrowest group (most envs per wave) that still yields >= 2 waves per CU; else the widest available
     int best = 0;
     for (int c : {4, 8, 16, 32, 64}) {
-      if (!check_lanes(m, c) || !have_kernel(c, m->nvp)) continue;
+      if (!check_lanes(m, c) || !have_kernel(c, m->nvp, 0)) continue;
       best = c;
       if ((a.s.nenv + (64 / c) - 1) / (64 / c) >= 512) break;
     }
@@ -1832,11 +2186,12 @@ static int launch(const mm_model* m, KArgs& a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   a.blob_words = m->blob_words;
   a.prof = g_prof;
-#define CASE(GG, NN) if (G == GG && m->nvp == NN) return launch_t<GG, NN>(m, a, grid, block, lds, st);
-  CASE(4, 4) CASE(8, 4) CASE(16, 4) CASE(32, 4) CASE(64, 4)
-  CASE(32, 24) CASE(64, 24)
-  CASE(32, 32) CASE(64, 32)
-  CASE(64, 40)
+#define CASE(GG, NN, GN) if (G == GG && m->nvp == NN && m->d.gen == GN) return launch_t<GG, NN, GN != 0>(m, a, grid, block, lds, st);
+  CASE(4, 4, 0) CASE(8, 4, 0) CASE(16, 4, 0) CASE(32, 4, 0) CASE(64, 4, 0)
+  CASE(32, 24, 0) CASE(64, 24, 0)
+  CASE(32, 32, 0) CASE(64, 32, 0)
+  CASE(64, 40, 0)
+  CASE(16, 4, 1) CASE(32, 24, 1) CASE(64, 40, 1)
 #undef CASE
   return fail(MM_EUNSUPPORTED, "no compiled kernel for this (lanes_per_env, nv) combination");
 }

@@ -439,6 +439,9 @@ class ModelSpec:
         A["EQ_SOLIMP"] = np.array([e["solimp"] for e in self.equalities], f32).reshape(neq, 5)
 
         npair = len(self.pairs)
+        for p in self.pairs:   # MuJoCo orders a pair so that type(geom1) <= type(geom2)
+            if self.geoms[self._gname[p["g1"]]]["type"] > self.geoms[self._gname[p["g2"]]]["type"]:
+                p["g1"], p["g2"] = p["g2"], p["g1"]
         A["PAIR_GEOM1"] = np.array([self._gname[p["g1"]] for p in self.pairs], i32)
         A["PAIR_GEOM2"] = np.array([self._gname[p["g2"]] for p in self.pairs], i32)
         A["PAIR_CONDIM"] = np.array([p["condim"] for p in self.pairs], i32)
@@ -510,7 +513,10 @@ class ModelSpec:
         con_rows = 0
         for p in self.pairs:
             con_rows = max(con_rows, 1 if p["condim"] == 1 else 2 * (p["condim"] - 1))
-        nconmax = self.nconmax if self.nconmax else npair
+        # a plane-capsule pair can produce two contacts (one per end cap), every other supported pair one
+        ncon_bound = sum(2 if (self.geoms[self._gname[p["g1"]]]["type"] == 0
+                               and self.geoms[self._gname[p["g2"]]]["type"] == 3) else 1 for p in self.pairs)
+        nconmax = self.nconmax if self.nconmax else ncon_bound
         njmax = neq + nlim_j + nlim_t + nconmax * con_rows
 
         oi = np.zeros(C["MM_OI_COUNT"], i32)
@@ -582,7 +588,12 @@ class ModelSpec:
             lo = np.zeros(nq); hi = np.zeros(nq)
             for ji, j in enumerate(self.joints):
                 if j.type in (C["MM_JNT_SLIDE"], C["MM_JNT_HINGE"]):
-                    lo[qposadr[ji]], hi[qposadr[ji]] = j.range if j.limited else (-np.pi, np.pi)
+                    if j.limited:
+                        lo[qposadr[ji]], hi[qposadr[ji]] = j.range
+                    elif j.type == C["MM_JNT_HINGE"] and not any(e["j1"] == j.name for e in self.equalities):
+                        lo[qposadr[ji]], hi[qposadr[ji]] = (-np.pi, np.pi)
+                    else:   # unlimited slide, or a coordinate driven by a joint equality: reference value
+                        lo[qposadr[ji]] = hi[qposadr[ji]] = qpos0[qposadr[ji]]
             free_mask = np.ones(nq, bool)
             qs = lo + (hi - lo) * rng.random((lengthrange_samples, nq))
             # corners-ish: each coordinate snapped to an end with prob 1/2 in half of the samples
@@ -594,6 +605,14 @@ class ModelSpec:
                 if j.type in (C["MM_JNT_FREE"], C["MM_JNT_BALL"]):
                     n = 7 if j.type == C["MM_JNT_FREE"] else 4
                     qs[:, qposadr[ji]:qposadr[ji] + n] = qpos0[qposadr[ji]:qposadr[ji] + n]
+            for e in self.equalities:   # coupled coordinates follow their polynomial
+                a1 = qposadr[self._jname[e["j1"]]]
+                if e["j2"] is None:
+                    qs[:, a1] = qpos0[a1] + e["data"][0]
+                else:
+                    a2 = qposadr[self._jname[e["j2"]]]
+                    x = qs[:, a2] - qpos0[a2]
+                    qs[:, a1] = qpos0[a1] + sum(c * x ** i for i, c in enumerate(e["data"]))
             Ls = km.tendon_length(qs)
             for i in need_lr:
                 t = trnid[i]; g = self.actuators[i].gear

@@ -268,12 +268,220 @@ def make_hand(with_object: bool = False) -> ModelSpec:
     return s
 
 
+# ----------------------------------------------------------------------------- legs
+LEG_JOINTS_SIDE = ["hip_flexion", "hip_adduction", "hip_rotation", "knee_angle_translation2", "knee_angle_translation1",
+                   "knee_angle", "knee_angle_rotation2", "knee_angle_rotation3", "ankle_angle", "subtalar_angle",
+                   "mtp_angle", "knee_angle_beta_translation2", "knee_angle_beta_translation1",
+                   "knee_angle_beta_rotation1"]
+LEG_MUSCLES_SIDE = ["addbrev", "addlong", "addmagDist", "addmagIsch", "addmagMid", "addmagProx", "bflh", "bfsh", "edl",
+                    "ehl", "fdl", "fhl", "gaslat", "gasmed", "glmax1", "glmax2", "glmax3", "glmed1", "glmed2",
+                    "glmed3", "glmin1", "glmin2", "glmin3", "grac", "iliacus", "perbrev", "perlong", "piri", "psoas",
+                    "recfem", "sart", "semimem", "semiten", "soleus", "tfl", "tibant", "tibpost", "vasint", "vaslat",
+                    "vasmed"]
+
+
+def _jname(base, side):
+    """MyoLeg naming: knee_angle_r_translation2, hip_flexion_r, ..."""
+    if base.startswith("knee_angle"):
+        return "knee_angle_" + side + base[len("knee_angle"):]
+    return base + "_" + side
+
+
+# knee coupling polynomials q = poly(knee_angle) (synthetic magnitudes, same structure as MyoLeg's 7 joint equalities
+# per knee): tibia translations / secondary rotations, patella translations / rotation
+_KNEE_POLY = {"knee_angle_translation2": (0.0, -0.004, 0.0015), "knee_angle_translation1": (0.0, 0.003, -0.001),
+              "knee_angle_rotation2": (0.0, 0.04, -0.01), "knee_angle_rotation3": (0.0, 0.09, -0.025),
+              "knee_angle_beta_translation2": (0.0, -0.018, 0.002), "knee_angle_beta_translation1": (0.0, -0.012, 0.0),
+              "knee_angle_beta_rotation1": (0.0, 0.75, -0.05)}
+
+
+def make_leg() -> ModelSpec:
+    """myoLeg: free-floating pelvis + torso, 2 x 14 leg joints (34 DoF, nq 35), 80 muscles, 14 knee joint-equalities,
+    8 foot-ground contact pairs.  Frame: x right, y forward (walk_v0.py: target_y_vel), z up.
+    Joint / muscle names and dimensions: SURVEY.md 8d (walk_v0.py:236-241,438-451; docs/source/suite.rst)."""
+    s = ModelSpec("myolegs", timestep=0.001)  # x frame_skip 10 (BaseV0 default) = 0.01 s per env step: hip_period 100 -> 1 s stride
+    s.add_geom("floor", "world", "plane", (0, 0, 0))
+    PZ = 0.982
+    s.add_body("pelvis", "world", pos=(0, 0, PZ), mass=11.8, ipos=(0, -0.04, 0.0), inertia=(0.10, 0.09, 0.06))
+    s.add_joint("root", "pelvis", "free")
+    s.add_body("torso", "pelvis", pos=(0, -0.03, 0.08), mass=34.0, ipos=(0, -0.01, 0.27), inertia=(1.47, 1.43, 0.76))
+    s.add_site("pelvis_mark", "pelvis", (0, 0, 0))
+    for side, sx in (("r", 1.0), ("l", -1.0)):
+        def X(p):
+            return (sx * p[0], p[1], p[2])
+        B = {k: f"{k}_{side}" for k in ("femur", "tibia", "talus", "calcn", "toes", "patella")}
+        B["pelvis"] = "pelvis"
+        hinge = dict(damping=0.1, armature=0.005)
+        s.add_body(B["femur"], "pelvis", pos=X((0.085, 0.0, -0.07)), mass=9.3, ipos=(0, 0, -0.17),
+                   inertia=(0.134, 0.134, 0.035))
+        s.add_joint(_jname("hip_flexion", side), B["femur"], "hinge", axis=(1, 0, 0), range=(-0.52, 2.09), **hinge)
+        s.add_joint(_jname("hip_adduction", side), B["femur"], "hinge", axis=(0, sx, 0), range=(-0.87, 0.52), **hinge)
+        s.add_joint(_jname("hip_rotation", side), B["femur"], "hinge", axis=(0, 0, sx), range=(-0.70, 0.70), **hinge)
+        s.add_body(B["tibia"], B["femur"], pos=(0, 0, -0.41), mass=3.7, ipos=(0, 0, -0.187), inertia=(0.05, 0.05, 0.005))
+        minor = dict(damping=0.5, armature=0.01)
+        s.add_joint(_jname("knee_angle_translation2", side), B["tibia"], "slide", axis=(0, 0, 1), **minor)
+        s.add_joint(_jname("knee_angle_translation1", side), B["tibia"], "slide", axis=(0, 1, 0), **minor)
+        s.add_joint(_jname("knee_angle", side), B["tibia"], "hinge", axis=(-1, 0, 0), range=(0.0, 2.09), **hinge)
+        s.add_joint(_jname("knee_angle_rotation2", side), B["tibia"], "hinge", axis=(0, sx, 0), damping=0.1, armature=0.002)
+        s.add_joint(_jname("knee_angle_rotation3", side), B["tibia"], "hinge", axis=(0, 0, sx), damping=0.1, armature=0.002)
+        s.add_body(B["talus"], B["tibia"], pos=(0, 0, -0.43), mass=0.1, inertia=(0.001, 0.001, 0.001))
+        s.add_joint(_jname("ankle_angle", side), B["talus"], "hinge", axis=(1, 0, 0), range=(-0.70, 0.52),
+                    damping=0.5, armature=0.03)
+        s.add_body(B["calcn"], B["talus"], pos=X((-0.005, -0.049, -0.042)), mass=1.25, ipos=(0, 0.09, 0.012),
+                   inertia=(0.004, 0.0014, 0.0041))
+        ax = np.array([sx * 0.12, 0.787, 0.605]); ax /= np.linalg.norm(ax)      # oblique subtalar axis (inversion +)
+        s.add_joint(_jname("subtalar_angle", side), B["calcn"], "hinge", axis=tuple(-ax if sx > 0 else ax),
+                    range=(-0.35, 0.35), damping=0.3, armature=0.015)
+        s.add_body(B["toes"], B["calcn"], pos=(0, 0.179, -0.002), mass=0.22, ipos=(0, 0.03, -0.005),
+                   inertia=(0.0001, 0.0002, 0.0002))
+        s.add_joint(_jname("mtp_angle", side), B["toes"], "hinge", axis=(1, 0, 0), range=(-0.52, 0.52),
+                    damping=0.1, armature=0.003, stiffness=2.0)
+        s.add_body(B["patella"], B["femur"], pos=(0, 0.045, -0.40), mass=0.09, inertia=(1e-4, 1e-4, 1e-4))
+        s.add_joint(_jname("knee_angle_beta_translation2", side), B["patella"], "slide", axis=(0, 0, 1), **minor)
+        s.add_joint(_jname("knee_angle_beta_translation1", side), B["patella"], "slide", axis=(0, 1, 0), **minor)
+        s.add_joint(_jname("knee_angle_beta_rotation1", side), B["patella"], "hinge", pos=(0, -0.045, -0.01),
+                    axis=(-1, 0, 0), damping=0.1, armature=0.002)
+        for base, pc in _KNEE_POLY.items():
+            s.add_equality_joint(_jname(base, side), _jname("knee_angle", side), pc)
+
+        # ---- foot contact geometry (four spheres per foot) against the floor plane
+        s.add_geom(f"heel_{side}", B["calcn"], "sphere", (0.025,), pos=X((0.0, 0.012, -0.005)))
+        s.add_geom(f"ball_lat_{side}", B["calcn"], "sphere", (0.02,), pos=X((0.035, 0.155, -0.01)))
+        s.add_geom(f"ball_med_{side}", B["calcn"], "sphere", (0.02,), pos=X((-0.025, 0.165, -0.01)))
+        s.add_geom(f"toe_{side}", B["toes"], "sphere", (0.016,), pos=X((0.0, 0.035, -0.012)))
+        for gname in (f"heel_{side}", f"ball_lat_{side}", f"ball_med_{side}", f"toe_{side}"):
+            s.add_contact_pair("floor", gname, condim=3, friction=(1.0, 0.005, 0.0001))
+
+        # ---- knee-extensor wrap cylinder on the femoral condyles (axis along x), anterior side site
+        s.add_geom(f"knee_wrap_{side}", B["femur"], "cylinder", size=(0.04, 0.06), pos=(0, 0, -0.41),
+                   quat=(math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0))
+        s.add_site(f"knee_side_{side}", B["femur"], (0, 0.09, -0.41))
+
+        cnt = [0]
+
+        def site(body, p):
+            nm = f"ls_{side}_{cnt[0]}"; cnt[0] += 1
+            s.add_site(nm, B[body], X(p))
+            return ("site", nm)
+
+        KW = ("cylinder", f"knee_wrap_{side}", f"knee_side_{side}")
+
+        def muscle(name, path, force):
+            tn = f"{name}_{side}_tendon"
+            s.add_tendon(tn, path)
+            # vmax 10 L0/s (physiological): with MuJoCo's default 1.5 the force-velocity slope of the big ankle /
+            # knee muscles is too stiff for explicit Euler at this timestep (see DESIGN.md, synthetic models)
+            s.add_muscle(f"{name}_{side}", tn, force=force, range=(0.60, 1.35), vmax=10.0)
+
+        P, F, T, Cn, TO = "pelvis", "femur", "tibia", "calcn", "toes"
+        muscle("addbrev", [site(P, (0.020, 0.010, -0.090)), site(F, (0.005, -0.005, -0.13))], 600.0)
+        muscle("addlong", [site(P, (0.020, 0.020, -0.085)), site(F, (0.005, -0.003, -0.21))], 900.0)
+        muscle("addmagDist", [site(P, (0.030, -0.060, -0.110)), site(F, (0.005, -0.005, -0.23))], 600.0)
+        muscle("addmagIsch", [site(P, (0.035, -0.070, -0.115)), site(F, (-0.010, 0.000, -0.39))], 600.0)
+        muscle("addmagMid", [site(P, (0.030, -0.050, -0.105)), site(F, (0.005, -0.005, -0.17))], 600.0)
+        muscle("addmagProx", [site(P, (0.025, -0.040, -0.100)), site(F, (0.005, -0.005, -0.11))], 600.0)
+        muscle("bflh", [site(P, (0.060, -0.080, -0.100)), site(T, (0.035, -0.020, -0.04))], 1300.0)
+        muscle("bfsh", [site(F, (0.010, -0.005, -0.220)), site(T, (0.035, -0.020, -0.04))], 600.0)
+        muscle("edl", [site(T, (0.020, 0.020, -0.12)), site(T, (0.010, 0.035, -0.40)), site(Cn, (0.005, 0.110, 0.030)),
+                       site(TO, (0.010, 0.040, 0.005))], 350.0)
+        muscle("ehl", [site(T, (0.010, 0.020, -0.20)), site(T, (0.000, 0.035, -0.40)), site(Cn, (-0.010, 0.120, 0.030)),
+                       site(TO, (-0.015, 0.045, 0.008))], 160.0)
+        muscle("fdl", [site(T, (-0.015, -0.015, -0.20)), site(T, (-0.020, -0.020, -0.42)), site(Cn, (-0.020, 0.050, 0.000)),
+                       site(TO, (0.000, 0.030, -0.008))], 300.0)
+        muscle("fhl", [site(T, (0.000, -0.020, -0.25)), site(T, (-0.015, -0.030, -0.42)), site(Cn, (-0.020, 0.060, -0.005)),
+                       site(TO, (-0.015, 0.040, -0.008))], 350.0)
+        muscle("gaslat", [site(F, (0.020, -0.015, -0.395)), site(Cn, (0.003, -0.010, 0.020))], 1100.0)
+        muscle("gasmed", [site(F, (-0.020, -0.015, -0.395)), site(Cn, (-0.003, -0.010, 0.020))], 1600.0)
+        muscle("glmax1", [site(P, (0.050, -0.080, 0.040)), site(F, (0.040, -0.020, -0.06))], 700.0)
+        muscle("glmax2", [site(P, (0.045, -0.090, 0.000)), site(F, (0.035, -0.020, -0.10))], 900.0)
+        muscle("glmax3", [site(P, (0.030, -0.100, -0.050)), site(F, (0.030, -0.015, -0.14))], 700.0)
+        muscle("glmed1", [site(P, (0.100, 0.030, 0.090)), site(F, (0.055, -0.003, -0.005))], 900.0)
+        muscle("glmed2", [site(P, (0.110, -0.010, 0.090)), site(F, (0.056, -0.006, -0.005))], 600.0)
+        muscle("glmed3", [site(P, (0.090, -0.050, 0.070)), site(F, (0.055, -0.010, -0.005))], 700.0)
+        muscle("glmin1", [site(P, (0.100, 0.020, 0.040)), site(F, (0.050, 0.005, -0.005))], 300.0)
+        muscle("glmin2", [site(P, (0.105, 0.000, 0.040)), site(F, (0.050, 0.002, -0.005))], 300.0)
+        muscle("glmin3", [site(P, (0.095, -0.020, 0.035)), site(F, (0.050, -0.002, -0.005))], 300.0)
+        muscle("grac", [site(P, (0.015, 0.000, -0.100)), site(T, (-0.020, 0.015, -0.06))], 250.0)
+        muscle("iliacus", [site(P, (0.060, 0.040, 0.050)), site(P, (0.075, 0.045, -0.060)), site(F, (0.000, -0.005, -0.07))], 1100.0)
+        muscle("perbrev", [site(T, (0.030, -0.010, -0.25)), site(T, (0.030, -0.030, -0.42)), site(Cn, (0.030, 0.060, 0.000))], 500.0)
+        muscle("perlong", [site(T, (0.030, -0.005, -0.15)), site(T, (0.032, -0.030, -0.42)), site(Cn, (0.025, 0.070, -0.010))], 900.0)
+        muscle("piri", [site(P, (0.020, -0.100, 0.020)), site(F, (0.050, -0.010, 0.005))], 500.0)
+        muscle("psoas", [site(P, (0.030, 0.030, 0.120)), site(P, (0.070, 0.050, -0.060)), site(F, (-0.005, -0.008, -0.06))], 1400.0)
+        muscle("recfem", [site(P, (0.080, 0.040, -0.030)), KW, site(T, (0.000, 0.035, -0.06))], 2200.0)
+        muscle("sart", [site(P, (0.090, 0.050, 0.000)), site(F, (-0.030, 0.000, -0.36)), site(T, (-0.020, 0.020, -0.06))], 250.0)
+        muscle("semimem", [site(P, (0.050, -0.080, -0.105)), site(T, (-0.030, -0.020, -0.05))], 1100.0)
+        muscle("semiten", [site(P, (0.050, -0.085, -0.110)), site(T, (-0.030, -0.015, -0.07))], 600.0)
+        muscle("soleus", [site(T, (0.000, -0.020, -0.10)), site(Cn, (0.000, -0.010, 0.020))], 3600.0)
+        muscle("tfl", [site(P, (0.110, 0.040, 0.050)), site(F, (0.050, 0.010, -0.10)), site(T, (0.040, 0.010, -0.04))], 450.0)
+        muscle("tibant", [site(T, (0.015, 0.020, -0.15)), site(T, (0.000, 0.035, -0.41)), site(Cn, (-0.015, 0.090, 0.025))], 1100.0)
+        muscle("tibpost", [site(T, (-0.005, -0.015, -0.15)), site(T, (-0.020, -0.025, -0.42)), site(Cn, (-0.025, 0.050, 0.005))], 1400.0)
+        muscle("vasint", [site(F, (0.010, 0.025, -0.20)), KW, site(T, (0.000, 0.035, -0.06))], 1700.0)
+        muscle("vaslat", [site(F, (0.030, 0.015, -0.22)), KW, site(T, (0.005, 0.035, -0.06))], 3500.0)
+        muscle("vasmed", [site(F, (-0.020, 0.015, -0.25)), KW, site(T, (-0.005, 0.035, -0.06))], 2300.0)
+
+    names = ["root"] + [_jname(b, sd) for sd in ("r", "l") for b in LEG_JOINTS_SIDE]
+    assert [j.name for j in s.joints] == names
+    assert [a.name for a in s.actuators] == [f"{m}_{sd}" for sd in ("r", "l") for m in LEG_MUSCLES_SIDE]
+
+    # ---- keyframes (walk_v0.py:282-283,334-352 uses key 0 = stand, key 2 / 3 = mid-stride right / left)
+    def key(hip_r, knee_r, ank_r, hip_l, knee_l, ank_l, vy):
+        q = np.zeros(35); q[2] = PZ; q[3] = 1.0
+        v = np.zeros(34); v[1] = vy
+        for k, sd in enumerate(("r", "l")):
+            o = 7 + 14 * k
+            hip, knee, ank = ((hip_r, knee_r, ank_r), (hip_l, knee_l, ank_l))[k]
+            q[o + 0] = hip; q[o + 5] = knee; q[o + 8] = ank
+            for base, pc in _KNEE_POLY.items():
+                q[o + LEG_JOINTS_SIDE.index(base)] = sum(c * knee ** i for i, c in enumerate(pc))
+        return q, v
+    stand = key(0, 0, 0, 0, 0, 0, 0.0)
+    strideR = key(0.45, 0.25, 0.05, -0.25, 0.15, 0.10, 1.2)
+    strideL = key(-0.25, 0.15, 0.10, 0.45, 0.25, 0.05, 1.2)
+    s.keys = [stand, stand, strideR, strideL]
+    return s
+
+
+# ----------------------------------------------------------------------------- contact toy
+def make_contact_toy() -> ModelSpec:
+    """Small model that exercises every contact primitive of the engine (plane-sphere, plane-capsule,
+    sphere-sphere, sphere-capsule, capsule-capsule), a free joint and a joint equality.  Test model only."""
+    s = ModelSpec("contact_toy", timestep=0.002)
+    s.add_geom("floor", "world", "plane", (0, 0, 0), quat=(math.cos(0.05), math.sin(0.05), 0.0, 0.0))   # 5.7 deg tilt
+    s.add_body("log", "world", pos=(0, 0, 0.08), mass=1.5, inertia=(0.006, 0.006, 0.002))
+    s.add_joint("log_free", "log", "free")
+    s.add_geom("log_cap", "log", "capsule", (0.05, 0.12), quat=(math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0))
+    s.add_body("ball", "world", pos=(0.03, 0.01, 0.30), mass=0.6, inertia=(0.0009, 0.0009, 0.0009))
+    s.add_joint("ball_x", "ball", "slide", axis=(1, 0, 0), damping=0.1)
+    s.add_joint("ball_y", "ball", "slide", axis=(0, 1, 0), damping=0.1)
+    s.add_joint("ball_z", "ball", "slide", axis=(0, 0, 1), damping=0.1)
+    s.add_geom("ball_s", "ball", "sphere", (0.06,))
+    s.add_body("arm", "world", pos=(0.0, -0.25, 0.32), mass=0.8, ipos=(0, 0, -0.12), inertia=(0.004, 0.004, 0.0004))
+    s.add_joint("arm_hinge", "arm", "hinge", axis=(1, 0, 0), range=(-1.2, 1.2), damping=0.05, armature=0.002)
+    s.add_geom("arm_cap", "arm", "capsule", (0.03, 0.10), pos=(0, 0, -0.14))
+    s.add_body("puck", "world", pos=(0.25, 0.01, 0.30), mass=0.4, inertia=(0.0004, 0.0004, 0.0004))
+    s.add_joint("puck_x", "puck", "slide", axis=(1, 0, 0), range=(-0.4, 0.1), damping=0.2)
+    s.add_geom("puck_s", "puck", "sphere", (0.05,))
+    s.add_body("rider", "world", pos=(0.5, 0.3, 0.2), mass=0.2, inertia=(0.0002, 0.0002, 0.0002))
+    s.add_joint("rider_z", "rider", "slide", axis=(0, 0, 1), damping=0.1, armature=0.01)
+    s.add_equality_joint("rider_z", "arm_hinge", (0.0, 0.1, 0.05))
+    s.add_contact_pair("floor", "log_cap", condim=3, friction=(0.8, 0.005, 0.0001))
+    s.add_contact_pair("floor", "ball_s", condim=3, friction=(0.6, 0.005, 0.0001))
+    s.add_contact_pair("ball_s", "log_cap", condim=3, friction=(0.7, 0.005, 0.0001))
+    s.add_contact_pair("arm_cap", "log_cap", condim=3, friction=(0.9, 0.005, 0.0001))
+    s.add_contact_pair("puck_s", "ball_s", condim=1, margin=0.002)
+    return s
+
+
 _CACHE = {}
 
 
 def get_model(name: str) -> CompiledModel:
-    """Compiled synthetic model by short name: 'elbow' | 'hand'."""
+    """Compiled synthetic model by short name: 'elbow' | 'hand' | 'leg'."""
     if name not in _CACHE:
-        spec = {"elbow": make_elbow, "hand": make_hand}[name]()
-        _CACHE[name] = spec.compile()
+        spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy}[name]()
+        cm = spec.compile()
+        keys = getattr(spec, "keys", None)
+        if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob
+            cm.key_qpos = np.array([k[0] for k in keys]); cm.key_qvel = np.array([k[1] for k in keys])
+        _CACHE[name] = cm
     return _CACHE[name]

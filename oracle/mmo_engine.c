@@ -118,6 +118,9 @@ typedef struct {
   real *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_solref, *efc_solimp;
   real *efc_R, *efc_D, *efc_vel, *efc_aref, *efc_force;
   real *qfrc_constraint, *qacc;
+  /* contacts */
+  int* con_pair;
+  real *con_dist, *con_pos, *con_frame;
   /* scratch */
   real *cacc, *cfrc, *tmp_nv, *qH, *qHDiagInv;
   /* per-user task parameters the engine does not interpret */
@@ -154,6 +157,11 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   d->efc_R = ralloc(nj); d->efc_D = ralloc(nj); d->efc_vel = ralloc(nj); d->efc_aref = ralloc(nj);
   d->efc_force = ralloc(nj);
   d->qfrc_constraint = ralloc(nv); d->qacc = ralloc(nv);
+  {
+    int nc = m->nconmax > 0 ? m->nconmax : 1;
+    d->con_pair = (int*)calloc(nc, sizeof(int)); d->con_dist = ralloc(nc); d->con_pos = ralloc(3 * nc);
+    d->con_frame = ralloc(9 * nc);
+  }
   d->cacc = ralloc(6 * nb); d->cfrc = ralloc(6 * nb); d->tmp_nv = ralloc(nv);
   d->qH = ralloc(m->nM); d->qHDiagInv = ralloc(nv);
   mmo_reset(m, d);
@@ -170,9 +178,9 @@ void mmo_data_free(mmo_data* d) {
                 &d->actuator_force, &d->qfrc_actuator, &d->qfrc_smooth, &d->qacc_smooth, &d->efc_J,
                 &d->efc_pos, &d->efc_margin, &d->efc_diagApprox, &d->efc_solref, &d->efc_solimp, &d->efc_R,
                 &d->efc_D, &d->efc_vel, &d->efc_aref, &d->efc_force, &d->qfrc_constraint, &d->qacc, &d->cacc,
-                &d->cfrc, &d->tmp_nv, &d->qH, &d->qHDiagInv};
+                &d->cfrc, &d->tmp_nv, &d->qH, &d->qHDiagInv, &d->con_dist, &d->con_pos, &d->con_frame};
   for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
-  free(d->efc_type); free(d->efc_id);
+  free(d->efc_type); free(d->efc_id); free(d->con_pair);
   free(d);
 }
 
@@ -1303,7 +1311,7 @@ static const field_t kFields[] = {
     FLD(cvel), FLD(cdof_dot), FLD(qfrc_passive), FLD(qfrc_bias), FLD(act_dot), FLD(actuator_force),
     FLD(qfrc_actuator), FLD(qfrc_smooth), FLD(qacc_smooth), FLD(efc_J), FLD(efc_pos), FLD(efc_margin),
     FLD(efc_R), FLD(efc_D), FLD(efc_vel), FLD(efc_aref), FLD(efc_force), FLD(qfrc_constraint), FLD(qacc),
-    FLD(cfrc), FLD(cacc)};
+    FLD(cfrc), FLD(cacc), FLD(con_dist), FLD(con_pos), FLD(con_frame), FLD(efc_diagApprox)};
 
 real* mmo_field(mmo_data* d, const char* name) {
   for (unsigned i = 0; i < sizeof(kFields) / sizeof(kFields[0]); i++)

@@ -94,6 +94,8 @@ _SHAPES = {
     "efc_vel": lambda m: (max(m.njmax, 1),), "efc_aref": lambda m: (max(m.njmax, 1),),
     "efc_force": lambda m: (max(m.njmax, 1),), "qfrc_constraint": lambda m: (m.nv,), "qacc": lambda m: (m.nv,),
     "cfrc": lambda m: (m.nbody, 6), "cacc": lambda m: (m.nbody, 6),
+    "con_dist": lambda m: (max(m.nconmax, 1),), "con_pos": lambda m: (max(m.nconmax, 1), 3),
+    "con_frame": lambda m: (max(m.nconmax, 1), 9), "efc_diagApprox": lambda m: (max(m.njmax, 1),),
 }
 
 

@@ -1,0 +1,149 @@
+"""Contacts / equalities / free joint: oracle invariants (CPU) and HIP-vs-oracle parity (GPU).
+
+The contact model restated in oracle/mmo_collision.inc is UNPINNED against MuJoCo (engine parity header); the CPU
+tests here pin it against closed-form statics, the GPU tests pin the HIP general-row path against the oracle.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from myosuite_amd.model import synth
+from myosuite_amd.model.spec import ModelSpec
+from oracle import oracle as O
+
+
+def _ball(mu=1.0):
+    s = ModelSpec("ball", timestep=0.002)
+    s.add_geom("floor", "world", "plane", (0, 0, 0))
+    s.add_body("b", pos=(0, 0, 0.2), mass=1.0, inertia=(0.004, 0.004, 0.004))
+    s.add_joint("root", "b", type="free")
+    s.add_geom("s", "b", "sphere", (0.1,))
+    s.add_contact_pair("floor", "s", condim=3, friction=(mu, 0.005, 0.0001))
+    return s.compile()
+
+
+def test_ball_rests_with_contact_force_equal_weight(oracle_lib):
+    cm = _ball(); d = O.OracleData(O.OracleModel(cm))
+    d.step(1000)
+    assert d.ncon == 1 and d.nefc == 4            # one contact, four pyramid edges
+    assert abs(d.efc_force[:4].sum() - 9.81) < 1e-4
+    assert 0.099 < d.qpos[2] < 0.1               # sub-millimetre penetration of the soft contact
+    assert np.abs(d.qvel).max() < 1e-8
+    n = d.con_frame[0, :3]
+    np.testing.assert_allclose(n, [0, 0, 1], atol=1e-12)
+
+
+def test_axis_aligned_sliding_friction_is_mu_g(oracle_lib):
+    for mu in (0.3, 0.8):
+        s = ModelSpec("slider", timestep=0.002)
+        s.add_geom("floor", "world", "plane", (0, 0, 0))
+        s.add_body("b", pos=(0, 0, 0.1), mass=1.0, inertia=(0.004, 0.004, 0.004))
+        for ax, v in (("x", (1, 0, 0)), ("y", (0, 1, 0)), ("z", (0, 0, 1))):
+            s.add_joint(ax, "b", type="slide", axis=v)
+        s.add_geom("c", "b", "capsule", (0.05, 0.1), quat=(math.cos(math.pi / 4), 0, math.sin(math.pi / 4), 0), pos=(0, 0, -0.05))
+        s.add_contact_pair("c", "floor", condim=3, friction=(mu, 0.005, 0.0001))     # order is normalised by the compiler
+        cm = s.compile()
+        assert cm.arrays["GEOM_TYPE"][cm.arrays["PAIR_GEOM1"][0]] == 0
+        d = O.OracleData(O.OracleModel(cm))
+        d.step(500)
+        assert d.ncon == 2 and d.nefc == 8        # plane-capsule: one contact per end cap
+        d.qvel[0] = 1.0
+        v = []
+        for _ in range(31):
+            d.step(); v.append(d.qvel[0])
+        decel = (v[0] - v[30]) / (30 * 0.002)
+        assert 0.85 * mu * 9.81 < decel <= 1.02 * mu * 9.81, (mu, decel)
+
+
+def test_leg_model_dimensions_and_names(oracle_lib):
+    cm = synth.get_model("leg")
+    # SURVEY 8d / walk_v0.py: nq 35, nv 34, 80 muscles; obs = 33+34+2+4+2+1+6+1+3*80+80 = 403
+    assert (cm.nq, cm.nv, cm.nu, cm.na) == (35, 34, 80, 80)
+    assert cm.neq == 14 and cm.npair == 8 and cm.njmax <= 64
+    for n in ("hip_flexion_l", "hip_flexion_r", "hip_adduction_l", "hip_adduction_r", "hip_rotation_l", "hip_rotation_r",
+              "knee_angle_r", "ankle_angle_l"):
+        assert n in cm.names["joint"]
+    for b in ("pelvis", "torso", "talus_l", "talus_r"):
+        assert b in cm.names["body"]
+    assert cm.key_qpos.shape == (4, 35) and cm.key_qvel.shape == (4, 34)
+    d = O.OracleData(O.OracleModel(cm))
+    d.qpos[:] = cm.key_qpos[0]; d.forward()
+    assert d.ncon == 8 and np.abs(d.con_dist[:8]).max() < 1e-6       # standing keyframe: all foot spheres touch the floor
+    assert np.abs(d.efc_pos[:14]).max() < 1e-12                      # knee couplings satisfied by the keyframes
+    d.qpos[:] = cm.key_qpos[2]; d.forward()
+    assert np.abs(d.efc_pos[:14]).max() < 1e-6
+
+
+def test_leg_free_joint_mass_matrix_matches_numpy(oracle_lib):
+    from myosuite_amd.model import kin_np as K
+    cm = synth.get_model("leg")
+    km = K.KinModel(cm.arrays, cm.nq, cm.nv, cm.nbody)
+    d = O.OracleData(O.OracleModel(cm))
+    rng = np.random.default_rng(0)
+    q = cm.key_qpos[2].copy(); q[7:] += rng.uniform(-0.3, 0.3, 28)
+    qq = rng.standard_normal(4); q[3:7] = qq / np.linalg.norm(qq)
+    d.qpos[:] = q; d.forward()
+    M = km.mass_matrix(q[None])[0] + np.diag(cm.arrays["DOF_ARMATURE"].astype(float))
+    assert np.abs(d.full_M() - M).max() < 1e-12
+    assert np.abs(km.tendon_length(q[None])[0] - d.ten_length).max() < 1e-12
+    # total momentum check of the free-floating tree: gravity only accelerates the root translation
+    d.qvel[:] = 0; d.act[:] = 0; d.ctrl[:] = 0
+    d.qpos[2] += 1.0; d.forward()                                   # lifted: no contacts
+    assert d.ncon == 0
+
+
+# ----------------------------------------------------------------------------------- GPU
+def _states(cm, name, n, rng):
+    q = np.tile(cm.qpos0.astype(np.float64), (n, 1))
+    if name == "contact_toy":
+        q[:, 2] += rng.uniform(-0.04, 0.05, n)
+        qq = rng.standard_normal((n, 4)) * 0.2 + np.array([1, 0, 0, 0]); q[:, 3:7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+        q[:, 7:10] += rng.uniform(-0.05, 0.05, (n, 3)); q[:, 9] -= rng.uniform(0.0, 0.2, n)
+        q[:, 10] = rng.uniform(-1.3, 1.3, n); q[:, 11] = rng.uniform(-0.45, 0.12, n); q[:, 12] = rng.uniform(-0.1, 0.1, n)
+        v = rng.standard_normal((n, cm.nv)) * 0.5
+    else:
+        for e in range(n):
+            q[e] = cm.key_qpos[(0, 2, 3)[e % 3]]
+        q[:, 7:] += rng.uniform(-0.15, 0.15, (n, cm.nq - 7))
+        q[:, 2] += rng.uniform(-0.03, 0.02, n)
+        qq = rng.standard_normal((n, 4)) * 0.05 + np.array([1, 0, 0, 0]); q[:, 3:7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+        v = rng.standard_normal((n, cm.nv)) * 0.3
+    return q.astype(np.float32), v.astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["contact_toy", "leg"])
+def test_gpu_general_rows_forward_and_rollout_match_oracle(oracle_lib, name):
+    import torch
+    from myosuite_amd import engine as E
+    cm = synth.get_model(name); hm = E.HipModel(cm); om = O.OracleModel(cm)
+    rng = np.random.default_rng(1)
+    n = 24
+    q, v = _states(cm, name, n, rng)
+    act = rng.random((n, cm.na)).astype(np.float32); ctrl = rng.random((n, cm.nu)).astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q)); st.qvel.copy_(torch.from_numpy(v)); st.act.copy_(torch.from_numpy(act))
+    dump = E.debug_dump(hm, st, torch.from_numpy(ctrl).cuda()).cpu().numpy()
+    ds = []
+    saw_contact = saw_multi_iter = 0
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q[e]; d.qvel[:] = v[e]; d.act[:] = act[e]; d.ctrl[:] = ctrl[e]
+        d.forward(); ds.append(d)
+        saw_contact += d.ncon > 0; saw_multi_iter += d.solver_niter > 1
+        for nm, ref in (("qaccsm", d.qacc_smooth), ("qacc", d.qacc), ("smooth", d.qfrc_smooth)):
+            got = dump[e, hm.layout(nm):hm.layout(nm) + ref.size]
+            assert np.abs(got - ref).max() < 2e-4 * max(1e-9, np.abs(ref).max()), (nm, e)
+        got = dump[e, hm.layout("qfrccon"):hm.layout("qfrccon") + cm.nv]
+        assert np.abs(got - d.qfrc_constraint).max() < 2e-4 * max(1.0, np.abs(d.qfrc_smooth).max())
+        assert int(dump[e, hm.layout("scal")]) == d.solver_niter          # same Newton path
+    assert saw_contact >= n // 2 and saw_multi_iter >= 1
+    c = torch.from_numpy(ctrl).cuda()
+    for _ in range(4):
+        E.step(hm, st, c, 25)
+        for d in ds:
+            d.step(25)
+    qo = np.array([d.qpos for d in ds])
+    err = np.abs(st.qpos.cpu().numpy() - qo).max(axis=1)
+    assert int(st.status.cpu().max()) == 0 and max(d.warn for d in ds) == 0
+    assert np.median(err) < 2e-5 and err.max() < 1e-3, (np.median(err), err.max())
