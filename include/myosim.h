@@ -104,7 +104,7 @@ typedef struct {
   /* outputs */
   float* obs;               /* [nenv][obs_dim] float32, key order of the task  */
   int   obs_dim;
-  float* rwd;               /* [nenv][8]: task reward terms, see MM_RWD_*      */
+  float* rwd;               /* [nenv][MM_RWD_COUNT] (MM_RWDW_COUNT for WALK): task reward terms */
   uint8_t* done;            /* [nenv]                                          */
   uint8_t* truncated;       /* [nenv] step_count >= max_episode_steps          */
   int32_t* step_count;      /* [nenv] in/out                                   */
@@ -120,11 +120,30 @@ typedef struct {
   int   ntip;
   const float* target_pos;  /* [nenv][3*ntip] world positions of the *_target sites */
   float reach_far_th;       /* far_th (per tip), reach_v0.py:57,131-135         */
+  /* WALK task (envs/myo/myobase/walk_v0.py:189-480): obs [qpos[2:], qvel*dt, com_vel(2), torso xquat(4),
+     feet_heights(2), height(1), feet_rel_positions(6), phase_var(1), muscle_length, muscle_velocity, muscle_force, act];
+     reward columns MM_RWDW_* (row stride MM_RWDW_COUNT).  Needs do_forward = 1. */
+  int   walk_body[4];       /* body ids: pelvis, torso, talus_l, talus_r        (walk_v0.py:405-436,498-500) */
+  int   walk_qadr[6];       /* qpos addresses: hip_flexion_l, hip_flexion_r (walk_v0.py:465), hip_adduction_l,
+                               hip_adduction_r, hip_rotation_l, hip_rotation_r (walk_v0.py:301-303) */
+  float walk_min_height;    /* walk_v0.py:248,382-388                           */
+  float walk_max_rot;       /* walk_v0.py:249,514-526                           */
+  int   walk_hip_period;    /* walk_v0.py:250,291,456                           */
+  float walk_target_x_vel, walk_target_y_vel;   /* walk_v0.py:252-253,444-451   */
+  float walk_target_rot[4]; /* init_qpos[3:7] unless given (walk_v0.py:472-479) */
+  float walk_w[5];          /* weights of vel_reward, done, cyclic_hip, ref_rot, joint_angle_rew (walk_v0.py:207-213) */
+  /* reset observation support (all tasks) */
+  const uint8_t* env_mask;  /* optional [nenv]: envs with 0 are left untouched  */
+  int   obs_only;           /* 1: no substeps, no ctrl map, no counters, no reward write: forward + obs of the CURRENT state
+                               (the observation returned by reset(): env_base.py:560-575) */
 } mm_task;
 
 /* columns of mm_task.rwd for MM_TASK_POSE (pose_v0.py:120-139) */
 enum { MM_RWD_POSE = 0, MM_RWD_BONUS, MM_RWD_PENALTY, MM_RWD_ACT_REG, MM_RWD_SPARSE, MM_RWD_SOLVED,
        MM_RWD_DONE, MM_RWD_DENSE, MM_RWD_COUNT };
+/* columns of mm_task.rwd for MM_TASK_WALK (walk_v0.py:305-325) */
+enum { MM_RWDW_VEL = 0, MM_RWDW_CYCLIC_HIP, MM_RWDW_REF_ROT, MM_RWDW_JOINT_ANGLE, MM_RWDW_ACT_MAG, MM_RWDW_SPARSE,
+       MM_RWDW_SOLVED, MM_RWDW_DONE, MM_RWDW_DENSE, MM_RWDW_COUNT };
 
 /* ---- model ---------------------------------------------------------------- */
 int  mm_model_create(const uint32_t* blob_host, int nwords, mm_model** out);
@@ -161,6 +180,13 @@ int  mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, co
 int  mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* tlo, const float* thi,
                     float* target, const float* tip0, int ntip, int32_t* episode, int32_t* step_count,
                     uint64_t seed, float* obs, int obs_dim, void* stream);
+/* Walk-task reset (walk_v0.py:327-365): reset_type 0 -> key_a, 1 ("random") -> key_a or key_b by a Philox coin, plus
+ * N(0, 0.02) on every qpos coordinate except root height (qpos[2]) and root quaternion (qpos[3:7]); qvel = the key's
+ * qvel; act = 0, time = 0, step_count = 0.  key_*: device [nq] / [nv].  The first observation is produced by
+ * mm_env_step with mm_task.obs_only = 1 and env_mask = mask. */
+int  mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* key_a_qpos,
+                   const float* key_a_qvel, const float* key_b_qpos, const float* key_b_qvel, int random,
+                   int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

@@ -1553,8 +1553,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   int e = (blockIdx.x * wpb + wave) * EPW + lane / G;
   const int nenv = a.s.nenv;
   if ((blockIdx.x * wpb + wave) * EPW >= nenv) return;  // whole wave idle
-  const bool dup = e >= nenv;
+  bool dup = e >= nenv;
   if (dup) e = nenv - 1;  // surplus groups recompute the last env (they never store)
+  if (a.mode == 2 && a.t.env_mask && !a.t.env_mask[e]) dup = true;   // masked-out envs are left untouched
+  const bool obs_only = a.mode == 2 && a.t.obs_only;
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * a.L.total;
   const Layout& L = a.L;
   const Dims& d = a.d;
@@ -1575,8 +1577,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   for (int u = g; u < d.nu; u += G) {
     float c = a.ctrl ? a.ctrl[(size_t)e * d.nu + u] : 0.f;
     const bool mus = MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE;
-    if (a.mode == 2 && t.normalize_act && mus) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
-    if (a.mode == 2 && t.fatigue && mus) {
+    if (obs_only) c = 0.f;
+    if (a.mode == 2 && !obs_only && t.normalize_act && mus) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
+    if (a.mode == 2 && !obs_only && t.fatigue && mus) {
       // 3CC-r muscle fatigue (fatigue.py:38-76), dt = timestep * frame_skip
       int aa = MI_(ACT_ACTADR)[u];
       size_t k = (size_t)e * d.na + aa;
@@ -1598,7 +1601,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     W[L.ctrl + u] = c;
   }
   GSYNC();
-  if (a.mode == 2 && t.reaf_src >= 0 && t.reaf_dst >= 0 && g == 0) {  // base_v0.py:104-108
+  if (a.mode == 2 && !obs_only && t.reaf_src >= 0 && t.reaf_dst >= 0 && g == 0) {  // base_v0.py:104-108
     W[L.ctrl + t.reaf_dst] = W[L.ctrl + t.reaf_src];
     W[L.ctrl + t.reaf_src] = 0.f;
   }
@@ -1606,8 +1609,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (a.mode == 2 && t.ctrl_out && !dup)
     for (int u = g; u < d.nu; u += G) t.ctrl_out[(size_t)e * d.nu + u] = W[L.ctrl + u];
 
-  int nsub = a.mode == 1 ? 0 : t.nsubsteps;
-  bool fwd = a.mode == 1 || (a.mode == 2 && t.do_forward);
+  int nsub = (a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
+  bool fwd = a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
   E.run(nsub, fwd, time);
 
   // ---- store state (surplus groups never write)
@@ -1671,8 +1674,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
 
   // ---- task stage: obs_dict / reward_dict (pose_v0.py:100-140), TimeLimit counter
   if (a.mode == 2) {
-    int sc = 0;
-    if (t.step_count) { sc = t.step_count[e] + 1; }
+    int sc = 0, sc0 = 0;
+    if (t.step_count) { sc0 = t.step_count[e]; sc = obs_only ? sc0 : sc0 + 1; }
     if (t.task == MM_TASK_POSE) {
       const float dt = t.obs_dt;
       const int o_err = t.obs_layout == 1 ? d.nq + d.nv + d.na : d.nq + d.nv;
@@ -1748,7 +1751,80 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         if (t.done) t.done[e] = done ? 1 : 0;
       }
     }
-    if (g == 0) {
+    if (t.task == MM_TASK_WALK) {
+      // obs / reward of WalkEnvV0 (walk_v0.py:283-325, 367-540); self.steps == step_count BEFORE this step's increment
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      const int nq2 = d.nq - 2;
+      const int o_qv = nq2, o_cv = o_qv + d.nv, o_tq = o_cv + 2, o_fh = o_tq + 4, o_h = o_fh + 2, o_fr = o_h + 1,
+                o_ph = o_fr + 6, o_ml = o_ph + 1, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = o_mf + d.nu;
+      const bool isb = g > 0 && g < d.nbody;
+      const float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+      const float mtot = gsum<G>(ms);
+      // com velocity with the reference's sign convention: mean of -cvel[:, 3:5]
+      const float cvx = gsum<G>(ms * -E.b_cvel[3]) / mtot, cvy = gsum<G>(ms * -E.b_cvel[4]) / mtot;
+      const float height = gsum<G>(ms * E.b_xipos.z) / mtot;
+      const int bp = t.walk_body[0], bt = t.walk_body[1], bl = t.walk_body[2], br = t.walk_body[3];
+      const V3 xp = v3(bc<G>(E.b_xpos.x, bp), bc<G>(E.b_xpos.y, bp), bc<G>(E.b_xpos.z, bp));
+      const V3 xl = v3(bc<G>(E.b_xpos.x, bl), bc<G>(E.b_xpos.y, bl), bc<G>(E.b_xpos.z, bl));
+      const V3 xr = v3(bc<G>(E.b_xpos.x, br), bc<G>(E.b_xpos.y, br), bc<G>(E.b_xpos.z, br));
+      const float tq0 = bc<G>(E.b_xquat.w, bt), tq1 = bc<G>(E.b_xquat.x, bt), tq2 = bc<G>(E.b_xquat.y, bt), tq3 = bc<G>(E.b_xquat.z, bt);
+      const float phase = fmodf((float)sc0 / (float)t.walk_hip_period, 1.f);
+      float act2 = 0.f;
+      if (ob) {
+        for (int i = g; i < nq2; i += G) ob[i] = W[L.qpos + 2 + i];
+        if (g < d.nv) ob[o_qv + g] = E.d_qvel * t.obs_dt;
+      }
+      for (int i = g; i < d.nu; i += G) {
+        if (ob) {
+          ob[o_ml + i] = W[L.actlen + i];
+          ob[o_mv + i] = clampf(W[L.actvel + i], -100.f, 100.f);
+          ob[o_mf + i] = clampf(W[L.actfrc + i] / 1000.f, -100.f, 100.f);
+        }
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[o_act + i] = x;
+      }
+      act2 = gsum<G>(act2);
+      if (g == 0) {
+        if (ob) {
+          ob[o_cv] = cvx; ob[o_cv + 1] = cvy;
+          ob[o_tq] = tq0; ob[o_tq + 1] = tq1; ob[o_tq + 2] = tq2; ob[o_tq + 3] = tq3;
+          ob[o_fh] = xl.z; ob[o_fh + 1] = xr.z;
+          ob[o_h] = height;
+          st3(ob + o_fr, xl - xp); st3(ob + o_fr + 3, xr - xp);
+          ob[o_ph] = phase;
+        }
+        const float* q = W + L.qpos;
+        const float dvy = t.walk_target_y_vel - cvy, dvx = t.walk_target_x_vel - cvx;
+        const float vel_reward = expf(-dvy * dvy) + expf(-dvx * dvx);
+        const float two_pi = 6.283185307179586f;
+        const float des_l = 0.8f * cosf(phase * two_pi + 3.141592653589793f), des_r = 0.8f * cosf(phase * two_pi);
+        const float el = des_l - q[t.walk_qadr[0]], er = des_r - q[t.walk_qadr[1]];
+        const float cyclic_hip = sqrtf(el * el + er * er);
+        float rr = 0.f;
+        for (int k = 0; k < 4; k++) { float dq = 5.f * (q[3 + k] - t.walk_target_rot[k]); rr += dq * dq; }
+        const float ref_rot = expf(-sqrtf(rr));
+        const float mag = 0.25f * (fabsf(q[t.walk_qadr[2]]) + fabsf(q[t.walk_qadr[3]]) + fabsf(q[t.walk_qadr[4]]) + fabsf(q[t.walk_qadr[5]]));
+        const float joint_angle_rew = expf(-5.f * mag);
+        const float act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        // |(quat2mat(qpos[3:7]) @ [1,0,0])[0]| > max_rot   (walk_v0.py:514-526)
+        const float nq_ = q[3] * q[3] + q[4] * q[4] + q[5] * q[5] + q[6] * q[6];   // quat_math.py:151-174
+        const float r00 = nq_ > 1.1920929e-07f * 4.f ? 1.f - (2.f / nq_) * (q[5] * q[5] + q[6] * q[6]) : 1.f;
+        const bool done = height < t.walk_min_height || fabsf(r00) > t.walk_max_rot;
+        if (t.rwd && !obs_only) {   // the reset observation leaves the terminal step's reward terms in place
+          float* r = t.rwd + (size_t)e * MM_RWDW_COUNT;
+          r[MM_RWDW_VEL] = vel_reward; r[MM_RWDW_CYCLIC_HIP] = cyclic_hip; r[MM_RWDW_REF_ROT] = ref_rot;
+          r[MM_RWDW_JOINT_ANGLE] = joint_angle_rew; r[MM_RWDW_ACT_MAG] = act_mag; r[MM_RWDW_SPARSE] = vel_reward;
+          r[MM_RWDW_SOLVED] = vel_reward >= 1.f ? 1.f : 0.f; r[MM_RWDW_DONE] = done ? 1.f : 0.f;
+          r[MM_RWDW_DENSE] = t.walk_w[0] * vel_reward + t.walk_w[1] * (done ? 1.f : 0.f) + t.walk_w[2] * cyclic_hip +
+                             t.walk_w[3] * ref_rot + t.walk_w[4] * joint_angle_rew;
+        }
+        if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
+      }
+    }
+    if (g == 0 && !obs_only) {
       if (t.step_count) t.step_count[e] = sc;
       if (t.truncated) t.truncated[e] = (t.max_episode_steps > 0 && sc >= t.max_episode_steps) ? 1 : 0;
     }
@@ -1783,6 +1859,7 @@ struct ResetArgs {
   int pose, random_qpos;
   float* obs; int obs_dim, obs_layout;
   int reach, ntip; const float* tip0;
+  int walk, walk_random; const float *ka_qpos, *ka_qvel, *kb_qpos, *kb_qvel;
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -1832,8 +1909,31 @@ __global__ void k_reset(ResetArgs r) {
       for (int i = 0; i < r.na; i++) ob[r.nq + r.nv + 2 * n3 + i] = 0.f;
     }
   }
+  if (r.walk) {
+    // walk_v0.py:327-365: key pose (random: coin between the two stride keys + N(0, 0.02) on every coordinate
+    // except root height and root quaternion); Philox counters (i, 2, env, episode), coin at i = 0xFFFF
+    int ep = r.episode ? r.episode[e] : 0;
+    if (r.episode) r.episode[e] = ep + 1;
+    const float *kq = r.ka_qpos, *kv = r.ka_qvel;
+    if (r.walk_random) {
+      uint32_t c[4] = {0xFFFFu, 2u, (uint32_t)e, (uint32_t)ep};
+      philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+      if (!(u01(c[0]) < 0.5f)) { kq = r.kb_qpos; kv = r.kb_qvel; }
+    }
+    for (int i = 0; i < r.nq; i++) {
+      float q = kq[i];
+      if (r.walk_random && !(i >= 2 && i < 7)) {
+        uint32_t c[4] = {(uint32_t)i, 2u, (uint32_t)e, (uint32_t)ep};
+        philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+        float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = u01(c[1]);
+        q += 0.02f * sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+      }
+      r.s.qpos[(size_t)e * r.nq + i] = q;
+    }
+    for (int i = 0; i < r.nv; i++) r.s.qvel[(size_t)e * r.nv + i] = kv[i];
+  }
   for (int i = 0; i < r.nv; i++) {
-    r.s.qvel[(size_t)e * r.nv + i] = r.qvel_src ? r.qvel_src[(size_t)e * r.nv + i] : 0.f;
+    if (!r.walk) r.s.qvel[(size_t)e * r.nv + i] = r.qvel_src ? r.qvel_src[(size_t)e * r.nv + i] : 0.f;
     r.s.qacc_warmstart[(size_t)e * r.nv + i] = 0.f;
   }
   for (int i = 0; i < r.na; i++) r.s.act[(size_t)e * r.na + i] = 0.f;
@@ -2224,7 +2324,14 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
   if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
   if (t->task == MM_TASK_REACH && (!t->tip_sites || !t->target_pos || t->ntip <= 0)) return fail(MM_EARG, "reach task needs tip_sites/target_pos");
-  if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH) return fail(MM_EUNSUPPORTED, "task not implemented");
+  if (t->task == MM_TASK_WALK) {
+    if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "walk task needs do_forward");
+    for (int k = 0; k < 4; k++) if (t->walk_body[k] <= 0 || t->walk_body[k] >= m->d.nbody) return fail(MM_EARG, "walk task: bad body id");
+    for (int k = 0; k < 6; k++) if (t->walk_qadr[k] < 0 || t->walk_qadr[k] >= m->d.nq) return fail(MM_EARG, "walk task: bad qpos address");
+    if (m->d.nq < 7 || t->walk_hip_period <= 0) return fail(MM_EARG, "walk task needs a free root joint and hip_period > 0");
+  }
+  if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH && t->task != MM_TASK_WALK)
+    return fail(MM_EUNSUPPORTED, "task not implemented");
   if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "fatigue needs MA/MR/MF");
   KArgs a; fill_common(m, a, s);
   a.ctrl = action; a.mode = 2; a.t = *t;
@@ -2278,6 +2385,20 @@ extern "C" int mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_
   r.nenv = s->nenv; r.s = *s; r.mask = mask;
   r.tlo = tlo; r.thi = thi; r.target = target; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.reach = 1; r.ntip = ntip; r.tip0 = tip0; r.obs = obs; r.obs_dim = obs_dim;
+  hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* key_a_qpos,
+                             const float* key_a_qvel, const float* key_b_qpos, const float* key_b_qvel, int random,
+                             int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
+  if (!m || !s || !key_a_qpos || !key_a_qvel) return fail(MM_EARG, "mm_walk_reset: bad argument");
+  if (random && (!key_b_qpos || !key_b_qvel)) return fail(MM_EARG, "mm_walk_reset: random reset needs the second key");
+  ResetArgs r; memset(&r, 0, sizeof(r));
+  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
+  r.walk = 1; r.walk_random = random; r.ka_qpos = key_a_qpos; r.ka_qvel = key_a_qvel; r.kb_qpos = key_b_qpos; r.kb_qvel = key_b_qvel;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;

@@ -25,6 +25,7 @@ _lib = None
 MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK = 0, 1, 2, 3, 4
 RWD_KEYS_POSE = ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 RWD_KEYS_REACH = ["reach", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
  INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK) = range(12)
 
@@ -71,7 +72,11 @@ class mm_task(C.Structure):
                 ("obs", C.c_void_p), ("obs_dim", C.c_int), ("rwd", C.c_void_p), ("done", C.c_void_p),
                 ("truncated", C.c_void_p), ("step_count", C.c_void_p), ("ctrl_out", C.c_void_p),
                 ("reaf_src", C.c_int), ("reaf_dst", C.c_int), ("obs_layout", C.c_int), ("act_reg_mean", C.c_int), ("obs_dt", C.c_float),
-                ("tip_sites", C.c_void_p), ("ntip", C.c_int), ("target_pos", C.c_void_p), ("reach_far_th", C.c_float)]
+                ("tip_sites", C.c_void_p), ("ntip", C.c_int), ("target_pos", C.c_void_p), ("reach_far_th", C.c_float),
+                ("walk_body", C.c_int * 4), ("walk_qadr", C.c_int * 6), ("walk_min_height", C.c_float),
+                ("walk_max_rot", C.c_float), ("walk_hip_period", C.c_int), ("walk_target_x_vel", C.c_float),
+                ("walk_target_y_vel", C.c_float), ("walk_target_rot", C.c_float * 4), ("walk_w", C.c_float * 5),
+                ("env_mask", C.c_void_p), ("obs_only", C.c_int)]
 
 
 def lib():
@@ -98,6 +103,8 @@ def lib():
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
         L.mm_reach_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+        L.mm_walk_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
@@ -216,10 +223,23 @@ def forward(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] = N
                           derived.c if derived is not None else None, _stream()), "mm_forward")
 
 
-def env_step(model: HipModel, state: BatchState, action: torch.Tensor, task: mm_task, derived: Optional[Derived] = None):
-    assert action.shape == (state.nenv, model.cm.nu) and action.dtype == torch.float32 and action.is_contiguous()
+def env_step(model: HipModel, state: BatchState, action: Optional[torch.Tensor], task: mm_task,
+             derived: Optional[Derived] = None):
+    if action is not None:
+        assert action.shape == (state.nenv, model.cm.nu) and action.dtype == torch.float32 and action.is_contiguous()
+    else:
+        assert task.obs_only, "action may only be omitted for an obs_only pass"
     _chk(lib().mm_env_step(model.h, state.c, _ptr(action), C.byref(task), derived.c if derived is not None else None,
                            _stream()), "mm_env_step")
+
+
+def reset_observation(model: HipModel, state: BatchState, task: mm_task, mask: Optional[torch.Tensor] = None):
+    """Observation (and reward terms) of the CURRENT state of the masked envs: one forward pass, no stepping, no
+    counters -- what MujocoEnv.reset returns after Robot.reset (env_base.py:560-575)."""
+    t = mm_task.from_buffer_copy(task)
+    t.obs_only = 1
+    t.env_mask = _ptr(mask)
+    env_step(model, state, None, t)
 
 
 def reset(model: HipModel, state: BatchState, mask: Optional[torch.Tensor] = None, qpos: Optional[torch.Tensor] = None,
@@ -242,6 +262,13 @@ def reach_reset(model: HipModel, state: BatchState, mask, tlo, thi, target, tip0
     _chk(lib().mm_reach_reset(model.h, state.c, _ptr(mask), _ptr(tlo), _ptr(thi), _ptr(target), _ptr(tip0), int(ntip),
                               _ptr(episode), _ptr(step_count), C.c_uint64(seed), _ptr(obs),
                               0 if obs is None else int(obs.shape[1]), _stream()), "mm_reach_reset")
+
+
+def walk_reset(model: HipModel, state: BatchState, mask, key_a_qpos, key_a_qvel, key_b_qpos, key_b_qvel, random: bool,
+               episode, step_count, seed: int):
+    _chk(lib().mm_walk_reset(model.h, state.c, _ptr(mask), _ptr(key_a_qpos), _ptr(key_a_qvel), _ptr(key_b_qpos),
+                             _ptr(key_b_qvel), int(random), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()),
+         "mm_walk_reset")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

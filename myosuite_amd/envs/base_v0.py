@@ -31,13 +31,20 @@ def _compiled_model(name: str, muscle_condition: str):
     (base_v0.py:63-67: gainprm[:,2] *= 0.5; biasprm is left untouched)."""
     key = (name, muscle_condition == "sarcopenia")
     if key not in _MODEL_CACHE:
-        spec = {"elbow": synth.make_elbow, "hand": synth.make_hand}[name]()
-        if muscle_condition == "sarcopenia":
+        if muscle_condition != "sarcopenia":
+            _MODEL_CACHE[key] = synth.get_model(name)
+        else:
+            spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg}[name]()
             for a in spec.actuators:
                 g = list(a.gainprm)
                 g[2] = 0.5 * g[2]
                 a.gainprm = tuple(g)
-        _MODEL_CACHE[key] = spec.compile()
+            cm = spec.compile()
+            base = synth.get_model(name)
+            for k in ("key_qpos", "key_qvel"):     # keyframes are geometry only: identical for the weakened model
+                if hasattr(base, k):
+                    setattr(cm, k, getattr(base, k))
+            _MODEL_CACHE[key] = cm
     return _MODEL_CACHE[key]
 
 

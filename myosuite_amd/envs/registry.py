@@ -80,6 +80,11 @@ def _reach(**kw):
     return ReachEnvV0(**kw)
 
 
+def _walk(**kw):
+    from .walk_v0 import WalkEnvV0
+    return WalkEnvV0(**kw)
+
+
 # Elbow posing (myobase/__init__.py:108-138)
 register_env_with_variants(
     id="myoElbowPose1D6MFixed-v0", entry_point=_pose, max_episode_steps=100,
@@ -139,3 +144,11 @@ register_env_with_variants(
                 "MFtip": ((-0.146 - 0.040, -0.547 - 0.020, 1.447 - 0.010), (-0.146 + 0.040, -0.547 + 0.020, 1.447 + 0.010)),
                 "RFtip": ((-0.148 - 0.040, -0.543 - 0.020, 1.445 - 0.010), (-0.148 + 0.040, -0.543 + 0.020, 1.445 + 0.010)),
                 "LFtip": ((-0.148 - 0.040, -0.528 - 0.020, 1.434 - 0.010), (-0.148 + 0.040, -0.528 + 0.020, 1.434 + 0.010))}})
+
+
+# Gait: torso walking (myobase/__init__.py:442-458).  The terrain variants (Rough/Hilly/Stair, :460-520) need
+# height-field collision and are not registered.
+register_env_with_variants(
+    id="myoLegWalk-v0", entry_point=_walk, max_episode_steps=1000,
+    kwargs={"model": "leg", "normalize_act": True, "min_height": 0.8, "max_rot": 0.8, "hip_period": 100,
+            "reset_type": "init", "target_x_vel": 0.0, "target_y_vel": 1.2, "target_rot": None})

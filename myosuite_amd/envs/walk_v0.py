@@ -1,0 +1,137 @@
+"""Batched WalkEnvV0 -- host-side mirror of myosuite/envs/myo/myobase/walk_v0.py:189-540.
+
+obs keys ``qpos_without_xy, qvel, com_vel, torso_angle, feet_heights, height, feet_rel_positions, phase_var,
+muscle_length, muscle_velocity, muscle_force`` (+ ``act``), reward keys ``vel_reward, done, cyclic_hip, ref_rot,
+joint_angle_rew``; ``self.steps`` of the reference is the device-side ``step_count``.  The whole env-step (ctrl map /
+fatigue, frame_skip x mj_step with foot-ground contacts and knee equalities, final forward, obs, reward) is one fused
+kernel launch; reset draws (keyframe coin + N(0, 0.02) noise, walk_v0.py:327-352) are Philox-keyed on the device.
+
+Not covered: the terrain variants (``TerrainEnvV0``, walk_v0.py:543-680) need height-field collision.
+"""
+from __future__ import annotations
+
+import collections
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import engine as E
+from .base_v0 import BaseV0
+from .spaces import Box
+
+
+class WalkEnvV0(BaseV0):
+    DEFAULT_OBS_KEYS = ["qpos_without_xy", "qvel", "com_vel", "torso_angle", "feet_heights", "height",
+                        "feet_rel_positions", "phase_var", "muscle_length", "muscle_velocity", "muscle_force"]   # walk_v0.py:191-203
+    DEFAULT_RWD_KEYS_AND_WEIGHTS = {"vel_reward": 5.0, "done": -100, "cyclic_hip": -10, "ref_rot": 10.0,
+                                    "joint_angle_rew": 5.0}                                                        # walk_v0.py:205-211
+
+    def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=1000,
+                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+        self._setup(**kwargs)
+
+    def _setup(self, obs_keys=DEFAULT_OBS_KEYS, weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS, min_height=0.8,
+               max_rot=0.8, hip_period=100, reset_type="init", target_x_vel=0.0, target_y_vel=1.2, target_rot=None,
+               **kwargs):
+        self.min_height, self.max_rot, self.hip_period = float(min_height), float(max_rot), int(hip_period)
+        self.reset_type = reset_type
+        self.target_x_vel, self.target_y_vel, self.target_rot = float(target_x_vel), float(target_y_vel), target_rot
+        super()._setup(obs_keys=list(obs_keys), weighted_reward_keys=weighted_reward_keys, **kwargs)
+        cm, n, dev = self.cm, self.num_envs, self.device
+        f = dict(dtype=torch.float32, device=dev)
+        self.init_qpos = cm.key_qpos[0].astype(np.float32).copy()      # walk_v0.py:271-272
+        self.init_qvel = np.zeros(cm.nv, np.float32)
+        self._keys_q = [torch.from_numpy(cm.key_qpos[k].astype(np.float32)).to(dev) for k in range(cm.key_qpos.shape[0])]
+        self._keys_v = [torch.from_numpy(cm.key_qvel[k].astype(np.float32)).to(dev) for k in range(cm.key_qvel.shape[0])]
+        nu = cm.nu
+        self.obs_dim = (cm.nq - 2) + cm.nv + 2 + 4 + 2 + 1 + 6 + 1 + 3 * nu + cm.na
+        self.obs = torch.zeros(n, self.obs_dim, **f)
+        self.rwd = torch.zeros(n, len(E.RWD_KEYS_WALK), **f)
+        self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
+                                     dtype=np.float32)
+        w = self.rwd_keys_wt
+        t = E.mm_task()
+        t.task = E.MM_TASK_WALK; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
+        t.do_forward = 1; t.fatigue = int(self.muscle_condition == "fatigue"); t.max_episode_steps = self.max_episode_steps
+        if self.fat_MA is not None:
+            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
+        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15
+        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
+        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
+        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
+        t.reaf_src, t.reaf_dst = self.reaf
+        t.obs_dt = self.dt
+        for i, b in enumerate(("pelvis", "torso", "talus_l", "talus_r")):
+            t.walk_body[i] = cm.body_id(b)
+        qadr = cm.arrays["JNT_QPOSADR"]
+        for i, j in enumerate(("hip_flexion_l", "hip_flexion_r", "hip_adduction_l", "hip_adduction_r", "hip_rotation_l",
+                               "hip_rotation_r")):
+            t.walk_qadr[i] = int(qadr[cm.joint_id(j)])
+        t.walk_min_height, t.walk_max_rot, t.walk_hip_period = self.min_height, self.max_rot, self.hip_period
+        t.walk_target_x_vel, t.walk_target_y_vel = self.target_x_vel, self.target_y_vel
+        rot = self.target_rot if self.target_rot is not None else self.init_qpos[3:7]
+        for i in range(4):
+            t.walk_target_rot[i] = float(rot[i])
+        for i, k in enumerate(("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew")):
+            t.walk_w[i] = float(w.get(k, 0.0))
+        self._task = t
+        self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
+        self.reset()
+
+    @property
+    def steps(self) -> torch.Tensor:            # walk_v0.py:256,355-358
+        return self.step_count
+
+    def _refresh_dicts(self):
+        cm = self.cm
+        o = self.obs
+        sizes = [("qpos_without_xy", cm.nq - 2), ("qvel", cm.nv), ("com_vel", 2), ("torso_angle", 4), ("feet_heights", 2),
+                 ("height", 1), ("feet_rel_positions", 6), ("phase_var", 1), ("muscle_length", cm.nu),
+                 ("muscle_velocity", cm.nu), ("muscle_force", cm.nu), ("act", cm.na)]
+        od = collections.OrderedDict(t=self.state.time, time=self.state.time)
+        k0 = 0
+        for k, sz in sizes:
+            od[k] = o[:, k0:k0 + sz]; k0 += sz
+        self.obs_dict = od
+        r = self.rwd
+        self.rwd_dict = collections.OrderedDict((k, r[:, i]) for i, k in enumerate(E.RWD_KEYS_WALK))
+        self.rwd_dict["solved"] = self.rwd_dict["solved"] > 0.5
+        self.rwd_dict["done"] = self.rwd_dict["done"] > 0.5
+
+    def reset(self, seed=None, mask: Optional[torch.Tensor] = None, **kwargs):
+        if seed is not None:
+            self.seed(seed)
+            self._seed_u64 = int(seed)
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
+        self._fatigue_reset(mask)
+        if self.reset_type == "random":          # walk_v0.py:327-352
+            E.walk_reset(self.hm, self.state, mask, self._keys_q[2], self._keys_v[2], self._keys_q[3], self._keys_v[3],
+                         True, self.episode, self.step_count, self._seed_u64)
+        else:
+            k = 2 if self.reset_type == "init" else 0
+            E.walk_reset(self.hm, self.state, mask, self._keys_q[k], self._keys_v[k], None, None, False, self.episode,
+                         self.step_count, self._seed_u64)
+        E.reset_observation(self.hm, self.state, self._task, mask)
+        self._refresh_dicts()
+        return self.obs, {}
+
+    def step(self, a, **kwargs):
+        a = torch.as_tensor(a, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.expand(self.num_envs, -1)
+        a = a.contiguous()
+        E.env_step(self.hm, self.state, a, self._task)
+        self._refresh_dicts()
+        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
+        terminated = self.done.bool()
+        truncated = self.truncated.bool() & ~terminated
+        info = self.get_env_infos()
+        obs = self.obs
+        if self.autoreset:
+            info["final_obs"] = obs.clone()
+            self.reset(mask=(self.done | self.truncated))
+            obs = self.obs
+        return obs, reward, terminated, truncated, info

@@ -295,9 +295,36 @@ _KNEE_POLY = {"knee_angle_translation2": (0.0, -0.004, 0.0015), "knee_angle_tran
               "knee_angle_beta_rotation1": (0.0, 0.75, -0.05)}
 
 
+
+def _qmul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                     a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                     a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def _reframe_z(s: ModelSpec, angle: float):
+    """Re-express every body-local quantity of `s` in body frames rotated by `angle` about z (authoring aid:
+    the leg is authored with y forward and handed over with MyoLeg's x-forward frames)."""
+    r = np.array([math.cos(angle / 2), 0.0, 0.0, math.sin(angle / 2)]); rc = r * np.array([1, -1, -1, -1])
+    c, sn = math.cos(angle), math.sin(angle)
+    R = np.array([[c, -sn, 0], [sn, c, 0], [0, 0, 1.0]])
+    for b in s.bodies[1:]:
+        b.pos = R @ b.pos; b.ipos = R @ b.ipos
+        b.quat = _qmul(_qmul(r, b.quat), rc); b.iquat = _qmul(r, b.iquat)
+    for j in s.joints:
+        j.pos = R @ j.pos; j.axis = R @ j.axis
+    s.sites = [(n, b, R @ p) for (n, b, p) in s.sites]
+    for g in s.geoms:
+        g["pos"] = R @ g["pos"]; g["quat"] = _qmul(r, g["quat"])
+
+
 def make_leg() -> ModelSpec:
     """myoLeg: free-floating pelvis + torso, 2 x 14 leg joints (34 DoF, nq 35), 80 muscles, 14 knee joint-equalities,
-    8 foot-ground contact pairs.  Frame: x right, y forward (walk_v0.py: target_y_vel), z up.
+    8 foot-ground contact pairs.  Authored below with x right / y forward / z up, then re-framed to MyoLeg's body frames
+    (x forward, y left, z up).  The keyframes carry the root quaternion (0.7071, 0, 0, -0.7071), i.e. the model faces
+    world -y: that is what makes the reference's reward / termination arithmetic consistent (walk_v0.py:438-446 negates
+    cvel and rewards y-velocity 1.2; walk_v0.py:461-472 terminates when |R[0,0]| of the root exceeds max_rot).
     Joint / muscle names and dimensions: SURVEY.md 8d (walk_v0.py:236-241,438-451; docs/source/suite.rst)."""
     s = ModelSpec("myolegs", timestep=0.001)  # x frame_skip 10 (BaseV0 default) = 0.01 s per env step: hip_period 100 -> 1 s stride
     s.add_geom("floor", "world", "plane", (0, 0, 0))
@@ -419,14 +446,15 @@ def make_leg() -> ModelSpec:
         muscle("vaslat", [site(F, (0.030, 0.015, -0.22)), KW, site(T, (0.005, 0.035, -0.06))], 3500.0)
         muscle("vasmed", [site(F, (-0.020, 0.015, -0.25)), KW, site(T, (-0.005, 0.035, -0.06))], 2300.0)
 
+    _reframe_z(s, -math.pi / 2)      # authored (x right, y forward)  ->  handed over (x forward, y left)
     names = ["root"] + [_jname(b, sd) for sd in ("r", "l") for b in LEG_JOINTS_SIDE]
     assert [j.name for j in s.joints] == names
     assert [a.name for a in s.actuators] == [f"{m}_{sd}" for sd in ("r", "l") for m in LEG_MUSCLES_SIDE]
 
     # ---- keyframes (walk_v0.py:282-283,334-352 uses key 0 = stand, key 2 / 3 = mid-stride right / left)
     def key(hip_r, knee_r, ank_r, hip_l, knee_l, ank_l, vy):
-        q = np.zeros(35); q[2] = PZ; q[3] = 1.0
-        v = np.zeros(34); v[1] = vy
+        q = np.zeros(35); q[2] = PZ; q[3] = math.cos(math.pi / 4); q[6] = -math.sin(math.pi / 4)   # facing world -y
+        v = np.zeros(34); v[1] = -vy
         for k, sd in enumerate(("r", "l")):
             o = 7 + 14 * k
             hip, knee, ank = ((hip_r, knee_r, ank_r), (hip_l, knee_l, ank_l))[k]
@@ -472,6 +500,27 @@ def make_contact_toy() -> ModelSpec:
     return s
 
 
+def _ground_keyframes(cm):
+    """Shift the root height of every keyframe so that the lowest foot sphere just touches the floor (z = 0)."""
+    from . import kin_np as K
+    km = K.KinModel(cm.arrays, cm.nq, cm.nv, cm.nbody)
+    A = cm.arrays
+    gt = A["GEOM_TYPE"]; gb = A["GEOM_BODYID"]; gp = A["GEOM_POS"].reshape(-1, 3).astype(np.float64)
+    gs = A["GEOM_SIZE"].reshape(-1, 3).astype(np.float64)
+    feet = sorted(set(int(g) for g in A["PAIR_GEOM2"]))
+    xpos, xquat, _, _ = km.fk(cm.key_qpos)
+    for k in range(cm.key_qpos.shape[0]):
+        low = np.inf
+        for g in feet:
+            assert gt[g] == 2
+            w, x, y, z = xquat[k, gb[g]]
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            low = min(low, (xpos[k, gb[g]] + R @ gp[g])[2] - gs[g, 0])
+        cm.key_qpos[k, 2] -= low
+
+
 _CACHE = {}
 
 
@@ -483,5 +532,7 @@ def get_model(name: str) -> CompiledModel:
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob
             cm.key_qpos = np.array([k[0] for k in keys]); cm.key_qvel = np.array([k[1] for k in keys])
+            if name == "leg":
+                _ground_keyframes(cm)
         _CACHE[name] = cm
     return _CACHE[name]

@@ -250,3 +250,107 @@ class ReachEnvOracle(PoseEnvOracle):
             ("done", reach_dist > far_th)))
         rwd["dense"] = np.sum([wt * rwd[k] for k, wt in self.rwd_keys_wt.items()], axis=0)
         return rwd
+
+
+# ---------------------------------------------------------------------- WalkEnvV0
+def walk_reset_draws(nq: int, env: int, episode: int, seed: int):
+    """(coin, noise[nq]) of the device-side walk reset (csrc/myosim_engine.hip:k_reset, walk branch):
+    coin = u01(philox(0xFFFF, 2, env, episode)[0]); noise_i = 0.02 * sqrt(-2 ln u1) cos(2 pi u2), float32."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    c = philox4x32_10(0xFFFF, 2, env, episode, k0, k1)
+    coin = float(u01(c[0]))
+    i = np.arange(nq)
+    c = philox4x32_10(i, np.full(nq, 2), np.full(nq, env), np.full(nq, episode), k0, k1)
+    u1 = (((c[0] >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+    u2 = u01(c[1])
+    z = np.float32(0.02) * np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)
+    z = z.astype(np.float32)
+    z[2:7] = 0
+    return coin, z
+
+
+def walk_obs_reward(body_mass, qpos, qvel, act, xpos, xipos, xquat, cvel, actuator_length, actuator_velocity,
+                    actuator_force, steps, dt, ids, prm, rwd_keys_wt):
+    """WalkEnvV0.get_obs_dict + obsdict2obsvec + get_reward_dict on raw arrays (walk_v0.py:283-325, 367-540).
+    ids: dict(pelvis, torso, talus_l, talus_r body ids; qadr of hip_flexion_l/r, hip_adduction_l/r, hip_rotation_l/r);
+    prm: dict(min_height, max_rot, hip_period, target_x_vel, target_y_vel, target_rot)."""
+    mass = np.asarray(body_mass, np.float64)[:, None]
+    com_vel = (np.sum(mass * -cvel, 0) / np.sum(mass))[3:5]                       # walk_v0.py:438-446
+    com = np.sum(mass * xipos, 0) / np.sum(mass)                                  # walk_v0.py:528-535
+    height = com[2]
+    feet_heights = np.array([xpos[ids["talus_l"]][2], xpos[ids["talus_r"]][2]])   # walk_v0.py:400-412
+    feet_rel = np.array([xpos[ids["talus_l"]] - xpos[ids["pelvis"]], xpos[ids["talus_r"]] - xpos[ids["pelvis"]]])
+    phase = (steps / prm["hip_period"]) % 1                                       # walk_v0.py:291
+    od = collections.OrderedDict(
+        qpos_without_xy=qpos[2:].copy(), qvel=qvel * dt, com_vel=com_vel, torso_angle=xquat[ids["torso"]].copy(),
+        feet_heights=feet_heights, height=np.array([height]), feet_rel_positions=feet_rel.ravel(),
+        phase_var=np.array([phase]), muscle_length=actuator_length.copy(),
+        muscle_velocity=np.clip(actuator_velocity, -100, 100), muscle_force=np.clip(actuator_force / 1000, -100, 100),
+        act=act.copy())
+    obs = np.concatenate([np.asarray(v, np.float64).ravel() for v in od.values()])
+    vel_reward = np.exp(-np.square(prm["target_y_vel"] - com_vel[1])) + np.exp(-np.square(prm["target_x_vel"] - com_vel[0]))
+    des = np.array([0.8 * np.cos(phase * 2 * np.pi + np.pi), 0.8 * np.cos(phase * 2 * np.pi)], dtype=np.float32)
+    ang = np.array([qpos[ids["hip_flexion_l"]], qpos[ids["hip_flexion_r"]]])
+    cyclic_hip = np.linalg.norm(des - ang)                                        # walk_v0.py:453-468
+    ref_rot = np.exp(-np.linalg.norm(5.0 * (qpos[3:7] - np.asarray(prm["target_rot"], np.float64))))
+    ja = np.array([qpos[ids[k]] for k in ("hip_adduction_l", "hip_adduction_r", "hip_rotation_l", "hip_rotation_r")])
+    joint_angle_rew = np.exp(-5 * np.mean(np.abs(ja)))                            # walk_v0.py:390-398
+    na = act.size
+    act_mag = np.linalg.norm(act) / na if na else 0.0
+    q = qpos[3:7]; nq_ = np.sum(q * q)
+    r00 = 1.0 - (2.0 / nq_) * (q[2] * q[2] + q[3] * q[3])                         # quat_math.py:151-174
+    done = 1 if (height < prm["min_height"] or abs(r00) > prm["max_rot"]) else 0   # walk_v0.py:382-388,514-526
+    rwd = collections.OrderedDict((
+        ("vel_reward", vel_reward), ("cyclic_hip", cyclic_hip), ("ref_rot", ref_rot), ("joint_angle_rew", joint_angle_rew),
+        ("act_mag", act_mag), ("sparse", vel_reward), ("solved", vel_reward >= 1.0), ("done", done)))
+    rwd["dense"] = np.sum([wt * rwd[k] for k, wt in rwd_keys_wt.items()], axis=0)
+    return obs, rwd
+
+
+class WalkEnvOracle(PoseEnvOracle):
+    """Single-env CPU restatement of WalkEnvV0 (walk_v0.py:189-540) on the fp64 oracle engine."""
+    RWD_KEYS_WT = {"vel_reward": 5.0, "done": -100, "cyclic_hip": -10, "ref_rot": 10.0, "joint_angle_rew": 5.0}
+
+    def __init__(self, compiled, frame_skip=10, normalize_act=True, muscle_condition="", min_height=0.8, max_rot=0.8,
+                 hip_period=100, target_x_vel=0.0, target_y_vel=1.2, target_rot=None):
+        super().__init__(compiled, 0.0, frame_skip, normalize_act, muscle_condition, dict(self.RWD_KEYS_WT))
+        cm = compiled
+        qadr = cm.arrays["JNT_QPOSADR"]
+        self.ids = {b: cm.body_id(b) for b in ("pelvis", "torso", "talus_l", "talus_r")}
+        for j in ("hip_flexion_l", "hip_flexion_r", "hip_adduction_l", "hip_adduction_r", "hip_rotation_l", "hip_rotation_r"):
+            self.ids[j] = int(qadr[cm.joint_id(j)])
+        rot = target_rot if target_rot is not None else cm.key_qpos[0][3:7].astype(np.float32)
+        self.prm = dict(min_height=min_height, max_rot=max_rot, hip_period=hip_period, target_x_vel=target_x_vel,
+                        target_y_vel=target_y_vel, target_rot=np.asarray(rot, np.float64))
+
+    def reset(self, qpos, qvel):
+        self.d.reset()
+        self.d.qpos[:] = qpos; self.d.qvel[:] = qvel
+        self.steps = 0
+        if self.muscle_condition == "fatigue":
+            self.fatigue.reset()
+        self.d.ctrl[:] = 0
+        self.d.forward()
+        return self._obs_rwd()[0]
+
+    def _obs_rwd(self):
+        d = self.d
+        return walk_obs_reward(self.cm.arrays["BODY_MASS"], d.qpos, d.qvel, d.act, d.xpos, d.xipos, d.xquat, d.cvel,
+                               d.actuator_length, d.actuator_velocity, d.actuator_force, self.steps, self.dt, self.ids,
+                               self.prm, self.rwd_keys_wt)
+
+    def step(self, a):
+        a = np.asarray(a, np.float64)
+        ctrl = a.copy()
+        if self.cm.na and self.normalize_act:
+            ctrl[self.muscle] = 1.0 / (1.0 + np.exp(-5.0 * (ctrl[self.muscle] - 0.5)))
+        if self.muscle_condition == "fatigue":
+            ctrl[self.muscle], _, _ = self.fatigue.compute_act(ctrl[self.muscle])
+        self.d.ctrl[:] = ctrl
+        self.last_ctrl = ctrl
+        self.d.step(self.frame_skip)
+        self.d.forward()
+        obs, rwd = self._obs_rwd()            # self.steps is incremented AFTER the base step (walk_v0.py:354-357)
+        self.steps += 1
+        self.rwd_dict = rwd
+        return obs, float(rwd["dense"]), bool(rwd["done"]), rwd

@@ -8,6 +8,8 @@ What can be executed from /root/reference without `mujoco`/`gym` (both absent he
   * myosuite/envs/myo/fatigue.py            CumulativeFatigue (3CC-r)        -> ref_fatigue.npz
   * myosuite/envs/myo/myobase/pose_v0.py    get_obs_dict / get_reward_dict    -> ref_pose_env.npz
   * myosuite/envs/obs_vec_dict.py           obsdict2obsvec                    -> ref_pose_env.npz
+  * myosuite/envs/myo/myobase/reach_v0.py   get_obs_dict / get_reward_dict    -> ref_reach_env.npz
+  * myosuite/envs/myo/myobase/walk_v0.py    get_obs_dict / get_reward_dict    -> ref_walk_env.npz
   * myosuite/utils/quat_math.py, vector_math.py                               -> ref_math.npz
 `mujoco` and `myosuite.utils.gym` are replaced by stubs that only provide the names those files
 touch at import time (mjtDyn.mjDYN_MUSCLE, gym.utils.seeding.np_random, EzPickle); no arithmetic
@@ -156,6 +158,65 @@ def gen_reach_env():
     np.savez(os.path.join(OUT, "ref_reach_env.npz"), **out)
 
 
+def gen_walk_env():
+    """WalkEnvV0.get_obs_dict / get_reward_dict (walk_v0.py:283-325 and the helpers :367-540) executed on synthetic
+    mjData-like arrays with the synthetic leg's dimensions (15 bodies, nq 35, nv 34, 80 muscles)."""
+    st = _stubs()
+    st["myosuite.utils.quat_math"] = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})    # the reference's own module
+    walk = _load("ref_walk_v0", f"{REF}/envs/myo/myobase/walk_v0.py", st)
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(9)
+    n, nb, nq, nv, nu = 48, 15, 35, 34, 80
+    body_ids = {"pelvis": 1, "torso": 2, "talus_r": 5, "talus_l": 11}
+    jnt_ids = {"hip_flexion_r": 1, "hip_adduction_r": 2, "hip_rotation_r": 3, "hip_flexion_l": 15, "hip_adduction_l": 16,
+               "hip_rotation_l": 17}
+    jnt_qposadr = np.concatenate([[0], 7 + np.arange(28)])
+    body_mass = np.concatenate([[0.0], rng.uniform(0.1, 30, nb - 1)])
+    key0 = np.zeros(nq); key0[2] = 0.98; key0[3] = 0.7071067811865476; key0[6] = -0.7071067811865476
+    qpos = key0 + rng.uniform(-0.3, 0.3, (n, nq)); qvel = rng.standard_normal((n, nv)) * 2
+    quat = qpos[:, 3:7] + rng.uniform(-0.3, 0.3, (n, 4)); quat[n // 2:] = rng.standard_normal((n - n // 2, 4))
+    qpos[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    act = rng.random((n, nu))
+    xpos = rng.uniform(-1, 1, (n, nb, 3)); xpos[:, :, 2] = rng.uniform(0, 1.5, (n, nb))
+    xipos = xpos + rng.uniform(-0.1, 0.1, (n, nb, 3)); xipos[: n // 3, :, 2] *= 0.5      # low COM -> done
+    xquat = rng.standard_normal((n, nb, 4)); xquat /= np.linalg.norm(xquat, axis=2, keepdims=True)
+    cvel = rng.standard_normal((n, nb, 6)); cvel[:, :, 4] -= 1.2
+    alen = rng.uniform(0.05, 0.5, (n, nu)); avel = rng.standard_normal((n, nu)) * 60; afrc = -rng.uniform(0, 4000, (n, nu)) * 40
+    steps = rng.integers(0, 400, n)
+    dt = 0.01
+    keys = list(walk.WalkEnvV0.DEFAULT_OBS_KEYS) + ["act"]
+    obs = []; rk = ("vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense")
+    rwd = {k: [] for k in rk}
+    for i in range(n):
+        model = types.SimpleNamespace(na=nu, body_mass=body_mass, jnt_qposadr=jnt_qposadr,
+                                      body=lambda name: types.SimpleNamespace(id=body_ids[name]),
+                                      joint=lambda name: types.SimpleNamespace(id=jnt_ids[name]))
+        data = types.SimpleNamespace(time=dt * steps[i], qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(),
+                                     xpos=xpos[i], xipos=xipos[i], xquat=xquat[i], cvel=cvel[i], actuator_length=alen[i],
+                                     actuator_velocity=avel[i], actuator_force=afrc[i])
+        env = object.__new__(walk.WalkEnvV0)
+        env.mj_model = model; env.mj_data = data; env.dt = dt; env.steps = int(steps[i]); env.hip_period = 100
+        env.target_x_vel = 0.0; env.target_y_vel = 1.2; env.target_rot = None; env.init_qpos = key0.copy()
+        env.min_height = 0.8; env.max_rot = 0.8
+        env.rwd_keys_wt = walk.WalkEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS
+        od = env.get_obs_dict(model, data)
+        _, vec = ovd.ObsVecDict().obsdict2obsvec(od, keys)
+        env.obs_dict = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+        rd = env.get_reward_dict(env.obs_dict)
+        obs.append(vec)
+        for k in rk:
+            rwd[k].append(np.squeeze(rd[k]))
+    out = dict(body_mass=body_mass, qpos=qpos, qvel=qvel, act=act, xpos=xpos, xipos=xipos, xquat=xquat, cvel=cvel,
+               actuator_length=alen, actuator_velocity=avel, actuator_force=afrc, steps=steps, dt=np.array(dt),
+               obs=np.array(obs), key0=key0,
+               ids=np.array([body_ids["pelvis"], body_ids["torso"], body_ids["talus_l"], body_ids["talus_r"]] +
+                            [int(jnt_qposadr[jnt_ids[k]]) for k in ("hip_flexion_l", "hip_flexion_r", "hip_adduction_l",
+                                                                     "hip_adduction_r", "hip_rotation_l", "hip_rotation_r")]))
+    for k in rk:
+        out[f"rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    np.savez(os.path.join(OUT, "ref_walk_env.npz"), **out)
+
+
 def gen_math():
     qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
     vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
@@ -176,5 +237,6 @@ if __name__ == "__main__":
     gen_fatigue()
     gen_pose_env()
     gen_reach_env()
+    gen_walk_env()
     gen_math()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))

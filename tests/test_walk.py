@@ -1,0 +1,141 @@
+"""WalkEnvV0 (myoLegWalk-v0): reference-pinned env arithmetic (CPU) and HIP-vs-oracle env parity (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from myosuite_amd.model import synth
+from oracle import env_oracle as EO
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RK = ("vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense")
+WT = {"vel_reward": 5.0, "done": -100, "cyclic_hip": -10, "ref_rot": 10.0, "joint_angle_rew": 5.0}
+
+
+def test_walk_oracle_arithmetic_matches_reference_vectors():
+    """oracle/env_oracle.walk_obs_reward against vectors produced by executing the reference's walk_v0.py."""
+    g = np.load(os.path.join(G, "ref_walk_env.npz"))
+    idv = g["ids"]
+    ids = dict(pelvis=idv[0], torso=idv[1], talus_l=idv[2], talus_r=idv[3], hip_flexion_l=idv[4], hip_flexion_r=idv[5],
+               hip_adduction_l=idv[6], hip_adduction_r=idv[7], hip_rotation_l=idv[8], hip_rotation_r=idv[9])
+    prm = dict(min_height=0.8, max_rot=0.8, hip_period=100, target_x_vel=0.0, target_y_vel=1.2, target_rot=g["key0"][3:7])
+    n = g["qpos"].shape[0]
+    seen_done = 0
+    for i in range(n):
+        obs, rwd = EO.walk_obs_reward(g["body_mass"], g["qpos"][i], g["qvel"][i], g["act"][i], g["xpos"][i], g["xipos"][i],
+                                      g["xquat"][i], g["cvel"][i], g["actuator_length"][i], g["actuator_velocity"][i],
+                                      g["actuator_force"][i], int(g["steps"][i]), float(g["dt"]), ids, prm, WT)
+        assert obs.shape == (403,)
+        np.testing.assert_allclose(obs, g["obs"][i], rtol=2e-6, atol=2e-6)      # reference vector is float32
+        for k in RK:
+            np.testing.assert_allclose(float(rwd[k]), g[f"rwd_{k}"][i], rtol=1e-6, atol=1e-6, err_msg=k)   # des_angles are float32 in the reference
+        seen_done += int(rwd["done"])
+    assert 0 < seen_done < n
+
+
+def test_walk_env_registered_like_reference():
+    from myosuite_amd.envs import registry
+    for vid in ("myoLegWalk-v0", "myoSarcLegWalk-v0", "myoFatiLegWalk-v0"):
+        s = registry.spec(vid)
+        assert s["max_episode_steps"] == 1000 and s["kwargs"]["min_height"] == 0.8 and s["kwargs"]["hip_period"] == 100
+    assert "myoReafLegWalk-v0" not in registry.registry_specs()       # Reaf variants exist for myoHand* only
+
+
+# ----------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_walk_env_matches_oracle_env(oracle_lib):
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    cm = synth.get_model("leg")
+    n, nsteps = 6, 12
+    env = registry.make("myoLegWalk-v0", num_envs=n, seed=5, autoreset=False)
+    obs0, _ = env.reset(seed=5)
+    assert obs0.shape == (n, 403) and env.obs_dim == 403
+    assert list(env.obs_dict.keys())[2:] == ["qpos_without_xy", "qvel", "com_vel", "torso_angle", "feet_heights", "height",
+                                              "feet_rel_positions", "phase_var", "muscle_length", "muscle_velocity",
+                                              "muscle_force", "act"]
+    orc = [EO.WalkEnvOracle(cm) for _ in range(n)]
+    for e in range(n):
+        o = orc[e].reset(cm.key_qpos[2], cm.key_qvel[2])       # reset_type "init" -> key 2 (walk_v0.py:362-363)
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), o, rtol=1e-4, atol=2e-5)
+    a = torch.empty(n, cm.nu, device="cuda")
+    for s in range(nsteps):
+        E.uniform(a, 11, s)
+        act = (0.6 * a).contiguous()                          # moderate co-contraction: the body stays up for the horizon
+        # teacher forcing: every env-step starts from the oracle's (float32-rounded) state.  Free-running comparison is
+        # not meaningful across foot strikes: a contact whose onset lands one substep apart in fp32 and fp64 changes the
+        # impact impulse by O(v dt B) -- a genuine discontinuity of time-stepped contact dynamics, not a rounding effect
+        st = env.get_env_state()
+        for e in range(n):
+            d = orc[e].d
+            st["qpos"][e] = torch.from_numpy(d.qpos.astype(np.float32)); st["qvel"][e] = torch.from_numpy(d.qvel.astype(np.float32))
+            st["act"][e] = torch.from_numpy(d.act.astype(np.float32)); st["qacc_warmstart"][e] = torch.from_numpy(d.qacc_warmstart.astype(np.float32))
+            d.qpos[:] = d.qpos.astype(np.float32); d.qvel[:] = d.qvel.astype(np.float32); d.act[:] = d.act.astype(np.float32)
+            d.qacc_warmstart[:] = d.qacc_warmstart.astype(np.float32)
+        env.set_env_state(st)
+        obs, r, term, trunc, info = env.step(act)
+        an = act.cpu().numpy()
+        for e in range(n):
+            o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
+            got = obs[e].cpu().numpy()
+            # fp32 vs fp64 after 10 contact-rich substeps; velocity-like entries (qvel*dt, com_vel, muscle_velocity, and the force-velocity part of muscle_force) carry
+            # the fp32 moment-arm cancellation error times joint speeds of several rad/s: looser bound there
+            tol = np.full(403, 2e-3); tol[33:69] = 1e-2; tol[83 + 80:83 + 160] = 2e-2; tol[83 + 160:83 + 240] = 1e-2
+            scale = np.maximum(1.0, np.abs(o))
+            bad = np.abs(got - o) / scale > tol
+            assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], (np.abs(got - o) / scale)[bad][:5])
+            for i, k in enumerate(E.RWD_KEYS_WALK):
+                ref = float(rd[k])
+                assert abs(float(env.rwd[e, i]) - ref) < 2e-3 * max(1.0, abs(ref)), (k, s, e)
+            assert bool(term[e]) == done
+    assert int(env.step_count[0]) == nsteps
+    assert list(info["rwd_dict"].keys()) == E.RWD_KEYS_WALK
+
+
+@pytest.mark.gpu
+def test_gpu_walk_random_reset_draws_and_autoreset(oracle_lib):
+    import torch
+    from myosuite_amd.envs import registry
+    cm = synth.get_model("leg")
+    n = 64
+    env = registry.make("myoLegWalk-v0", num_envs=n, seed=3, reset_type="random")
+    env.reset(seed=3)
+    q = env.state.qpos.cpu().numpy(); v = env.state.qvel.cpu().numpy()
+    ep = env.episode.cpu().numpy()
+    used = set()
+    for e in range(n):
+        coin, z = EO.walk_reset_draws(cm.nq, e, int(ep[e]) - 1, 3)
+        k = 2 if coin < 0.5 else 3
+        used.add(k)
+        np.testing.assert_allclose(q[e], cm.key_qpos[k].astype(np.float32) + z, atol=2e-6)
+        np.testing.assert_array_equal(v[e], cm.key_qvel[k].astype(np.float32))
+        np.testing.assert_array_equal(q[e, 2:7], cm.key_qpos[k, 2:7].astype(np.float32))    # height / rotation untouched
+    assert used == {2, 3}
+    # zero activation: everybody falls below min_height within a second -> done, penalty, auto-reset to a fresh episode
+    a = torch.zeros(n, cm.nu, device="cuda")
+    fell = torch.zeros(n, dtype=torch.bool, device="cuda")
+    for _ in range(120):
+        obs, r, term, trunc, info = env.step(a)
+        fell |= term
+        assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+        if bool(term.any()):
+            i = int(torch.nonzero(term)[0])
+            assert float(info["rwd_dict"]["dense"][i]) < -50            # done weight -100
+            assert int(env.step_count[i]) == 0                          # auto-reset
+            assert float(info["final_obs"][i, cm.nq - 2 + cm.nv + 2 + 4 + 2]) < 0.8   # final height below min_height
+    assert bool(fell.all())
+    assert int(env.state.status.max()) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_walk_fatigue_variant_runs_and_fatigues(oracle_lib):
+    import torch
+    from myosuite_amd.envs import registry
+    env = registry.make("myoFatiLegWalk-v0", num_envs=16, seed=1)
+    env.reset(seed=1)
+    a = torch.ones(16, env.cm.nu, device="cuda")
+    for _ in range(30):
+        obs, r, *_ = env.step(a)
+    assert torch.isfinite(obs).all()
+    assert float(env.fat_MF.max()) > 0 and float((env.fat_MA + env.fat_MR + env.fat_MF - 1).abs().max()) < 1e-4
