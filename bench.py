@@ -25,7 +25,16 @@ import torch
 
 # algorithmic HBM bytes per env-step (fp32; state read+written once, ctrl, target, obs, 4 reward scalars):
 # SURVEY.md 8(d)  B_alg = 4*[(nq+nv+na) + nu + n_task_in + (nq+nv+na) + obs_dim + 4]
-B_ALG = {"myoElbowPose1D6MRandom-v0": 144, "myoHandPoseRandom-v0": 1376}
+def algorithmic_bytes(env) -> int:
+    """144 B (elbow pose), 1 376 B (hand pose), 4 600 B (leg walk; +1 920 B with the fatigue state)."""
+    cm = env.cm
+    n_task_in = {1: cm.nq, 2: 3 * getattr(env, "ntip", 0)}.get(int(env._task.task), 0)
+    b = 4 * (2 * (cm.nq + cm.nv + cm.na) + cm.nu + n_task_in + env.obs_dim + 4)
+    if env.muscle_condition == "fatigue":
+        b += 4 * 6 * cm.na          # MA/MR/MF read + written
+    return b
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -42,13 +51,16 @@ def cpu_baseline(env_id: str, nenv: int, nsteps: int):
     lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
     ds = []
     for e in range(nenv):
-        uq, _ = EO.pose_reset_draws(cm.nq, e, 0, 0)
         d = O.OracleData(om)
-        d.qpos[:] = (lo + (hi - lo) * uq).astype(np.float32)
+        if hasattr(cm, "key_qpos"):                 # walk: the "init" keyframe (walk_v0.py:362-363)
+            d.qpos[:] = cm.key_qpos[2]; d.qvel[:] = cm.key_qvel[2]
+        else:
+            uq, _ = EO.pose_reset_draws(cm.nq, e, 0, 0)
+            d.qpos[:] = (lo + (hi - lo) * uq).astype(np.float32)
         ds.append(d)
     acts = np.stack([EO.uniform_stream(nenv * cm.nu, 0, s).reshape(nenv, cm.nu) for s in range(nsteps)]).astype(np.float64)
     t0 = time.perf_counter()
-    O.batch_rollout(om, ds, acts, nsub=10, nthreads=cores, normalize=True, do_forward=True)
+    O.batch_rollout(om, ds, acts, nsub=spec["kwargs"].get("frame_skip", 10), nthreads=cores, normalize=True, do_forward=True)
     dt = time.perf_counter() - t0
     return {"value": nenv * nsteps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{nenv} envs x {nsteps} env-steps of {env_id} (fp64 C oracle, {cores} threads, {dt:.1f} s)"}
@@ -79,6 +91,7 @@ def main():
     cm = env.cm
     act = torch.empty(n, cm.nu, device="cuda")
     ep_ret = torch.zeros(n, device="cuda"); ep_len = torch.zeros(n, device="cuda"); solved = torch.zeros(n, device="cuda")
+    dense_col = env.rwd.shape[1] - 1     # reward rows end with ..., sparse, solved, done, dense (MM_RWD_* / MM_RWDW_*)
 
     def one_step(s, ev=None):
         E.uniform(act, seed=rank, stream_id=s)
@@ -88,8 +101,8 @@ def main():
         if ev is not None:
             ev[1].record()
         # episode statistics + masked auto-reset (device side, no host sync)
-        r = env.rwd[:, 7]
-        ep_ret.add_(r); ep_len.add_(1); solved.copy_(torch.maximum(solved, env.rwd[:, 5]))
+        r = env.rwd[:, dense_col]
+        ep_ret.add_(r); ep_len.add_(1); solved.copy_(torch.maximum(solved, env.rwd[:, dense_col - 2]))
         need = env.done | env.truncated
         env.reset(mask=need)
 
@@ -112,25 +125,35 @@ def main():
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
-        b_alg = B_ALG.get(args.env)
+        b_alg = algorithmic_bytes(env)
+        # HBM traffic per launch: PMC counters cannot be read from inside the process; the committed rocprofv3 summary
+        # of this same command (tools/prof_round.sh -> profiles/*_pmc.json) is reported when it matches the workload
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc.json"))).get(f"{args.env}@{n}")
+            if pm:
+                traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
+        except (OSError, ValueError):
+            pass
         achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9 if b_alg else None
         out = {
             "metric": "env-steps/sec (whole node) at %d envs/GPU" % n,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1), frame_skip 10 + final forward + "
+            "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1), frame_skip {env.frame_skip} + final forward + "
                                    f"obs/reward + auto-reset (synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
                        "envs_per_gpu": n, "lanes_per_env": env.hm.info(E.INFO_LANES), "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": (b_alg * n) if b_alg else None},
             "stats": {"mean_episode_return": float(stats[:, 0].mean()), "solved_frac": float(stats[:, 2].mean()),
                       "status_or": int(env.state.status.max())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            nb, ns = (4096, 60) if cm.nv > 4 else (8192, 200)   # a few seconds of wall time on the host cores
+            # a few seconds of wall time on the host cores
+            nb, ns = (8192, 200) if cm.nv <= 4 else ((4096, 60) if cm.nv < 30 else (1024, 40))
             out["cpu_baseline"] = cpu_baseline(args.env, nb, ns)
         print(json.dumps(out))
     if torch.distributed.is_initialized():

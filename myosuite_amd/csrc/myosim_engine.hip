@@ -1557,6 +1557,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (dup) e = nenv - 1;  // surplus groups recompute the last env (they never store)
   if (a.mode == 2 && a.t.env_mask && !a.t.env_mask[e]) dup = true;   // masked-out envs are left untouched
   const bool obs_only = a.mode == 2 && a.t.obs_only;
+  if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * a.L.total;
   const Layout& L = a.L;
   const Dims& d = a.d;
