@@ -35,7 +35,33 @@ def rollout(name):
     return dict(qpos=qpos, qvel=qvel, act=act, model_hash=np.array(cm.hash()))
 
 
+def rollout_leg(nenv=6, nsteps=20):
+    """myoLegWalk-v0 env-steps (10 substeps of 1 ms, foot contacts + knee equalities) from the stride keyframes with the
+    walk-reset noise; actions 0.6 * uniform_stream(seed 0, stream_id = step)."""
+    cm = synth.get_model("leg")
+    orc = []
+    qpos = np.zeros((nsteps + 1, nenv, cm.nq)); qvel = np.zeros((nsteps + 1, nenv, cm.nv)); act = np.zeros((nsteps + 1, nenv, cm.na))
+    obs = np.zeros((nsteps + 1, nenv, 403)); dense = np.zeros((nsteps, nenv))
+    for e in range(nenv):
+        coin, z = EO.walk_reset_draws(cm.nq, e, 0, 0)
+        k = 2 if coin < 0.5 else 3
+        w = EO.WalkEnvOracle(cm)
+        obs[0, e] = w.reset((cm.key_qpos[k].astype(np.float32) + z).astype(np.float64), cm.key_qvel[k])
+        qpos[0, e] = w.d.qpos; qvel[0, e] = w.d.qvel
+        orc.append(w)
+    for s in range(nsteps):
+        a = 0.6 * EO.uniform_stream(nenv * cm.nu, 0, s).reshape(nenv, cm.nu).astype(np.float64)
+        for e, w in enumerate(orc):
+            o, r, done, _ = w.step(a[e])
+            obs[s + 1, e] = o; dense[s, e] = r
+            qpos[s + 1, e] = w.d.qpos; qvel[s + 1, e] = w.d.qvel; act[s + 1, e] = w.d.act
+    return dict(qpos=qpos, qvel=qvel, act=act, obs=obs, dense=dense, model_hash=np.array(cm.hash()))
+
+
 if __name__ == "__main__":
+    r = rollout_leg()
+    np.savez_compressed(os.path.join(OUT, "oracle_traj_leg.npz"), **r)
+    print("leg", r["model_hash"], float(np.abs(r["qpos"][-1]).max()))
     for name in ("elbow", "hand"):
         r = rollout(name)
         np.savez_compressed(os.path.join(OUT, f"oracle_traj_{name}.npz"), **r)

@@ -70,6 +70,19 @@ def test_oracle_trajectory_regression(oracle_lib, models, name):
         np.testing.assert_allclose(r[k], g[k], rtol=1e-9, atol=1e-11)
 
 
+def test_oracle_leg_walk_trajectory_regression(oracle_lib):
+    """Pins the oracle's contact / equality / free-joint path and WalkEnvOracle against the committed trajectory."""
+    import importlib.util
+    from myosuite_amd.model import synth
+    spec = importlib.util.spec_from_file_location("mgo", os.path.join(G, "make_golden_oracle.py"))
+    mgo = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgo)
+    g = np.load(os.path.join(G, "oracle_traj_leg.npz"))
+    assert str(g["model_hash"]) == synth.get_model("leg").hash(), "synthetic leg changed: regenerate tests/golden"
+    r = mgo.rollout_leg()
+    for k in ("qpos", "qvel", "act", "obs", "dense"):
+        np.testing.assert_allclose(r[k], g[k], rtol=1e-8, atol=1e-10)
+
+
 def test_registry_mirrors_reference_ids():
     from myosuite_amd.envs import registry
     ids = registry.registry_specs()

@@ -139,3 +139,32 @@ def test_gpu_walk_fatigue_variant_runs_and_fatigues(oracle_lib):
         obs, r, *_ = env.step(a)
     assert torch.isfinite(obs).all()
     assert float(env.fat_MF.max()) > 0 and float((env.fat_MA + env.fat_MR + env.fat_MF - 1).abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_gpu_walk_free_running_vs_committed_oracle_trajectory():
+    """20 free-running env-steps (200 substeps with foot strikes) against tests/golden/oracle_traj_leg.npz.  Foot-strike
+    timing makes individual envs diverge, so the bound is on the median env plus a loose cap."""
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    g = np.load(os.path.join(G, "oracle_traj_leg.npz"))
+    cm = synth.get_model("leg")
+    assert str(g["model_hash"]) == cm.hash()
+    nsteps, n = g["dense"].shape
+    env = registry.make("myoLegWalk-v0", num_envs=n, seed=0, autoreset=False)
+    st = env.get_env_state()
+    st["qpos"].copy_(torch.from_numpy(g["qpos"][0].astype(np.float32))); st["qvel"].copy_(torch.from_numpy(g["qvel"][0].astype(np.float32)))
+    env.set_env_state(st)
+    a = torch.empty(n, cm.nu, device="cuda")
+    med = []
+    for s in range(nsteps):
+        E.uniform(a, 0, s)
+        obs, r, term, trunc, info = env.step((0.6 * a).contiguous())
+        err = np.abs(env.state.qpos.cpu().numpy() - g["qpos"][s + 1]).max(axis=1)
+        med.append(float(np.median(err)))
+        if s == 4:
+            assert np.median(err) < 2e-4 and err.max() < 5e-3, (np.median(err), err.max())
+            np.testing.assert_allclose(r.cpu().numpy(), g["dense"][s], rtol=0.02, atol=0.05)
+    assert med[-1] < 2e-2, med
+    assert int(env.state.status.max()) == 0
