@@ -65,6 +65,7 @@ struct Aux {
   int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
   int root_list, nroot;
   int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
+  int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
 };
 
 struct KArgs {
@@ -625,79 +626,61 @@ struct Engine {
       V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[dof]);
       V3 ang = ld3(W + L.cdof + 6 * dof), lin = ld3(W + L.cdof + 6 * dof + 3);
       float val = dot(u, lin + cross(ang, off));
-      W[L.tenj + ent] += ep ? val : -val;
+      atomicAdd(&W[L.tenj + ent], ep ? val : -val);
     }
   }
 
+  // Path items are flattened over ALL tendons on the host (Aux.item_tab, 8 words each:
+  // {tendon, kind, k0, site0, site1, geom, sidesite, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site,
+  // 2 = site-cylinder-site, 3 = fixed-tendon joint term) and sorted so that the expensive wrap items come first: a sweep
+  // of G lanes then executes one kind of item, instead of every lane walking its own tendon with divergent item kinds.
+  // Lengths and Jacobian entries are accumulated with LDS float atomics (one wave: deterministic lane order).
   __device__ __forceinline__ void tendon() {
     const Layout& L = a.L;
-    const int *wt = MI_(WRAP_TYPE), *wo = MI_(WRAP_OBJID);
-    const float* wp = MF_(WRAP_PRM);
     const int *sa = AUXI(sega_adr), *sb = AUXI(segb_adr), *sc = AUXI(segc_adr);
+    const int* items = AUXI(item_tab);
     for (int e = g; e < a.d.ntenJ; e += G) W[L.tenj + e] = 0.f;
+    for (int t = g; t < a.d.ntendon; t += G) W[L.tenlen + t] = 0.f;
     GSYNC();
-    for (int t = g; t < a.d.ntendon; t += G) {
-      int adr = MI_(TENDON_ADR)[t], num = MI_(TENDON_NUM)[t];
-      float len = 0.f, inv_div = 1.f;
-      for (int k = 0; k < num; k++)
-        if (wt[adr + k] == MM_WRAP_JOINT) {
-          int jn = wo[adr + k];
-          len += wp[adr + k] * W[L.qpos + MI_(JNT_QPOSADR)[jn]];
-          int dof = MI_(JNT_DOFADR)[jn];
-          for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++)
-            if (MI_(TENJ_DOF)[e] == dof) { W[L.tenj + e] += wp[adr + k]; break; }
-        }
-      int j = 0;
-      while (j < num - 1) {
-        int t0 = wt[adr + j], t1 = wt[adr + j + 1];
-        if (t0 == MM_WRAP_JOINT) { j++; continue; }
-        if (t0 == MM_WRAP_PULLEY || t1 == MM_WRAP_PULLEY) {
-          if (t0 == MM_WRAP_PULLEY) inv_div = 1.f / wp[adr + j];
-          j++;
-          continue;
-        }
-        const int k0 = adr + j;
-        V3 p0 = site_pos(wo[k0]);
-        if (t1 == MM_WRAP_SITE) {
-          V3 p1 = site_pos(wo[k0 + 1]);
-          V3 dif = p1 - p0;
-          float n = sqrtf(dot(dif, dif));
-          len += n * inv_div;
-          if (sa[k0 + 1] > sa[k0]) {
-            V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
-            tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
-          }
-          j += 1;
-        } else {
-          int gi = wo[k0 + 1];
-          V3 p1 = site_pos(wo[k0 + 2]);
-          int sideid = (int)lrintf(wp[k0 + 1]);
-          V3 side = v3(0.f, 0.f, 0.f);
-          if (sideid >= 0) side = site_pos(sideid);
-          V3 w0, w1;
-          float wlen = wrap_geom(w0, w1, p0, p1, geom_pos(gi), geom_mat(gi), MF_(GEOM_SIZE)[3 * gi],
-                                 t1 == MM_WRAP_CYLINDER, sideid >= 0, side);
-          if (wlen < 0.f) {
-            V3 dif = p1 - p0;
-            float n = sqrtf(dot(dif, dif));
-            len += n * inv_div;
-            if (sa[k0 + 1] > sa[k0]) {
-              V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
-              tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
-            }
-          } else {
-            V3 d0 = w0 - p0, d1 = p1 - w1;
-            float n0 = sqrtf(dot(d0, d0)), n1 = sqrtf(dot(d1, d1));
-            len += (n0 + wlen + n1) * inv_div;
-            if (sb[k0 + 1] > sb[k0])
-              tenj_segment(sb[k0], sb[k0 + 1], p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
-            if (sc[k0 + 1] > sc[k0])
-              tenj_segment(sc[k0], sc[k0 + 1], w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
-          }
-          j += 2;
-        }
+    for (int it = g; it < a.x.nitem; it += G) {
+      const int* I = items + 8 * it;
+      const int t = I[0], kind = I[1], k0 = I[2];
+      const float inv_div = __int_as_float(I[7]);
+      if (kind == 3) {   // fixed tendon: coef * q_joint
+        const int jn = I[3];
+        const float coef = __int_as_float(I[4]);
+        atomicAdd(&W[L.tenlen + t], coef * W[L.qpos + MI_(JNT_QPOSADR)[jn]]);
+        const int dof = MI_(JNT_DOFADR)[jn];
+        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++)
+          if (MI_(TENJ_DOF)[e] == dof) { atomicAdd(&W[L.tenj + e], coef); break; }
+        continue;
       }
-      W[L.tenlen + t] = len;
+      V3 p0 = site_pos(I[3]), p1 = site_pos(I[4]);
+      float wlen = -1.f;
+      V3 w0, w1;
+      if (kind != 0) {
+        const int gi = I[5], sideid = I[6];
+        V3 side = v3(0.f, 0.f, 0.f);
+        if (sideid >= 0) side = site_pos(sideid);
+        wlen = wrap_geom(w0, w1, p0, p1, geom_pos(gi), geom_mat(gi), MF_(GEOM_SIZE)[3 * gi], kind == 2, sideid >= 0, side);
+      }
+      if (wlen < 0.f) {
+        V3 dif = p1 - p0;
+        float n = sqrtf(dot(dif, dif));
+        atomicAdd(&W[L.tenlen + t], n * inv_div);
+        if (sa[k0 + 1] > sa[k0]) {
+          V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
+          tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
+        }
+      } else {
+        V3 d0 = w0 - p0, d1 = p1 - w1;
+        float n0 = sqrtf(dot(d0, d0)), n1 = sqrtf(dot(d1, d1));
+        atomicAdd(&W[L.tenlen + t], (n0 + wlen + n1) * inv_div);
+        if (sb[k0 + 1] > sb[k0])
+          tenj_segment(sb[k0], sb[k0 + 1], p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
+        if (sc[k0 + 1] > sc[k0])
+          tenj_segment(sc[k0], sc[k0 + 1], w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
+      }
     }
     GSYNC();
   }
@@ -2159,6 +2142,42 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     }
   }
   if (!seg_ok) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian pattern in the blob does not cover a path segment"); }
+  // flattened path items (see Engine::tendon): wraps first, then straight segments, then fixed-tendon joint terms
+  std::vector<int32_t> item_tab;
+  {
+    const float* wprm = (const float*)(blob + m->sec[MM_SEC_WRAP_PRM]);
+    struct Item { int w[8]; };
+    std::vector<Item> wraps, straights, joints;
+    auto fbits = [](float f) { int32_t i; memcpy(&i, &f, 4); return i; };
+    for (int t = 0; t < d.ntendon; t++) {
+      int adr = tadr[t], num = tnum[t], j = 0;
+      float inv_div = 1.f;
+      for (int k = 0; k < num; k++)
+        if (wt[adr + k] == MM_WRAP_JOINT) joints.push_back(Item{{t, 3, adr + k, wo[adr + k], fbits(wprm[adr + k]), 0, 0, fbits(1.f)}});
+      while (j < num - 1) {
+        int t0 = wt[adr + j], t1 = wt[adr + j + 1];
+        if (t0 == MM_WRAP_JOINT) { j++; continue; }
+        if (t0 == MM_WRAP_PULLEY || t1 == MM_WRAP_PULLEY) {
+          if (t0 == MM_WRAP_PULLEY) inv_div = 1.f / wprm[adr + j];
+          j++;
+          continue;
+        }
+        const int k0 = adr + j;
+        if (t1 == MM_WRAP_SITE) {
+          straights.push_back(Item{{t, 0, k0, wo[k0], wo[k0 + 1], 0, -1, fbits(inv_div)}});
+          j += 1;
+        } else {
+          int side = (int)lrintf(wprm[k0 + 1]);
+          wraps.push_back(Item{{t, t1 == MM_WRAP_CYLINDER ? 2 : 1, k0, wo[k0], wo[k0 + 2], wo[k0 + 1], side, fbits(inv_div)}});
+          j += 2;
+        }
+      }
+    }
+    // spheres and cylinders apart, so that a sweep of lanes runs one wrap flavour
+    std::stable_sort(wraps.begin(), wraps.end(), [](const Item& x, const Item& y) { return x.w[1] > y.w[1]; });
+    for (auto* v : {&wraps, &straights, &joints})
+      for (const Item& it : *v) for (int k = 0; k < 8; k++) item_tab.push_back(it.w[k]);
+  }
 
   std::vector<uint32_t> dev(m->h_blob);
   auto append = [&](const std::vector<int32_t>& v) {
@@ -2172,6 +2191,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
   m->x.sega_adr = append(sega); m->x.segb_adr = append(segb); m->x.segc_adr = append(segc);
   m->x.seg_list = append(seg_list);
+  m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
   m->blob_words = (int)dev.size();
 
   // default group width: the smallest that can own every body / dof / constraint row and has a compiled kernel
