@@ -45,7 +45,7 @@ struct Dims {
 struct Layout {
   int qpos, qvel, act, ctrl, actdot;
   int xpos, xmat, xanchor, xaxis, com, cdof;
-  int u1;   // union: xquat[4nb] during FK | cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
+  int u1;   // union: xquat[4nb] during FK | (cvel,cacc)[12nb] then cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
   int vec;  // nv: joint-transmission actuator forces
@@ -214,27 +214,64 @@ __device__ __forceinline__ float bc(float v, int j) {
 template <int G>
 __device__ __forceinline__ float sh(float v, int src) { return __shfl(v, src, G); }
 
-// Group sum, BITWISE IDENTICAL in every lane of the group.  Two things make that true by construction:
-// (1) the butterfly adds are explicit (__fadd_rn), so the compiler cannot contract `a*b + shfl(..)` into an
-//     FMA -- contraction makes lane i compute fma(a_i,b_i,c_j) and lane j fma(a_j,b_j,c_i), which differ in the
-//     last bits and would let "group-uniform" decisions (line-search alpha, loop exits) diverge between lanes;
-// (2) lane 0's total is broadcast to the whole group.
+// ---- group reductions on the DPP network (no LDS crossbar round trips) ----------------------------------------
+// Stages: xor 1 / xor 2 inside quads (quad_perm), quads -> 8 lanes (row_half_mirror), 8 -> 16 lanes (row_mirror); rows of
+// 16 are combined through v_readlane.  Every stage is symmetric (lane i and its partner compute a op b and b op a), so
+// the result is BITWISE IDENTICAL in every lane of the group -- group-uniform decisions (line-search alpha, loop exits)
+// rely on that.  The adds are explicit (__fadd_rn): a contracted fma(a_i, b_i, partner) would differ between partners.
+#define DPP_QUAD_XOR1 0xB1
+#define DPP_QUAD_XOR2 0x4E
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 template <int G>
 __device__ __forceinline__ float gsum(float v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v = __fadd_rn(v, __shfl_xor(v, m, G));
-  return bc<G>(v, 0);
+  v = __fadd_rn(v, dppf<DPP_QUAD_XOR1>(v));
+  v = __fadd_rn(v, dppf<DPP_QUAD_XOR2>(v));
+  if constexpr (G >= 8) v = __fadd_rn(v, dppf<DPP_ROW_HALF_MIRROR>(v));
+  if constexpr (G >= 16) v = __fadd_rn(v, dppf<DPP_ROW_MIRROR>(v));
+  if constexpr (G == 32) {
+    float a0 = __fadd_rn(rl(v, 0), rl(v, 16)), a1 = __fadd_rn(rl(v, 32), rl(v, 48));
+    v = (threadIdx.x & 32) ? a1 : a0;
+  }
+  if constexpr (G == 64) v = __fadd_rn(__fadd_rn(rl(v, 0), rl(v, 16)), __fadd_rn(rl(v, 32), rl(v, 48)));
+  return v;
 }
 template <int G>
 __device__ __forceinline__ float gmax(float v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, G));
+  v = fmaxf(v, dppf<DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dppf<DPP_QUAD_XOR2>(v));
+  if constexpr (G >= 8) v = fmaxf(v, dppf<DPP_ROW_HALF_MIRROR>(v));
+  if constexpr (G >= 16) v = fmaxf(v, dppf<DPP_ROW_MIRROR>(v));
+  if constexpr (G == 32) {
+    float a0 = fmaxf(rl(v, 0), rl(v, 16)), a1 = fmaxf(rl(v, 32), rl(v, 48));
+    v = (threadIdx.x & 32) ? a1 : a0;
+  }
+  if constexpr (G == 64) v = fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
   return v;
 }
 template <int G>
 __device__ __forceinline__ int gor(int v) {
-#pragma unroll
-  for (int m = G / 2; m >= 1; m >>= 1) v |= __shfl_xor(v, m, G);
+  v |= dppi<DPP_QUAD_XOR1>(v);
+  v |= dppi<DPP_QUAD_XOR2>(v);
+  if constexpr (G >= 8) v |= dppi<DPP_ROW_HALF_MIRROR>(v);
+  if constexpr (G >= 16) v |= dppi<DPP_ROW_MIRROR>(v);
+  if constexpr (G == 32) {
+    int a0 = __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16);
+    int a1 = __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+    v = (threadIdx.x & 32) ? a1 : a0;
+  }
+  if constexpr (G == 64)
+    v = __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
   return v;
 }
 
@@ -762,14 +799,18 @@ struct Engine {
     float cv[6], ca[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) { cv[k] = 0.f; ca[k] = 0.f; }
-    if (g == 0) { ca[3] = -a.d.gx; ca[4] = -a.d.gy; ca[5] = -a.d.gz; }
-    for (int lv = 1; lv <= a.d.nlevel; lv++) {
-      float pv[6], pa[6];
+    // parents publish (cvel, cacc) in LDS (u1 region, 12 words per body: three 128-bit accesses instead of twelve
+    // cross-lane permutes per level)
+    if (g == 0) {
+      ca[3] = -a.d.gx; ca[4] = -a.d.gy; ca[5] = -a.d.gz;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { pv[k] = sh<G>(cv[k], b_parent); pa[k] = sh<G>(ca[k], b_parent); }
+      for (int k = 0; k < 6; k++) { W[L.u1 + k] = 0.f; W[L.u1 + 6 + k] = ca[k]; }
+    }
+    GSYNC();
+    for (int lv = 1; lv <= a.d.nlevel; lv++) {
       if (b_depth == lv) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { cv[k] = pv[k]; ca[k] = pa[k]; }
+        for (int k = 0; k < 6; k++) { cv[k] = W[L.u1 + 12 * b_parent + k]; ca[k] = W[L.u1 + 12 * b_parent + 6 + k]; }
         for (int i = 0; i < c_jn; i++) {
           int type, da;
           if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
@@ -797,7 +838,10 @@ struct Engine {
             for (int k = 0; k < 6; k++) { cv[k] += cd[k] * qv; ca[k] += cdd[k] * qv; }
           }
         }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { W[L.u1 + 12 * g + k] = cv[k]; W[L.u1 + 12 * g + 6 + k] = ca[k]; }
       }
+      GSYNC();
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) b_cvel[k] = cv[k];
@@ -1105,11 +1149,7 @@ struct Engine {
     for (int d = 1; d < G; d <<= 1) { int t = __shfl_up(incl, d, G); if (g >= d) incl += t; }
     return incl - v;
   }
-  __device__ __forceinline__ int gsum_i(int v) const {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, G);
-    return v;
-  }
+  __device__ __forceinline__ int gsum_i(int v) const { return (int)(gsum<G>((float)v) + 0.5f); }   // counts <= 64: exact
   __device__ __forceinline__ V3 geom_zaxis(int gi) const {
     M3 R = geom_mat(gi);
     return v3(R.m[2], R.m[5], R.m[8]);
@@ -1977,7 +2017,7 @@ static void build_layout(mm_model* m) {
   L.xpos = take(3 * d.nbody); L.xmat = take(9 * d.nbody);
   L.com = take(3 * m->x.nroot); L.cdof = take(6 * d.nv);
   o = (o + 3) & ~3;
-  L.u1 = take(std::max(std::max(4 * d.nbody, 6 * d.nbody), m->nvp * m->nvp));
+  L.u1 = take(std::max(12 * d.nbody, m->nvp * m->nvp));
   L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
   L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
