@@ -451,21 +451,41 @@ def make_leg() -> ModelSpec:
     assert [j.name for j in s.joints] == names
     assert [a.name for a in s.actuators] == [f"{m}_{sd}" for sd in ("r", "l") for m in LEG_MUSCLES_SIDE]
 
-    # ---- keyframes (walk_v0.py:282-283,334-352 uses key 0 = stand, key 2 / 3 = mid-stride right / left)
-    def key(hip_r, knee_r, ank_r, hip_l, knee_l, ank_l, vy):
-        q = np.zeros(35); q[2] = PZ; q[3] = math.cos(math.pi / 4); q[6] = -math.sin(math.pi / 4)   # facing world -y
-        v = np.zeros(34); v[1] = -vy
-        for k, sd in enumerate(("r", "l")):
+    # ---- keyframes: the independent coordinates (hip x3, knee, ankle, subtalar, mtp) and their velocities are the
+    # reference's own numbers (myosuite/envs/myo/assets/leg/myolegs_chasetag.xml:53-56; walk_v0.py:271,334-363 uses
+    # key 0 = stand, key 2 / 3 = mid-stride); the 7 coupled knee / patella coordinates follow OUR coupling polynomials
+    # and the root height is re-grounded on the synthetic feet (_ground_keyframes).
+    IND = [0, 1, 2, 5, 8, 9, 10]     # hip_flexion, hip_adduction, hip_rotation, knee_angle, ankle, subtalar, mtp
+
+    def key(qr, ql, vr=None, vl=None, vy=0.0):
+        q = np.zeros(35); q[2] = PZ; q[3] = 0.707388; q[6] = -0.706825        # facing world -y
+        q[3:7] /= np.linalg.norm(q[3:7])
+        v = np.zeros(34); v[1] = vy
+        for k, (qq, vv) in enumerate(((qr, vr), (ql, vl))):
             o = 7 + 14 * k
-            hip, knee, ank = ((hip_r, knee_r, ank_r), (hip_l, knee_l, ank_l))[k]
-            q[o + 0] = hip; q[o + 5] = knee; q[o + 8] = ank
+            for i, val in zip(IND, qq):
+                q[o + i] = val
+            knee = q[o + 5]
             for base, pc in _KNEE_POLY.items():
                 q[o + LEG_JOINTS_SIDE.index(base)] = sum(c * knee ** i for i, c in enumerate(pc))
+            if vv is not None:
+                for i, val in zip(IND, vv):
+                    v[6 + 14 * k + i] = val
+                dknee = v[6 + 14 * k + 5]
+                for base, pc in _KNEE_POLY.items():   # velocities consistent with the couplings
+                    v[6 + 14 * k + LEG_JOINTS_SIDE.index(base)] = dknee * sum(i * c * knee ** (i - 1) for i, c in enumerate(pc) if i > 0)
         return q, v
-    stand = key(0, 0, 0, 0, 0, 0, 0.0)
-    strideR = key(0.45, 0.25, 0.05, -0.25, 0.15, 0.10, 1.2)
-    strideL = key(-0.25, 0.15, 0.10, 0.45, 0.25, 0.05, 1.2)
-    s.keys = [stand, stand, strideR, strideL]
+    stand = key((0.161153, -0.0279385, -0.041886, 0.461137, 0.334, -0.00117055, -0.000125295),) * 2 if False else \
+        key((0.161153, -0.0279385, -0.041886, 0.461137, 0.334, -0.00117055, -0.000125295),
+            (0.161153, -0.0279385, -0.041886, 0.461137, 0.334, -0.00117055, -0.000125295))
+    crouch = key((0.405648, -0.020957, -0.118677, 0.7329, 0.40143, -0.006982, -0.02618),
+                 (0.405648, -0.020957, -0.118677, 0.7329, 0.40143, -0.006982, -0.02618))
+    swing = (-0.2326, -0.0279385, -0.041886, 1.227, 0.1672, -0.00117055, -0.000125295)
+    stance = (-0.1652, -0.0279385, -0.041886, 0.0888, -0.019, -0.00117055, -0.000125295)
+    v_swing = (4.9066, 0.0, 0.0, -3.597, 0.633, 0.0, 0.0)
+    strideR = key(swing, stance, v_swing, (0.175, 0.0, 0.0, 0.175, 0.988, 0.0, 0.0), vy=-1.5)
+    strideL = key(stance, swing, (-0.576, 0.0, 0.0, 0.175, 0.988, 0.0, 0.0), v_swing, vy=-1.5)
+    s.keys = [stand, crouch, strideR, strideL]
     return s
 
 
