@@ -28,7 +28,8 @@ import torch
 def algorithmic_bytes(env) -> int:
     """144 B (elbow pose), 1 376 B (hand pose), 4 600 B (leg walk; +1 920 B with the fatigue state)."""
     cm = env.cm
-    n_task_in = {1: cm.nq, 2: 3 * getattr(env, "ntip", 0)}.get(int(env._task.task), 0)
+    # per-step task inputs: pose targets [nq] | reach targets [3 ntip] | reorient des_rot 3 + axis_half 1 + geom_size 3
+    n_task_in = {1: cm.nq, 2: 3 * getattr(env, "ntip", 0), 3: 7}.get(int(env._task.task), 0)
     b = 4 * (2 * (cm.nq + cm.nv + cm.na) + cm.nu + n_task_in + env.obs_dim + 4)
     if env.muscle_condition == "fatigue":
         b += 4 * 6 * cm.na          # MA/MR/MF read + written
@@ -54,6 +55,11 @@ def cpu_baseline(env_id: str, nenv: int, nsteps: int):
         d = O.OracleData(om)
         if hasattr(cm, "key_qpos"):                 # walk: the "init" keyframe (walk_v0.py:362-363)
             d.qpos[:] = cm.key_qpos[2]; d.qvel[:] = cm.key_qvel[2]
+        elif "Object" in cm.names["body"]:          # reorient: open hand, palm up, capsule size of the episode
+            q = cm.qpos0.astype(np.float64).copy(); q[:-6] = 0; q[0] = -1.5
+            d.qpos[:] = q
+            size, _, _ = EO.reorient_reset_draws(synth.REORIENT_CAPS_100, e, 0, 0, 0.07)
+            d.set_geom_size(cm.names["geom"]["obj"], size)
         else:
             uq, _ = EO.pose_reset_draws(cm.nq, e, 0, 0)
             d.qpos[:] = (lo + (hi - lo) * uq).astype(np.float32)
@@ -153,7 +159,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             # a few seconds of wall time on the host cores
-            nb, ns = (8192, 200) if cm.nv <= 4 else ((4096, 60) if cm.nv < 30 else (1024, 40))
+            nb, ns = (8192, 200) if cm.nv <= 4 else ((4096, 60) if cm.nv < 25 else (1024, 40))
             out["cpu_baseline"] = cpu_baseline(args.env, nb, ns)
         print(json.dumps(out))
     if torch.distributed.is_initialized():

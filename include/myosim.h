@@ -65,6 +65,9 @@ typedef struct {
   float* time;            /* [nenv]                                       */
   int32_t* status;        /* [nenv] bit0: bad-state auto reset, bit1: constraint rows overflowed,
                                     bit2: solver hit the iteration cap (sticky; cleared by reset) */
+  /* per-env model delta (the reference mutates mjModel at reset: reorient_sar_v0.py:407-409): size of ONE geom */
+  const float* geom_size_env; /* [nenv][3] or NULL: replaces geom_size[geom_env_id] in collision           */
+  int    geom_env_id;         /* geom id the per-env size applies to (-1 = none)                           */
 } mm_state;
 
 /* Optional derived outputs of the final forward pass (NULL = not requested). */
@@ -132,6 +135,16 @@ typedef struct {
   float walk_target_x_vel, walk_target_y_vel;   /* walk_v0.py:252-253,444-451   */
   float walk_target_rot[4]; /* init_qpos[3:7] unless given (walk_v0.py:472-479) */
   float walk_w[5];          /* weights of vel_reward, done, cyclic_hip, ref_rot, joint_angle_rew (walk_v0.py:207-213) */
+  /* REORIENT task (envs/myo/myobase/reorient_sar_v0.py:116-174): obs [hand_jnt = qpos[:-6], obj_pos, obj_vel = qvel[-6:]*dt,
+     obj_rot, obj_des_rot, obj_err_pos, obj_err_rot, mlen, mvel, mforce, act]; reward columns MM_RWDR_*.  The reference
+     moves the top/bot marker geoms to +-axis_half along the object's z at reset (:403-406) but keeps pen_length /
+     tar_length from setup (:84-91): obj_rot = R_obj * (0,0,2*axis_half) / pen_length. */
+  int   reor_obj_body;      /* "Object" body id                                 */
+  int   reor_eps_site;      /* "eps_ball" site id (obj_des_pos)                 */
+  float reor_pen_length;    /* |geom_pos[top] - geom_pos[bot]| of the compiled model */
+  const float* reor_axis_half; /* [nenv]                                        */
+  const float* reor_des_rot;   /* [nenv][3] obj_des_rot of the episode (target body quat applied, / tar_length) */
+  float reor_w[5];          /* weights of pos_align, rot_align, act_reg, drop, bonus (reorient_sar_v0.py:38-44) */
   /* reset observation support (all tasks) */
   const uint8_t* env_mask;  /* optional [nenv]: envs with 0 are left untouched  */
   int   obs_only;           /* 1: no substeps, no ctrl map, no counters, no reward write: forward + obs of the CURRENT state
@@ -144,6 +157,10 @@ enum { MM_RWD_POSE = 0, MM_RWD_BONUS, MM_RWD_PENALTY, MM_RWD_ACT_REG, MM_RWD_SPA
 /* columns of mm_task.rwd for MM_TASK_WALK (walk_v0.py:305-325) */
 enum { MM_RWDW_VEL = 0, MM_RWDW_CYCLIC_HIP, MM_RWDW_REF_ROT, MM_RWDW_JOINT_ANGLE, MM_RWDW_ACT_MAG, MM_RWDW_SPARSE,
        MM_RWDW_SOLVED, MM_RWDW_DONE, MM_RWDW_DENSE, MM_RWDW_COUNT };
+
+/* columns of mm_task.rwd for MM_TASK_REORIENT (reorient_sar_v0.py:136-166) */
+enum { MM_RWDR_POS_ALIGN = 0, MM_RWDR_ROT_ALIGN, MM_RWDR_ACT_REG, MM_RWDR_DROP, MM_RWDR_BONUS, MM_RWDR_SPARSE,
+       MM_RWDR_SOLVED, MM_RWDR_DONE, MM_RWDR_DENSE, MM_RWDR_COUNT };
 
 /* ---- model ---------------------------------------------------------------- */
 int  mm_model_create(const uint32_t* blob_host, int nwords, mm_model** out);
@@ -187,6 +204,13 @@ int  mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, c
 int  mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* key_a_qpos,
                    const float* key_a_qvel, const float* key_b_qpos, const float* key_b_qvel, int random,
                    int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
+/* Reorient-task reset (reorient_sar_v0.py:265-437, capsule branch): per env a size row of `size_table` [ntab][3]
+ * (Philox index draw) -> geom_size_env[e], axis_half[e] = 1.3 * size[1]; desired orientation
+ * euler2quat([U(-1,1), U(-0.8,1.2), 0]) (utils/quat_math.py:70-86) -> des_rot[e] = R * (0,0,2*axis_half) / tar_length;
+ * state = init_qpos [nq], qvel = act = 0.  First observation: mm_env_step with obs_only. */
+int  mm_reorient_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
+                       const float* size_table, int ntab, float* geom_size_env, float* axis_half, float* des_rot,
+                       float tar_length, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

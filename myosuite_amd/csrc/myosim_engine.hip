@@ -464,6 +464,7 @@ struct Engine {
   // ---- general rows (GEN): lane r owns row r of efc_J (LDS); equality rows are always active
   bool r_eq;
   int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
+  const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
 
   __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
       : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
@@ -492,7 +493,7 @@ struct Engine {
         c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
       }
     }
-    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
     b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
@@ -1258,8 +1259,12 @@ struct Engine {
       rowsper = MI_(PAIR_CONDIM)[p] == 1 ? 1 : 4;
       b1 = MI_(GEOM_BODYID)[g1]; b2 = MI_(GEOM_BODYID)[g2];
       V3 x1 = geom_pos(g1), x2 = geom_pos(g2);
-      const float r1 = MF_(GEOM_SIZE)[3 * g1], h1 = MF_(GEOM_SIZE)[3 * g1 + 1];
-      const float r2 = MF_(GEOM_SIZE)[3 * g2], h2 = MF_(GEOM_SIZE)[3 * g2 + 1];
+      float r1 = MF_(GEOM_SIZE)[3 * g1], h1 = MF_(GEOM_SIZE)[3 * g1 + 1];
+      float r2 = MF_(GEOM_SIZE)[3 * g2], h2 = MF_(GEOM_SIZE)[3 * g2 + 1];
+      if (env_gsize) {   // per-env model delta: size of one geom (mm_state.geom_size_env)
+        if (g1 == a.s.geom_env_id) { r1 = env_gsize[0]; h1 = env_gsize[1]; }
+        if (g2 == a.s.geom_env_id) { r2 = env_gsize[0]; h2 = env_gsize[1]; }
+      }
       if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_SPHERE) {
         nc = pln_sph(x1, geom_zaxis(g1), x2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
       } else if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_CAPSULE) {
@@ -1585,6 +1590,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   const Layout& L = a.L;
   const Dims& d = a.d;
   Engine<G, NVP, GEN> E(a, mb, W, g);
+  if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
 
   // ---- load state (HBM -> LDS tables / owner registers)
   for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
@@ -1848,6 +1854,51 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
       }
     }
+    if (t.task == MM_TASK_REORIENT) {
+      // obs / reward of ProprioceptiveEnvV0 (reorient_sar_v0.py:116-174)
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      const int nh = d.nq - 6;
+      const int o_pos = nh, o_vel = o_pos + 3, o_rot = o_vel + 6, o_des = o_rot + 3, o_ep = o_des + 3, o_er = o_ep + 3,
+                o_ml = o_er + 3, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = o_mf + d.nu;
+      float act2 = 0.f;
+      if (ob) {
+        for (int i = g; i < nh; i += G) ob[i] = W[L.qpos + i];
+        if (g < d.nv && g >= d.nv - 6) ob[o_vel + g - (d.nv - 6)] = E.d_qvel * t.obs_dt;
+        for (int i = g; i < d.nu; i += G) { ob[o_ml + i] = W[L.actlen + i]; ob[o_mv + i] = W[L.actvel + i]; ob[o_mf + i] = W[L.actfrc + i]; }
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[o_act + i] = x;
+      }
+      act2 = gsum<G>(act2);
+      if (g == 0) {
+        const int bo = t.reor_obj_body;
+        V3 opos = ld3(W + L.xpos + 3 * bo);
+        const float* R = W + L.xmat + 9 * bo;
+        const float sc_ = 2.f * t.reor_axis_half[e] / t.reor_pen_length;
+        V3 orot = v3(R[2] * sc_, R[5] * sc_, R[8] * sc_);
+        V3 odes = ld3(t.reor_des_rot + (size_t)e * 3);
+        V3 epos = opos - E.site_pos(t.reor_eps_site), erot = orot - odes;
+        if (ob) { st3(ob + o_pos, opos); st3(ob + o_rot, orot); st3(ob + o_des, odes); st3(ob + o_ep, epos); st3(ob + o_er, erot); }
+        const float pos_align = sqrtf(dot(epos, epos));
+        float nrm = sqrtf(dot(orot, orot)) * sqrtf(dot(odes, odes));
+        if (nrm == 0.f) nrm = 1.f;                                   // vector_math.py:26-32
+        const float rot_align = dot(orot, odes) / nrm;
+        const bool dropped = pos_align > 0.075f;
+        const float act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        const float bonus = ((rot_align > 0.9f && pos_align < 0.075f) ? 1.f : 0.f) + ((rot_align > 0.95f && pos_align < 0.075f) ? 5.f : 0.f);
+        if (t.rwd && !obs_only) {
+          float* r = t.rwd + (size_t)e * MM_RWDR_COUNT;
+          r[MM_RWDR_POS_ALIGN] = -pos_align; r[MM_RWDR_ROT_ALIGN] = rot_align; r[MM_RWDR_ACT_REG] = -act_mag;
+          r[MM_RWDR_DROP] = dropped ? -1.f : 0.f; r[MM_RWDR_BONUS] = bonus; r[MM_RWDR_SPARSE] = -pos_align + rot_align;
+          r[MM_RWDR_SOLVED] = (rot_align > 0.95f && !dropped) ? 1.f : 0.f; r[MM_RWDR_DONE] = dropped ? 1.f : 0.f;
+          r[MM_RWDR_DENSE] = t.reor_w[0] * -pos_align + t.reor_w[1] * rot_align + t.reor_w[2] * -act_mag +
+                             t.reor_w[3] * (dropped ? -1.f : 0.f) + t.reor_w[4] * bonus;
+        }
+        if (t.done && !obs_only) t.done[e] = dropped ? 1 : 0;
+      }
+    }
     if (g == 0 && !obs_only) {
       if (t.step_count) t.step_count[e] = sc;
       if (t.truncated) t.truncated[e] = (t.max_episode_steps > 0 && sc >= t.max_episode_steps) ? 1 : 0;
@@ -1878,12 +1929,13 @@ __global__ void k_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
 
 struct ResetArgs {
   const uint32_t* blob; int qpos0_off; int nq, nv, na, nenv;
-  mm_state s; const uint8_t* mask; const float* qpos_src; const float* qvel_src;
+  mm_state s; const uint8_t* mask; const float* qpos_src; const float* qvel_src; const float* qpos_bcast;
   const float *qlo, *qhi, *tlo, *thi; float* target; int32_t* episode; int32_t* step_count; uint64_t seed;
   int pose, random_qpos;
   float* obs; int obs_dim, obs_layout;
   int reach, ntip; const float* tip0;
   int walk, walk_random; const float *ka_qpos, *ka_qvel, *kb_qpos, *kb_qvel;
+  int reor, reor_ntab; const float* reor_tab; float *reor_gsize, *reor_axis_half, *reor_des_rot; float reor_tar_length;
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -1894,7 +1946,7 @@ __global__ void k_reset(ResetArgs r) {
   int ep = 0;
   if (r.pose && r.episode) { ep = r.episode[e]; r.episode[e] = ep + 1; }
   for (int i = 0; i < r.nq; i++) {
-    float q = r.qpos_src ? r.qpos_src[(size_t)e * r.nq + i] : qpos0[i];
+    float q = r.qpos_src ? r.qpos_src[(size_t)e * r.nq + i] : (r.qpos_bcast ? r.qpos_bcast[i] : qpos0[i]);
     if (r.pose) {
       // counter = (i/2, 0, env, episode): words 0/1 -> qpos draw of coordinate i (even/odd), words 2/3 -> target
       uint32_t c[4] = {(uint32_t)(i >> 1), 0u, (uint32_t)e, (uint32_t)ep};
@@ -1932,6 +1984,30 @@ __global__ void k_reset(ResetArgs r) {
       for (int i = 0; i < r.nv; i++) ob[r.nq + i] = 0.f;
       for (int i = 0; i < r.na; i++) ob[r.nq + r.nv + 2 * n3 + i] = 0.f;
     }
+  }
+  if (r.reor) {
+    // reorient_sar_v0.py:386-432 (capsule branch): Philox counter (0, 3, env, episode): word 0 -> size-table row,
+    // words 1 / 2 -> desired_orien[0] ~ U(-1,1), desired_orien[1] ~ U(-0.8,1.2)
+    int ep = r.episode ? r.episode[e] : 0;
+    if (r.episode) r.episode[e] = ep + 1;
+    uint32_t c[4] = {0u, 3u, (uint32_t)e, (uint32_t)ep};
+    philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    int idx = (int)(u01(c[0]) * (float)r.reor_ntab);
+    if (idx >= r.reor_ntab) idx = r.reor_ntab - 1;
+    const float* sz = r.reor_tab + 3 * idx;
+    for (int k = 0; k < 3; k++) r.reor_gsize[(size_t)e * 3 + k] = sz[k];
+    const float ah = 1.3f * sz[1];
+    r.reor_axis_half[e] = ah;
+    const float e0 = -1.f + 2.f * u01(c[1]), e1 = -0.8f + 2.f * u01(c[2]);
+    // euler2quat([e0, e1, 0]) (utils/quat_math.py:70-86): ai = 0, aj = -e1/2, ak = e0/2
+    const float aj = -0.5f * e1, ak = 0.5f * e0;
+    const float sj = sinf(aj), cj = cosf(aj), sk = sinf(ak), ck = cosf(ak);
+    const float qw = cj * ck, qx = cj * sk, qy = -(sj * ck), qz = -sj * sk;
+    // third column of quat2mat(q) times 2*axis_half / tar_length
+    const float sc_ = 2.f * ah / r.reor_tar_length;
+    r.reor_des_rot[(size_t)e * 3 + 0] = 2.f * (qx * qz + qw * qy) * sc_;
+    r.reor_des_rot[(size_t)e * 3 + 1] = 2.f * (qy * qz - qw * qx) * sc_;
+    r.reor_des_rot[(size_t)e * 3 + 2] = (1.f - 2.f * (qx * qx + qy * qy)) * sc_;
   }
   if (r.walk) {
     // walk_v0.py:327-365: key pose (random: coin between the two stride keys + N(0, 0.02) on every coordinate
@@ -2000,7 +2076,7 @@ static const int kNvpChoices[] = {4, 24, 32, 40};
 
 // compiled (lanes_per_env, padded nv, general-rows) kernel instantiations -- keep in sync with the CASE table in launch()
 static bool have_kernel(int G, int nvp, int gen) {
-  if (gen) return (nvp == 4 && G == 16) || (nvp == 24 && G == 32) || (nvp == 40 && G == 64);
+  if (gen) return (nvp == 4 && G == 16) || (nvp == 24 && G == 32) || (nvp == 32 && G == 64) || (nvp == 40 && G == 64);
   if (nvp == 4) return G == 4 || G == 8 || G == 16 || G == 32 || G == 64;
   if (nvp == 24) return G == 32 || G == 64;
   if (nvp == 32) return G == 32 || G == 64;
@@ -2352,7 +2428,7 @@ static int launch(const mm_model* m, KArgs& a, void* stream) {
   CASE(32, 24, 0) CASE(64, 24, 0)
   CASE(32, 32, 0) CASE(64, 32, 0)
   CASE(64, 40, 0)
-  CASE(16, 4, 1) CASE(32, 24, 1) CASE(64, 40, 1)
+  CASE(16, 4, 1) CASE(32, 24, 1) CASE(64, 32, 1) CASE(64, 40, 1)
 #undef CASE
   return fail(MM_EUNSUPPORTED, "no compiled kernel for this (lanes_per_env, nv) combination");
 }
@@ -2362,6 +2438,7 @@ static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
   a.blob = m->d_blob;
   memcpy(a.sec, m->sec, sizeof(a.sec));
   a.d = m->d; a.L = m->L; a.D = m->D; a.x = m->x; a.s = *s;
+  if (!a.s.geom_size_env || a.s.geom_env_id < 0 || a.s.geom_env_id >= m->d.ngeom) { a.s.geom_size_env = nullptr; a.s.geom_env_id = -1; }
 }
 
 extern "C" int mm_step(const mm_model* m, const mm_state* s, const float* ctrl, int nsub, void* stream) {
@@ -2391,7 +2468,14 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
     for (int k = 0; k < 6; k++) if (t->walk_qadr[k] < 0 || t->walk_qadr[k] >= m->d.nq) return fail(MM_EARG, "walk task: bad qpos address");
     if (m->d.nq < 7 || t->walk_hip_period <= 0) return fail(MM_EARG, "walk task needs a free root joint and hip_period > 0");
   }
-  if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH && t->task != MM_TASK_WALK)
+  if (t->task == MM_TASK_REORIENT) {
+    if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "reorient task needs do_forward");
+    if (t->reor_obj_body <= 0 || t->reor_obj_body >= m->d.nbody || t->reor_eps_site < 0 || t->reor_eps_site >= m->d.nsite ||
+        !t->reor_axis_half || !t->reor_des_rot || !(t->reor_pen_length > 0.f) || m->d.nq < 7)
+      return fail(MM_EARG, "reorient task: bad body/site id or missing per-env buffers");
+  }
+  if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH && t->task != MM_TASK_WALK &&
+      t->task != MM_TASK_REORIENT)
     return fail(MM_EUNSUPPORTED, "task not implemented");
   if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "fatigue needs MA/MR/MF");
   KArgs a; fill_common(m, a, s);
@@ -2460,6 +2544,22 @@ extern "C" int mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t
   r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.walk = 1; r.walk_random = random; r.ka_qpos = key_a_qpos; r.ka_qvel = key_a_qvel; r.kb_qpos = key_b_qpos; r.kb_qvel = key_b_qvel;
+  hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_reorient_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
+                                 const float* size_table, int ntab, float* geom_size_env, float* axis_half, float* des_rot,
+                                 float tar_length, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
+  if (!m || !s || !init_qpos || !size_table || ntab <= 0 || !geom_size_env || !axis_half || !des_rot || !(tar_length > 0.f))
+    return fail(MM_EARG, "mm_reorient_reset: bad argument");
+  ResetArgs r; memset(&r, 0, sizeof(r));
+  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
+  r.qpos_bcast = init_qpos;
+  r.reor = 1; r.reor_ntab = ntab; r.reor_tab = size_table; r.reor_gsize = geom_size_env; r.reor_axis_half = axis_half;
+  r.reor_des_rot = des_rot; r.reor_tar_length = tar_length;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;

@@ -25,6 +25,7 @@ _lib = None
 MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK = 0, 1, 2, 3, 4
 RWD_KEYS_POSE = ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 RWD_KEYS_REACH = ["reach", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense"]
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
  INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK) = range(12)
@@ -50,7 +51,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 class mm_state(C.Structure):
     _fields_ = [("nenv", C.c_int), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("act", C.c_void_p),
-                ("qacc_warmstart", C.c_void_p), ("time", C.c_void_p), ("status", C.c_void_p)]
+                ("qacc_warmstart", C.c_void_p), ("time", C.c_void_p), ("status", C.c_void_p),
+                ("geom_size_env", C.c_void_p), ("geom_env_id", C.c_int)]
 
 
 _DERIVED_FIELDS = ["xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "cvel", "subtree_com", "actuator_length",
@@ -76,6 +78,8 @@ class mm_task(C.Structure):
                 ("walk_body", C.c_int * 4), ("walk_qadr", C.c_int * 6), ("walk_min_height", C.c_float),
                 ("walk_max_rot", C.c_float), ("walk_hip_period", C.c_int), ("walk_target_x_vel", C.c_float),
                 ("walk_target_y_vel", C.c_float), ("walk_target_rot", C.c_float * 4), ("walk_w", C.c_float * 5),
+                ("reor_obj_body", C.c_int), ("reor_eps_site", C.c_int), ("reor_pen_length", C.c_float),
+                ("reor_axis_half", C.c_void_p), ("reor_des_rot", C.c_void_p), ("reor_w", C.c_float * 5),
                 ("env_mask", C.c_void_p), ("obs_only", C.c_int)]
 
 
@@ -105,6 +109,9 @@ def lib():
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.mm_walk_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.mm_reorient_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
@@ -179,8 +186,15 @@ class BatchState:
         self.qacc_warmstart = torch.zeros(nenv, cm.nv, **f)
         self.time = torch.zeros(nenv, **f)
         self.status = torch.zeros(nenv, dtype=torch.int32, device=dev)
+        self.geom_size_env = None
         self._c = mm_state(nenv, _ptr(self.qpos), _ptr(self.qvel), self.act.data_ptr(), _ptr(self.qacc_warmstart),
-                           _ptr(self.time), _ptr(self.status))
+                           _ptr(self.time), _ptr(self.status), None, -1)
+
+    def set_geom_size_env(self, geom_id: int, sizes: torch.Tensor):
+        """per-env model delta: collision size [nenv][3] of one geom (mm_state.geom_size_env)"""
+        assert sizes.shape == (self.nenv, 3) and sizes.dtype == torch.float32 and sizes.is_contiguous() and sizes.is_cuda
+        self.geom_size_env = sizes
+        self._c.geom_size_env = sizes.data_ptr(); self._c.geom_env_id = int(geom_id)
 
     @property
     def c(self):
@@ -269,6 +283,14 @@ def walk_reset(model: HipModel, state: BatchState, mask, key_a_qpos, key_a_qvel,
     _chk(lib().mm_walk_reset(model.h, state.c, _ptr(mask), _ptr(key_a_qpos), _ptr(key_a_qvel), _ptr(key_b_qpos),
                              _ptr(key_b_qvel), int(random), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()),
          "mm_walk_reset")
+
+
+def reorient_reset(model: HipModel, state: BatchState, mask, init_qpos, size_table, axis_half, des_rot, tar_length: float,
+                   episode, step_count, seed: int):
+    assert state.geom_size_env is not None, "call BatchState.set_geom_size_env first"
+    _chk(lib().mm_reorient_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(size_table), int(size_table.shape[0]),
+                                 _ptr(state.geom_size_env), _ptr(axis_half), _ptr(des_rot), C.c_float(tar_length),
+                                 _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()), "mm_reorient_reset")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

@@ -80,6 +80,11 @@ def _reach(**kw):
     return ReachEnvV0(**kw)
 
 
+def _reorient(**kw):
+    from .reorient_v0 import ReorientEnvV0
+    return ReorientEnvV0(**kw)
+
+
 def _walk(**kw):
     from .walk_v0 import WalkEnvV0
     return WalkEnvV0(**kw)
@@ -152,3 +157,13 @@ register_env_with_variants(
     id="myoLegWalk-v0", entry_point=_walk, max_episode_steps=1000,
     kwargs={"model": "leg", "normalize_act": True, "min_height": 0.8, "max_rot": 0.8, "hip_period": 100,
             "reset_type": "init", "target_x_vel": 0.0, "target_y_vel": 1.2, "target_rot": None})
+
+
+# SAR reorient (myobase/__init__.py:703-725): frame_skip 5, horizon 50.  Object type restricted to capsules (reorient_v0.py).
+# myoHandReorientID / OOD (:727-749) use ellipsoid / box / cylinder-heavy test tables and are not registered.
+register_env_with_variants(
+    id="myoHandReorient8-v0", entry_point=_reorient, max_episode_steps=50,
+    kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "8"})
+register_env_with_variants(
+    id="myoHandReorient100-v0", entry_point=_reorient, max_episode_steps=50,
+    kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "100"})

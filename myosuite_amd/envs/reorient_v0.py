@@ -1,0 +1,122 @@
+"""Batched reorient envs -- host-side mirror of myosuite/envs/myo/myobase/reorient_sar_v0.py
+(``ProprioceptiveEnvV0`` :17-174, ``Geometries8EnvV0`` :177-262, ``Geometries100EnvV0`` :265-437).
+
+obs keys ``hand_jnt, obj_pos, obj_vel, obj_rot, obj_des_rot, obj_err_pos, obj_err_rot, mlen, mvel, mforce`` (+ ``act``) = 200,
+reward keys ``pos_align, rot_align, act_reg, drop, bonus``; every reset re-draws the object geometry and the desired
+orientation (per-env model deltas: ``mm_state.geom_size_env``, ``mm_task.reor_axis_half / reor_des_rot``).
+
+RESTRICTION (documented deviation): the reference draws the object type uniformly from {capsule, ellipsoid, cylinder, box};
+this engine's narrow phase has plane / sphere / capsule primitives only, so the object is always a CAPSULE, with its
+size drawn from the reference's own capsule tables (2 sizes for Reorient8, 25 for Reorient100).
+"""
+from __future__ import annotations
+
+import collections
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import engine as E
+from ..model import synth
+from .base_v0 import BaseV0
+from .spaces import Box
+
+
+class ReorientEnvV0(BaseV0):
+    DEFAULT_OBS_KEYS = ["hand_jnt", "obj_pos", "obj_vel", "obj_rot", "obj_des_rot", "obj_err_pos", "obj_err_rot", "mlen",
+                        "mvel", "mforce"]                                                    # reorient_sar_v0.py:97-108
+    DEFAULT_RWD_KEYS_AND_WEIGHTS = {"pos_align": 1.0, "rot_align": 1.0, "act_reg": 5.0, "drop": 5.0, "bonus": 10.0}   # :38-44
+
+    def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=50,
+                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+        self._setup(**kwargs)
+
+    def _setup(self, geometries: str = "100", obs_keys=DEFAULT_OBS_KEYS, weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS,
+               **kwargs):
+        super()._setup(obs_keys=list(obs_keys), weighted_reward_keys=weighted_reward_keys, **kwargs)
+        cm, n, dev = self.cm, self.num_envs, self.device
+        f = dict(dtype=torch.float32, device=dev)
+        gp = cm.arrays["GEOM_POS"].reshape(-1, 3).astype(np.float64)
+        g = cm.names["geom"]
+        self.pen_length = float(np.linalg.norm(gp[g["top"]] - gp[g["bot"]]))              # :84-91 (fixed at setup)
+        self.tar_length = float(np.linalg.norm(gp[g["t_top"]] - gp[g["t_bot"]]))
+        self.init_qpos = cm.qpos0.astype(np.float32).copy()
+        self.init_qpos[:-6] *= 0; self.init_qpos[0] = -1.5                                # :113-114 palm up, hand open
+        self._init_qpos_dev = torch.from_numpy(self.init_qpos).to(dev)
+        table = synth.REORIENT_CAPS_8 if str(geometries) == "8" else synth.REORIENT_CAPS_100
+        self._size_table = torch.tensor(table, **f).contiguous()
+        self.geom_size = torch.zeros(n, 3, **f); self.axis_half = torch.zeros(n, **f); self.des_rot = torch.zeros(n, 3, **f)
+        self.state.set_geom_size_env(g["obj"], self.geom_size)
+        self.obs_dim = (cm.nq - 6) + 3 + 6 + 3 + 3 + 3 + 3 + 3 * cm.nu + cm.na
+        self.obs = torch.zeros(n, self.obs_dim, **f)
+        self.rwd = torch.zeros(n, len(E.RWD_KEYS_REORIENT), **f)
+        self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
+                                     dtype=np.float32)
+        w = self.rwd_keys_wt
+        t = E.mm_task()
+        t.task = E.MM_TASK_REORIENT; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
+        t.do_forward = 1; t.fatigue = int(self.muscle_condition == "fatigue"); t.max_episode_steps = self.max_episode_steps
+        if self.fat_MA is not None:
+            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
+        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15
+        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
+        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
+        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
+        t.reaf_src, t.reaf_dst = self.reaf
+        t.obs_dt = self.dt
+        t.reor_obj_body = cm.body_id("Object"); t.reor_eps_site = cm.site_id("eps_ball"); t.reor_pen_length = self.pen_length
+        t.reor_axis_half = self.axis_half.data_ptr(); t.reor_des_rot = self.des_rot.data_ptr()
+        for i, k in enumerate(("pos_align", "rot_align", "act_reg", "drop", "bonus")):
+            t.reor_w[i] = float(w.get(k, 0.0))
+        self._task = t
+        self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
+        self.reset()
+
+    def _refresh_dicts(self):
+        cm = self.cm
+        o = self.obs
+        sizes = [("hand_jnt", cm.nq - 6), ("obj_pos", 3), ("obj_vel", 6), ("obj_rot", 3), ("obj_des_rot", 3), ("obj_err_pos", 3),
+                 ("obj_err_rot", 3), ("mlen", cm.nu), ("mvel", cm.nu), ("mforce", cm.nu), ("act", cm.na)]
+        od = collections.OrderedDict(time=self.state.time)
+        k0 = 0
+        for k, sz in sizes:
+            od[k] = o[:, k0:k0 + sz]; k0 += sz
+        od["obj_des_pos"] = od["obj_pos"] - od["obj_err_pos"]
+        self.obs_dict = od
+        r = self.rwd
+        self.rwd_dict = collections.OrderedDict((k, r[:, i]) for i, k in enumerate(E.RWD_KEYS_REORIENT))
+        self.rwd_dict["solved"] = self.rwd_dict["solved"] > 0.5
+        self.rwd_dict["done"] = self.rwd_dict["done"] > 0.5
+
+    def reset(self, seed=None, mask: Optional[torch.Tensor] = None, **kwargs):
+        if seed is not None:
+            self.seed(seed)
+            self._seed_u64 = int(seed)
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
+        self._fatigue_reset(mask)
+        E.reorient_reset(self.hm, self.state, mask, self._init_qpos_dev, self._size_table, self.axis_half, self.des_rot,
+                         self.tar_length, self.episode, self.step_count, self._seed_u64)
+        E.reset_observation(self.hm, self.state, self._task, mask)
+        self._refresh_dicts()
+        return self.obs, {}
+
+    def step(self, a, **kwargs):
+        a = torch.as_tensor(a, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.expand(self.num_envs, -1)
+        a = a.contiguous()
+        E.env_step(self.hm, self.state, a, self._task)
+        self._refresh_dicts()
+        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
+        terminated = self.done.bool()
+        truncated = self.truncated.bool() & ~terminated
+        info = self.get_env_infos()
+        obs = self.obs
+        if self.autoreset:
+            info["final_obs"] = obs.clone()
+            self.reset(mask=(self.done | self.truncated))
+            obs = self.obs
+        return obs, reward, terminated, truncated, info

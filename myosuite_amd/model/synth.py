@@ -86,7 +86,7 @@ HAND_MUSCLES = ["ECRL", "ECRB", "ECU", "FCR", "FCU", "PL", "PT", "PQ", "EIP", "E
                 "UI_UB2", "UI_UB3", "UI_UB4", "UI_UB5"]
 
 
-def make_hand(with_object: bool = False) -> ModelSpec:
+def make_hand() -> ModelSpec:
     """myoHand: 23 DoF, 39 muscle-tendon units, 29 bones.  Frame: +x distal, +z dorsal, -y radial."""
     s = ModelSpec("myohand")
     WX = 0.25  # wrist centre
@@ -489,6 +489,84 @@ def make_leg() -> ModelSpec:
     return s
 
 
+# ----------------------------------------------------------------------------- hand + object (reorient)
+# capsule sizes [radius, half-length, (unused)] of the reference's reset tables -- data, not code:
+# myosuite/envs/myo/myobase/reorient_sar_v0.py:207-210 (Geometries8EnvV0) and :322-348 (Geometries100EnvV0)
+REORIENT_CAPS_8 = [(0.013, 0.025, 0.025), (0.019, 0.040, 0.040)]
+REORIENT_CAPS_100 = [(0.0162, 0.0422, 0.0484), (0.016, 0.0457, 0.0496), (0.0187, 0.0259, 0.0248), (0.0192, 0.0483, 0.0216),
+                     (0.0213, 0.0218, 0.0481), (0.0169, 0.0331, 0.0388), (0.0138, 0.0299, 0.0471), (0.0194, 0.0252, 0.0419),
+                     (0.014, 0.0362, 0.0201), (0.0125, 0.029, 0.0298), (0.0162, 0.0396, 0.0323), (0.019, 0.0365, 0.0421),
+                     (0.0143, 0.0228, 0.0255), (0.0147, 0.0391, 0.0369), (0.0192, 0.0324, 0.043), (0.0145, 0.0491, 0.0234),
+                     (0.013, 0.0458, 0.0457), (0.0187, 0.0219, 0.0434), (0.0198, 0.0276, 0.0238), (0.0175, 0.0375, 0.0339),
+                     (0.0191, 0.049, 0.0472), (0.0145, 0.0425, 0.0356), (0.0134, 0.0291, 0.0379), (0.0185, 0.0445, 0.0454),
+                     (0.0164, 0.041, 0.0328)]
+
+
+def _quat_z_to(v):
+    """quaternion rotating the local z axis onto unit vector v"""
+    v = np.asarray(v, np.float64) / np.linalg.norm(v)
+    ax = np.cross([0.0, 0.0, 1.0], v); sn = np.linalg.norm(ax); cs = v[2]
+    if sn < 1e-12:
+        return (1.0, 0.0, 0.0, 0.0) if cs > 0 else (0.0, 1.0, 0.0, 0.0)
+    ang = math.atan2(sn, cs); ax = ax / sn
+    return (math.cos(ang / 2),) + tuple(math.sin(ang / 2) * ax)
+
+
+def make_hand_reorient() -> ModelSpec:
+    """myoHand + free-moving object (3 slide + 3 hinge joints, NOT a free joint) + static target, the structure of
+    myosuite/envs/myo/assets/hand/myohand_sar.xml:22-57: nq = nv = 29, 39 muscles, obs 200.  The forearm is mounted so that
+    init_qpos[0] = pro_sup = -1.5 (reorient_sar_v0.py:113-114) turns the palm up; collision capsules along metacarpals,
+    phalanges and the carpal row catch the object.  Object geom: a capsule whose size is re-drawn per episode from the
+    reference's capsule tables; the reference also draws ellipsoids, cylinders and boxes, which need a convex narrow phase
+    this engine does not have yet (scope table)."""
+    s = make_hand()
+    s.name = "myohand_sar"
+    s.nconmax = 8
+    phi = -(math.pi - 1.5)                         # base roll: pro_sup = -1.5 then sums to -pi, palm (local -z) up
+    s.bodies[s._bname["ulna"]].quat = np.array([math.cos(phi / 2), math.sin(phi / 2), 0.0, 0.0])
+    ZX = (math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0)      # capsule axis (local z) -> body x
+    caps = []
+
+    def cap(name, body, r, p0, p1):
+        p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
+        s.add_geom(name, body, "capsule", (r, 0.5 * np.linalg.norm(p1 - p0)), pos=tuple(0.5 * (p0 + p1)), quat=_quat_z_to(p1 - p0))
+        caps.append(name)
+
+    fmc = {2: 0.066, 3: 0.064, 4: 0.058, 5: 0.053}
+    flen = {2: (0.043, 0.025, 0.019), 3: (0.047, 0.029, 0.020), 4: (0.043, 0.027, 0.020), 5: (0.034, 0.020, 0.018)}
+    mcname = {2: "secondmc", 3: "thirdmc", 4: "fourthmc", 5: "fifthmc"}
+    for k in (2, 3, 4, 5):
+        cap(f"col_mc{k}", mcname[k], 0.009, (0.006, 0, 0), (fmc[k] - 0.006, 0, 0))
+        for body, L, r in ((f"proxph{k}", flen[k][0], 0.008), (f"midph{k}", flen[k][1], 0.007), (f"distph{k}", flen[k][2], 0.006)):
+            cap(f"col_{body}", body, r, (0.004, 0, 0), (L - 0.003, 0, 0))
+    tdir = np.array([0.55, -0.70, -0.46]); tdir /= np.linalg.norm(tdir)
+    for body, L, r in (("firstmc", 0.044, 0.009), ("proximal_thumb", 0.032, 0.008), ("distal_thumb", 0.026, 0.007)):
+        cap(f"col_{body}", body, r, 0.004 * tdir, (L - 0.003) * tdir)
+    cap("col_carpal", "capitate", 0.012, (0.008, -0.026, 0), (0.008, 0.028, 0))
+
+    # object above the palm centre (world frame at init: local (x, y, z) -> (x, -y, 1 - z) for the rolled forearm)
+    OX, OZ = 0.325, 1.0 + 0.009 + 0.022
+    eul = 1.27                                                              # myohand_sar.xml:26  euler="0 1.27 0"
+    oq = (math.cos(eul / 2), 0.0, math.sin(eul / 2), 0.0)
+    m0 = 4.0 / 3.0 * math.pi * 0.015 * 0.015 * 0.045 * 1500.0              # ellipsoid .015 .015 .045, density 1500 (xml:34)
+    s.add_body("Object", "world", pos=(OX, 0.004, OZ), quat=oq, mass=1.2,   # body_mass = 1.2 at every reset (py:417)
+               inertia=(m0 / 5 * (0.015 ** 2 + 0.045 ** 2), m0 / 5 * (0.015 ** 2 + 0.045 ** 2), m0 / 5 * 2 * 0.015 ** 2))
+    for nm, typ, ax in (("OBJTx", "slide", (1, 0, 0)), ("OBJTy", "slide", (0, 1, 0)), ("OBJTz", "slide", (0, 0, 1)),
+                        ("OBJRx", "hinge", (1, 0, 0)), ("OBJRy", "hinge", (0, 1, 0)), ("OBJRz", "hinge", (0, 0, 1))):
+        s.add_joint(nm, "Object", typ, axis=ax, armature=0.0)
+    s.add_geom("obj", "Object", "capsule", REORIENT_CAPS_100[0][:2])
+    s.add_geom("top", "Object", "sphere", (0.002,), pos=(0, 0, -0.035))     # xml:36-37 (names as in the reference)
+    s.add_geom("bot", "Object", "sphere", (0.002,), pos=(0, 0, 0.035))
+    s.add_site("eps_ball", "world", (OX, 0.004, OZ - 0.005))               # xml:24 vs :26: 5 mm below the object origin
+    s.add_site("success", "world", (OX, -0.004, OZ + 0.2))
+    s.add_body("target", "world", pos=(OX, -0.004, OZ + 0.2), quat=oq, mass=0.0)
+    s.add_geom("t_top", "target", "sphere", (0.002,), pos=(0, 0, -0.035))
+    s.add_geom("t_bot", "target", "sphere", (0.002,), pos=(0, 0, 0.035))
+    for c in caps:
+        s.add_contact_pair("obj", c, condim=3, friction=(1.0, 0.005, 0.0001))
+    return s
+
+
 # ----------------------------------------------------------------------------- contact toy
 def make_contact_toy() -> ModelSpec:
     """Small model that exercises every contact primitive of the engine (plane-sphere, plane-capsule,
@@ -547,7 +625,8 @@ _CACHE = {}
 def get_model(name: str) -> CompiledModel:
     """Compiled synthetic model by short name: 'elbow' | 'hand' | 'leg'."""
     if name not in _CACHE:
-        spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy}[name]()
+        spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
+                "hand_reorient": make_hand_reorient}[name]()
         cm = spec.compile()
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob

@@ -354,3 +354,97 @@ class WalkEnvOracle(PoseEnvOracle):
         self.steps += 1
         self.rwd_dict = rwd
         return obs, float(rwd["dense"]), bool(rwd["done"]), rwd
+
+
+# ---------------------------------------------------------------------- reorient (ProprioceptiveEnvV0 / Geometries*)
+def euler2quat(euler):
+    """utils/quat_math.py:70-86 restated."""
+    e = np.asarray(euler, np.float64)
+    ai, aj, ak = e[2] / 2, -e[1] / 2, e[0] / 2
+    si, sj, sk = np.sin(ai), np.sin(aj), np.sin(ak)
+    ci, cj, ck = np.cos(ai), np.cos(aj), np.cos(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    return np.array([cj * cc + sj * ss, cj * cs - sj * sc, -(cj * ss + sj * cc), cj * sc - sj * cs])
+
+
+def reorient_reset_draws(size_table, env: int, episode: int, seed: int, tar_length: float):
+    """(size[3], axis_half, des_rot[3]) of the device-side reorient reset (k_reset, reorient branch), float32 draws."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    c = philox4x32_10(0, 3, env, episode, k0, k1)
+    u = [float(u01(x)) for x in c]
+    tab = np.asarray(size_table, np.float32)
+    idx = min(int(np.float32(u[0]) * np.float32(len(tab))), len(tab) - 1)
+    size = tab[idx].astype(np.float64)
+    ah = float(np.float32(1.3) * tab[idx][1])
+    e0 = -1.0 + 2.0 * u[1]; e1 = -0.8 + 2.0 * u[2]
+    q = euler2quat([e0, e1, 0.0])
+    w, x, y, z = q
+    col = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
+    return size, ah, col * 2 * ah / tar_length
+
+
+def reorient_obs_reward(qpos, qvel, act, obj_xpos, obj_xmat, eps_pos, axis_half, des_rot, actuator_length,
+                        actuator_velocity, actuator_force, dt, pen_length, rwd_keys_wt):
+    """get_obs_dict + obsdict2obsvec + get_reward_dict of reorient_sar_v0.py:116-174 on raw arrays."""
+    R = np.asarray(obj_xmat, np.float64).reshape(3, 3)
+    obj_rot = R[:, 2] * 2 * axis_half / pen_length          # (geom_xpos[top] - geom_xpos[bot]) / pen_length
+    od = collections.OrderedDict(
+        hand_jnt=qpos[:-6].copy(), obj_pos=np.asarray(obj_xpos, np.float64).copy(), obj_vel=qvel[-6:] * dt, obj_rot=obj_rot,
+        obj_des_rot=np.asarray(des_rot, np.float64), obj_err_pos=obj_xpos - eps_pos, obj_err_rot=obj_rot - des_rot,
+        mlen=actuator_length.copy(), mvel=actuator_velocity.copy(), mforce=actuator_force.copy(), act=act.copy())
+    obs = np.concatenate([np.asarray(v, np.float64).ravel() for v in od.values()])
+    pos_align = np.linalg.norm(od["obj_err_pos"])
+    nrm = np.linalg.norm(obj_rot) * np.linalg.norm(des_rot)
+    rot_align = float(np.dot(obj_rot, des_rot) / (nrm if nrm != 0 else 1.0))        # vector_math.py:10-34
+    dropped = pos_align > 0.075
+    na = act.size
+    act_mag = np.linalg.norm(act) / na if na else 0.0
+    rwd = collections.OrderedDict((
+        ("pos_align", -1.0 * pos_align), ("rot_align", rot_align), ("act_reg", -1.0 * act_mag), ("drop", -1.0 * dropped),
+        ("bonus", 1.0 * (rot_align > 0.9) * (pos_align < 0.075) + 5.0 * (rot_align > 0.95) * (pos_align < 0.075)),
+        ("sparse", -1.0 * pos_align + rot_align), ("solved", (rot_align > 0.95) * (not dropped)), ("done", dropped)))
+    rwd["dense"] = np.sum([wt * rwd[k] for k, wt in rwd_keys_wt.items()], axis=0)
+    return obs, rwd
+
+
+class ReorientEnvOracle(PoseEnvOracle):
+    """Single-env CPU restatement of the reorient env on the fp64 oracle engine (capsule objects only)."""
+    RWD_KEYS_WT = {"pos_align": 1.0, "rot_align": 1.0, "act_reg": 5.0, "drop": 5.0, "bonus": 10.0}
+
+    def __init__(self, compiled, frame_skip=5, normalize_act=True, muscle_condition=""):
+        super().__init__(compiled, 0.0, frame_skip, normalize_act, muscle_condition, dict(self.RWD_KEYS_WT))
+        cm = compiled
+        gp = cm.arrays["GEOM_POS"].reshape(-1, 3).astype(np.float64); g = cm.names["geom"]
+        self.pen_length = float(np.linalg.norm(gp[g["top"]] - gp[g["bot"]]))
+        self.tar_length = float(np.linalg.norm(gp[g["t_top"]] - gp[g["t_bot"]]))
+        self.obj_b = cm.body_id("Object"); self.eps_s = cm.site_id("eps_ball"); self.obj_g = g["obj"]
+        self.init_qpos = cm.qpos0.astype(np.float64).copy(); self.init_qpos[:-6] *= 0; self.init_qpos[0] = -1.5
+
+    def reset(self, size, axis_half, des_rot):
+        self.d.reset()
+        self.d.qpos[:] = self.init_qpos
+        self.d.set_geom_size(self.obj_g, size)
+        self.axis_half = float(axis_half); self.des_rot = np.asarray(des_rot, np.float64)
+        self.steps = 0
+        self.d.ctrl[:] = 0
+        self.d.forward()
+        return self._obs_rwd()[0]
+
+    def _obs_rwd(self):
+        d = self.d
+        return reorient_obs_reward(d.qpos, d.qvel, d.act, d.xpos[self.obj_b], d.xmat[self.obj_b], d.site_xpos[self.eps_s],
+                                   self.axis_half, self.des_rot, d.actuator_length, d.actuator_velocity, d.actuator_force,
+                                   self.dt, self.pen_length, self.rwd_keys_wt)
+
+    def step(self, a):
+        a = np.asarray(a, np.float64)
+        ctrl = a.copy()
+        if self.cm.na and self.normalize_act:
+            ctrl[self.muscle] = 1.0 / (1.0 + np.exp(-5.0 * (ctrl[self.muscle] - 0.5)))
+        self.d.ctrl[:] = ctrl
+        self.d.step(self.frame_skip)
+        self.d.forward()
+        obs, rwd = self._obs_rwd()
+        self.steps += 1
+        self.rwd_dict = rwd
+        return obs, float(rwd["dense"]), bool(rwd["done"]), rwd

@@ -118,6 +118,8 @@ typedef struct {
   real *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_solref, *efc_solimp;
   real *efc_R, *efc_D, *efc_vel, *efc_aref, *efc_force;
   real *qfrc_constraint, *qacc;
+  /* per-env model delta: size override of one geom (mm_state.geom_size_env) */
+  int gsize_id; real gsize_val[3];
   /* contacts */
   int* con_pair;
   real *con_dist, *con_pos, *con_frame;
@@ -164,6 +166,7 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   }
   d->cacc = ralloc(6 * nb); d->cfrc = ralloc(6 * nb); d->tmp_nv = ralloc(nv);
   d->qH = ralloc(m->nM); d->qHDiagInv = ralloc(nv);
+  d->gsize_id = -1;
   mmo_reset(m, d);
   return d;
 }
@@ -1318,6 +1321,7 @@ real* mmo_field(mmo_data* d, const char* name) {
     if (!strcmp(kFields[i].name, name)) return *(real**)((char*)d + kFields[i].off);
   return NULL;
 }
+void mmo_set_geom_size(mmo_data* d, int geom, double a, double b, double c) { d->gsize_id = geom; d->gsize_val[0] = a; d->gsize_val[1] = b; d->gsize_val[2] = c; }
 double mmo_time(const mmo_data* d) { return d->time; }
 void mmo_set_time(mmo_data* d, double t) { d->time = t; }
 int mmo_nefc(const mmo_data* d) { return d->nefc; }

@@ -45,6 +45,7 @@ def lib():
         L.mmo_time.restype = C.c_double
         L.mmo_time.argtypes = [C.c_void_p]
         L.mmo_set_time.argtypes = [C.c_void_p, C.c_double]
+        L.mmo_set_geom_size.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         for f in ("mmo_nefc", "mmo_ncon", "mmo_solver_niter", "mmo_warn"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.c_int
@@ -149,6 +150,10 @@ class OracleData:
 
     def reset(self):
         lib().mmo_reset(self.model.ptr, self.ptr)
+
+    def set_geom_size(self, geom: int, size):
+        """per-env model delta: collision size of one geom (the reference writes mj_model.geom_size at reset)"""
+        lib().mmo_set_geom_size(self.ptr, int(geom), float(size[0]), float(size[1]), float(size[2]))
 
     def forward(self):
         lib().mmo_forward(self.model.ptr, self.ptr)

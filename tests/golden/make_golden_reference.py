@@ -10,6 +10,7 @@ What can be executed from /root/reference without `mujoco`/`gym` (both absent he
   * myosuite/envs/obs_vec_dict.py           obsdict2obsvec                    -> ref_pose_env.npz
   * myosuite/envs/myo/myobase/reach_v0.py   get_obs_dict / get_reward_dict    -> ref_reach_env.npz
   * myosuite/envs/myo/myobase/walk_v0.py    get_obs_dict / get_reward_dict    -> ref_walk_env.npz
+  * myosuite/envs/myo/myobase/reorient_sar_v0.py  get_obs_dict / get_reward_dict -> ref_reorient_env.npz
   * myosuite/utils/quat_math.py, vector_math.py                               -> ref_math.npz
 `mujoco` and `myosuite.utils.gym` are replaced by stubs that only provide the names those files
 touch at import time (mjtDyn.mjDYN_MUSCLE, gym.utils.seeding.np_random, EzPickle); no arithmetic
@@ -217,6 +218,57 @@ def gen_walk_env():
     np.savez(os.path.join(OUT, "ref_walk_env.npz"), **out)
 
 
+def gen_reorient_env():
+    """ProprioceptiveEnvV0.get_obs_dict / get_reward_dict (reorient_sar_v0.py:116-174) executed on synthetic mjData-like
+    arrays (nq 29, 39 muscles), plus the reference's euler2quat on the reset's desired-orientation draws."""
+    st = _stubs()
+    st["myosuite.utils.quat_math"] = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
+    st["myosuite.utils.vector_math"] = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
+    reo = _load("ref_reorient_sar_v0", f"{REF}/envs/myo/myobase/reorient_sar_v0.py", st)
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(21)
+    n, nq, nu, nb, ng, ns = 48, 29, 39, 32, 6, 3
+    obj_bid, eps_sid, t_gid, b_gid, tt_gid, tb_gid = 30, 1, 2, 3, 4, 5
+    qpos = rng.uniform(-1, 1, (n, nq)); qvel = rng.standard_normal((n, nq)) * 3; act = rng.random((n, nu))
+    xpos = rng.uniform(-0.5, 0.5, (n, nb, 3)); site = rng.uniform(-0.5, 0.5, (n, ns, 3))
+    site[:16, eps_sid] = xpos[:16, obj_bid] + rng.uniform(-0.02, 0.02, (16, 3))       # near: not dropped
+    gx = rng.uniform(-0.5, 0.5, (n, ng, 3))
+    d1 = rng.standard_normal((n, 3)); d1 *= rng.uniform(0.03, 0.13, (n, 1)) / np.linalg.norm(d1, axis=1, keepdims=True)
+    d2 = d1 + rng.standard_normal((n, 3)) * 0.02; d2[24:] = rng.standard_normal((n - 24, 3)) * 0.05
+    gx[:, t_gid] = gx[:, b_gid] + d1; gx[:, tt_gid] = gx[:, tb_gid] + d2
+    alen = rng.uniform(0.05, 0.4, (n, nu)); avel = rng.standard_normal((n, nu)); afrc = -rng.uniform(0, 300, (n, nu))
+    dt, pen_length, tar_length = 0.01, 0.07, 0.07
+    keys = ["hand_jnt", "obj_pos", "obj_vel", "obj_rot", "obj_des_rot", "obj_err_pos", "obj_err_rot", "mlen", "mvel", "mforce", "act"]
+    rk = ("pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense")
+    obs = []; rwd = {k: [] for k in rk}
+    for i in range(n):
+        model = types.SimpleNamespace(na=nu, site_rgba=np.zeros((ns, 4)))
+        data = types.SimpleNamespace(time=0.1 * i, qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(), xpos=xpos[i],
+                                     site_xpos=site[i], geom_xpos=gx[i], actuator_length=alen[i], actuator_velocity=avel[i],
+                                     actuator_force=afrc[i])
+        env = object.__new__(reo.ProprioceptiveEnvV0)
+        env.mj_model = model; env.dt = dt; env.obj_bid = obj_bid; env.eps_ball_sid = eps_sid; env.obj_t_gid = t_gid
+        env.obj_b_gid = b_gid; env.tar_t_gid = tt_gid; env.tar_b_gid = tb_gid; env.pen_length = pen_length
+        env.tar_length = tar_length; env.success_indicator_sid = 2
+        env.rwd_keys_wt = reo.ProprioceptiveEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS
+        od = env.get_obs_dict(model, data)
+        _, vec = ovd.ObsVecDict().obsdict2obsvec(od, keys)
+        env.obs_dict = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+        rd = env.get_reward_dict(env.obs_dict)
+        obs.append(vec)
+        for k in rk:
+            rwd[k].append(np.squeeze(rd[k]))
+    eul = np.stack([rng.uniform(-1, 1, 32), rng.uniform(-0.8, 1.2, 32), np.zeros(32)], 1)
+    qm = st["myosuite.utils.quat_math"]
+    out = dict(qpos=qpos, qvel=qvel, act=act, obj_xpos=xpos[:, obj_bid], eps_pos=site[:, eps_sid], top_minus_bot=d1,
+               ttop_minus_tbot=d2, actuator_length=alen, actuator_velocity=avel, actuator_force=afrc, dt=np.array(dt),
+               pen_length=np.array(pen_length), tar_length=np.array(tar_length), obs=np.array(obs), euler=eul,
+               euler2quat=np.array([qm.euler2quat(e) for e in eul]), quat2mat=np.array([qm.quat2mat(qm.euler2quat(e)) for e in eul]))
+    for k in rk:
+        out[f"rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    np.savez(os.path.join(OUT, "ref_reorient_env.npz"), **out)
+
+
 def gen_math():
     qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
     vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
@@ -238,5 +290,6 @@ if __name__ == "__main__":
     gen_pose_env()
     gen_reach_env()
     gen_walk_env()
+    gen_reorient_env()
     gen_math()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))

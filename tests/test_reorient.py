@@ -1,0 +1,118 @@
+"""Reorient envs (myoHandReorient8/100-v0, capsule objects): reference-pinned env arithmetic (CPU), HIP-vs-oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from myosuite_amd.model import synth
+from oracle import env_oracle as EO
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RK = ("pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense")
+WT = {"pos_align": 1.0, "rot_align": 1.0, "act_reg": 5.0, "drop": 5.0, "bonus": 10.0}
+
+
+def test_reorient_oracle_arithmetic_matches_reference_vectors():
+    g = np.load(os.path.join(G, "ref_reorient_env.npz"))
+    n = g["qpos"].shape[0]
+    pen, tar = float(g["pen_length"]), float(g["tar_length"])
+    seen = {"drop": 0, "bonus": 0}
+    for i in range(n):
+        # the oracle takes (R_obj, axis_half): feed a rotation whose third column reproduces the golden top-bot vector
+        d1 = g["top_minus_bot"][i]; ah = 0.5 * np.linalg.norm(d1)
+        z = d1 / np.linalg.norm(d1)
+        x = np.cross(z, [0.3, 0.5, 0.8]); x /= np.linalg.norm(x); y = np.cross(z, x)
+        R = np.stack([x, y, z], 1)
+        obs, rwd = EO.reorient_obs_reward(g["qpos"][i], g["qvel"][i], g["act"][i], g["obj_xpos"][i], R, g["eps_pos"][i], ah,
+                                          g["ttop_minus_tbot"][i] / tar, g["actuator_length"][i], g["actuator_velocity"][i],
+                                          g["actuator_force"][i], float(g["dt"]), pen, WT)
+        assert obs.shape == (200,)
+        np.testing.assert_allclose(obs, g["obs"][i], rtol=2e-6, atol=2e-6)
+        for k in RK:
+            np.testing.assert_allclose(float(rwd[k]), g[f"rwd_{k}"][i], rtol=1e-9, atol=1e-9, err_msg=k)
+        seen["drop"] += int(rwd["done"]); seen["bonus"] += int(rwd["bonus"] > 0)
+    assert 0 < seen["drop"] < n and seen["bonus"] > 0
+    for e, q, m in zip(g["euler"], g["euler2quat"], g["quat2mat"]):
+        np.testing.assert_allclose(EO.euler2quat(e), q, atol=1e-14)
+        w, x, y, z = q
+        np.testing.assert_allclose([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], m[:, 2], atol=1e-14)
+
+
+def test_reorient_model_and_registry():
+    from myosuite_amd.envs import registry
+    cm = synth.get_model("hand_reorient")
+    assert (cm.nq, cm.nv, cm.nu) == (29, 29, 39) and cm.njmax <= 64 and cm.npair == 20
+    jn = list(cm.names["joint"].keys())
+    assert jn[-6:] == ["OBJTx", "OBJTy", "OBJTz", "OBJRx", "OBJRy", "OBJRz"]                # myohand_sar.xml:27-32
+    for vid in ("myoHandReorient8-v0", "myoHandReorient100-v0", "myoFatiHandReorient100-v0", "myoReafHandReorient8-v0"):
+        s = registry.spec(vid)
+        assert s["max_episode_steps"] == 50 and s["kwargs"]["frame_skip"] == 5
+    assert len(synth.REORIENT_CAPS_100) == 25 and len(synth.REORIENT_CAPS_8) == 2
+
+
+@pytest.mark.gpu
+def test_gpu_reorient_env_matches_oracle_env(oracle_lib):
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    cm = synth.get_model("hand_reorient")
+    n, nsteps = 8, 8
+    env = registry.make("myoHandReorient100-v0", num_envs=n, seed=9, autoreset=False)
+    obs0, _ = env.reset(seed=9)
+    assert obs0.shape == (n, 200)
+    ep = env.episode.cpu().numpy()
+    orc = []
+    sizes = set()
+    for e in range(n):
+        size, ah, des = EO.reorient_reset_draws(synth.REORIENT_CAPS_100, e, int(ep[e]) - 1, 9, env.tar_length)
+        np.testing.assert_allclose(env.geom_size[e].cpu().numpy(), size, atol=1e-7)
+        np.testing.assert_allclose(float(env.axis_half[e]), ah, rtol=1e-6)
+        np.testing.assert_allclose(env.des_rot[e].cpu().numpy(), des, atol=2e-6)
+        sizes.add(tuple(np.round(size, 4)))
+        w = EO.ReorientEnvOracle(cm)
+        o = w.reset(size, ah, env.des_rot[e].cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), o, rtol=1e-4, atol=3e-5)
+        orc.append(w)
+    assert len(sizes) >= 3
+    a = torch.empty(n, cm.nu, device="cuda")
+    for s in range(nsteps):
+        # teacher forcing (contact onsets are discontinuities of time-stepped dynamics)
+        st = env.get_env_state()
+        for e in range(n):
+            d = orc[e].d
+            for k in ("qpos", "qvel", "act", "qacc_warmstart"):
+                v = getattr(d, k).astype(np.float32); getattr(d, k)[:] = v
+                st[k][e] = torch.from_numpy(v)
+        env.set_env_state(st)
+        E.uniform(a, 13, s)
+        act = (0.3 + 0.5 * a).contiguous()
+        obs, r, term, trunc, info = env.step(act)
+        an = act.cpu().numpy()
+        for e in range(n):
+            o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
+            got = obs[e].cpu().numpy()
+            tol = np.full(200, 2e-3); tol[26:32] = 2e-2; tol[44 + 39:44 + 78] = 2e-2; tol[44 + 78:44 + 117] = 0.5   # obj_vel, mvel, mforce (N)
+            scale = np.maximum(1.0, np.abs(o))
+            bad = np.abs(got - o) / scale > tol
+            assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], (np.abs(got - o) / scale)[bad][:5])
+            for i, k in enumerate(E.RWD_KEYS_REORIENT):
+                ref = float(rd[k])
+                assert abs(float(env.rwd[e, i]) - ref) < 5e-3 * max(1.0, abs(ref)), (k, s, e)
+            assert bool(term[e]) == done
+    assert list(info["rwd_dict"].keys()) == E.RWD_KEYS_REORIENT
+
+
+@pytest.mark.gpu
+def test_gpu_reorient_drop_terminates_and_autoresets(oracle_lib):
+    import torch
+    from myosuite_amd.envs import registry
+    env = registry.make("myoHandReorient8-v0", num_envs=64, seed=2)
+    env.reset(seed=2)
+    a = torch.zeros(64, env.cm.nu, device="cuda")        # relaxed hand: the 1.2 kg object slides off -> dropped
+    dropped = torch.zeros(64, dtype=torch.bool, device="cuda")
+    for _ in range(50):
+        obs, r, term, trunc, info = env.step(a)
+        dropped |= term
+        assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+    assert float(dropped.float().mean()) > 0.5
+    assert int((env.state.status & 0xA).max()) == 0       # no row overflow / no solver failure (bit0 = gimbal auto-reset is legal)
