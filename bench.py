@@ -58,8 +58,8 @@ def cpu_baseline(env_id: str, nenv: int, nsteps: int):
         elif "Object" in cm.names["body"]:          # reorient: open hand, palm up, capsule size of the episode
             q = cm.qpos0.astype(np.float64).copy(); q[:-6] = 0; q[0] = -1.5
             d.qpos[:] = q
-            size, _, _ = EO.reorient_reset_draws(synth.REORIENT_CAPS_100, e, 0, 0, 0.07)
-            d.set_geom_size(cm.names["geom"]["obj"], size)
+            gt, size, _, _ = EO.reorient_reset_draws(synth.reorient_tables("100"), e, 0, 0, 0.07)
+            d.set_geom_size(cm.names["geom"]["obj"], size, gt)
         else:
             uq, _ = EO.pose_reset_draws(cm.nq, e, 0, 0)
             d.qpos[:] = (lo + (hi - lo) * uq).astype(np.float32)

@@ -68,6 +68,9 @@ typedef struct {
   /* per-env model delta (the reference mutates mjModel at reset: reorient_sar_v0.py:407-409): size of ONE geom */
   const float* geom_size_env; /* [nenv][3] or NULL: replaces geom_size[geom_env_id] in collision           */
   int    geom_env_id;         /* geom id the per-env size applies to (-1 = none)                           */
+  const int32_t* geom_type_env; /* [nenv] or NULL: replaces geom_type[geom_env_id] (MM_GEOM_CAPSULE / ELLIPSOID /
+                                   CYLINDER / BOX; reorient_sar_v0.py:408); pairs with that geom must be authored
+                                   against capsules                                                          */
 } mm_state;
 
 /* Optional derived outputs of the final forward pass (NULL = not requested). */
@@ -211,6 +214,13 @@ int  mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, co
 int  mm_reorient_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
                        const float* size_table, int ntab, float* geom_size_env, float* axis_half, float* des_rot,
                        float tar_length, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
+/* Same with the object TYPE drawn too (reorient_sar_v0.py:388-406): size_tables [4][ntab][3] in the order capsule,
+ * ellipsoid, cylinder, box (geom types 3,4,5,6); geom_type_env[e] receives the type; axis_half = 1.3*size[1] (capsule),
+ * size[2] (ellipsoid, box), size[1] (cylinder). */
+int  mm_reorient_reset_typed(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
+                             const float* size_tables, int ntab, float* geom_size_env, int32_t* geom_type_env,
+                             float* axis_half, float* des_rot, float tar_length, int32_t* episode, int32_t* step_count,
+                             uint64_t seed, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

@@ -377,6 +377,89 @@ __device__ __forceinline__ float wrap_geom(V3& w0, V3& w1, V3 x0, V3 x1, V3 gpos
   return wlen;
 }
 
+
+// ---- capsule axis vs convex primitive (mmo_collision.inc: sd_box / sd_cylinder / sd_ellipsoid / seg_shape) -----------
+__device__ __forceinline__ float sd_box(V3 s, V3 q, V3& grad) {
+  V3 d = v3(fabsf(q.x) - s.x, fabsf(q.y) - s.y, fabsf(q.z) - s.z);
+  const V3 sg = v3(q.x < 0.f ? -1.f : 1.f, q.y < 0.f ? -1.f : 1.f, q.z < 0.f ? -1.f : 1.f);
+  if (d.x > 0.f || d.y > 0.f || d.z > 0.f) {
+    V3 e = v3(fmaxf(d.x, 0.f), fmaxf(d.y, 0.f), fmaxf(d.z, 0.f));
+    float n = sqrtf(dot(e, e));
+    grad = v3(e.x / n * sg.x, e.y / n * sg.y, e.z / n * sg.z);
+    return n;
+  }
+  if (d.x >= d.y && d.x >= d.z) { grad = v3(sg.x, 0.f, 0.f); return d.x; }
+  if (d.y >= d.z) { grad = v3(0.f, sg.y, 0.f); return d.y; }
+  grad = v3(0.f, 0.f, sg.z); return d.z;
+}
+__device__ __forceinline__ float sd_cylinder(V3 s, V3 q, V3& grad) {
+  float rho = sqrtf(q.x * q.x + q.y * q.y), dr = rho - s.x, dz = fabsf(q.z) - s.y;
+  float rx = rho > MINVALF ? q.x / rho : 1.f, ry = rho > MINVALF ? q.y / rho : 0.f, sz = q.z < 0.f ? -1.f : 1.f;
+  if (dr > 0.f && dz > 0.f) { float n = sqrtf(dr * dr + dz * dz); grad = v3(dr * rx / n, dr * ry / n, dz * sz / n); return n; }
+  if (dr > dz) { grad = v3(rx, ry, 0.f); return dr; }
+  grad = v3(0.f, 0.f, sz); return dz;
+}
+__device__ __forceinline__ float sd_ellipsoid(V3 s, V3 q0, V3& grad) {
+  const float sv[3] = {s.x, s.y, s.z}, qi[3] = {q0.x, q0.y, q0.z};
+  float q[3], f0 = -1.f, amin = sv[0];
+  int imin = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    q[i] = fabsf(qi[i]) < 1e-9f ? (qi[i] < 0.f ? -1e-9f : 1e-9f) : qi[i];
+    f0 += (q[i] / sv[i]) * (q[i] / sv[i]);
+    if (sv[i] < amin) { amin = sv[i]; imin = i; }
+  }
+  float t = f0 >= 0.f ? 0.f : -amin * amin + amin * fabsf(q[imin]);
+  for (int it = 0; it < 10; it++) {
+    float F = -1.f, dF = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { float den = t + sv[i] * sv[i], w = sv[i] * q[i] / den; F += w * w; dF -= 2.f * w * w / den; }
+    if (dF > -MINVALF) break;
+    t -= F / dF;
+  }
+  float g[3], n2 = 0.f, d2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float x = sv[i] * sv[i] * q[i] / (t + sv[i] * sv[i]);
+    g[i] = x / (sv[i] * sv[i]); n2 += g[i] * g[i]; d2 += (q[i] - x) * (q[i] - x);
+  }
+  float inv = 1.f / sqrtf(n2);
+  grad = v3(g[0] * inv, g[1] * inv, g[2] * inv);
+  return f0 >= 0.f ? sqrtf(d2) : -sqrtf(d2);
+}
+__device__ __forceinline__ float sd_shape(int type, V3 s, V3 q, V3& grad) {
+  if (type == MM_GEOM_BOX) return sd_box(s, q, grad);
+  if (type == MM_GEOM_CYLINDER) return sd_cylinder(s, q, grad);
+  return sd_ellipsoid(s, q, grad);
+}
+// minimiser of the convex g(t) = sd(a + t u) on [-h, h]: bisection on the sign of g'(t) = grad.u; flat stretches are
+// bracketed with a +-tau tolerance and their midpoint is used (same rule as the oracle)
+__device__ __forceinline__ float seg_shape(int type, V3 s, V3 a0, V3 u, float h, float& tbest, V3& grad) {
+  const float tau = 1e-4f;
+  float te[2] = {0.f, 0.f};
+  const int nside = type == MM_GEOM_ELLIPSOID ? 1 : 2;
+  for (int side = 0; side < nside; side++) {
+    const float thr = side == 0 ? -tau : tau;
+    float lo = -h, hi = h;
+    V3 g;
+    sd_shape(type, s, a0 - h * u, g);
+    if (dot(g, u) > thr) { te[side] = -h; continue; }
+    sd_shape(type, s, a0 + h * u, g);
+    if (dot(g, u) <= thr) { te[side] = h; continue; }
+    const int iters = type == MM_GEOM_ELLIPSOID ? 16 : 22;
+    for (int it = 0; it < iters; it++) {
+      float mid = 0.5f * (lo + hi);
+      sd_shape(type, s, a0 + mid * u, g);
+      if (dot(g, u) > thr) hi = mid; else lo = mid;
+    }
+    te[side] = 0.5f * (lo + hi);
+  }
+  if (nside == 1) te[1] = te[0];
+  const float t = 0.5f * (te[0] + te[1]);
+  tbest = t;
+  return sd_shape(type, s, a0 + t * u, grad);
+}
+
 // ------------------------------------------------------------------ muscle model (A6)
 __device__ __forceinline__ float muscle_fl(float L, float lmin, float lmax) {
   if (L < lmin || L > lmax) return 0.f;
@@ -465,6 +548,7 @@ struct Engine {
   bool r_eq;
   int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
   const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
+  int env_gtype;            // this env's entry of mm_state.geom_type_env (or -1)
 
   __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
       : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
@@ -493,7 +577,7 @@ struct Engine {
         c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
       }
     }
-    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
     b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
@@ -1252,7 +1336,11 @@ struct Engine {
     cpos[0] = cpos[1] = cn[0] = cn[1] = v3(0.f, 0.f, 0.f);
     if (g < a.d.npair) {
       const int p = g, g1 = MI_(PAIR_GEOM1)[p], g2 = MI_(PAIR_GEOM2)[p];
-      const int t1 = MI_(GEOM_TYPE)[g1], t2 = MI_(GEOM_TYPE)[g2];
+      int t1 = MI_(GEOM_TYPE)[g1], t2 = MI_(GEOM_TYPE)[g2];
+      if (env_gtype >= 0) {   // per-env model delta: type of one geom (mm_state.geom_type_env)
+        if (g1 == a.s.geom_env_id) t1 = env_gtype;
+        if (g2 == a.s.geom_env_id) t2 = env_gtype;
+      }
       const float margin = MF_(PAIR_MARGIN)[p];
       incl = margin - MF_(PAIR_GAP)[p];
       mu = MF_(PAIR_FRICTION)[3 * p];
@@ -1287,6 +1375,26 @@ struct Engine {
         float s2 = ee + bb * s1;
         if (s2 < -h2 || s2 > h2) { s2 = s2 < -h2 ? -h2 : h2; s1 = clampf(bb * s2 - dd, -h1, h1); }
         nc = sph_sph(x1 + s1 * u1, r1, x2 + s2 * u2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if ((t1 == MM_GEOM_CAPSULE && t2 >= MM_GEOM_ELLIPSOID) || (t2 == MM_GEOM_CAPSULE && t1 >= MM_GEOM_ELLIPSOID)) {
+        // capsule vs ellipsoid / cylinder / box (mmo_collision.inc: capsule_convex); flip: the convex geom is geom1
+        const bool flip = t2 == MM_GEOM_CAPSULE;
+        const int gc = flip ? g2 : g1, gs = flip ? g1 : g2, ts = flip ? t1 : t2;
+        const V3 xc = flip ? x2 : x1, xs = flip ? x1 : x2;
+        const float rc = flip ? r2 : r1, hc = flip ? h2 : h1;
+        V3 ss = ld3(MF_(GEOM_SIZE) + 3 * gs);
+        if (env_gsize && gs == a.s.geom_env_id) ss = ld3(env_gsize);
+        const V3 uc = geom_zaxis(gc);
+        const M3 ms = geom_mat(gs);
+        float tt; V3 gsh;
+        const float sd = seg_shape(ts, ss, mtv(ms, xc - xs), mtv(ms, uc), hc, tt, gsh);
+        const float dd = sd - rc;
+        if (dd < margin) {
+          V3 gw = mv(ms, gsh);
+          cdist[0] = dd;
+          cpos[0] = (xc + tt * uc) - (rc + 0.5f * dd) * gw;
+          cn[0] = flip ? gw : -1.f * gw;
+          nc = 1;
+        }
       }
     }
     int myrows = 0;
@@ -1591,6 +1699,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   const Dims& d = a.d;
   Engine<G, NVP, GEN> E(a, mb, W, g);
   if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
+  if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
 
   // ---- load state (HBM -> LDS tables / owner registers)
   for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
@@ -1936,6 +2045,7 @@ struct ResetArgs {
   int reach, ntip; const float* tip0;
   int walk, walk_random; const float *ka_qpos, *ka_qvel, *kb_qpos, *kb_qvel;
   int reor, reor_ntab; const float* reor_tab; float *reor_gsize, *reor_axis_half, *reor_des_rot; float reor_tar_length;
+  int32_t* reor_gtype;   // non-null: also draw the object type (tables [4][ntab][3])
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -1994,9 +2104,11 @@ __global__ void k_reset(ResetArgs r) {
     philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
     int idx = (int)(u01(c[0]) * (float)r.reor_ntab);
     if (idx >= r.reor_ntab) idx = r.reor_ntab - 1;
-    const float* sz = r.reor_tab + 3 * idx;
+    int ty = 0;   // 0 capsule, 1 ellipsoid, 2 cylinder, 3 box  (geom types 3..6; word 3 of the counter)
+    if (r.reor_gtype) { ty = (int)(u01(c[3]) * 4.f); if (ty > 3) ty = 3; r.reor_gtype[e] = MM_GEOM_CAPSULE + ty; }
+    const float* sz = r.reor_tab + 3 * (ty * r.reor_ntab + idx);
     for (int k = 0; k < 3; k++) r.reor_gsize[(size_t)e * 3 + k] = sz[k];
-    const float ah = 1.3f * sz[1];
+    const float ah = ty == 0 ? 1.3f * sz[1] : (ty == 2 ? sz[1] : sz[2]);   // reorient_sar_v0.py:390-406
     r.reor_axis_half[e] = ah;
     const float e0 = -1.f + 2.f * u01(c[1]), e1 = -0.8f + 2.f * u01(c[2]);
     // euler2quat([e0, e1, 0]) (utils/quat_math.py:70-86): ai = 0, aj = -e1/2, ak = e0/2
@@ -2158,8 +2270,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
       const int t1 = gt[p1[p]], t2 = gt[p2[p]];
       const bool ok = (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
                       (t1 == MM_GEOM_SPHERE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
-                      (t1 == MM_GEOM_CAPSULE && t2 == MM_GEOM_CAPSULE);
-      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane/sphere/capsule only (geom1 type <= geom2 type)"); }
+                      (t1 == MM_GEOM_CAPSULE && (t2 == MM_GEOM_CAPSULE || t2 == MM_GEOM_ELLIPSOID || t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX));
+      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane/sphere/capsule, and capsule vs ellipsoid/cylinder/box (geom1 type <= geom2 type)"); }
       if (pc[p] != 1 && pc[p] != 3) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1 or 3"); }
     }
   }
@@ -2438,7 +2550,7 @@ static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
   a.blob = m->d_blob;
   memcpy(a.sec, m->sec, sizeof(a.sec));
   a.d = m->d; a.L = m->L; a.D = m->D; a.x = m->x; a.s = *s;
-  if (!a.s.geom_size_env || a.s.geom_env_id < 0 || a.s.geom_env_id >= m->d.ngeom) { a.s.geom_size_env = nullptr; a.s.geom_env_id = -1; }
+  if (!a.s.geom_size_env || a.s.geom_env_id < 0 || a.s.geom_env_id >= m->d.ngeom) { a.s.geom_size_env = nullptr; a.s.geom_type_env = nullptr; a.s.geom_env_id = -1; }
 }
 
 extern "C" int mm_step(const mm_model* m, const mm_state* s, const float* ctrl, int nsub, void* stream) {
@@ -2560,6 +2672,24 @@ extern "C" int mm_reorient_reset(const mm_model* m, const mm_state* s, const uin
   r.qpos_bcast = init_qpos;
   r.reor = 1; r.reor_ntab = ntab; r.reor_tab = size_table; r.reor_gsize = geom_size_env; r.reor_axis_half = axis_half;
   r.reor_des_rot = des_rot; r.reor_tar_length = tar_length;
+  hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_reorient_reset_typed(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
+                                       const float* size_tables, int ntab, float* geom_size_env, int32_t* geom_type_env,
+                                       float* axis_half, float* des_rot, float tar_length, int32_t* episode,
+                                       int32_t* step_count, uint64_t seed, void* stream) {
+  if (!m || !s || !init_qpos || !size_tables || ntab <= 0 || !geom_size_env || !geom_type_env || !axis_half || !des_rot ||
+      !(tar_length > 0.f))
+    return fail(MM_EARG, "mm_reorient_reset_typed: bad argument");
+  ResetArgs r; memset(&r, 0, sizeof(r));
+  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
+  r.qpos_bcast = init_qpos;
+  r.reor = 1; r.reor_ntab = ntab; r.reor_tab = size_tables; r.reor_gsize = geom_size_env; r.reor_axis_half = axis_half;
+  r.reor_des_rot = des_rot; r.reor_tar_length = tar_length; r.reor_gtype = geom_type_env;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;

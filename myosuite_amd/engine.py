@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 class mm_state(C.Structure):
     _fields_ = [("nenv", C.c_int), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("act", C.c_void_p),
                 ("qacc_warmstart", C.c_void_p), ("time", C.c_void_p), ("status", C.c_void_p),
-                ("geom_size_env", C.c_void_p), ("geom_env_id", C.c_int)]
+                ("geom_size_env", C.c_void_p), ("geom_env_id", C.c_int), ("geom_type_env", C.c_void_p)]
 
 
 _DERIVED_FIELDS = ["xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "cvel", "subtree_com", "actuator_length",
@@ -112,6 +112,9 @@ def lib():
         L.mm_reorient_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64,
                                         C.c_void_p]
+        L.mm_reorient_reset_typed.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                              C.c_void_p, C.c_uint64, C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
@@ -188,13 +191,20 @@ class BatchState:
         self.status = torch.zeros(nenv, dtype=torch.int32, device=dev)
         self.geom_size_env = None
         self._c = mm_state(nenv, _ptr(self.qpos), _ptr(self.qvel), self.act.data_ptr(), _ptr(self.qacc_warmstart),
-                           _ptr(self.time), _ptr(self.status), None, -1)
+                           _ptr(self.time), _ptr(self.status), None, -1, None)
+        self.geom_type_env = None
 
     def set_geom_size_env(self, geom_id: int, sizes: torch.Tensor):
         """per-env model delta: collision size [nenv][3] of one geom (mm_state.geom_size_env)"""
         assert sizes.shape == (self.nenv, 3) and sizes.dtype == torch.float32 and sizes.is_contiguous() and sizes.is_cuda
         self.geom_size_env = sizes
         self._c.geom_size_env = sizes.data_ptr(); self._c.geom_env_id = int(geom_id)
+
+    def set_geom_type_env(self, types: torch.Tensor):
+        """per-env model delta: type [nenv] int32 of the geom named in set_geom_size_env (mm_state.geom_type_env)"""
+        assert types.shape == (self.nenv,) and types.dtype == torch.int32 and types.is_contiguous() and types.is_cuda
+        self.geom_type_env = types
+        self._c.geom_type_env = types.data_ptr()
 
     @property
     def c(self):
@@ -291,6 +301,16 @@ def reorient_reset(model: HipModel, state: BatchState, mask, init_qpos, size_tab
     _chk(lib().mm_reorient_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(size_table), int(size_table.shape[0]),
                                  _ptr(state.geom_size_env), _ptr(axis_half), _ptr(des_rot), C.c_float(tar_length),
                                  _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()), "mm_reorient_reset")
+
+
+def reorient_reset_typed(model: HipModel, state: BatchState, mask, init_qpos, size_tables, axis_half, des_rot,
+                         tar_length: float, episode, step_count, seed: int):
+    """size_tables [4][ntab][3]: capsule, ellipsoid, cylinder, box"""
+    assert state.geom_size_env is not None and state.geom_type_env is not None and size_tables.shape[0] == 4
+    _chk(lib().mm_reorient_reset_typed(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(size_tables),
+                                       int(size_tables.shape[1]), _ptr(state.geom_size_env), _ptr(state.geom_type_env),
+                                       _ptr(axis_half), _ptr(des_rot), C.c_float(tar_length), _ptr(episode),
+                                       _ptr(step_count), C.c_uint64(seed), _stream()), "mm_reorient_reset_typed")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

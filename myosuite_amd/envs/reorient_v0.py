@@ -5,9 +5,9 @@ obs keys ``hand_jnt, obj_pos, obj_vel, obj_rot, obj_des_rot, obj_err_pos, obj_er
 reward keys ``pos_align, rot_align, act_reg, drop, bonus``; every reset re-draws the object geometry and the desired
 orientation (per-env model deltas: ``mm_state.geom_size_env``, ``mm_task.reor_axis_half / reor_des_rot``).
 
-RESTRICTION (documented deviation): the reference draws the object type uniformly from {capsule, ellipsoid, cylinder, box};
-this engine's narrow phase has plane / sphere / capsule primitives only, so the object is always a CAPSULE, with its
-size drawn from the reference's own capsule tables (2 sizes for Reorient8, 25 for Reorient100).
+Object type ~ uniform over {capsule, ellipsoid, cylinder, box} and size ~ uniform over the type's table (2 rows each for
+Reorient8, 25 each for Reorient100) exactly as the reference's reset (:388-406); collision of the non-capsule shapes
+against the hand capsules uses the engine's segment-vs-convex narrow phase (one contact per pair).
 """
 from __future__ import annotations
 
@@ -45,10 +45,12 @@ class ReorientEnvV0(BaseV0):
         self.init_qpos = cm.qpos0.astype(np.float32).copy()
         self.init_qpos[:-6] *= 0; self.init_qpos[0] = -1.5                                # :113-114 palm up, hand open
         self._init_qpos_dev = torch.from_numpy(self.init_qpos).to(dev)
-        table = synth.REORIENT_CAPS_8 if str(geometries) == "8" else synth.REORIENT_CAPS_100
-        self._size_table = torch.tensor(table, **f).contiguous()
+        self.size_tables_np = synth.reorient_tables(geometries)
+        self._size_tables = torch.from_numpy(self.size_tables_np).to(dev).contiguous()
         self.geom_size = torch.zeros(n, 3, **f); self.axis_half = torch.zeros(n, **f); self.des_rot = torch.zeros(n, 3, **f)
+        self.geom_type = torch.full((n,), 3, dtype=torch.int32, device=dev)
         self.state.set_geom_size_env(g["obj"], self.geom_size)
+        self.state.set_geom_type_env(self.geom_type)
         self.obs_dim = (cm.nq - 6) + 3 + 6 + 3 + 3 + 3 + 3 + 3 * cm.nu + cm.na
         self.obs = torch.zeros(n, self.obs_dim, **f)
         self.rwd = torch.zeros(n, len(E.RWD_KEYS_REORIENT), **f)
@@ -97,8 +99,8 @@ class ReorientEnvV0(BaseV0):
         if mask is not None:
             mask = mask.to(torch.uint8).contiguous()
         self._fatigue_reset(mask)
-        E.reorient_reset(self.hm, self.state, mask, self._init_qpos_dev, self._size_table, self.axis_half, self.des_rot,
-                         self.tar_length, self.episode, self.step_count, self._seed_u64)
+        E.reorient_reset_typed(self.hm, self.state, mask, self._init_qpos_dev, self._size_tables, self.axis_half,
+                               self.des_rot, self.tar_length, self.episode, self.step_count, self._seed_u64)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
         return self.obs, {}

@@ -502,6 +502,22 @@ REORIENT_CAPS_100 = [(0.0162, 0.0422, 0.0484), (0.016, 0.0457, 0.0496), (0.0187,
                      (0.0164, 0.041, 0.0328)]
 
 
+# ellipsoid / cylinder / box tables of the same reset code (reorient_sar_v0.py:179-205 and :267-377)
+REORIENT_ELLIPS_8 = [(0.011, 0.025, 0.025), (0.019, 0.04, 0.04)]
+REORIENT_CYL_8 = [(0.013, 0.025, 0.025), (0.019, 0.04, 0.04)]
+REORIENT_BOX_8 = [(0.017, 0.017, 0.017), (0.023, 0.023, 0.023)]
+REORIENT_ELLIPS_100 = [(0.02843, 0.0256, 0.02902), (0.01057, 0.02655, 0.0328), (0.01126, 0.0273, 0.04264), (0.02641, 0.03524, 0.02831), (0.02804, 0.03722, 0.04313), (0.02305, 0.04456, 0.03709), (0.02332, 0.02673, 0.02606), (0.01247, 0.03233, 0.03759), (0.02199, 0.029, 0.04484), (0.02674, 0.0428, 0.03764), (0.02278, 0.04006, 0.03556), (0.02392, 0.04095, 0.03467), (0.01928, 0.0348, 0.03044), (0.02388, 0.03644, 0.02817), (0.02739, 0.04338, 0.03457), (0.00962, 0.04047, 0.02614), (0.0163, 0.04443, 0.04326), (0.02417, 0.03157, 0.04038), (0.01927, 0.02814, 0.03786), (0.02477, 0.04456, 0.04493), (0.01656, 0.0291, 0.03996), (0.01763, 0.03877, 0.03636), (0.01915, 0.0346, 0.04245), (0.02485, 0.03324, 0.02881), (0.00856, 0.04185, 0.03749)]
+REORIENT_BOX_100 = [(0.02295, 0.02306, 0.02221), (0.02447, 0.0185, 0.02192), (0.01853, 0.01837, 0.01546), (0.01586, 0.02079, 0.022), (0.02293, 0.02116, 0.02255), (0.01542, 0.01651, 0.02381), (0.0186, 0.02402, 0.02333), (0.01782, 0.01584, 0.02208), (0.01907, 0.0195, 0.02161), (0.01751, 0.0211, 0.01864), (0.02258, 0.02334, 0.01856), (0.02195, 0.01617, 0.02438), (0.01627, 0.02254, 0.02073), (0.02364, 0.01946, 0.01777), (0.01754, 0.02463, 0.01549), (0.02394, 0.02382, 0.02387), (0.01997, 0.02372, 0.02032), (0.01741, 0.02316, 0.02203), (0.02032, 0.0217, 0.02432), (0.01961, 0.0248, 0.0176), (0.01906, 0.01999, 0.02399), (0.02472, 0.01826, 0.0151), (0.01636, 0.0158, 0.01958), (0.01542, 0.02434, 0.02237), (0.01731, 0.02185, 0.02019)]
+REORIENT_CYL_100 = [(0.0118, 0.044, 0.0265), (0.0189, 0.0316, 0.0415), (0.0123, 0.0364, 0.0238), (0.0145, 0.0362, 0.032), (0.0146, 0.0306, 0.0283), (0.0155, 0.0237, 0.0383), (0.0198, 0.0323, 0.03), (0.011, 0.0368, 0.0343), (0.0197, 0.0305, 0.0206), (0.0162, 0.0277, 0.0329), (0.0202, 0.0339, 0.0223), (0.0181, 0.0204, 0.0314), (0.0118, 0.0374, 0.0228), (0.0197, 0.0319, 0.0375), (0.0133, 0.0392, 0.0448), (0.0157, 0.0236, 0.0301), (0.0178, 0.0351, 0.0414), (0.0123, 0.024, 0.0399), (0.0158, 0.0254, 0.022), (0.0192, 0.021, 0.0355), (0.011, 0.0266, 0.0261), (0.0121, 0.0369, 0.0226), (0.012, 0.0221, 0.0254), (0.0213, 0.0298, 0.0297), (0.0164, 0.0302, 0.025)]
+
+
+def reorient_tables(geometries: str):
+    """[4][ntab][3] size tables in geom-type order capsule(3), ellipsoid(4), cylinder(5), box(6)"""
+    if str(geometries) == "8":
+        return np.array([REORIENT_CAPS_8, REORIENT_ELLIPS_8, REORIENT_CYL_8, REORIENT_BOX_8], np.float32)
+    return np.array([REORIENT_CAPS_100, REORIENT_ELLIPS_100, REORIENT_CYL_100, REORIENT_BOX_100], np.float32)
+
+
 def _quat_z_to(v):
     """quaternion rotating the local z axis onto unit vector v"""
     v = np.asarray(v, np.float64) / np.linalg.norm(v)
@@ -516,9 +532,8 @@ def make_hand_reorient() -> ModelSpec:
     """myoHand + free-moving object (3 slide + 3 hinge joints, NOT a free joint) + static target, the structure of
     myosuite/envs/myo/assets/hand/myohand_sar.xml:22-57: nq = nv = 29, 39 muscles, obs 200.  The forearm is mounted so that
     init_qpos[0] = pro_sup = -1.5 (reorient_sar_v0.py:113-114) turns the palm up; collision capsules along metacarpals,
-    phalanges and the carpal row catch the object.  Object geom: a capsule whose size is re-drawn per episode from the
-    reference's capsule tables; the reference also draws ellipsoids, cylinders and boxes, which need a convex narrow phase
-    this engine does not have yet (scope table)."""
+    phalanges and the carpal row catch the object.  Object geom: compiled as a capsule; type (capsule / ellipsoid /
+    cylinder / box) and size are per-env model deltas re-drawn every episode from the reference's tables."""
     s = make_hand()
     s.name = "myohand_sar"
     s.nconmax = 8

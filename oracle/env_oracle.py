@@ -367,20 +367,24 @@ def euler2quat(euler):
     return np.array([cj * cc + sj * ss, cj * cs - sj * sc, -(cj * ss + sj * cc), cj * sc - sj * cs])
 
 
-def reorient_reset_draws(size_table, env: int, episode: int, seed: int, tar_length: float):
-    """(size[3], axis_half, des_rot[3]) of the device-side reorient reset (k_reset, reorient branch), float32 draws."""
+def reorient_reset_draws(size_tables, env: int, episode: int, seed: int, tar_length: float, typed: bool = True):
+    """(geom_type, size[3], axis_half, des_rot[3]) of the device-side reorient reset (k_reset, reorient branch), float32
+    draws.  size_tables: [4][ntab][3] (capsule, ellipsoid, cylinder, box) when typed, else one [ntab][3] capsule table."""
     k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
     c = philox4x32_10(0, 3, env, episode, k0, k1)
     u = [float(u01(x)) for x in c]
-    tab = np.asarray(size_table, np.float32)
-    idx = min(int(np.float32(u[0]) * np.float32(len(tab))), len(tab) - 1)
-    size = tab[idx].astype(np.float64)
-    ah = float(np.float32(1.3) * tab[idx][1])
+    tab = np.asarray(size_tables, np.float32)
+    ntab = tab.shape[-2]
+    idx = min(int(np.float32(u[0]) * np.float32(ntab)), ntab - 1)
+    ty = min(int(np.float32(u[3]) * np.float32(4.0)), 3) if typed else 0
+    row = tab[ty][idx] if typed else tab[idx]
+    size = row.astype(np.float64)
+    ah = float(np.float32(1.3) * row[1]) if ty == 0 else float(row[1] if ty == 2 else row[2])      # reorient_sar_v0.py:390-406
     e0 = -1.0 + 2.0 * u[1]; e1 = -0.8 + 2.0 * u[2]
     q = euler2quat([e0, e1, 0.0])
     w, x, y, z = q
     col = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
-    return size, ah, col * 2 * ah / tar_length
+    return 3 + ty, size, ah, col * 2 * ah / tar_length
 
 
 def reorient_obs_reward(qpos, qvel, act, obj_xpos, obj_xmat, eps_pos, axis_half, des_rot, actuator_length,
@@ -408,7 +412,7 @@ def reorient_obs_reward(qpos, qvel, act, obj_xpos, obj_xmat, eps_pos, axis_half,
 
 
 class ReorientEnvOracle(PoseEnvOracle):
-    """Single-env CPU restatement of the reorient env on the fp64 oracle engine (capsule objects only)."""
+    """Single-env CPU restatement of the reorient env on the fp64 oracle engine."""
     RWD_KEYS_WT = {"pos_align": 1.0, "rot_align": 1.0, "act_reg": 5.0, "drop": 5.0, "bonus": 10.0}
 
     def __init__(self, compiled, frame_skip=5, normalize_act=True, muscle_condition=""):
@@ -420,10 +424,10 @@ class ReorientEnvOracle(PoseEnvOracle):
         self.obj_b = cm.body_id("Object"); self.eps_s = cm.site_id("eps_ball"); self.obj_g = g["obj"]
         self.init_qpos = cm.qpos0.astype(np.float64).copy(); self.init_qpos[:-6] *= 0; self.init_qpos[0] = -1.5
 
-    def reset(self, size, axis_half, des_rot):
+    def reset(self, size, axis_half, des_rot, gtype: int = 3):
         self.d.reset()
         self.d.qpos[:] = self.init_qpos
-        self.d.set_geom_size(self.obj_g, size)
+        self.d.set_geom_size(self.obj_g, size, gtype)
         self.axis_half = float(axis_half); self.des_rot = np.asarray(des_rot, np.float64)
         self.steps = 0
         self.d.ctrl[:] = 0

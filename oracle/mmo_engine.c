@@ -119,7 +119,7 @@ typedef struct {
   real *efc_R, *efc_D, *efc_vel, *efc_aref, *efc_force;
   real *qfrc_constraint, *qacc;
   /* per-env model delta: size override of one geom (mm_state.geom_size_env) */
-  int gsize_id; real gsize_val[3];
+  int gsize_id, gtype; real gsize_val[3];
   /* contacts */
   int* con_pair;
   real *con_dist, *con_pos, *con_frame;
@@ -166,7 +166,7 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   }
   d->cacc = ralloc(6 * nb); d->cfrc = ralloc(6 * nb); d->tmp_nv = ralloc(nv);
   d->qH = ralloc(m->nM); d->qHDiagInv = ralloc(nv);
-  d->gsize_id = -1;
+  d->gsize_id = -1; d->gtype = -1;
   mmo_reset(m, d);
   return d;
 }
@@ -1322,6 +1322,9 @@ real* mmo_field(mmo_data* d, const char* name) {
   return NULL;
 }
 void mmo_set_geom_size(mmo_data* d, int geom, double a, double b, double c) { d->gsize_id = geom; d->gsize_val[0] = a; d->gsize_val[1] = b; d->gsize_val[2] = c; }
+void mmo_set_geom_type(mmo_data* d, int type) { d->gtype = type; }
+/* test hook: capsule-axis segment vs convex primitive in the primitive's frame -> signed distance, t, outward normal */
+double mmo_test_seg_shape(int type, const double* size, const double* a, const double* u, double h, double* t, double* grad);
 double mmo_time(const mmo_data* d) { return d->time; }
 void mmo_set_time(mmo_data* d, double t) { d->time = t; }
 int mmo_nefc(const mmo_data* d) { return d->nefc; }
@@ -1339,4 +1342,8 @@ void mmo_full_m(const mmo_model* m, const mmo_data* d, real* out) {
     int j = i, a = 0;
     while (j >= 0) { out[i * nv + j] = out[j * nv + i] = d->qM[MI(m, DOF_MADR)[i] + a]; j = MI(m, DOF_PARENTID)[j]; a++; }
   }
+}
+
+double mmo_test_seg_shape(int type, const double* size, const double* a, const double* u, double h, double* t, double* grad) {
+  return seg_shape(type, size, a, u, h, t, grad);
 }

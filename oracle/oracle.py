@@ -46,6 +46,9 @@ def lib():
         L.mmo_time.argtypes = [C.c_void_p]
         L.mmo_set_time.argtypes = [C.c_void_p, C.c_double]
         L.mmo_set_geom_size.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.mmo_set_geom_type.argtypes = [C.c_void_p, C.c_int]
+        L.mmo_test_seg_shape.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double, C.c_void_p, C.c_void_p]
+        L.mmo_test_seg_shape.restype = C.c_double
         for f in ("mmo_nefc", "mmo_ncon", "mmo_solver_niter", "mmo_warn"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.c_int
@@ -151,9 +154,11 @@ class OracleData:
     def reset(self):
         lib().mmo_reset(self.model.ptr, self.ptr)
 
-    def set_geom_size(self, geom: int, size):
-        """per-env model delta: collision size of one geom (the reference writes mj_model.geom_size at reset)"""
+    def set_geom_size(self, geom: int, size, gtype: int = -1):
+        """per-env model delta: collision size (and optionally type) of one geom (the reference writes
+        mj_model.geom_size / geom_type at reset)"""
         lib().mmo_set_geom_size(self.ptr, int(geom), float(size[0]), float(size[1]), float(size[2]))
+        lib().mmo_set_geom_type(self.ptr, int(gtype))
 
     def forward(self):
         lib().mmo_forward(self.model.ptr, self.ptr)
@@ -178,3 +183,11 @@ def batch_rollout(model: OracleModel, datas, actions: np.ndarray, nsub: int, nth
     arr = (C.c_void_p * nenv)(*[d.ptr for d in datas])
     lib().mmo_batch_rollout(model.ptr, arr, nenv, nthreads, nsub, nsteps, actions.ctypes.data,
                             int(normalize), int(do_forward))
+
+
+def seg_shape(gtype: int, size, a, u, h: float):
+    """test hook: (signed distance, t, outward normal) of the segment a + t u, |t| <= h, against a convex primitive"""
+    size = np.ascontiguousarray(size, np.float64); a = np.ascontiguousarray(a, np.float64); u = np.ascontiguousarray(u, np.float64)
+    t = C.c_double(); g = np.zeros(3)
+    sd = lib().mmo_test_seg_shape(int(gtype), size.ctypes.data, a.ctypes.data, u.ctypes.data, float(h), C.byref(t), g.ctypes.data)
+    return sd, t.value, g

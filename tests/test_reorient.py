@@ -1,4 +1,4 @@
-"""Reorient envs (myoHandReorient8/100-v0, capsule objects): reference-pinned env arithmetic (CPU), HIP-vs-oracle (GPU)."""
+"""Reorient envs (myoHandReorient8/100-v0): reference-pinned env arithmetic and convex narrow phase (CPU), HIP-vs-oracle (GPU)."""
 import os
 
 import numpy as np
@@ -50,30 +50,65 @@ def test_reorient_model_and_registry():
     assert len(synth.REORIENT_CAPS_100) == 25 and len(synth.REORIENT_CAPS_8) == 2
 
 
+def test_segment_vs_convex_signed_distance_against_sampling(oracle_lib):
+    """oracle/mmo_collision.inc seg_shape (capsule axis vs box / cylinder / ellipsoid) against dense sampling of the
+    closed-form signed distance along the segment."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    th = np.linspace(0, np.pi, 240); ph = np.linspace(0, 2 * np.pi, 480)
+    T, Ph = np.meshgrid(th, ph, indexing="ij")
+    for gtype in (6, 5, 4):
+        for trial in range(24):
+            size = rng.uniform(0.01, 0.045, 3)
+            a = rng.standard_normal(3); a *= rng.uniform(0.01, 0.09) / np.linalg.norm(a)
+            u = rng.standard_normal(3)
+            if trial % 4 == 0:
+                u[2] = 0                                   # axis parallel to a face / to the cylinder caps
+            u /= np.linalg.norm(u)
+            h = rng.uniform(0.01, 0.03)
+            sd, t, g = O.seg_shape(gtype, size, a, u, h)
+            assert abs(np.linalg.norm(g) - 1) < 1e-9 and -h - 1e-12 <= t <= h + 1e-12
+            ts = np.linspace(-h, h, 2001 if gtype != 4 else 121)
+            P = a[None] + ts[:, None] * u[None]
+            if gtype == 6:
+                d = np.abs(P) - size
+                ref = (np.linalg.norm(np.maximum(d, 0), axis=1) + np.minimum(d.max(axis=1), 0)).min()
+            elif gtype == 5:
+                dr = np.linalg.norm(P[:, :2], axis=1) - size[0]; dz = np.abs(P[:, 2]) - size[1]
+                ref = np.where((dr > 0) & (dz > 0), np.hypot(np.maximum(dr, 0), np.maximum(dz, 0)), np.maximum(dr, dz)).min()
+            else:
+                S = np.stack([size[0] * np.sin(T) * np.cos(Ph), size[1] * np.sin(T) * np.sin(Ph), size[2] * np.cos(T)], -1).reshape(-1, 3)
+                dist = np.array([np.linalg.norm(S - p, axis=1).min() for p in P])
+                ref = np.where(((P / size) ** 2).sum(1) < 1, -dist, dist).min()
+            assert abs(sd - ref) < (2e-5 if gtype != 4 else 2e-4), (gtype, trial, sd, ref)
+
+
 @pytest.mark.gpu
 def test_gpu_reorient_env_matches_oracle_env(oracle_lib):
     import torch
     from myosuite_amd import engine as E
     from myosuite_amd.envs import registry
     cm = synth.get_model("hand_reorient")
-    n, nsteps = 8, 8
+    n, nsteps = 16, 8
     env = registry.make("myoHandReorient100-v0", num_envs=n, seed=9, autoreset=False)
     obs0, _ = env.reset(seed=9)
     assert obs0.shape == (n, 200)
     ep = env.episode.cpu().numpy()
     orc = []
-    sizes = set()
+    sizes = set(); types = set()
     for e in range(n):
-        size, ah, des = EO.reorient_reset_draws(synth.REORIENT_CAPS_100, e, int(ep[e]) - 1, 9, env.tar_length)
+        gt, size, ah, des = EO.reorient_reset_draws(env.size_tables_np, e, int(ep[e]) - 1, 9, env.tar_length)
+        assert int(env.geom_type[e]) == gt
+        types.add(gt)
         np.testing.assert_allclose(env.geom_size[e].cpu().numpy(), size, atol=1e-7)
         np.testing.assert_allclose(float(env.axis_half[e]), ah, rtol=1e-6)
         np.testing.assert_allclose(env.des_rot[e].cpu().numpy(), des, atol=2e-6)
         sizes.add(tuple(np.round(size, 4)))
         w = EO.ReorientEnvOracle(cm)
-        o = w.reset(size, ah, env.des_rot[e].cpu().numpy().astype(np.float64))
+        o = w.reset(size, ah, env.des_rot[e].cpu().numpy().astype(np.float64), gt)
         np.testing.assert_allclose(obs0[e].cpu().numpy(), o, rtol=1e-4, atol=3e-5)
         orc.append(w)
-    assert len(sizes) >= 3
+    assert len(sizes) >= 3 and len(types) >= 3, types
     a = torch.empty(n, cm.nu, device="cuda")
     for s in range(nsteps):
         # teacher forcing (contact onsets are discontinuities of time-stepped dynamics, see DESIGN.md section 3)

@@ -61,7 +61,7 @@ def reset_walk(env, w, e):
     cm = w.cm
     w.reset(cm.key_qpos[2], cm.key_qvel[2])
 def reset_reor(env, w, e):
-    w.reset(env.geom_size[e].cpu().numpy().astype(np.float64), float(env.axis_half[e]), env.des_rot[e].cpu().numpy().astype(np.float64))
+    w.reset(env.geom_size[e].cpu().numpy().astype(np.float64), float(env.axis_half[e]), env.des_rot[e].cpu().numpy().astype(np.float64), int(env.geom_type[e]))
 out["teacher_forced"]["myoLegWalk-v0"] = forced("myoLegWalk-v0", EO.WalkEnvOracle, reset_walk)
 print(out["teacher_forced"]["myoLegWalk-v0"])
 out["teacher_forced"]["myoHandReorient100-v0"] = forced("myoHandReorient100-v0", EO.ReorientEnvOracle, reset_reor, scale=0.8)
