@@ -49,7 +49,7 @@ struct Layout {
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
   int vec;  // nv: joint-transmission actuator forces
-  int efcJ, rowtab;   // general constraint rows: J [G][NVP+1], row table [G][3] (GEN models only)
+  int efcJ, rowtab;   // general constraint rows: J [G][NVP+4] (16-byte aligned rows), row table [G][3] (GEN models only)
   int total;
 };
 
@@ -1223,10 +1223,11 @@ struct Engine {
 
 
   // ===================================================== general constraint rows (GEN models)
-  // Row r of efc_J lives in LDS (row stride NVP+1: odd, so both "lane = row" and "lane = column" sweeps are
-  // bank-conflict free); lane r owns the row's scalars (D, aref, jar).  Row order: equalities, active joint
+  // Row r of efc_J lives in LDS with a 16-byte aligned row stride (NVP+4 words): the Hessian build and J x read rows with
+  // 128-bit LDS loads (a wave-uniform row is one broadcast ds_read_b128 per four columns); lane r owns the row's scalars
+  // (D, aref, jar).  Row order: equalities, active joint
   // limits (compacted), contact pyramid edges (compacted).  Restates mmo_make_constraint / mmo_collision.inc.
-  static constexpr int RS = NVP + 1;
+  static constexpr int RS = NVP + 4;
   __device__ __forceinline__ float* Jrow(int r) const { return W + a.L.efcJ + r * RS; }
   __device__ __forceinline__ int gscan_excl(int v) const {
     int incl = v;
@@ -1284,7 +1285,10 @@ struct Engine {
   __device__ __forceinline__ void make_constraint_gen() {
     const Layout& L = a.L;
     float* RT = W + L.rowtab;
-    for (int e = g; e < G * RS; e += G) W[L.efcJ + e] = 0.f;
+    {
+      float4* Jz = reinterpret_cast<float4*>(W + L.efcJ);
+      for (int e = g; e < G * RS / 4; e += G) Jz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     GSYNC();
     const int neq = a.d.neq;
     // ---- equality rows: joint coupling q1 - q1_0 = poly(q2 - q2_0)
@@ -1452,10 +1456,13 @@ struct Engine {
 
   // (J x)_r for the row owned by this lane; x lives in the dof lanes
   __device__ __forceinline__ float jac_mul(float x) const {
-    const float* J = Jrow(g);
+    const float4* J = reinterpret_cast<const float4*>(Jrow(g));
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < NVP; k++) s += J[k] * bc<G>(x, k);
+    for (int k = 0; k < NVP / 4; k++) {
+      const float4 j4 = J[k];
+      s += j4.x * bc<G>(x, 4 * k) + j4.y * bc<G>(x, 4 * k + 1) + j4.z * bc<G>(x, 4 * k + 2) + j4.w * bc<G>(x, 4 * k + 3);
+    }
     return s;
   }
   // (J' f)_i for the dof owned by this lane; f lives in the row lanes
@@ -1513,8 +1520,12 @@ struct Engine {
           if (__ballot(sD != 0.f) == 0ull) continue;
           const float* Jr = W + a.L.efcJ + r * RS;
           const float c = g < NVP ? sD * Jr[col] : 0.f;
+          const float4* Jr4 = reinterpret_cast<const float4*>(Jr);
 #pragma unroll
-          for (int k = 0; k < NVP; k++) A[k] += c * Jr[k];
+          for (int k = 0; k < NVP / 4; k++) {
+            const float4 j4 = Jr4[k];
+            A[4 * k] += c * j4.x; A[4 * k + 1] += c * j4.y; A[4 * k + 2] += c * j4.z; A[4 * k + 3] += c * j4.w;
+          }
         }
       }
       factor_core(A);
@@ -2212,7 +2223,7 @@ static void build_layout(mm_model* m) {
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
   L.efcJ = L.rowtab = 0;
-  if (d.gen) { L.efcJ = take(m->lanes * (m->nvp + 1)); L.rowtab = take(3 * m->lanes); }
+  if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(m->lanes * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
   o = (o + 3) & ~3;
