@@ -384,80 +384,104 @@ __device__ __forceinline__ float sd_box(V3 s, V3 q, V3& grad) {
   const V3 sg = v3(q.x < 0.f ? -1.f : 1.f, q.y < 0.f ? -1.f : 1.f, q.z < 0.f ? -1.f : 1.f);
   if (d.x > 0.f || d.y > 0.f || d.z > 0.f) {
     V3 e = v3(fmaxf(d.x, 0.f), fmaxf(d.y, 0.f), fmaxf(d.z, 0.f));
-    float n = sqrtf(dot(e, e));
-    grad = v3(e.x / n * sg.x, e.y / n * sg.y, e.z / n * sg.z);
-    return n;
+    const float n2 = dot(e, e), in_ = __frsqrt_rn(n2);
+    grad = v3(e.x * in_ * sg.x, e.y * in_ * sg.y, e.z * in_ * sg.z);
+    return n2 * in_;
   }
   if (d.x >= d.y && d.x >= d.z) { grad = v3(sg.x, 0.f, 0.f); return d.x; }
   if (d.y >= d.z) { grad = v3(0.f, sg.y, 0.f); return d.y; }
   grad = v3(0.f, 0.f, sg.z); return d.z;
 }
 __device__ __forceinline__ float sd_cylinder(V3 s, V3 q, V3& grad) {
-  float rho = sqrtf(q.x * q.x + q.y * q.y), dr = rho - s.x, dz = fabsf(q.z) - s.y;
-  float rx = rho > MINVALF ? q.x / rho : 1.f, ry = rho > MINVALF ? q.y / rho : 0.f, sz = q.z < 0.f ? -1.f : 1.f;
-  if (dr > 0.f && dz > 0.f) { float n = sqrtf(dr * dr + dz * dz); grad = v3(dr * rx / n, dr * ry / n, dz * sz / n); return n; }
+  const float r2 = q.x * q.x + q.y * q.y;
+  const float irho = r2 > MINVALF ? __frsqrt_rn(r2) : 0.f, rho = r2 * irho, dr = rho - s.x, dz = fabsf(q.z) - s.y;
+  const float rx = r2 > MINVALF ? q.x * irho : 1.f, ry = q.y * irho, sz = q.z < 0.f ? -1.f : 1.f;
+  if (dr > 0.f && dz > 0.f) { const float n2 = dr * dr + dz * dz, in_ = __frsqrt_rn(n2); grad = v3(dr * rx * in_, dr * ry * in_, dz * sz * in_); return n2 * in_; }
   if (dr > dz) { grad = v3(rx, ry, 0.f); return dr; }
   grad = v3(0.f, 0.f, sz); return dz;
 }
-__device__ __forceinline__ float sd_ellipsoid(V3 s, V3 q0, V3& grad) {
+// `tw` carries the Lagrange multiplier between calls: consecutive query points along the capsule axis are close, so a
+// warm-started Newton needs few iterations (F is convex and decreasing: from the right of the root the first step lands
+// left of it and the rest converge monotonically).  tw = NaN requests a cold start.
+__device__ __forceinline__ float sd_ellipsoid(V3 s, V3 q0, V3& grad, float& tw) {
   const float sv[3] = {s.x, s.y, s.z}, qi[3] = {q0.x, q0.y, q0.z};
-  float q[3], f0 = -1.f, amin = sv[0];
+  float q[3], sq[3], s2[3], f0 = -1.f, amin = sv[0];
   int imin = 0;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     q[i] = fabsf(qi[i]) < 1e-9f ? (qi[i] < 0.f ? -1e-9f : 1e-9f) : qi[i];
-    f0 += (q[i] / sv[i]) * (q[i] / sv[i]);
+    s2[i] = sv[i] * sv[i]; sq[i] = sv[i] * q[i];
+    const float r = q[i] * __builtin_amdgcn_rcpf(sv[i]);
+    f0 += r * r;
     if (sv[i] < amin) { amin = sv[i]; imin = i; }
   }
-  float t = f0 >= 0.f ? 0.f : -amin * amin + amin * fabsf(q[imin]);
-  for (int it = 0; it < 10; it++) {
+  const float tlo = f0 >= 0.f ? 0.f : -amin * amin + amin * fabsf(q[imin]);
+  const bool cold = !(tw == tw);
+  float t = cold ? tlo : fmaxf(tw, tlo);
+  const int iters = cold ? 9 : 4;
+  for (int it = 0; it < iters; it++) {
     float F = -1.f, dF = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { float den = t + sv[i] * sv[i], w = sv[i] * q[i] / den; F += w * w; dF -= 2.f * w * w / den; }
+    for (int i = 0; i < 3; i++) { const float ri = __builtin_amdgcn_rcpf(t + s2[i]), w = sq[i] * ri; F += w * w; dF -= 2.f * w * w * ri; }
     if (dF > -MINVALF) break;
-    t -= F / dF;
+    t = fmaxf(t - F * __builtin_amdgcn_rcpf(dF), tlo);
   }
+  tw = t;
   float g[3], n2 = 0.f, d2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    float x = sv[i] * sv[i] * q[i] / (t + sv[i] * sv[i]);
-    g[i] = x / (sv[i] * sv[i]); n2 += g[i] * g[i]; d2 += (q[i] - x) * (q[i] - x);
+    const float ri = __builtin_amdgcn_rcpf(t + s2[i]);
+    const float x = s2[i] * q[i] * ri;
+    g[i] = q[i] * ri; n2 += g[i] * g[i]; d2 += (q[i] - x) * (q[i] - x);
   }
-  float inv = 1.f / sqrtf(n2);
+  const float inv = __frsqrt_rn(n2);
   grad = v3(g[0] * inv, g[1] * inv, g[2] * inv);
   return f0 >= 0.f ? sqrtf(d2) : -sqrtf(d2);
 }
-__device__ __forceinline__ float sd_shape(int type, V3 s, V3 q, V3& grad) {
+__device__ __forceinline__ float sd_shape(int type, V3 s, V3 q, V3& grad, float& tw) {
   if (type == MM_GEOM_BOX) return sd_box(s, q, grad);
   if (type == MM_GEOM_CYLINDER) return sd_cylinder(s, q, grad);
-  return sd_ellipsoid(s, q, grad);
+  return sd_ellipsoid(s, q, grad, tw);
 }
 // minimiser of the convex g(t) = sd(a + t u) on [-h, h]: bisection on the sign of g'(t) = grad.u; flat stretches are
 // bracketed with a +-tau tolerance and their midpoint is used (same rule as the oracle)
+struct SegHit { float sd, t; V3 g; };
+__device__ __forceinline__ SegHit seg_shape_call(int type, V3 s, V3 a0, V3 u, float h);
+__device__ __forceinline__ float seg_dg(int type, V3 s, V3 a0, V3 u, float t, float& tw) {
+  V3 g;
+  sd_shape(type, s, a0 + t * u, g, tw);
+  return dot(g, u);
+}
+__device__ __forceinline__ float seg_bisect(int type, V3 s, V3 a0, V3 u, float lo, float hi, float thr, int iters, float& tw) {
+  if (seg_dg(type, s, a0, u, lo, tw) > thr) return lo;
+  if (seg_dg(type, s, a0, u, hi, tw) <= thr) return hi;
+  for (int it = 0; it < iters; it++) {
+    const float mid = 0.5f * (lo + hi);
+    if (seg_dg(type, s, a0, u, mid, tw) > thr) hi = mid; else lo = mid;
+  }
+  return 0.5f * (lo + hi);
+}
+// same rule as the oracle's seg_shape (mmo_collision.inc): root of g', flat minima of box / cylinder replaced by the
+// midpoint of their +-tau interval; 13 bisection steps resolve t to h * 2^-13 ~ 4e-6 m
 __device__ __forceinline__ float seg_shape(int type, V3 s, V3 a0, V3 u, float h, float& tbest, V3& grad) {
   const float tau = 1e-4f;
-  float te[2] = {0.f, 0.f};
-  const int nside = type == MM_GEOM_ELLIPSOID ? 1 : 2;
-  for (int side = 0; side < nside; side++) {
-    const float thr = side == 0 ? -tau : tau;
-    float lo = -h, hi = h;
-    V3 g;
-    sd_shape(type, s, a0 - h * u, g);
-    if (dot(g, u) > thr) { te[side] = -h; continue; }
-    sd_shape(type, s, a0 + h * u, g);
-    if (dot(g, u) <= thr) { te[side] = h; continue; }
-    const int iters = type == MM_GEOM_ELLIPSOID ? 16 : 22;
-    for (int it = 0; it < iters; it++) {
-      float mid = 0.5f * (lo + hi);
-      sd_shape(type, s, a0 + mid * u, g);
-      if (dot(g, u) > thr) hi = mid; else lo = mid;
-    }
-    te[side] = 0.5f * (lo + hi);
+  float tw = __builtin_nanf("");
+  float t = seg_bisect(type, s, a0, u, -h, h, 0.f, 13, tw);
+  if (type != MM_GEOM_ELLIPSOID) {
+    const float dl = 0.02f * h;
+    float tl = t, tr = t;
+    if (seg_dg(type, s, a0, u, fmaxf(t - dl, -h), tw) > -tau) tl = seg_bisect(type, s, a0, u, -h, t, -tau, 13, tw);
+    if (seg_dg(type, s, a0, u, fminf(t + dl, h), tw) <= tau) tr = seg_bisect(type, s, a0, u, t, h, tau, 13, tw);
+    t = 0.5f * (tl + tr);
   }
-  if (nside == 1) te[1] = te[0];
-  const float t = 0.5f * (te[0] + te[1]);
   tbest = t;
-  return sd_shape(type, s, a0 + t * u, grad);
+  return sd_shape(type, s, a0 + t * u, grad, tw);
+}
+
+__device__ __forceinline__ SegHit seg_shape_call(int type, V3 s, V3 a0, V3 u, float h) {
+  SegHit r;
+  r.sd = seg_shape(type, s, a0, u, h, r.t, r.g);
+  return r;
 }
 
 // ------------------------------------------------------------------ muscle model (A6)
@@ -1334,6 +1358,7 @@ struct Engine {
       } else over = 1;
     }
     // ---- contacts: lane p handles explicit pair p (up to two contacts for plane-capsule)
+    const unsigned long long tc0_ = a.prof ? clock64() : 0;
     int nc = 0, rowsper = 0, b1 = 0, b2 = 0;
     float cdist[2] = {0.f, 0.f}, mu = 0.f, incl = 0.f;
     V3 cpos[2], cn[2];
@@ -1389,8 +1414,9 @@ struct Engine {
         if (env_gsize && gs == a.s.geom_env_id) ss = ld3(env_gsize);
         const V3 uc = geom_zaxis(gc);
         const M3 ms = geom_mat(gs);
-        float tt; V3 gsh;
-        const float sd = seg_shape(ts, ss, mtv(ms, xc - xs), mtv(ms, uc), hc, tt, gsh);
+        const SegHit hit = seg_shape_call(ts, ss, mtv(ms, xc - xs), mtv(ms, uc), hc);
+        const float tt = hit.t, sd = hit.sd;
+        const V3 gsh = hit.g;
         const float dd = sd - rc;
         if (dd < margin) {
           V3 gw = mv(ms, gsh);
@@ -1401,6 +1427,7 @@ struct Engine {
         }
       }
     }
+    if (a.prof) pf[PF_IO] += clock64() - tc0_;   // narrow phase only (reported as 'io' = collide)
     int myrows = 0;
     for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
     int base = neq + nlim + gscan_excl(myrows);
