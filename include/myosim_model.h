@@ -69,6 +69,8 @@ enum { MM_GAIN_FIXED = 0, MM_GAIN_MUSCLE = 2 };
 enum { MM_BIAS_NONE = 0, MM_BIAS_MUSCLE = 2 };
 /* equality types */
 enum { MM_EQ_JOINT = 2 };
+/* mjtIntegrator values carried in MM_OI_INTEGRATOR */
+enum { MM_INT_EULER = 0, MM_INT_RK4 = 1 };
 /* constraint row types (oracle + engine internal) */
 enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
        MM_CON_CONTACT = 3 };

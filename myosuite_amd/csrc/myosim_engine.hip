@@ -38,6 +38,7 @@ struct Dims {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, njmax, ntenJ;
   int iterations, ls_iterations, eulerdamp, any_damping;
   int gen;   // model has equality / contact rows: general (dense-J) constraint path
+  int integrator;   // MM_INT_EULER | MM_INT_RK4
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
 };
 
@@ -49,6 +50,7 @@ struct Layout {
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
   int vec;  // nv: joint-transmission actuator forces
+  int rk_qpos0, rk_act0, rk_adot;   // RK4: state at the start of the step, weighted act_dot sum (RK4 models only)
   int efcJ, rowtab;   // general constraint rows: J [G][NVP+4] (16-byte aligned rows), row table [G][3] (GEN models only)
   int total;
 };
@@ -572,6 +574,7 @@ struct Engine {
   bool r_eq;
   int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
   const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
+  float rk_v0, rk_vsum, rk_asum;   // RK4: qvel at the start of the step, weighted sums of stage qvel / qacc
   int env_gtype;            // this env's entry of mm_state.geom_type_env (or -1)
 
   __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
@@ -601,7 +604,7 @@ struct Engine {
         c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
       }
     }
-    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
     b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
@@ -1663,15 +1666,23 @@ struct Engine {
       W[L.qvel + g] = d_qvel;
     }
     GSYNC();
+    integrate_pos(L.qvel, h);
+    time += h;
+    GSYNC();
+  }
+
+  // qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos); vel = LDS vector at word offset `voff`
+  __device__ __forceinline__ void integrate_pos(int voff, float hh) {
+    const Layout& L = a.L;
     for (int j = g; j < a.d.njnt; j += G) {
       int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j], da = MI_(JNT_DOFADR)[j];
-      if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[L.qpos + qa] += h * W[L.qvel + da]; continue; }
+      if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[L.qpos + qa] += hh * W[voff + da]; continue; }
       if (type == MM_JNT_FREE) {
-        for (int k = 0; k < 3; k++) W[L.qpos + qa + k] += h * W[L.qvel + da + k];
+        for (int k = 0; k < 3; k++) W[L.qpos + qa + k] += hh * W[voff + da + k];
         qa += 3; da += 3;
       }
-      V3 w = ld3(W + L.qvel + da);
-      float nw = sqrtf(dot(w, w)), ang = h * nw;
+      V3 w = ld3(W + voff + da);
+      float nw = sqrtf(dot(w, w)), ang = hh * nw;
       if (ang > MINVALF) {
         float sn, cs;
         sincos_small(0.5f * ang, &sn, &cs);
@@ -1681,7 +1692,42 @@ struct Engine {
         W[L.qpos + qa] = qn.w; W[L.qpos + qa + 1] = qn.x; W[L.qpos + qa + 2] = qn.y; W[L.qpos + qa + 3] = qn.z;
       }
     }
-    time += h;
+  }
+
+  // One stage of classical RK4 (mj_RungeKutta, N = 4; oracle: mmo_rk4).  Called after the forward pass of stage `i`
+  // (i = 0 is mj_step's own forward).  Stages 0..2 move the state to X0 + h a_i F_i; stage 3 applies the weighted update.
+  __device__ __forceinline__ void rk4_stage(int i, float& time, float t0) {
+    const Layout& L = a.L;
+    const float h = a.d.timestep;
+    const float A_ = i == 2 ? 1.f : 0.5f;
+    const float B_ = (i == 0 || i == 3) ? (1.f / 6.f) : (1.f / 3.f);
+    d_warm = d_qacc;
+    if (i == 0) {
+      rk_v0 = d_qvel; rk_vsum = 0.f; rk_asum = 0.f;
+      for (int k = g; k < a.d.nq; k += G) W[L.rk_qpos0 + k] = W[L.qpos + k];
+      for (int k = g; k < a.d.na; k += G) { W[L.rk_act0 + k] = W[L.act + k]; W[L.rk_adot + k] = 0.f; }
+    }
+    rk_vsum += B_ * d_qvel; rk_asum += B_ * d_qacc;
+    for (int k = g; k < a.d.na; k += G) W[L.rk_adot + k] += B_ * W[L.actdot + k];
+    GSYNC();
+    // velocity used for the position update of this stage goes through the (free) L.vec scratch vector
+    const float hh = i < 3 ? h * A_ : h;
+    if (g < a.d.nv) W[L.vec + g] = i < 3 ? d_qvel : rk_vsum;
+    for (int k = g; k < a.d.nq; k += G) W[L.qpos + k] = W[L.rk_qpos0 + k];
+    GSYNC();
+    integrate_pos(L.vec, hh);
+    if (g < a.d.nv) {
+      d_qvel = i < 3 ? rk_v0 + hh * d_qacc : rk_v0 + h * rk_asum;
+      W[L.qvel + g] = d_qvel;
+    }
+    for (int u = g; u < a.d.nu; u += G) {
+      int aa = MI_(ACT_ACTADR)[u];
+      if (aa < 0) continue;
+      float x = i < 3 ? W[L.rk_act0 + aa] + hh * W[L.actdot + aa] : W[L.rk_act0 + aa] + h * W[L.rk_adot + aa];
+      if (i == 3 && MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
+      W[L.act + aa] = x;
+    }
+    time = i < 3 ? t0 + hh : t0 + h;
     GSYNC();
   }
 
@@ -1689,16 +1735,22 @@ struct Engine {
   // optional mj_forward on the final state.  One call site of forward() keeps the code size bounded.
   __device__ __forceinline__ void run(int nsub, bool final_forward, float& time) {
     int total = nsub + (final_forward ? 1 : 0);
-    int s = 0;
+    int s = 0, rk = 0;
+    float t0 = time;
     bool redo = false;
+    const bool rk4 = a.d.integrator == MM_INT_RK4;
     while (s < total) {
       const bool stepping = s < nsub;
-      if (stepping && !redo && bad_state(false)) { reset_data(); time = 0.f; status |= 1; }
+      if (stepping && rk == 0 && !redo && bad_state(false)) { reset_data(); time = 0.f; status |= 1; }
       forward();
       if (stepping) {
-        if (!redo && bad_state(true)) { reset_data(); time = 0.f; status |= 1; redo = true; continue; }
-        PFT(PF_EULER, euler(time));
-        redo = false;
+        if (rk == 0 && !redo && bad_state(true)) { reset_data(); time = 0.f; status |= 1; redo = true; continue; }
+        if (!rk4) { PFT(PF_EULER, euler(time)); redo = false; s++; continue; }
+        if (rk == 0) t0 = time;
+        PFT(PF_EULER, rk4_stage(rk, time, t0));
+        rk = (rk + 1) & 3;
+        if (rk == 0) { redo = false; s++; }
+        continue;
       }
       s++;
     }
@@ -2250,6 +2302,8 @@ static void build_layout(mm_model* m) {
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
   L.efcJ = L.rowtab = 0;
+  L.rk_qpos0 = L.rk_act0 = L.rk_adot = 0;
+  if (d.integrator == MM_INT_RK4) { L.rk_qpos0 = take(d.nq); L.rk_act0 = take(d.na); L.rk_adot = take(d.na); }
   if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(m->lanes * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
@@ -2294,7 +2348,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.iterations = oi[MM_OI_ITERATIONS]; d.ls_iterations = oi[MM_OI_LS_ITERATIONS]; d.eulerdamp = oi[MM_OI_EULERDAMP];
   d.timestep = of[MM_OF_TIMESTEP]; d.gx = of[MM_OF_GRAV_X]; d.gy = of[MM_OF_GRAV_Y]; d.gz = of[MM_OF_GRAV_Z];
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
-  if (oi[MM_OI_INTEGRATOR] != 0) { delete m; return fail(MM_EUNSUPPORTED, "only the Euler integrator is implemented"); }
+  d.integrator = oi[MM_OI_INTEGRATOR];
+  if (d.integrator != MM_INT_EULER && d.integrator != MM_INT_RK4) { delete m; return fail(MM_EUNSUPPORTED, "integrator must be Euler (0) or RK4 (1)"); }
   d.gen = (d.neq > 0 || d.npair > 0) ? 1 : 0;
   {
     const int32_t* et = (const int32_t*)(blob + m->sec[MM_SEC_EQ_TYPE]);

@@ -1290,6 +1290,68 @@ static void mmo_euler(const mmo_model* m, mmo_data* d) {
   d->time += h;
 }
 
+/* qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos) */
+static void integrate_pos(const mmo_model* m, real* qpos, const real* vel, real hh) {
+  for (int j = 0; j < m->njnt; j++) {
+    int type = MI(m, JNT_TYPE)[j], qa = MI(m, JNT_QPOSADR)[j], da = MI(m, JNT_DOFADR)[j];
+    if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { qpos[qa] += hh * vel[da]; continue; }
+    if (type == MM_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += hh * vel[da + k];
+      qa += 3; da += 3;
+    }
+    real w[3] = {vel[da], vel[da + 1], vel[da + 2]};
+    real ang = hh * norm3(w);
+    if (ang > MINVAL) {
+      real ax[3] = {w[0], w[1], w[2]}, dq[4], qn[4];
+      normalize3(ax);
+      axisangle2quat(dq, ax, ang);
+      quat_mul(qn, qpos + qa, dq);
+      quat_normalize(qn);
+      memcpy(qpos + qa, qn, sizeof(qn));
+    }
+  }
+}
+
+/* classical 4th-order Runge-Kutta over the state (qpos, qvel, act) with derivative (qvel, qacc, act_dot)
+   (mj_RungeKutta, N = 4: a = {1/2, 1/2, 1}, b = {1/6, 1/3, 1/3, 1/6}); stage 0 is the forward pass mmo_step already ran.
+   No implicit damping in this integrator; muscle activations are clamped to [0,1] at the final update only. */
+static void mmo_rk4(const mmo_model* m, mmo_data* d) {
+  int nv = m->nv, nq = m->nq, na = m->na;
+  real h = m->timestep, t0 = d->time;
+  static const real A[3] = {0.5, 0.5, 1.0}, B[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+  real* q0 = ralloc(nq); real* v0 = ralloc(nv); real* a0 = ralloc(na);
+  real* vel = ralloc(4 * nv); real* acc = ralloc(4 * nv); real* adot = ralloc(4 * (na > 0 ? na : 1));
+  memcpy(q0, d->qpos, sizeof(real) * nq); memcpy(v0, d->qvel, sizeof(real) * nv); memcpy(a0, d->act, sizeof(real) * na);
+  for (int i = 0; i < 4; i++) {
+    memcpy(vel + i * nv, d->qvel, sizeof(real) * nv); memcpy(acc + i * nv, d->qacc, sizeof(real) * nv);
+    memcpy(adot + i * na, d->act_dot, sizeof(real) * na);
+    if (i == 3) break;
+    memcpy(d->qpos, q0, sizeof(real) * nq);
+    integrate_pos(m, d->qpos, vel + i * nv, h * A[i]);
+    for (int k = 0; k < nv; k++) d->qvel[k] = v0[k] + h * A[i] * acc[i * nv + k];
+    for (int k = 0; k < na; k++) d->act[k] = a0[k] + h * A[i] * adot[i * na + k];
+    d->time = t0 + h * A[i];
+    mmo_forward(m, d);
+    memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * nv);
+  }
+  real* dv = d->tmp_nv;
+  memcpy(d->qpos, q0, sizeof(real) * nq);
+  for (int k = 0; k < nv; k++) { dv[k] = 0; for (int i = 0; i < 4; i++) dv[k] += B[i] * vel[i * nv + k]; }
+  integrate_pos(m, d->qpos, dv, h);
+  for (int k = 0; k < nv; k++) { real s_ = 0; for (int i = 0; i < 4; i++) s_ += B[i] * acc[i * nv + k]; d->qvel[k] = v0[k] + h * s_; }
+  for (int a = 0; a < m->nu; a++) {
+    int aa = MI(m, ACT_ACTADR)[a];
+    if (aa < 0) continue;
+    real s_ = 0;
+    for (int i = 0; i < 4; i++) s_ += B[i] * adot[i * na + aa];
+    real x = a0[aa] + h * s_;
+    if (MI(m, ACT_DYNTYPE)[a] == MM_DYN_MUSCLE) x = x < 0 ? 0 : (x > 1 ? 1 : x);
+    d->act[aa] = x;
+  }
+  d->time = t0 + h;
+  free(q0); free(v0); free(a0); free(vel); free(acc); free(adot);
+}
+
 /* mj_step: forward + integrate, with MuJoCo's bad-state auto-reset semantics */
 void mmo_step(const mmo_model* m, mmo_data* d) {
   if (bad_state(m, d, 0)) { real c[256]; int nu = m->nu < 256 ? m->nu : 256;
@@ -1299,7 +1361,7 @@ void mmo_step(const mmo_model* m, mmo_data* d) {
     memcpy(c, d->ctrl, sizeof(real) * nu); mmo_reset(m, d); memcpy(d->ctrl, c, sizeof(real) * nu); d->warn_bad |= 1;
     mmo_forward(m, d); }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * m->nv);
-  mmo_euler(m, d);
+  if (m->integrator == MM_INT_RK4) mmo_rk4(m, d); else mmo_euler(m, d);
 }
 
 /* ---------------------------------------------------------- accessors */

@@ -327,3 +327,34 @@ def test_mjx_style_state_api_matches_playground_semantics(models):
     ref = -dist - amag + 4.0 * ((dist < 0.7) * 1.0 + (dist < 1.05) * 1.0) - 1.0 * (dist > 2 * np.pi)
     np.testing.assert_allclose(st2.reward.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
     assert int(st2.info["step_count"].max()) == 1 and set(st2.metrics) >= {"pose_reward", "solved_frac"}
+
+
+@pytest.mark.parametrize("name", ["elbow", "hand", "contact_toy"])
+def test_rk4_integrator_matches_oracle(oracle_lib, name):
+    """integrator = RK4 (north_star: "RK4/semi-implicit integration"): 40 substeps against the oracle's mmo_rk4."""
+    spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "contact_toy": synth.make_contact_toy}[name]()
+    spec.integrator = 1
+    cm = spec.compile()
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    n = 12
+    rng = np.random.default_rng(2)
+    q = np.tile(cm.qpos0.astype(np.float64), (n, 1))
+    if name != "contact_toy":
+        lo, hi = cm.jnt_range[:, 0].astype(np.float64), cm.jnt_range[:, 1].astype(np.float64)
+        q = lo + (hi - lo) * rng.random((n, cm.nq))
+    v = rng.standard_normal((n, cm.nv)) * 0.5
+    ctrl = rng.random((n, cm.nu)).astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q.astype(np.float32))); st.qvel.copy_(torch.from_numpy(v.astype(np.float32)))
+    ds = []
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q[e].astype(np.float32); d.qvel[:] = v[e].astype(np.float32); d.ctrl[:] = ctrl[e]; ds.append(d)
+    c = torch.from_numpy(ctrl).cuda().reshape(n, cm.nu).contiguous()
+    E.step(hm, st, c, 40)
+    for d in ds:
+        d.step(40)
+    qo = np.array([d.qpos for d in ds]); to = np.array([d.time for d in ds])
+    err = np.abs(st.qpos.cpu().numpy() - qo).max(axis=1)
+    assert np.median(err) < 5e-5 and err.max() < 2e-3, (np.median(err), err.max())
+    np.testing.assert_allclose(st.time.cpu().numpy(), to, rtol=1e-5)
+    assert int(st.status.max()) == 0
