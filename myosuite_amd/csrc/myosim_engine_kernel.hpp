@@ -1,0 +1,2124 @@
+#pragma once
+// myosim_engine_kernel.hpp -- MI355X (gfx950 / CDNA4) batched musculoskeletal physics step, engine v2: device code.
+// (The fused kernel template; explicit instantiations live in myosim_inst_*.hip so that they compile in parallel, the
+// host side of the C ABI in myosim_engine.hip.)
+//
+// Execution model ("lane = item"): every environment is owned by a GROUP of G adjacent lanes of one
+// 64-wide wavefront (G in {8,16,32,64}; 64/G envs per wave).  Inside the group each lane permanently
+// OWNS one item of every kind -- lane g is body g, dof g, joint-limit row g (lower) / g-G/2 (upper) --
+// and keeps that item's data in REGISTERS for the whole fused env-step (frame_skip substeps + final
+// forward + obs/reward).  Variable-length work (tendon paths, actuators) is swept with lane-strided
+// loops.  Only data that other lanes must gather lives in LDS (pose / cdof / composite-inertia tables,
+// sparse tendon Jacobian, a dense nv x nv scratch tile); HBM is touched once to load state+action and
+// once to store state+obs+reward.
+//
+// Linear algebra is DENSE and register resident: lane i holds row i of M / H / L.  Cholesky, the two
+// triangular solves and M*x run as fully unrolled lane-parallel loops whose only communication is a
+// cross-lane broadcast (v_readlane for G = 64, ds_bpermute otherwise): no LDS round trips, no level
+// synchronisation.  The constraint Newton solver keeps one (potential) joint-limit row per lane, so no
+// compaction is needed.  A wavefront executes in lock-step and the LDS services one wave's
+// instructions in order, so stage boundaries need only a compiler fence (GSYNC), never s_barrier.
+//
+// Pipeline restated (stage order of mj_step; reference call site
+// myosuite/robot/robot.py:856-861): kinematics -> comPos -> tendon(+wrap) -> limit rows -> comVel/RNE
+// -> CRB -> Cholesky -> passive/actuation -> Newton -> semi-implicit Euler (implicit joint damping).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+
+#include "../../include/myosim_model.h"
+#include "../../include/myosim.h"
+
+#define MINVALF 1e-15f
+
+// ------------------------------------------------------------------ kernel args
+struct Dims {
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, njmax, ntenJ;
+  int iterations, ls_iterations, eulerdamp, any_damping;
+  int gen;   // model has equality / contact rows: general (dense-J) constraint path
+  int integrator;   // MM_INT_EULER | MM_INT_RK4
+  float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
+};
+
+// per-env LDS tables (offsets in 32-bit words from the env's base)
+struct Layout {
+  int qpos, qvel, act, ctrl, actdot;
+  int xpos, xmat, xanchor, xaxis, com, cdof;
+  int u1;   // union: xquat[4nb] during FK | (cvel,cacc)[12nb] then cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
+  int crb;
+  int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
+  int vec;  // nv: joint-transmission actuator forces
+  int rk_qpos0, rk_act0, rk_adot;   // RK4: state at the start of the step, weighted act_dot sum (RK4 models only)
+  int efcJ, rowtab;   // general constraint rows: J [G][NVP+4] (16-byte aligned rows), row table [G][3] (GEN models only)
+  int total;
+};
+
+// debug dump layout (tests only): one record per env in global memory
+struct DbgLayout {
+  int xpos, xquat, xipos, cdof, cvel, tenlen, tenvel, tenj, actfrc, actdot, M, bias, smooth, qaccsm, qacc, qfrccon,
+      efc_active, efc_D, efc_aref, scal, total;
+};
+
+// engine-private tables appended behind the model blob on the device
+struct Aux {
+  int body_depth, body_rootslot, dof_rootslot;
+  int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
+  int root_list, nroot;
+  int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
+  int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
+};
+
+struct KArgs {
+  const uint32_t* blob;
+  int sec[MM_NSEC];
+  Dims d;
+  Layout L;
+  DbgLayout D;
+  Aux x;
+  mm_state s;
+  const float* ctrl;
+  mm_task t;
+  mm_derived o;
+  int has_derived;
+  int mode;              // 0: step(s) only, 1: forward only, 2: env step
+  float* dbg;
+  int blob_words;
+  unsigned long long* prof;
+};
+enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_ACT, PF_SOLVE0, PF_NEWTON, PF_EULER,
+       PF_IO, PF_TOTAL, NPROF };
+
+#define MI_(S) (reinterpret_cast<const int*>(mb + a.sec[MM_SEC_##S]))
+#define MF_(S) (reinterpret_cast<const float*>(mb + a.sec[MM_SEC_##S]))
+#define AUXI(f) (reinterpret_cast<const int*>(mb + a.x.f))
+
+#define GSYNC()                                           \
+  do {                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                      \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// ------------------------------------------------------------------ small math
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ Q4 ldq(const float* p) { Q4 q = {p[0], p[1], p[2], p[3]}; return q; }
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  Q4 r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  return r;
+}
+__device__ __forceinline__ Q4 qnorm(Q4 q) {
+  float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n < MINVALF) { Q4 r = {1.f, 0.f, 0.f, 0.f}; return r; }
+  float i = 1.f / n;
+  Q4 r = {q.w * i, q.x * i, q.y * i, q.z * i};
+  return r;
+}
+struct M3 { float m[9]; };
+__device__ __forceinline__ M3 q2m(Q4 q) {
+  M3 r;
+  float w = q.w, x = q.x, y = q.y, z = q.z;
+  r.m[0] = w * w + x * x - y * y - z * z; r.m[4] = w * w - x * x + y * y - z * z; r.m[8] = w * w - x * x - y * y + z * z;
+  r.m[1] = 2.f * (x * y - w * z); r.m[3] = 2.f * (x * y + w * z);
+  r.m[2] = 2.f * (x * z + w * y); r.m[6] = 2.f * (x * z - w * y);
+  r.m[5] = 2.f * (y * z - w * x); r.m[7] = 2.f * (y * z + w * x);
+  return r;
+}
+__device__ __forceinline__ M3 ldm(const float* p) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.m[i] = p[i];
+  return r;
+}
+__device__ __forceinline__ V3 mv(const M3& m, V3 v) {
+  return v3(m.m[0] * v.x + m.m[1] * v.y + m.m[2] * v.z, m.m[3] * v.x + m.m[4] * v.y + m.m[5] * v.z,
+            m.m[6] * v.x + m.m[7] * v.y + m.m[8] * v.z);
+}
+__device__ __forceinline__ V3 mtv(const M3& m, V3 v) {
+  return v3(m.m[0] * v.x + m.m[3] * v.y + m.m[6] * v.z, m.m[1] * v.x + m.m[4] * v.y + m.m[7] * v.z,
+            m.m[2] * v.x + m.m[5] * v.y + m.m[8] * v.z);
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// sin/cos for |x| <= ~8 (joint half-angles): Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials
+// (max abs error ~1.5e-7: at the fp32 rounding level of the quaternion it feeds).
+__device__ __forceinline__ void sincos_small(float x, float* s, float* c) {
+  float k = rintf(x * 0.636619772367581f);
+  float r = fmaf(-k, 1.5707963705062866f, x);
+  r = fmaf(-k, -4.371138828673793e-8f, r);
+  float r2 = r * r;
+  float sp = fmaf(fmaf(fmaf(2.718311493989822e-6f, r2, -1.984090227e-4f), r2, 8.3333169e-3f), r2, -0.16666667f);
+  float sn = fmaf(sp * r2, r, r);
+  float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625e-3f), r2, 4.166664568e-2f), r2, -0.5f);
+  float cs = fmaf(cp, r2, 1.f);
+  int q = (int)k & 3;
+  float ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// spatial inertia (Ixx Iyy Izz Ixy Ixz Iyz, m*r[3], m) times motion vector [w; v]
+__device__ __forceinline__ void inert_mul(float* res, const float* I, const float* v) {
+  V3 w = ld3(v), l = ld3(v + 3), mr = ld3(I + 6);
+  V3 c1 = cross(mr, l), c2 = cross(mr, w);
+  res[0] = I[0] * w.x + I[3] * w.y + I[4] * w.z + c1.x;
+  res[1] = I[3] * w.x + I[1] * w.y + I[5] * w.z + c1.y;
+  res[2] = I[4] * w.x + I[5] * w.y + I[2] * w.z + c1.z;
+  res[3] = I[9] * l.x - c2.x; res[4] = I[9] * l.y - c2.y; res[5] = I[9] * l.z - c2.z;
+}
+__device__ __forceinline__ void cross_motion(float* res, const float* v, const float* s) {
+  V3 w = ld3(v), l = ld3(v + 3), sa = ld3(s), sl = ld3(s + 3);
+  st3(res, cross(w, sa)); st3(res + 3, cross(w, sl) + cross(l, sa));
+}
+__device__ __forceinline__ void cross_force(float* res, const float* v, const float* f) {
+  V3 w = ld3(v), l = ld3(v + 3), fa = ld3(f), fl = ld3(f + 3);
+  st3(res, cross(w, fa) + cross(l, fl));
+  st3(res + 3, cross(w, fl));
+}
+
+// ---------------------------------------------------------------- group helpers
+// broadcast lane j (group-uniform index) of the group
+template <int G>
+__device__ __forceinline__ float bc(float v, int j) {
+  const int iv = __builtin_bit_cast(int, v);
+  if constexpr (G == 64) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, j));
+  } else if constexpr (G == 32) {
+    // one v_readlane per env of the wave + a select: no LDS crossbar round trip
+    int s0 = __builtin_amdgcn_readlane(iv, j), s1 = __builtin_amdgcn_readlane(iv, j + 32);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? s1 : s0);
+  } else if constexpr (G == 16) {
+    int s0 = __builtin_amdgcn_readlane(iv, j), s1 = __builtin_amdgcn_readlane(iv, j + 16);
+    int s2 = __builtin_amdgcn_readlane(iv, j + 32), s3 = __builtin_amdgcn_readlane(iv, j + 48);
+    const int q = (threadIdx.x >> 4) & 3;
+    return __builtin_bit_cast(float, q == 0 ? s0 : (q == 1 ? s1 : (q == 2 ? s2 : s3)));
+  } else {
+    return __shfl(v, j, G);
+  }
+}
+// gather from a lane-varying source inside the group
+template <int G>
+__device__ __forceinline__ float sh(float v, int src) { return __shfl(v, src, G); }
+
+// ---- group reductions on the DPP network (no LDS crossbar round trips) ----------------------------------------
+// Stages: xor 1 / xor 2 inside quads (quad_perm), quads -> 8 lanes (row_half_mirror), 8 -> 16 lanes (row_mirror); rows of
+// 16 are combined through v_readlane.  Every stage is symmetric (lane i and its partner compute a op b and b op a), so
+// the result is BITWISE IDENTICAL in every lane of the group -- group-uniform decisions (line-search alpha, loop exits)
+// rely on that.  The adds are explicit (__fadd_rn): a contracted fma(a_i, b_i, partner) would differ between partners.
+#define DPP_QUAD_XOR1 0xB1
+#define DPP_QUAD_XOR2 0x4E
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+template <int G>
+__device__ __forceinline__ float gsum(float v) {
+  v = __fadd_rn(v, dppf<DPP_QUAD_XOR1>(v));
+  v = __fadd_rn(v, dppf<DPP_QUAD_XOR2>(v));
+  if constexpr (G >= 8) v = __fadd_rn(v, dppf<DPP_ROW_HALF_MIRROR>(v));
+  if constexpr (G >= 16) v = __fadd_rn(v, dppf<DPP_ROW_MIRROR>(v));
+  if constexpr (G == 32) {
+    float a0 = __fadd_rn(rl(v, 0), rl(v, 16)), a1 = __fadd_rn(rl(v, 32), rl(v, 48));
+    v = (threadIdx.x & 32) ? a1 : a0;
+  }
+  if constexpr (G == 64) v = __fadd_rn(__fadd_rn(rl(v, 0), rl(v, 16)), __fadd_rn(rl(v, 32), rl(v, 48)));
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float gmax(float v) {
+  v = fmaxf(v, dppf<DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dppf<DPP_QUAD_XOR2>(v));
+  if constexpr (G >= 8) v = fmaxf(v, dppf<DPP_ROW_HALF_MIRROR>(v));
+  if constexpr (G >= 16) v = fmaxf(v, dppf<DPP_ROW_MIRROR>(v));
+  if constexpr (G == 32) {
+    float a0 = fmaxf(rl(v, 0), rl(v, 16)), a1 = fmaxf(rl(v, 32), rl(v, 48));
+    v = (threadIdx.x & 32) ? a1 : a0;
+  }
+  if constexpr (G == 64) v = fmaxf(fmaxf(rl(v, 0), rl(v, 16)), fmaxf(rl(v, 32), rl(v, 48)));
+  return v;
+}
+template <int G>
+__device__ __forceinline__ int gor(int v) {
+  v |= dppi<DPP_QUAD_XOR1>(v);
+  v |= dppi<DPP_QUAD_XOR2>(v);
+  if constexpr (G >= 8) v |= dppi<DPP_ROW_HALF_MIRROR>(v);
+  if constexpr (G >= 16) v |= dppi<DPP_ROW_MIRROR>(v);
+  if constexpr (G == 32) {
+    int a0 = __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16);
+    int a1 = __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+    v = (threadIdx.x & 32) ? a1 : a0;
+  }
+  if constexpr (G == 64)
+    v = __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+  return v;
+}
+
+// ------------------------------------------------------------- tendon wrapping (A2)
+__device__ __forceinline__ bool seg_intersect(float p1x, float p1y, float p2x, float p2y, float p3x, float p3y,
+                                               float p4x, float p4y) {
+  float det = (p4y - p3y) * (p2x - p1x) - (p4x - p3x) * (p2y - p1y);
+  // (nearly) parallel segments never cross; the relative test keeps the decision out of fp32 rounding noise
+  // at wrap onset, where both tangent segments lie along the chord
+  float n12 = (p2x - p1x) * (p2x - p1x) + (p2y - p1y) * (p2y - p1y), n34 = (p4x - p3x) * (p4x - p3x) + (p4y - p3y) * (p4y - p3y);
+  if (fabsf(det) < MINVALF || det * det < 4e-6f * n12 * n34) return false;
+  float a = ((p4x - p3x) * (p1y - p3y) - (p4y - p3y) * (p1x - p3x)) / det;
+  float b = ((p2x - p1x) * (p1y - p3y) - (p2y - p1y) * (p1x - p3x)) / det;
+  return a >= 0.f && a <= 1.f && b >= 0.f && b <= 1.f;
+}
+
+__device__ __forceinline__ float wrap_circle(float pnt[4], float d0x, float d0y, float d1x, float d1y, bool has_side,
+                                             float sdx, float sdy, float radius) {
+  float sqlen0 = d0x * d0x + d0y * d0y, sqlen1 = d1x * d1x + d1y * d1y, sqrad = radius * radius;
+  float difx = d1x - d0x, dify = d1y - d0y;
+  float dd = difx * difx + dify * dify;
+  float aa = clampf(-(difx * d0x + dify * d0y) / fmaxf(dd, MINVALF), 0.f, 1.f);
+  float tx = d0x + aa * difx, ty = d0y + aa * dify;
+  if (tx * tx + ty * ty > sqrad && (!has_side || sdx * tx + sdy * ty >= 0.f)) return -1.f;
+  if (sqlen0 < sqrad || sqlen1 < sqrad) return -1.f;
+  float sqrt0 = sqrtf(sqlen0 - sqrad), sqrt1 = sqrtf(sqlen1 - sqrad);
+  float s0[4], s1[4], good0, good1;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    float sgn = i == 0 ? 1.f : -1.f;
+    float* sol = i == 0 ? s0 : s1;
+    sol[0] = (d0x * sqrad + sgn * radius * d0y * sqrt0) / sqlen0;
+    sol[1] = (d0y * sqrad - sgn * radius * d0x * sqrt0) / sqlen0;
+    sol[2] = (d1x * sqrad - sgn * radius * d1y * sqrt1) / sqlen1;
+    sol[3] = (d1y * sqrad + sgn * radius * d1x * sqrt1) / sqlen1;
+    float good;
+    if (has_side) {
+      float ux = sol[0] + sol[2], uy = sol[1] + sol[3];
+      float n = fmaxf(sqrtf(ux * ux + uy * uy), MINVALF);
+      good = (ux * sdx + uy * sdy) / n;
+    } else {
+      float ux = sol[0] - sol[2], uy = sol[1] - sol[3];
+      good = -(ux * ux + uy * uy);
+    }
+    if (seg_intersect(d0x, d0y, sol[0], sol[1], d1x, d1y, sol[2], sol[3])) good = -10000.f;
+    if (i == 0) good0 = good; else good1 = good;
+  }
+  bool pick0 = good0 > good1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) pnt[k] = pick0 ? s0[k] : s1[k];
+  if (seg_intersect(d0x, d0y, pnt[0], pnt[1], d1x, d1y, pnt[2], pnt[3])) return -1.f;
+  float c = clampf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqrad, -1.f, 1.f);
+  return radius * acosf(c);
+}
+
+__device__ __forceinline__ float wrap_geom(V3& w0, V3& w1, V3 x0, V3 x1, V3 gpos, const M3& gmat, float radius,
+                                           bool is_cyl, bool has_side, V3 side) {
+  V3 p0 = mtv(gmat, x0 - gpos), p1 = mtv(gmat, x1 - gpos);
+  float n0 = sqrtf(dot(p0, p0)), n1 = sqrtf(dot(p1, p1));
+  if (n0 < MINVALF || n1 < MINVALF) return -1.f;
+  V3 ax0, ax1;
+  if (is_cyl) {
+    ax0 = v3(1.f, 0.f, 0.f); ax1 = v3(0.f, 1.f, 0.f);
+  } else {
+    ax0 = (1.f / n0) * p0;
+    V3 nrm = cross(p0, p1);
+    float nn = sqrtf(dot(nrm, nrm));
+    if (nn < MINVALF) {
+      V3 e = v3(1.f, 0.f, 0.f);
+      float m = fabsf(ax0.x);
+      if (fabsf(ax0.y) < m) { e = v3(0.f, 1.f, 0.f); m = fabsf(ax0.y); }
+      if (fabsf(ax0.z) < m) { e = v3(0.f, 0.f, 1.f); }
+      nrm = cross(ax0, e);
+      nn = sqrtf(dot(nrm, nrm));
+    }
+    nrm = (1.f / fmaxf(nn, MINVALF)) * nrm;
+    ax1 = cross(nrm, ax0);
+    ax1 = (1.f / fmaxf(sqrtf(dot(ax1, ax1)), MINVALF)) * ax1;
+  }
+  float d0x = dot(p0, ax0), d0y = dot(p0, ax1), d1x = dot(p1, ax0), d1y = dot(p1, ax1);
+  float sdx = 0.f, sdy = 0.f;
+  if (has_side) {
+    V3 s = mtv(gmat, side - gpos);
+    sdx = dot(s, ax0); sdy = dot(s, ax1);
+    float n = fmaxf(sqrtf(sdx * sdx + sdy * sdy), MINVALF);
+    sdx /= n; sdy /= n;
+  }
+  float pnt[4];
+  float wlen = wrap_circle(pnt, d0x, d0y, d1x, d1y, has_side, sdx, sdy, radius);
+  if (wlen < 0.f) return -1.f;
+  V3 r0 = pnt[0] * ax0 + pnt[1] * ax1, r1 = pnt[2] * ax0 + pnt[3] * ax1;
+  if (is_cyl) {
+    float L0 = sqrtf((p0.x - pnt[0]) * (p0.x - pnt[0]) + (p0.y - pnt[1]) * (p0.y - pnt[1]));
+    float L1 = sqrtf((p1.x - pnt[2]) * (p1.x - pnt[2]) + (p1.y - pnt[3]) * (p1.y - pnt[3]));
+    float tot = fmaxf(L0 + wlen + L1, MINVALF);
+    r0.z = p0.z + (p1.z - p0.z) * L0 / tot;
+    r1.z = p0.z + (p1.z - p0.z) * (L0 + wlen) / tot;
+    float h = fabsf(r1.z - r0.z);
+    wlen = sqrtf(wlen * wlen + h * h);
+  }
+  w0 = mv(gmat, r0) + gpos;
+  w1 = mv(gmat, r1) + gpos;
+  return wlen;
+}
+
+
+// ---- capsule axis vs convex primitive (mmo_collision.inc: sd_box / sd_cylinder / sd_ellipsoid / seg_shape) -----------
+__device__ __forceinline__ float sd_box(V3 s, V3 q, V3& grad) {
+  V3 d = v3(fabsf(q.x) - s.x, fabsf(q.y) - s.y, fabsf(q.z) - s.z);
+  const V3 sg = v3(q.x < 0.f ? -1.f : 1.f, q.y < 0.f ? -1.f : 1.f, q.z < 0.f ? -1.f : 1.f);
+  if (d.x > 0.f || d.y > 0.f || d.z > 0.f) {
+    V3 e = v3(fmaxf(d.x, 0.f), fmaxf(d.y, 0.f), fmaxf(d.z, 0.f));
+    const float n2 = dot(e, e), in_ = __frsqrt_rn(n2);
+    grad = v3(e.x * in_ * sg.x, e.y * in_ * sg.y, e.z * in_ * sg.z);
+    return n2 * in_;
+  }
+  if (d.x >= d.y && d.x >= d.z) { grad = v3(sg.x, 0.f, 0.f); return d.x; }
+  if (d.y >= d.z) { grad = v3(0.f, sg.y, 0.f); return d.y; }
+  grad = v3(0.f, 0.f, sg.z); return d.z;
+}
+__device__ __forceinline__ float sd_cylinder(V3 s, V3 q, V3& grad) {
+  const float r2 = q.x * q.x + q.y * q.y;
+  const float irho = r2 > MINVALF ? __frsqrt_rn(r2) : 0.f, rho = r2 * irho, dr = rho - s.x, dz = fabsf(q.z) - s.y;
+  const float rx = r2 > MINVALF ? q.x * irho : 1.f, ry = q.y * irho, sz = q.z < 0.f ? -1.f : 1.f;
+  if (dr > 0.f && dz > 0.f) { const float n2 = dr * dr + dz * dz, in_ = __frsqrt_rn(n2); grad = v3(dr * rx * in_, dr * ry * in_, dz * sz * in_); return n2 * in_; }
+  if (dr > dz) { grad = v3(rx, ry, 0.f); return dr; }
+  grad = v3(0.f, 0.f, sz); return dz;
+}
+// `tw` carries the Lagrange multiplier between calls: consecutive query points along the capsule axis are close, so a
+// warm-started Newton needs few iterations (F is convex and decreasing: from the right of the root the first step lands
+// left of it and the rest converge monotonically).  tw = NaN requests a cold start.
+__device__ __forceinline__ float sd_ellipsoid(V3 s, V3 q0, V3& grad, float& tw) {
+  const float sv[3] = {s.x, s.y, s.z}, qi[3] = {q0.x, q0.y, q0.z};
+  float q[3], sq[3], s2[3], f0 = -1.f, amin = sv[0];
+  int imin = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    q[i] = fabsf(qi[i]) < 1e-9f ? (qi[i] < 0.f ? -1e-9f : 1e-9f) : qi[i];
+    s2[i] = sv[i] * sv[i]; sq[i] = sv[i] * q[i];
+    const float r = q[i] * __builtin_amdgcn_rcpf(sv[i]);
+    f0 += r * r;
+    if (sv[i] < amin) { amin = sv[i]; imin = i; }
+  }
+  const float tlo = f0 >= 0.f ? 0.f : -amin * amin + amin * fabsf(q[imin]);
+  const bool cold = !(tw == tw);
+  float t = cold ? tlo : fmaxf(tw, tlo);
+  const int iters = cold ? 9 : 4;
+  for (int it = 0; it < iters; it++) {
+    float F = -1.f, dF = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const float ri = __builtin_amdgcn_rcpf(t + s2[i]), w = sq[i] * ri; F += w * w; dF -= 2.f * w * w * ri; }
+    if (dF > -MINVALF) break;
+    t = fmaxf(t - F * __builtin_amdgcn_rcpf(dF), tlo);
+  }
+  tw = t;
+  float g[3], n2 = 0.f, d2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const float ri = __builtin_amdgcn_rcpf(t + s2[i]);
+    const float x = s2[i] * q[i] * ri;
+    g[i] = q[i] * ri; n2 += g[i] * g[i]; d2 += (q[i] - x) * (q[i] - x);
+  }
+  const float inv = __frsqrt_rn(n2);
+  grad = v3(g[0] * inv, g[1] * inv, g[2] * inv);
+  return f0 >= 0.f ? sqrtf(d2) : -sqrtf(d2);
+}
+__device__ __forceinline__ float sd_shape(int type, V3 s, V3 q, V3& grad, float& tw) {
+  if (type == MM_GEOM_BOX) return sd_box(s, q, grad);
+  if (type == MM_GEOM_CYLINDER) return sd_cylinder(s, q, grad);
+  return sd_ellipsoid(s, q, grad, tw);
+}
+// minimiser of the convex g(t) = sd(a + t u) on [-h, h]: bisection on the sign of g'(t) = grad.u; flat stretches are
+// bracketed with a +-tau tolerance and their midpoint is used (same rule as the oracle)
+struct SegHit { float sd, t; V3 g; };
+__device__ __forceinline__ SegHit seg_shape_call(int type, V3 s, V3 a0, V3 u, float h);
+__device__ __forceinline__ float seg_dg(int type, V3 s, V3 a0, V3 u, float t, float& tw) {
+  V3 g;
+  sd_shape(type, s, a0 + t * u, g, tw);
+  return dot(g, u);
+}
+__device__ __forceinline__ float seg_bisect(int type, V3 s, V3 a0, V3 u, float lo, float hi, float thr, int iters, float& tw) {
+  if (seg_dg(type, s, a0, u, lo, tw) > thr) return lo;
+  if (seg_dg(type, s, a0, u, hi, tw) <= thr) return hi;
+  for (int it = 0; it < iters; it++) {
+    const float mid = 0.5f * (lo + hi);
+    if (seg_dg(type, s, a0, u, mid, tw) > thr) hi = mid; else lo = mid;
+  }
+  return 0.5f * (lo + hi);
+}
+// same rule as the oracle's seg_shape (mmo_collision.inc): root of g', flat minima of box / cylinder replaced by the
+// midpoint of their +-tau interval; 13 bisection steps resolve t to h * 2^-13 ~ 4e-6 m
+__device__ __forceinline__ float seg_shape(int type, V3 s, V3 a0, V3 u, float h, float& tbest, V3& grad) {
+  const float tau = 1e-4f;
+  float tw = __builtin_nanf("");
+  float t = seg_bisect(type, s, a0, u, -h, h, 0.f, 13, tw);
+  if (type != MM_GEOM_ELLIPSOID) {
+    const float dl = 0.02f * h;
+    float tl = t, tr = t;
+    if (seg_dg(type, s, a0, u, fmaxf(t - dl, -h), tw) > -tau) tl = seg_bisect(type, s, a0, u, -h, t, -tau, 13, tw);
+    if (seg_dg(type, s, a0, u, fminf(t + dl, h), tw) <= tau) tr = seg_bisect(type, s, a0, u, t, h, tau, 13, tw);
+    t = 0.5f * (tl + tr);
+  }
+  tbest = t;
+  return sd_shape(type, s, a0 + t * u, grad, tw);
+}
+
+__device__ __forceinline__ SegHit seg_shape_call(int type, V3 s, V3 a0, V3 u, float h) {
+  SegHit r;
+  r.sd = seg_shape(type, s, a0, u, h, r.t, r.g);
+  return r;
+}
+
+// ------------------------------------------------------------------ muscle model (A6)
+__device__ __forceinline__ float muscle_fl(float L, float lmin, float lmax) {
+  if (L < lmin || L > lmax) return 0.f;
+  float a = 0.5f * (lmin + 1.f), b = 0.5f * (1.f + lmax), x;
+  if (L <= a) { x = (L - lmin) / fmaxf(MINVALF, a - lmin); return 0.5f * x * x; }
+  if (L <= 1.f) { x = (1.f - L) / fmaxf(MINVALF, 1.f - a); return 1.f - 0.5f * x * x; }
+  if (L <= b) { x = (L - 1.f) / fmaxf(MINVALF, b - 1.f); return 1.f - 0.5f * x * x; }
+  x = (lmax - L) / fmaxf(MINVALF, lmax - b);
+  return 0.5f * x * x;
+}
+__device__ __forceinline__ float muscle_f0(const float* prm, float acc0) {
+  return prm[2] >= 0.f ? prm[2] : prm[3] / fmaxf(MINVALF, acc0);
+}
+__device__ __forceinline__ float muscle_gain(float len, float vel, float lr0, float lr1, float acc0, const float* prm) {
+  float force = muscle_f0(prm, acc0);
+  float L0 = (lr1 - lr0) / fmaxf(MINVALF, prm[1] - prm[0]);
+  float L = prm[0] + (len - lr0) / fmaxf(MINVALF, L0);
+  float V = vel / fmaxf(MINVALF, L0 * prm[6]);
+  float FL = muscle_fl(L, prm[4], prm[5]);
+  float fvmax = prm[8], y = fvmax - 1.f, FV;
+  if (V <= -1.f) FV = 0.f;
+  else if (V <= 0.f) FV = (V + 1.f) * (V + 1.f);
+  else if (V <= y) FV = fvmax - (y - V) * (y - V) / fmaxf(MINVALF, y);
+  else FV = fvmax;
+  return -force * FL * FV;
+}
+__device__ __forceinline__ float muscle_bias(float len, float lr0, float lr1, float acc0, const float* prm) {
+  float force = muscle_f0(prm, acc0);
+  float L0 = (lr1 - lr0) / fmaxf(MINVALF, prm[1] - prm[0]);
+  float L = prm[0] + (len - lr0) / fmaxf(MINVALF, L0);
+  float b = 0.5f * (1.f + prm[5]), fpmax = prm[7], x;
+  if (L <= 1.f) return 0.f;
+  if (L <= b) { x = (L - 1.f) / fmaxf(MINVALF, b - 1.f); return -force * fpmax * 0.5f * x * x; }
+  x = (L - b) / fmaxf(MINVALF, b - 1.f);
+  return -force * fpmax * (0.5f + x);
+}
+__device__ __forceinline__ float sigmoid5(float x) {
+  if (x <= 0.f) return 0.f;
+  if (x >= 1.f) return 1.f;
+  return x * x * x * (3.f * x * (2.f * x - 5.f) + 10.f);
+}
+__device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const float* prm) {
+  float cc = clampf(ctrl, 0.f, 1.f), ac = clampf(act, 0.f, 1.f);
+  float tau_act = prm[0] * (0.5f + 1.5f * ac), tau_deact = prm[1] / (0.5f + 1.5f * ac);
+  float dctrl = cc - act, tau;
+  if (prm[2] < MINVALF) tau = dctrl > 0.f ? tau_act : tau_deact;
+  else tau = tau_deact + (tau_act - tau_deact) * sigmoid5(dctrl / prm[2] + 0.5f);
+  return dctrl / fmaxf(MINVALF, tau);
+}
+
+// =========================================================================== engine
+// All member functions are collective over the G lanes of one env group.  NVP = padded nv (compile time).
+template <int G, int NVP, bool GEN, bool RK4>
+struct Engine {
+  const KArgs& a;
+  const uint32_t* mb;  // model words (LDS-resident copy or global)
+  unsigned long long pf[NPROF];
+  float* W;     // LDS tables of this env
+  const int g;  // lane within group == owned body / dof index
+  int status;   // sticky status bits (group-uniform)
+  int nefc, niter;
+  // ---- body-lane registers (valid for g < nbody)
+  V3 b_xpos, b_xipos;
+  Q4 b_xquat;
+  float b_cinert[10];
+  float b_cvel[6];
+  int b_depth, b_parent;
+  // model constants of the owned body and of its first two joints (loaded once per kernel)
+  V3 c_bpos, c_bipos;
+  Q4 c_bquat;
+  int c_jn, c_ja;
+  int c_jtype[2], c_jqadr[2], c_jdadr[2];
+  V3 c_jpos[2], c_jaxis[2];
+  float c_jq0[2];
+  // ---- dof-lane registers (valid for g < nv)
+  float d_cdof[6];
+  float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
+  float Mrow[NVP];   // row g of M (dense, symmetric)
+  float Lrow[NVP];   // row g of the current Cholesky factor  (L[g][k], k <= g)
+  float d_dinv;      // 1 / L[g][g]
+  // ---- joint-limit row owned by this lane (lower side: lanes < G/2, upper side: lanes >= G/2)
+  bool r_active;
+  float r_D, r_aref, r_sign, r_jar;
+  int r_dof;
+  // ---- general rows (GEN): lane r owns row r of efc_J (LDS); equality rows are always active
+  bool r_eq;
+  int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
+  const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
+  float rk_v0, rk_vsum, rk_asum;   // RK4: qvel at the start of the step, weighted sums of stage qvel / qacc
+  int env_gtype;            // this env's entry of mm_state.geom_type_env (or -1)
+
+  __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
+      : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
+#pragma unroll
+    for (int i = 0; i < NPROF; i++) pf[i] = 0;
+    d_warm = 0.f; d_qvel = 0.f;
+    b_depth = (g < a.d.nbody) ? AUXI(body_depth)[g] : -1;
+    b_parent = (g > 0 && g < a.d.nbody) ? MI_(BODY_PARENT)[g] : 0;
+    {
+      const bool isb = g > 0 && g < a.d.nbody;
+      c_bpos = isb ? ld3(MF_(BODY_POS) + 3 * g) : v3(0.f, 0.f, 0.f);
+      c_bipos = isb ? ld3(MF_(BODY_IPOS) + 3 * g) : v3(0.f, 0.f, 0.f);
+      Q4 q1 = {1.f, 0.f, 0.f, 0.f};
+      c_bquat = isb ? ldq(MF_(BODY_QUAT) + 4 * g) : q1;
+      c_ja = isb ? MI_(BODY_JNTADR)[g] : 0;
+      c_jn = isb ? MI_(BODY_JNTNUM)[g] : 0;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const bool has = i < c_jn;
+        const int j = has ? c_ja + i : 0;
+        c_jtype[i] = has ? MI_(JNT_TYPE)[j] : -1;
+        c_jqadr[i] = has ? MI_(JNT_QPOSADR)[j] : 0;
+        c_jdadr[i] = has ? MI_(JNT_DOFADR)[j] : 0;
+        c_jpos[i] = has ? ld3(MF_(JNT_POS) + 3 * j) : v3(0.f, 0.f, 0.f);
+        c_jaxis[i] = has ? ld3(MF_(JNT_AXIS) + 3 * j) : v3(0.f, 0.f, 1.f);
+        c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
+      }
+    }
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
+    // lanes that own no body / dof still take part in reductions with zero weights: their registers must
+    // hold finite values (0 * garbage could be NaN)
+    b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
+    Q4 qi = {1.f, 0.f, 0.f, 0.f};
+    b_xquat = qi;
+#pragma unroll
+    for (int k = 0; k < 10; k++) b_cinert[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { b_cvel[k] = 0.f; d_cdof[k] = 0.f; }
+    d_bias = d_smooth = d_qaccsm = d_qacc = d_qfrccon = 0.f; d_dinv = 1.f;
+#pragma unroll
+    for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; }
+  }
+
+  __device__ __forceinline__ float com_of_body(int b, int k) const { return W[a.L.com + 3 * AUXI(body_rootslot)[b] + k]; }
+
+  // ---------------------------------------------------------------- A1 kinematics
+  __device__ __forceinline__ void kinematics() {
+    const Layout& L = a.L;
+    if (g == 0) {
+      b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
+      Q4 q = {1.f, 0.f, 0.f, 0.f};
+      b_xquat = q;
+      st3(W + L.xpos, b_xpos);
+      W[L.u1] = 1.f; W[L.u1 + 1] = 0.f; W[L.u1 + 2] = 0.f; W[L.u1 + 3] = 0.f;
+      for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+    }
+    GSYNC();
+    for (int lv = 1; lv <= a.d.nlevel; lv++) {
+      if (b_depth == lv) {
+        const int b = g, p = b_parent;
+        M3 pm = ldm(W + L.xmat + 9 * p);
+        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, c_bpos);
+        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), c_bquat);
+        for (int i = 0; i < c_jn; i++) {
+          const int j = c_ja + i;
+          int type, qa; V3 jpos, jax; float q0;
+          if (i == 0) { type = c_jtype[0]; qa = c_jqadr[0]; jpos = c_jpos[0]; jax = c_jaxis[0]; q0 = c_jq0[0]; }
+          else if (i == 1) { type = c_jtype[1]; qa = c_jqadr[1]; jpos = c_jpos[1]; jax = c_jaxis[1]; q0 = c_jq0[1]; }
+          else { type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
+          if (type == MM_JNT_FREE) {
+            pos = ld3(W + L.qpos + qa);
+            quat = qnorm(ldq(W + L.qpos + qa + 3));
+            st3(W + L.xanchor + 3 * j, pos);
+            M3 m = q2m(quat);
+            st3(W + L.xaxis + 3 * j, v3(m.m[2], m.m[5], m.m[8]));
+            continue;
+          }
+          M3 m = q2m(quat);
+          V3 anchor = pos + mv(m, jpos), axis = mv(m, jax);
+          st3(W + L.xanchor + 3 * j, anchor);
+          st3(W + L.xaxis + 3 * j, axis);
+          if (type == MM_JNT_SLIDE) {
+            pos = pos + (W[L.qpos + qa] - q0) * axis;
+          } else if (type == MM_JNT_HINGE) {
+            float ang = W[L.qpos + qa] - q0;
+            float sn, cs;
+            sincos_small(0.5f * ang, &sn, &cs);
+            Q4 ql = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
+            quat = qmul(quat, ql);
+            pos = anchor - mv(q2m(quat), jpos);
+          } else {  // ball
+            quat = qmul(quat, qnorm(ldq(W + L.qpos + qa)));
+            pos = anchor - mv(q2m(quat), jpos);
+          }
+        }
+        quat = qnorm(quat);
+        M3 m = q2m(quat);
+        b_xpos = pos; b_xquat = quat;
+        st3(W + L.xpos + 3 * b, pos);
+        W[L.u1 + 4 * b] = quat.w; W[L.u1 + 4 * b + 1] = quat.x; W[L.u1 + 4 * b + 2] = quat.y; W[L.u1 + 4 * b + 3] = quat.z;
+        for (int k = 0; k < 9; k++) W[L.xmat + 9 * b + k] = m.m[k];
+        b_xipos = pos + mv(m, c_bipos);
+      }
+      GSYNC();
+    }
+  }
+
+  __device__ __forceinline__ V3 site_pos(int s) const {
+    int b = MI_(SITE_BODYID)[s];
+    return ld3(W + a.L.xpos + 3 * b) + mv(ldm(W + a.L.xmat + 9 * b), ld3(MF_(SITE_POS) + 3 * s));
+  }
+  __device__ __forceinline__ V3 geom_pos(int gi) const {
+    int b = MI_(GEOM_BODYID)[gi];
+    return ld3(W + a.L.xpos + 3 * b) + mv(ldm(W + a.L.xmat + 9 * b), ld3(MF_(GEOM_POS) + 3 * gi));
+  }
+  __device__ __forceinline__ M3 geom_mat(int gi) const {  // xmat_body * R(geom_quat)
+    int b = MI_(GEOM_BODYID)[gi];
+    M3 A = ldm(W + a.L.xmat + 9 * b), B = q2m(ldq(MF_(GEOM_QUAT) + 4 * gi)), R;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) R.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return R;
+  }
+
+  // subtree COM of each tree root, body inertias about it (registers), dof motion axes (LDS + registers)
+  __device__ __forceinline__ void com_pos() {
+    const Layout& L = a.L;
+    const int nb = a.d.nbody;
+    const bool isb = g > 0 && g < nb;
+    float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+    int myslot = isb ? AUXI(body_rootslot)[g] : -1;
+    for (int r = 0; r < a.x.nroot; r++) {
+      float w = (myslot == r) ? ms : 0.f;
+      float sm = gsum<G>(w), sx = gsum<G>(w * b_xipos.x), sy = gsum<G>(w * b_xipos.y), sz = gsum<G>(w * b_xipos.z);
+      if (g == 0) {
+        int rb = AUXI(root_list)[r];
+        V3 c;
+        if (sm < MINVALF) c = ld3(W + L.xpos + 3 * rb);
+        else c = (1.f / sm) * v3(sx, sy, sz);
+        st3(W + L.com + 3 * r, c);
+      }
+    }
+    GSYNC();
+    if (isb) {
+      V3 c = ld3(W + L.com + 3 * myslot);
+      M3 R = q2m(qmul(b_xquat, ldq(MF_(BODY_IQUAT) + 4 * g)));
+      V3 I = ld3(MF_(BODY_INERTIA) + 3 * g);
+      V3 r = b_xipos - c;
+      float xx = 0.f, yy = 0.f, zz = 0.f, xy = 0.f, xz = 0.f, yz = 0.f;
+      const float Iv[3] = {I.x, I.y, I.z};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        xx += R.m[k] * Iv[k] * R.m[k]; yy += R.m[3 + k] * Iv[k] * R.m[3 + k]; zz += R.m[6 + k] * Iv[k] * R.m[6 + k];
+        xy += R.m[k] * Iv[k] * R.m[3 + k]; xz += R.m[k] * Iv[k] * R.m[6 + k]; yz += R.m[3 + k] * Iv[k] * R.m[6 + k];
+      }
+      float r2 = dot(r, r);
+      b_cinert[0] = xx + ms * (r2 - r.x * r.x); b_cinert[1] = yy + ms * (r2 - r.y * r.y); b_cinert[2] = zz + ms * (r2 - r.z * r.z);
+      b_cinert[3] = xy - ms * r.x * r.y; b_cinert[4] = xz - ms * r.x * r.z; b_cinert[5] = yz - ms * r.y * r.z;
+      b_cinert[6] = ms * r.x; b_cinert[7] = ms * r.y; b_cinert[8] = ms * r.z; b_cinert[9] = ms;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 10; k++) b_cinert[k] = 0.f;
+    }
+    // motion axes of the dof(s) owned by this lane (lane g == dof g)
+    if (g < a.d.nv) {
+      int j = MI_(DOF_JNTID)[g], b = MI_(JNT_BODYID)[j], type = MI_(JNT_TYPE)[j], da = MI_(JNT_DOFADR)[j];
+      V3 off = ld3(W + L.com + 3 * AUXI(dof_rootslot)[g]) - ld3(W + L.xanchor + 3 * j);
+      V3 ang, lin;
+      if (type == MM_JNT_HINGE) { ang = ld3(W + L.xaxis + 3 * j); lin = cross(ang, off); }
+      else if (type == MM_JNT_SLIDE) { ang = v3(0.f, 0.f, 0.f); lin = ld3(W + L.xaxis + 3 * j); }
+      else {
+        int k = g - da;
+        if (type == MM_JNT_FREE && k < 3) { ang = v3(0.f, 0.f, 0.f); lin = v3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f); }
+        else {
+          if (type == MM_JNT_FREE) k -= 3;
+          const float* R = W + L.xmat + 9 * b;
+          ang = v3(R[k], R[3 + k], R[6 + k]); lin = cross(ang, off);
+        }
+      }
+      d_cdof[0] = ang.x; d_cdof[1] = ang.y; d_cdof[2] = ang.z; d_cdof[3] = lin.x; d_cdof[4] = lin.y; d_cdof[5] = lin.z;
+#pragma unroll
+      for (int k = 0; k < 6; k++) W[L.cdof + 6 * g + k] = d_cdof[k];
+    }
+    GSYNC();
+  }
+
+  // ---------------------------------------------------------------- A2 tendons
+  // add the contributions of one straight segment (point p0 -> p1, unit direction u) to the sparse J row
+  __device__ __forceinline__ void tenj_segment(int l0, int l1, V3 p0, V3 p1, V3 u) {
+    const Layout& L = a.L;
+    const int* lst = AUXI(seg_list);
+    for (int e = l0; e < l1; e++) {
+      int w = lst[e];
+      int dof = w & 0xff, ep = (w >> 8) & 1, ent = w >> 9;
+      V3 p = ep ? p1 : p0;
+      V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[dof]);
+      V3 ang = ld3(W + L.cdof + 6 * dof), lin = ld3(W + L.cdof + 6 * dof + 3);
+      float val = dot(u, lin + cross(ang, off));
+      atomicAdd(&W[L.tenj + ent], ep ? val : -val);
+    }
+  }
+
+  // Path items are flattened over ALL tendons on the host (Aux.item_tab, 8 words each:
+  // {tendon, kind, k0, site0, site1, geom, sidesite, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site,
+  // 2 = site-cylinder-site, 3 = fixed-tendon joint term) and sorted so that the expensive wrap items come first: a sweep
+  // of G lanes then executes one kind of item, instead of every lane walking its own tendon with divergent item kinds.
+  // Lengths and Jacobian entries are accumulated with LDS float atomics (one wave: deterministic lane order).
+  __device__ __forceinline__ void tendon() {
+    const Layout& L = a.L;
+    const int *sa = AUXI(sega_adr), *sb = AUXI(segb_adr), *sc = AUXI(segc_adr);
+    const int* items = AUXI(item_tab);
+    for (int e = g; e < a.d.ntenJ; e += G) W[L.tenj + e] = 0.f;
+    for (int t = g; t < a.d.ntendon; t += G) W[L.tenlen + t] = 0.f;
+    GSYNC();
+    for (int it = g; it < a.x.nitem; it += G) {
+      const int* I = items + 8 * it;
+      const int t = I[0], kind = I[1], k0 = I[2];
+      const float inv_div = __int_as_float(I[7]);
+      if (kind == 3) {   // fixed tendon: coef * q_joint
+        const int jn = I[3];
+        const float coef = __int_as_float(I[4]);
+        atomicAdd(&W[L.tenlen + t], coef * W[L.qpos + MI_(JNT_QPOSADR)[jn]]);
+        const int dof = MI_(JNT_DOFADR)[jn];
+        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++)
+          if (MI_(TENJ_DOF)[e] == dof) { atomicAdd(&W[L.tenj + e], coef); break; }
+        continue;
+      }
+      V3 p0 = site_pos(I[3]), p1 = site_pos(I[4]);
+      float wlen = -1.f;
+      V3 w0, w1;
+      if (kind != 0) {
+        const int gi = I[5], sideid = I[6];
+        V3 side = v3(0.f, 0.f, 0.f);
+        if (sideid >= 0) side = site_pos(sideid);
+        wlen = wrap_geom(w0, w1, p0, p1, geom_pos(gi), geom_mat(gi), MF_(GEOM_SIZE)[3 * gi], kind == 2, sideid >= 0, side);
+      }
+      if (wlen < 0.f) {
+        V3 dif = p1 - p0;
+        float n = sqrtf(dot(dif, dif));
+        atomicAdd(&W[L.tenlen + t], n * inv_div);
+        if (sa[k0 + 1] > sa[k0]) {
+          V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
+          tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
+        }
+      } else {
+        V3 d0 = w0 - p0, d1 = p1 - w1;
+        float n0 = sqrtf(dot(d0, d0)), n1 = sqrtf(dot(d1, d1));
+        atomicAdd(&W[L.tenlen + t], (n0 + wlen + n1) * inv_div);
+        if (sb[k0 + 1] > sb[k0])
+          tenj_segment(sb[k0], sb[k0 + 1], p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
+        if (sc[k0 + 1] > sc[k0])
+          tenj_segment(sc[k0], sc[k0 + 1], w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
+      }
+    }
+    GSYNC();
+  }
+
+  // ------------------------------------------------------------- A7 joint-limit rows (one per lane)
+  __device__ __forceinline__ void impedance(const float* si, const float* sr, float x, float diagApprox, float vel,
+                                            float& D, float& aref) const {
+    float dmin = clampf(si[0], 0.0001f, 0.9999f), dmax = clampf(si[1], 0.0001f, 0.9999f);
+    float width = fmaxf(0.f, si[2]), mid = clampf(si[3], 0.0001f, 0.9999f), power = fmaxf(1.f, si[4]);
+    float imp;
+    if (width < MINVALF || dmin == dmax) imp = 0.5f * (dmin + dmax);
+    else {
+      float xa = fabsf(x) / width, y;
+      if (xa >= 1.f) imp = dmax;
+      else if (xa == 0.f) imp = dmin;
+      else {
+        if (power == 1.f) y = xa;
+        else if (power == 2.f) y = xa <= mid ? xa * xa / mid : 1.f - (1.f - xa) * (1.f - xa) / (1.f - mid);
+        else if (xa <= mid) y = powf(xa, power) / powf(mid, power - 1.f);
+        else y = 1.f - powf(1.f - xa, power) / powf(1.f - mid, power - 1.f);
+        imp = dmin + y * (dmax - dmin);
+      }
+    }
+    float R = fmaxf(MINVALF, (1.f - imp) * diagApprox / imp);
+    float K, B;
+    if (sr[0] > 0.f) {
+      float tc = fmaxf(sr[0], 2.f * a.d.timestep), dr = sr[1];
+      K = 1.f / fmaxf(MINVALF, dmax * dmax * tc * tc * dr * dr);
+      B = 2.f / fmaxf(MINVALF, dmax * tc);
+    } else { K = -sr[0] / fmaxf(MINVALF, dmax * dmax); B = -sr[1] / fmaxf(MINVALF, dmax); }
+    D = 1.f / R;
+    aref = -B * vel - K * imp * x;
+  }
+
+  // One potential limit row per JOINT, owned by lane j: a joint can violate only one side of its range at a
+  // time (mm_model_create rejects ranges narrower than 2*margin).
+  __device__ __forceinline__ void make_constraint() {
+    if constexpr (GEN) { make_constraint_gen(); return; }
+    const Layout& L = a.L;
+    const int j = g;
+    r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = 1.f;
+    if (j < a.d.njnt) {
+      int type = MI_(JNT_TYPE)[j];
+      if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+        r_dof = MI_(JNT_DOFADR)[j];
+        float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
+        float margin = MF_(JNT_MARGIN)[j];
+        float dlo = q - MF_(JNT_RANGE)[2 * j], dhi = MF_(JNT_RANGE)[2 * j + 1] - q;
+        float dist = dlo;
+        if (!(dlo < margin) && dhi < margin) { dist = dhi; r_sign = -1.f; }
+        if (dist < margin) {
+          r_active = true;
+          impedance(MF_(JNT_SOLIMP) + 5 * j, MF_(JNT_SOLREF) + 2 * j, dist - margin, MF_(DOF_INVWEIGHT0)[r_dof],
+                    r_sign * W[L.qvel + r_dof], r_D, r_aref);
+        }
+      }
+    }
+    nefc = (int)(gsum<G>(r_active ? 1.f : 0.f) + 0.5f);
+  }
+
+  // value of the limit row of the joint that owns dof g (0 for dofs that are not a hinge/slide joint's dof)
+  __device__ __forceinline__ float rows_to_dof(float val) const {
+    int j = g < a.d.nv ? MI_(DOF_JNTID)[g] : 0;
+    float v = sh<G>(val, j);
+    bool mine = g < a.d.nv && MI_(JNT_DOFADR)[j] == g;
+    return mine ? v : 0.f;
+  }
+
+  // ----------------------------------------------------- A5 velocity stage + bias forces
+  __device__ __forceinline__ void velocity_bias() {
+    const Layout& L = a.L;
+    const int nb = a.d.nbody;
+    for (int t = g; t < a.d.ntendon; t += G) {
+      float s = 0.f;
+      for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) s += W[L.tenj + e] * W[L.qvel + MI_(TENJ_DOF)[e]];
+      W[L.tenvel + t] = s;
+    }
+    // forward pass over tree levels; parent values come straight from the parent's lane
+    float cv[6], ca[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cv[k] = 0.f; ca[k] = 0.f; }
+    // parents publish (cvel, cacc) in LDS (u1 region, 12 words per body: three 128-bit accesses instead of twelve
+    // cross-lane permutes per level)
+    if (g == 0) {
+      ca[3] = -a.d.gx; ca[4] = -a.d.gy; ca[5] = -a.d.gz;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { W[L.u1 + k] = 0.f; W[L.u1 + 6 + k] = ca[k]; }
+    }
+    GSYNC();
+    for (int lv = 1; lv <= a.d.nlevel; lv++) {
+      if (b_depth == lv) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cv[k] = W[L.u1 + 12 * b_parent + k]; ca[k] = W[L.u1 + 12 * b_parent + 6 + k]; }
+        for (int i = 0; i < c_jn; i++) {
+          int type, da;
+          if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
+          else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
+          else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
+          if (type == MM_JNT_FREE) {
+            for (int d3 = 0; d3 < 3; d3++) {
+              float qv = W[L.qvel + da + d3];
+              for (int k = 0; k < 6; k++) cv[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
+            }
+            da += 3;
+            type = MM_JNT_BALL;
+          }
+          int nd = type == MM_JNT_BALL ? 3 : 1;
+          float base[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) base[k] = cv[k];
+          for (int d3 = 0; d3 < nd; d3++) {
+            float cd[6], cdd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cd[k] = W[L.cdof + 6 * (da + d3) + k];
+            cross_motion(cdd, base, cd);
+            float qv = W[L.qvel + da + d3];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { cv[k] += cd[k] * qv; ca[k] += cdd[k] * qv; }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { W[L.u1 + 12 * g + k] = cv[k]; W[L.u1 + 12 * g + 6 + k] = ca[k]; }
+      }
+      GSYNC();
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) b_cvel[k] = cv[k];
+    // cfrc_body = I*cacc + cvel x* (I*cvel)
+    float cf[6];
+    {
+      float Ia[6], Iv[6], x[6];
+      inert_mul(Ia, b_cinert, ca); inert_mul(Iv, b_cinert, cv); cross_force(x, cv, Iv);
+#pragma unroll
+      for (int k = 0; k < 6; k++) cf[k] = (g > 0 && g < nb) ? Ia[k] + x[k] : 0.f;
+    }
+    // backward accumulation through LDS (u1 region now holds cfrc[6*nbody]); deepest level first
+    GSYNC();
+    if (g < nb)
+#pragma unroll
+      for (int k = 0; k < 6; k++) W[L.u1 + 6 * g + k] = 0.f;
+    GSYNC();
+    for (int lv = a.d.nlevel; lv >= 1; lv--) {
+      if (b_depth == lv) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          float tot = cf[k] + W[L.u1 + 6 * g + k];
+          W[L.u1 + 6 * g + k] = tot;
+          if (b_parent > 0) atomicAdd(&W[L.u1 + 6 * b_parent + k], tot);
+        }
+      }
+      GSYNC();
+    }
+    d_bias = 0.f;
+    if (g < a.d.nv) {
+      int b = MI_(DOF_BODYID)[g];
+#pragma unroll
+      for (int k = 0; k < 6; k++) d_bias += d_cdof[k] * W[L.u1 + 6 * b + k];
+    }
+    GSYNC();
+  }
+
+  // ---------------------------------------------------------------- A4 CRB -> dense M rows
+  __device__ __forceinline__ void crb() {
+    const Layout& L = a.L;
+    const int nb = a.d.nbody, nv = a.d.nv;
+    if (g < nb)
+#pragma unroll
+      for (int k = 0; k < 10; k++) W[L.crb + 10 * g + k] = b_cinert[k];
+    // zero the dense tile (u1 region; cfrc is dead now) and put 1 on the padded diagonal
+    for (int e = g; e < NVP * NVP; e += G) W[L.u1 + e] = 0.f;
+    GSYNC();
+    for (int lv = a.d.nlevel; lv >= 2; lv--) {
+      if (b_depth == lv && b_parent > 0)
+#pragma unroll
+        for (int k = 0; k < 10; k++) atomicAdd(&W[L.crb + 10 * b_parent + k], W[L.crb + 10 * g + k]);
+      GSYNC();
+    }
+    if (g < nv) {
+      float I[10], buf[6];
+      int b = MI_(DOF_BODYID)[g];
+#pragma unroll
+      for (int k = 0; k < 10; k++) I[k] = W[L.crb + 10 * b + k];
+      inert_mul(buf, I, d_cdof);
+      const int* dpar = MI_(DOF_PARENTID);
+      int j = g;
+      while (j >= 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += W[L.cdof + 6 * j + k] * buf[k];
+        if (j == g) s += MF_(DOF_ARMATURE)[g];
+        W[L.u1 + g * NVP + j] = s;
+        W[L.u1 + j * NVP + g] = s;
+        j = dpar[j];
+      }
+    } else if (g < NVP) {
+      W[L.u1 + g * NVP + g] = 1.f;
+    }
+    GSYNC();
+    if (g < NVP) {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) Mrow[k] = W[L.u1 + g * NVP + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) Mrow[k] = 0.f;
+    }
+    GSYNC();
+  }
+
+  // dense Cholesky H = L L' with lane i holding row i; `dadd` is added to this lane's diagonal element.
+  // Right-looking form: after column j is scaled, the updates of the trailing columns are independent FMAs
+  // (instruction-level parallelism) instead of one serial dot-product chain per column.
+  // Leaves Lrow (L[g][k]) and d_dinv (1/L[g][g]) in registers and L in the LDS tile (for the L' solve).
+  __device__ __forceinline__ void factor(float dadd) {
+    float A[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == g ? dadd : 0.f);
+    factor_core(A);
+  }
+  __device__ __forceinline__ void factor_core(float (&A)[NVP]) {
+    const Layout& L = a.L;
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      float piv = bc<G>(A[j], j);
+      float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
+      float lj = (g >= j) ? A[j] * inv : 0.f;
+      Lrow[j] = lj;
+      if (g == j) d_dinv = inv;
+#pragma unroll
+      for (int k = j + 1; k < NVP; k++) A[k] -= lj * bc<G>(lj, k);
+    }
+    // leave L in the dense LDS tile: the backward substitution reads its columns (= rows of L') from there
+    if (g < NVP)
+#pragma unroll
+      for (int k = 0; k < NVP; k++) W[L.u1 + g * NVP + k] = Lrow[k];
+    else d_dinv = 1.f;
+    GSYNC();
+  }
+
+  // x <- (L L')^-1 x ; lane i holds x_i
+  __device__ __forceinline__ float solve(float x) const {
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      float yj = bc<G>(x * d_dinv, j);
+      x = (g == j) ? yj : (g > j ? x - Lrow[j] * yj : x);
+    }
+    const float* LT = W + a.L.u1 + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
+#pragma unroll
+    for (int i = NVP - 1; i >= 0; i--) {
+      float zi = bc<G>(x * d_dinv, i);
+      x = (g == i) ? zi : (g < i ? x - LT[i * NVP] * zi : x);
+    }
+    return x;
+  }
+
+  // y_i = sum_j M[i][j] x_j
+  __device__ __forceinline__ float mul_m(float x) const {
+    float y = 0.f;
+#pragma unroll
+    for (int j = 0; j < NVP; j++) y += Mrow[j] * bc<G>(x, j);
+    return y;
+  }
+
+  // ------------------------------------------- A5/A6 passive + actuation -> qfrc_smooth
+  __device__ __forceinline__ void passive_actuation() {
+    const Layout& L = a.L;
+    for (int t = g; t < a.d.ntendon; t += G) {
+      float k = MF_(TENDON_STIFFNESS)[t], bd = MF_(TENDON_DAMPING)[t], f = 0.f;
+      if (k != 0.f || bd != 0.f) {
+        float len = W[L.tenlen + t], lo = MF_(TENDON_LENGTHSPRING)[2 * t], hi = MF_(TENDON_LENGTHSPRING)[2 * t + 1];
+        if (len > hi) f = k * (hi - len);
+        else if (len < lo) f = k * (lo - len);
+        f -= bd * W[L.tenvel + t];
+      }
+      W[L.tenfrc + t] = f;
+    }
+    if (g < a.d.nv) W[L.vec + g] = 0.f;
+    GSYNC();
+    for (int u = g; u < a.d.nu; u += G) {
+      float ctrl = W[L.ctrl + u];
+      if (MI_(ACT_CTRLLIMITED)[u]) ctrl = clampf(ctrl, MF_(ACT_CTRLRANGE)[2 * u], MF_(ACT_CTRLRANGE)[2 * u + 1]);
+      int aa = MI_(ACT_ACTADR)[u], id = MI_(ACT_TRNID)[u];
+      float gear = MF_(ACT_GEAR)[u], len, vel, input = ctrl;
+      bool ten = MI_(ACT_TRNTYPE)[u] == MM_TRN_TENDON;
+      if (ten) { len = gear * W[L.tenlen + id]; vel = gear * W[L.tenvel + id]; }
+      else { len = gear * W[L.qpos + MI_(JNT_QPOSADR)[id]]; vel = gear * W[L.qvel + MI_(JNT_DOFADR)[id]]; }
+      if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) {
+        float act = W[L.act + aa];
+        W[L.actdot + aa] = muscle_dynamics(ctrl, act, MF_(ACT_DYNPRM) + 3 * u);
+        input = act;
+      }
+      float lr0 = MF_(ACT_LENGTHRANGE)[2 * u], lr1 = MF_(ACT_LENGTHRANGE)[2 * u + 1], acc0 = MF_(ACT_ACC0)[u];
+      float gain, bias = 0.f;
+      if (MI_(ACT_GAINTYPE)[u] == MM_GAIN_MUSCLE) gain = muscle_gain(len, vel, lr0, lr1, acc0, MF_(ACT_GAINPRM) + 9 * u);
+      else gain = MF_(ACT_GAINPRM)[9 * u];
+      if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_MUSCLE) bias = muscle_bias(len, lr0, lr1, acc0, MF_(ACT_BIASPRM) + 9 * u);
+      float f = gain * input + bias;
+      if (MI_(ACT_FORCELIMITED)[u]) f = clampf(f, MF_(ACT_FORCERANGE)[2 * u], MF_(ACT_FORCERANGE)[2 * u + 1]);
+      W[L.actfrc + u] = f; W[L.actlen + u] = len; W[L.actvel + u] = vel;
+      if (ten) atomicAdd(&W[L.tenfrc + id], gear * f);
+      else atomicAdd(&W[L.vec + MI_(JNT_DOFADR)[id]], gear * f);
+    }
+    GSYNC();
+    // J' f: every tendon lane scatters its (<= 8) Jacobian entries into the per-dof accumulator with LDS float
+    // atomics (one wave => deterministic lane order); shorter critical path than gathering ~25 entries per wrist dof
+    for (int t = g; t < a.d.ntendon; t += G) {
+      float f = W[L.tenfrc + t];
+      if (f != 0.f)
+        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) atomicAdd(&W[L.vec + MI_(TENJ_DOF)[e]], W[L.tenj + e] * f);
+    }
+    GSYNC();
+    d_smooth = 0.f;
+    if (g < a.d.nv) {
+      float s = -MF_(DOF_DAMPING)[g] * d_qvel - d_bias + W[L.vec + g];
+      int j = MI_(DOF_JNTID)[g];
+      float ks = MF_(JNT_STIFFNESS)[j];
+      int type = MI_(JNT_TYPE)[j];
+      if (ks != 0.f && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+        int qa = MI_(JNT_QPOSADR)[j];
+        s -= ks * (W[L.qpos + qa] - MF_(QPOS_SPRING)[qa]);
+      }
+      d_smooth = s;
+    }
+  }
+
+  // ---------------------------------------------------------------- Newton solver (A7)
+  // total cost of candidate x (dof lanes) given Ma = M x; also latches r_jar
+  __device__ __forceinline__ float cost_of(float x, float Ma) {
+    float c = 0.5f * (x - d_qaccsm) * (Ma - d_smooth);
+    float xr = sh<G>(x, r_dof);
+    r_jar = r_sign * xr - r_aref;
+    if (r_active && r_jar < 0.f) c += 0.5f * r_D * r_jar * r_jar;
+    return gsum<G>(c);
+  }
+
+  __device__ __forceinline__ void solve_constraints() {
+    if constexpr (GEN) { solve_constraints_gen(); return; }
+    const int nv = a.d.nv;
+    niter = 0;
+    d_qfrccon = 0.f;
+    if (nefc == 0) { d_qacc = d_qaccsm; return; }
+    const float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
+    // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
+    float Ma_ws = mul_m(d_warm);
+    float cost_ws = cost_of(d_warm, Ma_ws);
+    float cost_sm = cost_of(d_qaccsm, d_smooth);
+    float Ma;
+    if (cost_ws < cost_sm) { d_qacc = d_warm; Ma = Ma_ws; (void)cost_of(d_qacc, Ma); }
+    else { d_qacc = d_qaccsm; Ma = d_smooth; }
+    // Termination in fp32: the cost (hundreds) carries ~1e-5 of rounding noise, far above MuJoCo's scaled
+    // tolerance, so "improvement < tol" would stop with a residual gradient.  The cost is piecewise quadratic:
+    // a FULL Newton step (alpha = 1) that leaves the active set unchanged lands on the exact minimiser, which is
+    // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
+    float alpha_prev = 0.f;
+    unsigned long long set_prev = 0ull;
+    for (int iter = 0; iter < a.d.iterations; iter++) {
+      const bool on = r_active && r_jar < 0.f;
+      const unsigned long long set_now = __ballot(on);
+      float f = on ? -r_D * r_jar : 0.f;
+      d_qfrccon = rows_to_dof(r_sign * f);
+      float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
+      float gn = sqrtf(gsum<G>(grad * grad));
+      if (scale * gn < a.d.tolerance) break;
+      if (iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
+        // compare the active sets of THIS group only
+        const int lane = threadIdx.x & 63;
+        const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
+        if (((set_now ^ set_prev) & gm) == 0ull) break;
+      }
+      set_prev = set_now;
+      float dadd = rows_to_dof(on ? r_D : 0.f);
+      factor(dadd);
+      float search = -solve(grad);
+      if (g >= nv) search = 0.f;
+      float sn = sqrtf(gsum<G>(search * search));
+      if (sn < MINVALF) break;
+      float Mv = mul_m(search);
+      float jv = r_sign * sh<G>(search, r_dof);
+      float dm = Ma - d_smooth;
+      float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
+      const float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
+      // exact line search on the convex piecewise-quadratic phi(alpha): safeguarded Newton on phi'(alpha) = 0
+      float alpha = 1.f, lo = 0.f, hi = -1.f;
+      for (int it = 0; it < a.d.ls_iterations; it++) {
+        float x = r_jar + alpha * jv;
+        float d1 = 0.f, d2 = 0.f;
+        if (r_active && x < 0.f) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
+        d1 = gsum<G>(d1) + q1 + 2.f * alpha * q2;
+        d2 = gsum<G>(d2) + 2.f * q2;
+        if (fabsf(d1) < fmaxf(gtol, 1e-6f * fabsf(q1))) break;
+        if (d1 < 0.f) lo = alpha; else hi = alpha;
+        float next = alpha - d1 / fmaxf(d2, MINVALF);
+        if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
+        else if (hi < 0.f && next <= lo) next = 2.f * lo + 1e-10f;
+        if (next == alpha) break;
+        alpha = next;
+      }
+      if (!(alpha > 0.f)) break;
+      d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
+      alpha_prev = alpha;
+      niter = iter + 1;
+      // a step below fp32 resolution of qacc cannot improve the solution (rows sitting at jar ~ 0 would
+      // otherwise toggle in and out of the active set for ever)
+      {
+        float stepmax = gmax<G>(fabsf(alpha * search)), qmax = gmax<G>(fabsf(d_qacc));
+        if (stepmax <= 2e-7f * fmaxf(qmax, 1.f)) {
+          const bool on2 = r_active && r_jar < 0.f;
+          d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
+          break;
+        }
+      }
+      if (iter == a.d.iterations - 1) {
+        const bool on2 = r_active && r_jar < 0.f;
+        d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
+        status |= 4;
+      }
+    }
+  }
+
+
+  // ===================================================== general constraint rows (GEN models)
+  // Row r of efc_J lives in LDS with a 16-byte aligned row stride (NVP+4 words): the Hessian build and J x read rows with
+  // 128-bit LDS loads (a wave-uniform row is one broadcast ds_read_b128 per four columns); lane r owns the row's scalars
+  // (D, aref, jar).  Row order: equalities, active joint
+  // limits (compacted), contact pyramid edges (compacted).  Restates mmo_make_constraint / mmo_collision.inc.
+  static constexpr int RS = NVP + 4;
+  __device__ __forceinline__ float* Jrow(int r) const { return W + a.L.efcJ + r * RS; }
+  __device__ __forceinline__ int gscan_excl(int v) const {
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) { int t = __shfl_up(incl, d, G); if (g >= d) incl += t; }
+    return incl - v;
+  }
+  __device__ __forceinline__ int gsum_i(int v) const { return (int)(gsum<G>((float)v) + 0.5f); }   // counts <= 64: exact
+  __device__ __forceinline__ V3 geom_zaxis(int gi) const {
+    M3 R = geom_mat(gi);
+    return v3(R.m[2], R.m[5], R.m[8]);
+  }
+  // Jacobian entries of one contact: rows r0.. get  +-(edge . (J_b2 - J_b1))  over the two kinematic chains
+  __device__ __forceinline__ void contact_rows(int r0, int nrow, int b1, int b2, V3 pos, V3 n, V3 t1, V3 t2, float mu) {
+    const Layout& L = a.L;
+    for (int side = 0; side < 2; side++) {
+      int b = side ? b2 : b1;
+      const float sg = side ? 1.f : -1.f;
+      while (b > 0) {
+        const int da = MI_(BODY_DOFADR)[b], dn = MI_(BODY_DOFNUM)[b];
+        for (int i = da; i < da + dn; i++) {
+          V3 ang = ld3(W + L.cdof + 6 * i), lin = ld3(W + L.cdof + 6 * i + 3);
+          V3 off = pos - ld3(W + L.com + 3 * AUXI(dof_rootslot)[i]);
+          V3 v = lin + cross(ang, off);
+          float vn = sg * dot(n, v), v1 = sg * mu * dot(t1, v), v2 = sg * mu * dot(t2, v);
+          if (nrow == 1) Jrow(r0)[i] += vn;
+          else { Jrow(r0)[i] += vn + v1; Jrow(r0 + 1)[i] += vn - v1; Jrow(r0 + 2)[i] += vn + v2; Jrow(r0 + 3)[i] += vn - v2; }
+        }
+        b = MI_(BODY_PARENT)[b];
+      }
+    }
+  }
+  // sphere-sphere building block (mmo_collision.inc: sphere_sphere); returns false when dist >= margin
+  __device__ __forceinline__ bool sph_sph(V3 c1, float r1, V3 c2, float r2, float margin, float& dist, V3& pos, V3& n) const {
+    V3 d = c2 - c1;
+    float len = sqrtf(dot(d, d));
+    dist = len - r1 - r2;
+    if (!(dist < margin)) return false;
+    n = len < MINVALF ? v3(0.f, 0.f, 1.f) : (1.f / len) * d;
+    pos = c1 + (r1 + 0.5f * dist) * n;
+    return true;
+  }
+  __device__ __forceinline__ bool pln_sph(V3 pp, V3 pn, V3 c, float r, float margin, float& dist, V3& pos, V3& n) const {
+    dist = dot(c - pp, pn) - r;
+    if (!(dist < margin)) return false;
+    n = pn;
+    pos = c - (r + 0.5f * dist) * pn;
+    return true;
+  }
+  __device__ __forceinline__ V3 seg_closest(V3 a0, V3 u, float h, V3 p) const {
+    float t = clampf(dot(p - a0, u), -h, h);
+    return a0 + t * u;
+  }
+
+  __device__ __forceinline__ void make_constraint_gen() {
+    const Layout& L = a.L;
+    float* RT = W + L.rowtab;
+    {
+      float4* Jz = reinterpret_cast<float4*>(W + L.efcJ);
+      for (int e = g; e < G * RS / 4; e += G) Jz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    GSYNC();
+    const int neq = a.d.neq;
+    // ---- equality rows: joint coupling q1 - q1_0 = poly(q2 - q2_0)
+    if (g < neq) {
+      const int e = g, j1 = MI_(EQ_OBJ1ID)[e], j2 = MI_(EQ_OBJ2ID)[e];
+      const float* c = MF_(EQ_DATA) + 5 * e;
+      const int q1 = MI_(JNT_QPOSADR)[j1], d1 = MI_(JNT_DOFADR)[j1];
+      float pos1 = W[L.qpos + q1] - MF_(QPOS0)[q1], res, deriv = 0.f;
+      float dA = MF_(DOF_INVWEIGHT0)[d1];
+      if (j2 >= 0) {
+        const int q2 = MI_(JNT_QPOSADR)[j2], d2 = MI_(JNT_DOFADR)[j2];
+        float x = W[L.qpos + q2] - MF_(QPOS0)[q2];
+        res = pos1 - (c[0] + x * (c[1] + x * (c[2] + x * (c[3] + x * c[4]))));
+        deriv = c[1] + x * (2.f * c[2] + x * (3.f * c[3] + x * 4.f * c[4]));
+        dA += MF_(DOF_INVWEIGHT0)[d2];
+        Jrow(e)[d2] = -deriv;
+      } else res = pos1 - c[0];
+      Jrow(e)[d1] = 1.f;
+      RT[3 * e] = __int_as_float(MM_CON_EQUALITY | (e << 2)); RT[3 * e + 1] = res; RT[3 * e + 2] = dA;
+    }
+    // ---- joint limits, compacted behind the equalities
+    int lim = 0, ldof = 0;
+    float ldist = 0.f, lsign = 1.f, lmargin = 0.f;
+    if (g < a.d.njnt) {
+      const int j = g, type = MI_(JNT_TYPE)[j];
+      if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+        ldof = MI_(JNT_DOFADR)[j];
+        float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
+        lmargin = MF_(JNT_MARGIN)[j];
+        float dlo = q - MF_(JNT_RANGE)[2 * j], dhi = MF_(JNT_RANGE)[2 * j + 1] - q;
+        ldist = dlo;
+        if (!(dlo < lmargin) && dhi < lmargin) { ldist = dhi; lsign = -1.f; }
+        lim = ldist < lmargin ? 1 : 0;
+      }
+    }
+    const int lrank = gscan_excl(lim), nlim = gsum_i(lim);
+    int over = 0;
+    if (lim) {
+      const int r = neq + lrank;
+      if (r < G) {
+        Jrow(r)[ldof] = lsign;
+        RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 2)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
+      } else over = 1;
+    }
+    // ---- contacts: lane p handles explicit pair p (up to two contacts for plane-capsule)
+    const unsigned long long tc0_ = a.prof ? clock64() : 0;
+    int nc = 0, rowsper = 0, b1 = 0, b2 = 0;
+    float cdist[2] = {0.f, 0.f}, mu = 0.f, incl = 0.f;
+    V3 cpos[2], cn[2];
+    cpos[0] = cpos[1] = cn[0] = cn[1] = v3(0.f, 0.f, 0.f);
+    if (g < a.d.npair) {
+      const int p = g, g1 = MI_(PAIR_GEOM1)[p], g2 = MI_(PAIR_GEOM2)[p];
+      int t1 = MI_(GEOM_TYPE)[g1], t2 = MI_(GEOM_TYPE)[g2];
+      if (env_gtype >= 0) {   // per-env model delta: type of one geom (mm_state.geom_type_env)
+        if (g1 == a.s.geom_env_id) t1 = env_gtype;
+        if (g2 == a.s.geom_env_id) t2 = env_gtype;
+      }
+      const float margin = MF_(PAIR_MARGIN)[p];
+      incl = margin - MF_(PAIR_GAP)[p];
+      mu = MF_(PAIR_FRICTION)[3 * p];
+      rowsper = MI_(PAIR_CONDIM)[p] == 1 ? 1 : 4;
+      b1 = MI_(GEOM_BODYID)[g1]; b2 = MI_(GEOM_BODYID)[g2];
+      V3 x1 = geom_pos(g1), x2 = geom_pos(g2);
+      float r1 = MF_(GEOM_SIZE)[3 * g1], h1 = MF_(GEOM_SIZE)[3 * g1 + 1];
+      float r2 = MF_(GEOM_SIZE)[3 * g2], h2 = MF_(GEOM_SIZE)[3 * g2 + 1];
+      if (env_gsize) {   // per-env model delta: size of one geom (mm_state.geom_size_env)
+        if (g1 == a.s.geom_env_id) { r1 = env_gsize[0]; h1 = env_gsize[1]; }
+        if (g2 == a.s.geom_env_id) { r2 = env_gsize[0]; h2 = env_gsize[1]; }
+      }
+      if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_SPHERE) {
+        nc = pln_sph(x1, geom_zaxis(g1), x2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_CAPSULE) {
+        V3 pn = geom_zaxis(g1), u2 = geom_zaxis(g2);
+        for (int sgn = 0; sgn < 2; sgn++) {
+          V3 c = x2 + (sgn ? h2 : -h2) * u2;
+          float dd; V3 pp, nn;
+          if (pln_sph(x1, pn, c, r2, margin, dd, pp, nn)) { cdist[nc] = dd; cpos[nc] = pp; cn[nc] = nn; nc++; }
+        }
+      } else if (t1 == MM_GEOM_SPHERE && t2 == MM_GEOM_SPHERE) {
+        nc = sph_sph(x1, r1, x2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if (t1 == MM_GEOM_SPHERE && t2 == MM_GEOM_CAPSULE) {
+        V3 c = seg_closest(x2, geom_zaxis(g2), h2, x1);
+        nc = sph_sph(x1, r1, c, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if (t1 == MM_GEOM_CAPSULE && t2 == MM_GEOM_CAPSULE) {
+        V3 u1 = geom_zaxis(g1), u2 = geom_zaxis(g2), w = x1 - x2;
+        float bb = dot(u1, u2), dd = dot(u1, w), ee = dot(u2, w), den = 1.f - bb * bb;
+        float s1 = den < 1e-9f ? 0.f : (bb * ee - dd) / den;
+        s1 = clampf(s1, -h1, h1);
+        float s2 = ee + bb * s1;
+        if (s2 < -h2 || s2 > h2) { s2 = s2 < -h2 ? -h2 : h2; s1 = clampf(bb * s2 - dd, -h1, h1); }
+        nc = sph_sph(x1 + s1 * u1, r1, x2 + s2 * u2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
+      } else if ((t1 == MM_GEOM_CAPSULE && t2 >= MM_GEOM_ELLIPSOID) || (t2 == MM_GEOM_CAPSULE && t1 >= MM_GEOM_ELLIPSOID)) {
+        // capsule vs ellipsoid / cylinder / box (mmo_collision.inc: capsule_convex); flip: the convex geom is geom1
+        const bool flip = t2 == MM_GEOM_CAPSULE;
+        const int gc = flip ? g2 : g1, gs = flip ? g1 : g2, ts = flip ? t1 : t2;
+        const V3 xc = flip ? x2 : x1, xs = flip ? x1 : x2;
+        const float rc = flip ? r2 : r1, hc = flip ? h2 : h1;
+        V3 ss = ld3(MF_(GEOM_SIZE) + 3 * gs);
+        if (env_gsize && gs == a.s.geom_env_id) ss = ld3(env_gsize);
+        const V3 uc = geom_zaxis(gc);
+        const M3 ms = geom_mat(gs);
+        const SegHit hit = seg_shape_call(ts, ss, mtv(ms, xc - xs), mtv(ms, uc), hc);
+        const float tt = hit.t, sd = hit.sd;
+        const V3 gsh = hit.g;
+        const float dd = sd - rc;
+        if (dd < margin) {
+          V3 gw = mv(ms, gsh);
+          cdist[0] = dd;
+          cpos[0] = (xc + tt * uc) - (rc + 0.5f * dd) * gw;
+          cn[0] = flip ? gw : -1.f * gw;
+          nc = 1;
+        }
+      }
+    }
+    if (a.prof) pf[PF_IO] += clock64() - tc0_;   // narrow phase only (reported as 'io' = collide)
+    int myrows = 0;
+    for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
+    int base = neq + nlim + gscan_excl(myrows);
+    const int ncrows = gsum_i(myrows);
+    for (int c = 0; c < 2; c++) {
+      if (!(c < nc && cdist[c] < incl)) continue;
+      if (base + rowsper > G) { over = 1; continue; }
+      // contact frame (mmo_collision.inc: make_frame)
+      V3 n = cn[c];
+      V3 y = (n.y < 0.5f && n.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
+      y = y - dot(n, y) * n;
+      y = (1.f / fmaxf(sqrtf(dot(y, y)), MINVALF)) * y;
+      V3 z = cross(n, y);
+      contact_rows(base, rowsper, b1, b2, cpos[c], n, y, z, mu);
+      const float tran = MF_(BODY_INVWEIGHT0)[2 * b1] + MF_(BODY_INVWEIGHT0)[2 * b2];
+      for (int k = 0; k < rowsper; k++) {
+        RT[3 * (base + k)] = __int_as_float(MM_CON_CONTACT | (g << 2));
+        RT[3 * (base + k) + 1] = cdist[c] - incl;
+        RT[3 * (base + k) + 2] = rowsper == 1 ? tran : tran + mu * mu * tran;
+      }
+      base += rowsper;
+    }
+    if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
+    nefc = neq + nlim + ncrows;
+    if (nefc > G) nefc = G;
+    {
+      int w = nefc;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) w = max(w, __shfl_xor(w, m, 64));
+      nrows_wave = __builtin_amdgcn_readfirstlane(w);
+    }
+    GSYNC();
+    // ---- owner stage: impedance / reference acceleration of row g (mmo_reference_constraint + pyramid R)
+    r_active = g < nefc; r_eq = false; r_D = 0.f; r_aref = 0.f; r_jar = 0.f;
+    if (r_active) {
+      const int desc = __float_as_int(RT[3 * g]), kind = desc & 3, id = desc >> 2;
+      const float x = RT[3 * g + 1], dA = RT[3 * g + 2];
+      float vel = 0.f;
+      const float* J = Jrow(g);
+      for (int k = 0; k < a.d.nv; k++) vel += J[k] * W[L.qvel + k];
+      const float *si, *sr;
+      if (kind == MM_CON_EQUALITY) { si = MF_(EQ_SOLIMP) + 5 * id; sr = MF_(EQ_SOLREF) + 2 * id; }
+      else if (kind == MM_CON_LIMIT_JOINT) { si = MF_(JNT_SOLIMP) + 5 * id; sr = MF_(JNT_SOLREF) + 2 * id; }
+      else { si = MF_(PAIR_SOLIMP) + 5 * id; sr = MF_(PAIR_SOLREF) + 2 * id; }
+      impedance(si, sr, x, dA, vel, r_D, r_aref);
+      if (kind == MM_CON_CONTACT && MI_(PAIR_CONDIM)[id] > 1) {
+        const float m_ = MF_(PAIR_FRICTION)[3 * id];
+        r_D = 1.f / fmaxf(MINVALF, 2.f * m_ * m_ / r_D);
+      }
+      r_eq = kind == MM_CON_EQUALITY;
+    }
+  }
+
+  // (J x)_r for the row owned by this lane; x lives in the dof lanes
+  __device__ __forceinline__ float jac_mul(float x) const {
+    const float4* J = reinterpret_cast<const float4*>(Jrow(g));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVP / 4; k++) {
+      const float4 j4 = J[k];
+      s += j4.x * bc<G>(x, 4 * k) + j4.y * bc<G>(x, 4 * k + 1) + j4.z * bc<G>(x, 4 * k + 2) + j4.w * bc<G>(x, 4 * k + 3);
+    }
+    return s;
+  }
+  // (J' f)_i for the dof owned by this lane; f lives in the row lanes
+  __device__ __forceinline__ float jacT_mul(float f) const {
+    const float* Jc = W + a.L.efcJ + (g < NVP ? g : 0);
+    float s = 0.f;
+    for (int r = 0; r < nrows_wave; r++) s += Jc[r * RS] * bc<G>(f, r);
+    return g < a.d.nv ? s : 0.f;
+  }
+  __device__ __forceinline__ float cost_gen(float x, float Ma) {
+    float c = 0.5f * (x - d_qaccsm) * (Ma - d_smooth);
+    r_jar = jac_mul(x) - r_aref;
+    if (r_active && (r_eq || r_jar < 0.f)) c += 0.5f * r_D * r_jar * r_jar;
+    return gsum<G>(c);
+  }
+
+  __device__ __forceinline__ void solve_constraints_gen() {
+    const int nv = a.d.nv;
+    niter = 0;
+    d_qfrccon = 0.f;
+    if (nrows_wave == 0) { d_qacc = d_qaccsm; return; }
+    const float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
+    float Ma_ws = mul_m(d_warm);
+    float cost_ws = cost_gen(d_warm, Ma_ws);
+    float cost_sm = cost_gen(d_qaccsm, d_smooth);
+    float Ma;
+    if (cost_ws < cost_sm) { d_qacc = d_warm; Ma = Ma_ws; (void)cost_gen(d_qacc, Ma); }
+    else { d_qacc = d_qaccsm; Ma = d_smooth; }
+    float alpha_prev = 0.f;
+    unsigned long long set_prev = 0ull;
+    bool done = nefc == 0;     // envs of the wave that have no rows idle through the loop (wave-collective code below)
+    for (int iter = 0; iter < a.d.iterations; iter++) {
+      const bool on = r_active && (r_eq || r_jar < 0.f);
+      const unsigned long long set_now = __ballot(on);
+      d_qfrccon = jacT_mul(on ? -r_D * r_jar : 0.f);
+      float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
+      float gn = sqrtf(gsum<G>(grad * grad));
+      if (scale * gn < a.d.tolerance) done = true;
+      if (!done && iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
+        const int lane = threadIdx.x & 63;
+        const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
+        if (((set_now ^ set_prev) & gm) == 0ull) done = true;
+      }
+      if (__ballot(!done) == 0ull) break;
+      set_prev = set_now;
+      // H = M + J_A' D J_A : lane i accumulates row i, the J row is an LDS broadcast
+      float A[NVP];
+#pragma unroll
+      for (int k = 0; k < NVP; k++) A[k] = Mrow[k];
+      {
+        const float dr = on ? r_D : 0.f;
+        const int col = g < NVP ? g : 0;
+        for (int r = 0; r < nrows_wave; r++) {
+          const float sD = bc<G>(dr, r);
+          if (__ballot(sD != 0.f) == 0ull) continue;
+          const float* Jr = W + a.L.efcJ + r * RS;
+          const float c = g < NVP ? sD * Jr[col] : 0.f;
+          const float4* Jr4 = reinterpret_cast<const float4*>(Jr);
+#pragma unroll
+          for (int k = 0; k < NVP / 4; k++) {
+            const float4 j4 = Jr4[k];
+            A[4 * k] += c * j4.x; A[4 * k + 1] += c * j4.y; A[4 * k + 2] += c * j4.z; A[4 * k + 3] += c * j4.w;
+          }
+        }
+      }
+      factor_core(A);
+      float search = -solve(grad);
+      if (g >= nv || done) search = 0.f;
+      float sn = sqrtf(gsum<G>(search * search));
+      if (sn < MINVALF) done = true;
+      float Mv = mul_m(search);
+      float jv = jac_mul(search);
+      float dm = Ma - d_smooth;
+      float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
+      const float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
+      float alpha = 1.f, lo = 0.f, hi = -1.f;
+      bool lsdone = done;
+      for (int it = 0; it < a.d.ls_iterations; it++) {
+        float x = r_jar + alpha * jv;
+        float d1 = 0.f, d2 = 0.f;
+        if (r_active && (r_eq || x < 0.f)) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
+        d1 = gsum<G>(d1) + q1 + 2.f * alpha * q2;
+        d2 = gsum<G>(d2) + 2.f * q2;
+        if (!lsdone) {
+          if (fabsf(d1) < fmaxf(gtol, 1e-6f * fabsf(q1))) lsdone = true;
+          else {
+            if (d1 < 0.f) lo = alpha; else hi = alpha;
+            float next = alpha - d1 / fmaxf(d2, MINVALF);
+            if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
+            else if (hi < 0.f && next <= lo) next = 2.f * lo + 1e-10f;
+            if (next == alpha) lsdone = true;
+            alpha = next;
+          }
+        }
+        if (__ballot(!lsdone) == 0ull) break;
+      }
+      if (!(alpha > 0.f)) done = true;
+      if (!done) {
+        d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
+        alpha_prev = alpha;
+        niter = iter + 1;
+      }
+      {
+        float stepmax = gmax<G>(fabsf(alpha * search)), qmax = gmax<G>(fabsf(d_qacc));
+        if (!done && stepmax <= 2e-7f * fmaxf(qmax, 1.f)) done = true;
+      }
+      if (iter == a.d.iterations - 1 && !done) status |= 4;
+    }
+    const bool on2 = r_active && (r_eq || r_jar < 0.f);
+    d_qfrccon = jacT_mul(on2 ? -r_D * r_jar : 0.f);
+  }
+
+  // ------------------------------------------------------------------ pipeline
+#define PFT(stage, call)                                   \
+  do {                                                     \
+    unsigned long long t0_ = a.prof ? clock64() : 0;       \
+    call;                                                  \
+    if (a.prof) pf[stage] += clock64() - t0_;              \
+  } while (0)
+  __device__ __forceinline__ void forward() {
+    PFT(PF_KIN, kinematics());
+    PFT(PF_COM, com_pos());
+    PFT(PF_TENDON, tendon());
+    PFT(PF_CONSTR, make_constraint());
+    PFT(PF_VEL, velocity_bias());
+    PFT(PF_CRB, crb());
+    PFT(PF_FACTOR, factor(0.f));
+    PFT(PF_ACT, passive_actuation());
+    PFT(PF_SOLVE0, d_qaccsm = solve(d_smooth));
+    PFT(PF_NEWTON, solve_constraints());
+  }
+
+  __device__ __forceinline__ bool bad_state(bool check_acc) {
+    const Layout& L = a.L;
+    int bad = 0;
+    for (int i = g; i < a.d.nq; i += G) bad |= !(fabsf(W[L.qpos + i]) < 1e10f);
+    if (g < a.d.nv) {
+      bad |= !(fabsf(d_qvel) < 1e10f);
+      if (check_acc) bad |= !(fabsf(d_qacc) < 1e10f);
+    }
+    return gor<G>(bad) != 0;
+  }
+  __device__ __forceinline__ void reset_data() {
+    const Layout& L = a.L;
+    for (int i = g; i < a.d.nq; i += G) W[L.qpos + i] = MF_(QPOS0)[i];
+    d_qvel = 0.f; d_warm = 0.f;
+    if (g < a.d.nv) W[L.qvel + g] = 0.f;
+    for (int i = g; i < a.d.na; i += G) W[L.act + i] = 0.f;
+    GSYNC();
+  }
+
+  // A9 semi-implicit Euler with implicit joint damping
+  __device__ __forceinline__ void euler(float& time) {
+    const Layout& L = a.L;
+    const float h = a.d.timestep;
+    d_warm = d_qacc;
+    float qa_ = d_qacc;
+    if (a.d.any_damping && a.d.eulerdamp) {
+      factor(g < a.d.nv ? h * MF_(DOF_DAMPING)[g] : 0.f);
+      qa_ = solve(g < a.d.nv ? d_smooth + d_qfrccon : 0.f);
+    }
+    for (int u = g; u < a.d.nu; u += G) {
+      int aa = MI_(ACT_ACTADR)[u];
+      if (aa < 0) continue;
+      float x = W[L.act + aa] + h * W[L.actdot + aa];
+      if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
+      W[L.act + aa] = x;
+    }
+    if (g < a.d.nv) {
+      d_qvel += h * qa_;
+      W[L.qvel + g] = d_qvel;
+    }
+    GSYNC();
+    integrate_pos(L.qvel, h);
+    time += h;
+    GSYNC();
+  }
+
+  // qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos); vel = LDS vector at word offset `voff`
+  __device__ __forceinline__ void integrate_pos(int voff, float hh) {
+    const Layout& L = a.L;
+    for (int j = g; j < a.d.njnt; j += G) {
+      int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j], da = MI_(JNT_DOFADR)[j];
+      if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[L.qpos + qa] += hh * W[voff + da]; continue; }
+      if (type == MM_JNT_FREE) {
+        for (int k = 0; k < 3; k++) W[L.qpos + qa + k] += hh * W[voff + da + k];
+        qa += 3; da += 3;
+      }
+      V3 w = ld3(W + voff + da);
+      float nw = sqrtf(dot(w, w)), ang = hh * nw;
+      if (ang > MINVALF) {
+        float sn, cs;
+        sincos_small(0.5f * ang, &sn, &cs);
+        float is = sn / nw;
+        Q4 dq = {cs, w.x * is, w.y * is, w.z * is};
+        Q4 qn = qnorm(qmul(ldq(W + L.qpos + qa), dq));
+        W[L.qpos + qa] = qn.w; W[L.qpos + qa + 1] = qn.x; W[L.qpos + qa + 2] = qn.y; W[L.qpos + qa + 3] = qn.z;
+      }
+    }
+  }
+
+  // One stage of classical RK4 (mj_RungeKutta, N = 4; oracle: mmo_rk4).  Called after the forward pass of stage `i`
+  // (i = 0 is mj_step's own forward).  Stages 0..2 move the state to X0 + h a_i F_i; stage 3 applies the weighted update.
+  __device__ __forceinline__ void rk4_stage(int i, float& time, float t0) {
+    const Layout& L = a.L;
+    const float h = a.d.timestep;
+    const float A_ = i == 2 ? 1.f : 0.5f;
+    const float B_ = (i == 0 || i == 3) ? (1.f / 6.f) : (1.f / 3.f);
+    d_warm = d_qacc;
+    if (i == 0) {
+      rk_v0 = d_qvel; rk_vsum = 0.f; rk_asum = 0.f;
+      for (int k = g; k < a.d.nq; k += G) W[L.rk_qpos0 + k] = W[L.qpos + k];
+      for (int k = g; k < a.d.na; k += G) { W[L.rk_act0 + k] = W[L.act + k]; W[L.rk_adot + k] = 0.f; }
+    }
+    rk_vsum += B_ * d_qvel; rk_asum += B_ * d_qacc;
+    for (int k = g; k < a.d.na; k += G) W[L.rk_adot + k] += B_ * W[L.actdot + k];
+    GSYNC();
+    // velocity used for the position update of this stage goes through the (free) L.vec scratch vector
+    const float hh = i < 3 ? h * A_ : h;
+    if (g < a.d.nv) W[L.vec + g] = i < 3 ? d_qvel : rk_vsum;
+    for (int k = g; k < a.d.nq; k += G) W[L.qpos + k] = W[L.rk_qpos0 + k];
+    GSYNC();
+    integrate_pos(L.vec, hh);
+    if (g < a.d.nv) {
+      d_qvel = i < 3 ? rk_v0 + hh * d_qacc : rk_v0 + h * rk_asum;
+      W[L.qvel + g] = d_qvel;
+    }
+    for (int u = g; u < a.d.nu; u += G) {
+      int aa = MI_(ACT_ACTADR)[u];
+      if (aa < 0) continue;
+      float x = i < 3 ? W[L.rk_act0 + aa] + hh * W[L.actdot + aa] : W[L.rk_act0 + aa] + h * W[L.rk_adot + aa];
+      if (i == 3 && MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
+      W[L.act + aa] = x;
+    }
+    time = i < 3 ? t0 + hh : t0 + h;
+    GSYNC();
+  }
+
+  // `nsub` mj_step substeps (forward + Euler, MuJoCo bad-state auto-reset semantics) followed by an
+  // optional mj_forward on the final state.  One call site of forward() keeps the code size bounded.
+  __device__ __forceinline__ void run(int nsub, bool final_forward, float& time) {
+    int total = nsub + (final_forward ? 1 : 0);
+    int s = 0;
+    bool redo = false;
+    if constexpr (!RK4) {
+      while (s < total) {
+        const bool stepping = s < nsub;
+        if (stepping && !redo && bad_state(false)) { reset_data(); time = 0.f; status |= 1; }
+        forward();
+        if (stepping) {
+          if (!redo && bad_state(true)) { reset_data(); time = 0.f; status |= 1; redo = true; continue; }
+          PFT(PF_EULER, euler(time));
+          redo = false;
+        }
+        s++;
+      }
+    } else {
+      // RK4 is a compile-time variant: its stage machine costs the Euler kernels registers if it shares their code
+      int rk = 0;
+      float t0 = time;
+      while (s < total) {
+        const bool stepping = s < nsub;
+        if (stepping && rk == 0 && !redo && bad_state(false)) { reset_data(); time = 0.f; status |= 1; }
+        forward();
+        if (stepping) {
+          if (rk == 0 && !redo && bad_state(true)) { reset_data(); time = 0.f; status |= 1; redo = true; continue; }
+          if (rk == 0) t0 = time;
+          PFT(PF_EULER, rk4_stage(rk, time, t0));
+          rk = (rk + 1) & 3;
+          if (rk == 0) { redo = false; s++; }
+          continue;
+        }
+        s++;
+      }
+    }
+  }
+};
+
+// =========================================================================== kernels
+template <int G, int NVP, bool LM, bool GEN, bool RK4>
+__global__ void __launch_bounds__(512) k_engine(KArgs a) {
+  extern __shared__ float lds[];
+  constexpr int EPW = 64 / G;  // envs per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int g = lane % G;
+  unsigned long long t_start = a.prof ? clock64() : 0;
+  // ---- stage the model tables into LDS once per block (all waves participate)
+  const uint32_t* mb = a.blob;
+  float* wsbase = lds;
+  if (LM) {
+    uint32_t* lm = reinterpret_cast<uint32_t*>(lds);
+    for (int i = threadIdx.x; i < a.blob_words; i += blockDim.x) lm[i] = a.blob[i];
+    __syncthreads();
+    mb = lm;
+    wsbase = lds + ((a.blob_words + 3) & ~3);
+  }
+  int e = (blockIdx.x * wpb + wave) * EPW + lane / G;
+  const int nenv = a.s.nenv;
+  if ((blockIdx.x * wpb + wave) * EPW >= nenv) return;  // whole wave idle
+  bool dup = e >= nenv;
+  if (dup) e = nenv - 1;  // surplus groups recompute the last env (they never store)
+  if (a.mode == 2 && a.t.env_mask && !a.t.env_mask[e]) dup = true;   // masked-out envs are left untouched
+  const bool obs_only = a.mode == 2 && a.t.obs_only;
+  if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
+  float* W = wsbase + (size_t)(wave * EPW + lane / G) * a.L.total;
+  const Layout& L = a.L;
+  const Dims& d = a.d;
+  Engine<G, NVP, GEN, RK4> E(a, mb, W, g);
+  if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
+  if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
+
+  // ---- load state (HBM -> LDS tables / owner registers)
+  for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
+  if (g < d.nv) {
+    E.d_qvel = a.s.qvel[(size_t)e * d.nv + g];
+    E.d_warm = a.s.qacc_warmstart[(size_t)e * d.nv + g];
+    W[L.qvel + g] = E.d_qvel;
+  }
+  for (int i = g; i < d.na; i += G) W[L.act + i] = a.s.act[(size_t)e * d.na + i];
+  float time = a.s.time[e];
+  E.status = a.s.status ? a.s.status[e] : 0;
+  const mm_task& t = a.t;
+  // ---- action -> ctrl (BaseV0.step: base_v0.py:82-108)
+  for (int u = g; u < d.nu; u += G) {
+    float c = a.ctrl ? a.ctrl[(size_t)e * d.nu + u] : 0.f;
+    const bool mus = MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE;
+    if (obs_only) c = 0.f;
+    if (a.mode == 2 && !obs_only && t.normalize_act && mus) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
+    if (a.mode == 2 && !obs_only && t.fatigue && mus) {
+      // 3CC-r muscle fatigue (fatigue.py:38-76), dt = timestep * frame_skip
+      int aa = MI_(ACT_ACTADR)[u];
+      size_t k = (size_t)e * d.na + aa;
+      float MA = t.fat_MA[k], MR = t.fat_MR[k], MF = t.fat_MF[k], TL = c;
+      float dt = d.timestep * (float)t.nsubsteps;
+      float tauact = MF_(ACT_DYNPRM)[3 * u], taudeact = MF_(ACT_DYNPRM)[3 * u + 1];
+      float LD = 1.f / tauact * (0.5f + 1.5f * MA), LR = (0.5f + 1.5f * MA) / taudeact;
+      float C, rR;
+      if (MA < TL) { C = MR > (TL - MA) ? LD * (TL - MA) : LD * MR; rR = t.fat_R; }
+      else { C = LR * (TL - MA); rR = t.fat_r * t.fat_R; }
+      float lo = fmaxf(-MA / dt + t.fat_F * MA, (MR - 1.f) / dt + rR * MF);
+      float hi = fminf((1.f - MA) / dt + t.fat_F * MA, MR / dt + rR * MF);
+      C = fminf(fmaxf(C, lo), hi);
+      float dMA = (C - t.fat_F * MA) * dt, dMR = (-C + rR * MF) * dt, dMF = (t.fat_F * MA - rR * MF) * dt;
+      MA += dMA; MR += dMR; MF += dMF;
+      if (!dup) { t.fat_MA[k] = MA; t.fat_MR[k] = MR; t.fat_MF[k] = MF; }
+      c = MA;
+    }
+    W[L.ctrl + u] = c;
+  }
+  GSYNC();
+  if (a.mode == 2 && !obs_only && t.reaf_src >= 0 && t.reaf_dst >= 0 && g == 0) {  // base_v0.py:104-108
+    W[L.ctrl + t.reaf_dst] = W[L.ctrl + t.reaf_src];
+    W[L.ctrl + t.reaf_src] = 0.f;
+  }
+  GSYNC();
+  if (a.mode == 2 && t.ctrl_out && !dup)
+    for (int u = g; u < d.nu; u += G) t.ctrl_out[(size_t)e * d.nu + u] = W[L.ctrl + u];
+
+  int nsub = (a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
+  bool fwd = a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
+  E.run(nsub, fwd, time);
+
+  // ---- store state (surplus groups never write)
+  if (dup) return;
+  for (int i = g; i < d.nq; i += G) a.s.qpos[(size_t)e * d.nq + i] = W[L.qpos + i];
+  if (g < d.nv) {
+    a.s.qvel[(size_t)e * d.nv + g] = E.d_qvel;
+    a.s.qacc_warmstart[(size_t)e * d.nv + g] = E.d_warm;
+  }
+  for (int i = g; i < d.na; i += G) a.s.act[(size_t)e * d.na + i] = W[L.act + i];
+  if (g == 0) { a.s.time[e] = time; if (a.s.status) a.s.status[e] = E.status; }
+
+  // ---- derived outputs of the final forward
+  if (fwd && a.has_derived) {
+    const mm_derived& o = a.o;
+    const bool isb = g < d.nbody;
+    if (o.xpos && isb) st3(o.xpos + ((size_t)e * d.nbody + g) * 3, E.b_xpos);
+    if (o.xquat && isb) { float* q = o.xquat + ((size_t)e * d.nbody + g) * 4; q[0] = E.b_xquat.w; q[1] = E.b_xquat.x; q[2] = E.b_xquat.y; q[3] = E.b_xquat.z; }
+    if (o.xipos && isb) st3(o.xipos + ((size_t)e * d.nbody + g) * 3, E.b_xipos);
+    if (o.cvel && isb) for (int k = 0; k < 6; k++) o.cvel[((size_t)e * d.nbody + g) * 6 + k] = E.b_cvel[k];
+    if (o.subtree_com && isb) st3(o.subtree_com + ((size_t)e * d.nbody + g) * 3, ld3(W + L.com + 3 * AUXI(body_rootslot)[g]));
+    if (o.site_xpos)
+      for (int s = g; s < d.nsite; s += G) st3(o.site_xpos + ((size_t)e * d.nsite + s) * 3, E.site_pos(s));
+    if (o.geom_xpos)
+      for (int s = g; s < d.ngeom; s += G) st3(o.geom_xpos + ((size_t)e * d.ngeom + s) * 3, E.geom_pos(s));
+    if (o.actuator_length) for (int i = g; i < d.nu; i += G) o.actuator_length[(size_t)e * d.nu + i] = W[L.actlen + i];
+    if (o.actuator_velocity) for (int i = g; i < d.nu; i += G) o.actuator_velocity[(size_t)e * d.nu + i] = W[L.actvel + i];
+    if (o.actuator_force) for (int i = g; i < d.nu; i += G) o.actuator_force[(size_t)e * d.nu + i] = W[L.actfrc + i];
+    if (o.qacc && g < d.nv) o.qacc[(size_t)e * d.nv + g] = E.d_qacc;
+    if (o.ten_length) for (int i = g; i < d.ntendon; i += G) o.ten_length[(size_t)e * d.ntendon + i] = W[L.tenlen + i];
+    if (g == 0 && o.nefc) o.nefc[e] = E.nefc;
+    if (g == 0 && o.solver_niter) o.solver_niter[e] = E.niter;
+  }
+  if (a.dbg) {  // tests only: owner registers and tables in a flat record
+    float* D = a.dbg + (size_t)e * a.D.total;
+    if (g < d.nbody) {
+      st3(D + a.D.xpos + 3 * g, E.b_xpos); st3(D + a.D.xipos + 3 * g, E.b_xipos);
+      D[a.D.xquat + 4 * g] = E.b_xquat.w; D[a.D.xquat + 4 * g + 1] = E.b_xquat.x;
+      D[a.D.xquat + 4 * g + 2] = E.b_xquat.y; D[a.D.xquat + 4 * g + 3] = E.b_xquat.z;
+      for (int k = 0; k < 6; k++) D[a.D.cvel + 6 * g + k] = E.b_cvel[k];
+    }
+    if (g < d.nv) {
+      for (int k = 0; k < 6; k++) D[a.D.cdof + 6 * g + k] = E.d_cdof[k];
+#pragma unroll
+      for (int k = 0; k < NVP; k++) if (k < d.nv) D[a.D.M + g * d.nv + k] = E.Mrow[k];
+      D[a.D.bias + g] = E.d_bias; D[a.D.smooth + g] = E.d_smooth; D[a.D.qaccsm + g] = E.d_qaccsm;
+      D[a.D.qacc + g] = E.d_qacc; D[a.D.qfrccon + g] = E.d_qfrccon;
+    }
+    for (int i = g; i < d.ntendon; i += G) { D[a.D.tenlen + i] = W[L.tenlen + i]; D[a.D.tenvel + i] = W[L.tenvel + i]; }
+    for (int i = g; i < d.ntenJ; i += G) D[a.D.tenj + i] = W[L.tenj + i];
+    for (int i = g; i < d.nu; i += G) D[a.D.actfrc + i] = W[L.actfrc + i];
+    for (int i = g; i < d.na; i += G) D[a.D.actdot + i] = W[L.actdot + i];
+    D[a.D.efc_active + g] = E.r_active ? 1.f : 0.f; D[a.D.efc_D + g] = E.r_D; D[a.D.efc_aref + g] = E.r_aref;
+    if (g == 0) D[a.D.scal] = (float)E.niter;
+  }
+  if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
+    E.pf[PF_TOTAL] = clock64() - t_start;
+#pragma unroll
+    for (int i = 0; i < NPROF; i++) a.prof[i] = E.pf[i];
+  }
+
+  // ---- task stage: obs_dict / reward_dict (pose_v0.py:100-140), TimeLimit counter
+  if (a.mode == 2) {
+    int sc = 0, sc0 = 0;
+    if (t.step_count) { sc0 = t.step_count[e]; sc = obs_only ? sc0 : sc0 + 1; }
+    if (t.task == MM_TASK_POSE) {
+      const float dt = t.obs_dt;
+      const int o_err = t.obs_layout == 1 ? d.nq + d.nv + d.na : d.nq + d.nv;
+      const int o_act = t.obs_layout == 1 ? d.nq + d.nv : 2 * d.nq + d.nv;
+      float err2 = 0.f, act2 = 0.f;
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      for (int i = g; i < d.nq; i += G) {
+        float q = W[L.qpos + i];
+        float pe = t.target_jnt_value[(size_t)e * d.nq + i] - q;
+        err2 += pe * pe;
+        if (ob) { ob[i] = q; ob[o_err + i] = pe; }
+      }
+      if (ob && g < d.nv) ob[d.nq + g] = E.d_qvel * dt;
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[o_act + i] = x;
+      }
+      err2 = gsum<G>(err2); act2 = gsum<G>(act2);
+      if (g == 0) {
+        float pose_dist = sqrtf(err2), act_mag = sqrtf(act2);
+        if (d.na != 0 && t.act_reg_mean) act_mag = act_mag / (float)d.na;
+        float r_pose = -pose_dist;
+        float r_bonus = (pose_dist < t.pose_thd ? 1.f : 0.f) + (pose_dist < 1.5f * t.pose_thd ? 1.f : 0.f);
+        float r_pen = pose_dist > t.far_th ? -1.f : 0.f;
+        float r_act = -act_mag;
+        bool done = pose_dist > t.far_th;
+        if (t.rwd) {
+          float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
+          r[MM_RWD_POSE] = r_pose; r[MM_RWD_BONUS] = r_bonus; r[MM_RWD_PENALTY] = r_pen; r[MM_RWD_ACT_REG] = r_act;
+          r[MM_RWD_SPARSE] = -pose_dist; r[MM_RWD_SOLVED] = pose_dist < t.pose_thd ? 1.f : 0.f;
+          r[MM_RWD_DONE] = done ? 1.f : 0.f;
+          r[MM_RWD_DENSE] = t.w_pose * r_pose + t.w_bonus * r_bonus + t.w_act_reg * r_act + t.w_penalty * r_pen;
+        }
+        if (t.done) t.done[e] = done ? 1 : 0;
+      }
+    }
+    if (t.task == MM_TASK_REACH) {
+      // obs [qpos, qvel*dt, tip_pos, reach_err, act]; reward dict of reach_v0.py:123-151
+      const int n3 = 3 * t.ntip;
+      float err2 = 0.f, act2 = 0.f;
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      for (int i = g; i < d.nq; i += G) if (ob) ob[i] = W[L.qpos + i];
+      if (ob && g < d.nv) ob[d.nq + g] = E.d_qvel * t.obs_dt;
+      for (int i = g; i < t.ntip; i += G) {
+        V3 tip = E.site_pos(t.tip_sites[i]);
+        V3 tgt = ld3(t.target_pos + (size_t)e * n3 + 3 * i);
+        V3 er = tgt - tip;
+        err2 += dot(er, er);
+        if (ob) { st3(ob + d.nq + d.nv + 3 * i, tip); st3(ob + d.nq + d.nv + n3 + 3 * i, er); }
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[d.nq + d.nv + 2 * n3 + i] = x;
+      }
+      err2 = gsum<G>(err2); act2 = gsum<G>(act2);
+      if (g == 0) {
+        float reach_dist = sqrtf(err2), act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        float far_th = time > 2.f * t.obs_dt ? t.reach_far_th * (float)t.ntip : INFINITY;
+        float near_th = (float)t.ntip * 0.0125f;
+        float r_reach = -reach_dist;
+        float r_bonus = (reach_dist < 2.f * near_th ? 1.f : 0.f) + (reach_dist < near_th ? 1.f : 0.f);
+        float r_pen = reach_dist > far_th ? -1.f : 0.f;
+        bool done = reach_dist > far_th;
+        if (t.rwd) {
+          float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
+          r[MM_RWD_POSE] = r_reach; r[MM_RWD_BONUS] = r_bonus; r[MM_RWD_PENALTY] = r_pen; r[MM_RWD_ACT_REG] = -act_mag;
+          r[MM_RWD_SPARSE] = -reach_dist; r[MM_RWD_SOLVED] = reach_dist < near_th ? 1.f : 0.f;
+          r[MM_RWD_DONE] = done ? 1.f : 0.f;
+          r[MM_RWD_DENSE] = t.w_pose * r_reach + t.w_bonus * r_bonus + t.w_act_reg * (-act_mag) + t.w_penalty * r_pen;
+        }
+        if (t.done) t.done[e] = done ? 1 : 0;
+      }
+    }
+    if (t.task == MM_TASK_WALK) {
+      // obs / reward of WalkEnvV0 (walk_v0.py:283-325, 367-540); self.steps == step_count BEFORE this step's increment
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      const int nq2 = d.nq - 2;
+      const int o_qv = nq2, o_cv = o_qv + d.nv, o_tq = o_cv + 2, o_fh = o_tq + 4, o_h = o_fh + 2, o_fr = o_h + 1,
+                o_ph = o_fr + 6, o_ml = o_ph + 1, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = o_mf + d.nu;
+      const bool isb = g > 0 && g < d.nbody;
+      const float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+      const float mtot = gsum<G>(ms);
+      // com velocity with the reference's sign convention: mean of -cvel[:, 3:5]
+      const float cvx = gsum<G>(ms * -E.b_cvel[3]) / mtot, cvy = gsum<G>(ms * -E.b_cvel[4]) / mtot;
+      const float height = gsum<G>(ms * E.b_xipos.z) / mtot;
+      const int bp = t.walk_body[0], bt = t.walk_body[1], bl = t.walk_body[2], br = t.walk_body[3];
+      const V3 xp = v3(bc<G>(E.b_xpos.x, bp), bc<G>(E.b_xpos.y, bp), bc<G>(E.b_xpos.z, bp));
+      const V3 xl = v3(bc<G>(E.b_xpos.x, bl), bc<G>(E.b_xpos.y, bl), bc<G>(E.b_xpos.z, bl));
+      const V3 xr = v3(bc<G>(E.b_xpos.x, br), bc<G>(E.b_xpos.y, br), bc<G>(E.b_xpos.z, br));
+      const float tq0 = bc<G>(E.b_xquat.w, bt), tq1 = bc<G>(E.b_xquat.x, bt), tq2 = bc<G>(E.b_xquat.y, bt), tq3 = bc<G>(E.b_xquat.z, bt);
+      const float phase = fmodf((float)sc0 / (float)t.walk_hip_period, 1.f);
+      float act2 = 0.f;
+      if (ob) {
+        for (int i = g; i < nq2; i += G) ob[i] = W[L.qpos + 2 + i];
+        if (g < d.nv) ob[o_qv + g] = E.d_qvel * t.obs_dt;
+      }
+      for (int i = g; i < d.nu; i += G) {
+        if (ob) {
+          ob[o_ml + i] = W[L.actlen + i];
+          ob[o_mv + i] = clampf(W[L.actvel + i], -100.f, 100.f);
+          ob[o_mf + i] = clampf(W[L.actfrc + i] / 1000.f, -100.f, 100.f);
+        }
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[o_act + i] = x;
+      }
+      act2 = gsum<G>(act2);
+      if (g == 0) {
+        if (ob) {
+          ob[o_cv] = cvx; ob[o_cv + 1] = cvy;
+          ob[o_tq] = tq0; ob[o_tq + 1] = tq1; ob[o_tq + 2] = tq2; ob[o_tq + 3] = tq3;
+          ob[o_fh] = xl.z; ob[o_fh + 1] = xr.z;
+          ob[o_h] = height;
+          st3(ob + o_fr, xl - xp); st3(ob + o_fr + 3, xr - xp);
+          ob[o_ph] = phase;
+        }
+        const float* q = W + L.qpos;
+        const float dvy = t.walk_target_y_vel - cvy, dvx = t.walk_target_x_vel - cvx;
+        const float vel_reward = expf(-dvy * dvy) + expf(-dvx * dvx);
+        const float two_pi = 6.283185307179586f;
+        const float des_l = 0.8f * cosf(phase * two_pi + 3.141592653589793f), des_r = 0.8f * cosf(phase * two_pi);
+        const float el = des_l - q[t.walk_qadr[0]], er = des_r - q[t.walk_qadr[1]];
+        const float cyclic_hip = sqrtf(el * el + er * er);
+        float rr = 0.f;
+        for (int k = 0; k < 4; k++) { float dq = 5.f * (q[3 + k] - t.walk_target_rot[k]); rr += dq * dq; }
+        const float ref_rot = expf(-sqrtf(rr));
+        const float mag = 0.25f * (fabsf(q[t.walk_qadr[2]]) + fabsf(q[t.walk_qadr[3]]) + fabsf(q[t.walk_qadr[4]]) + fabsf(q[t.walk_qadr[5]]));
+        const float joint_angle_rew = expf(-5.f * mag);
+        const float act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        // |(quat2mat(qpos[3:7]) @ [1,0,0])[0]| > max_rot   (walk_v0.py:514-526)
+        const float nq_ = q[3] * q[3] + q[4] * q[4] + q[5] * q[5] + q[6] * q[6];   // quat_math.py:151-174
+        const float r00 = nq_ > 1.1920929e-07f * 4.f ? 1.f - (2.f / nq_) * (q[5] * q[5] + q[6] * q[6]) : 1.f;
+        const bool done = height < t.walk_min_height || fabsf(r00) > t.walk_max_rot;
+        if (t.rwd && !obs_only) {   // the reset observation leaves the terminal step's reward terms in place
+          float* r = t.rwd + (size_t)e * MM_RWDW_COUNT;
+          r[MM_RWDW_VEL] = vel_reward; r[MM_RWDW_CYCLIC_HIP] = cyclic_hip; r[MM_RWDW_REF_ROT] = ref_rot;
+          r[MM_RWDW_JOINT_ANGLE] = joint_angle_rew; r[MM_RWDW_ACT_MAG] = act_mag; r[MM_RWDW_SPARSE] = vel_reward;
+          r[MM_RWDW_SOLVED] = vel_reward >= 1.f ? 1.f : 0.f; r[MM_RWDW_DONE] = done ? 1.f : 0.f;
+          r[MM_RWDW_DENSE] = t.walk_w[0] * vel_reward + t.walk_w[1] * (done ? 1.f : 0.f) + t.walk_w[2] * cyclic_hip +
+                             t.walk_w[3] * ref_rot + t.walk_w[4] * joint_angle_rew;
+        }
+        if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
+      }
+    }
+    if (t.task == MM_TASK_REORIENT) {
+      // obs / reward of ProprioceptiveEnvV0 (reorient_sar_v0.py:116-174)
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      const int nh = d.nq - 6;
+      const int o_pos = nh, o_vel = o_pos + 3, o_rot = o_vel + 6, o_des = o_rot + 3, o_ep = o_des + 3, o_er = o_ep + 3,
+                o_ml = o_er + 3, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = o_mf + d.nu;
+      float act2 = 0.f;
+      if (ob) {
+        for (int i = g; i < nh; i += G) ob[i] = W[L.qpos + i];
+        if (g < d.nv && g >= d.nv - 6) ob[o_vel + g - (d.nv - 6)] = E.d_qvel * t.obs_dt;
+        for (int i = g; i < d.nu; i += G) { ob[o_ml + i] = W[L.actlen + i]; ob[o_mv + i] = W[L.actvel + i]; ob[o_mf + i] = W[L.actfrc + i]; }
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[o_act + i] = x;
+      }
+      act2 = gsum<G>(act2);
+      if (g == 0) {
+        const int bo = t.reor_obj_body;
+        V3 opos = ld3(W + L.xpos + 3 * bo);
+        const float* R = W + L.xmat + 9 * bo;
+        const float sc_ = 2.f * t.reor_axis_half[e] / t.reor_pen_length;
+        V3 orot = v3(R[2] * sc_, R[5] * sc_, R[8] * sc_);
+        V3 odes = ld3(t.reor_des_rot + (size_t)e * 3);
+        V3 epos = opos - E.site_pos(t.reor_eps_site), erot = orot - odes;
+        if (ob) { st3(ob + o_pos, opos); st3(ob + o_rot, orot); st3(ob + o_des, odes); st3(ob + o_ep, epos); st3(ob + o_er, erot); }
+        const float pos_align = sqrtf(dot(epos, epos));
+        float nrm = sqrtf(dot(orot, orot)) * sqrtf(dot(odes, odes));
+        if (nrm == 0.f) nrm = 1.f;                                   // vector_math.py:26-32
+        const float rot_align = dot(orot, odes) / nrm;
+        const bool dropped = pos_align > 0.075f;
+        const float act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        const float bonus = ((rot_align > 0.9f && pos_align < 0.075f) ? 1.f : 0.f) + ((rot_align > 0.95f && pos_align < 0.075f) ? 5.f : 0.f);
+        if (t.rwd && !obs_only) {
+          float* r = t.rwd + (size_t)e * MM_RWDR_COUNT;
+          r[MM_RWDR_POS_ALIGN] = -pos_align; r[MM_RWDR_ROT_ALIGN] = rot_align; r[MM_RWDR_ACT_REG] = -act_mag;
+          r[MM_RWDR_DROP] = dropped ? -1.f : 0.f; r[MM_RWDR_BONUS] = bonus; r[MM_RWDR_SPARSE] = -pos_align + rot_align;
+          r[MM_RWDR_SOLVED] = (rot_align > 0.95f && !dropped) ? 1.f : 0.f; r[MM_RWDR_DONE] = dropped ? 1.f : 0.f;
+          r[MM_RWDR_DENSE] = t.reor_w[0] * -pos_align + t.reor_w[1] * rot_align + t.reor_w[2] * -act_mag +
+                             t.reor_w[3] * (dropped ? -1.f : 0.f) + t.reor_w[4] * bonus;
+        }
+        if (t.done && !obs_only) t.done[e] = dropped ? 1 : 0;
+      }
+    }
+    if (g == 0 && !obs_only) {
+      if (t.step_count) t.step_count[e] = sc;
+      if (t.truncated) t.truncated[e] = (t.max_episode_steps > 0 && sc >= t.max_episode_steps) ? 1 : 0;
+    }
+  }
+}
+

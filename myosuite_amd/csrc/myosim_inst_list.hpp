@@ -1,0 +1,18 @@
+// myosim_inst_list.hpp -- the ONE list of compiled k_engine<G, NVP, LM, GEN, RK4> instantiations (both LM variants each).
+// X(lanes_per_env, padded_nv, general_rows, rk4).  Used for: explicit instantiation (myosim_inst_*.hip, one group per
+// translation unit so they build in parallel), extern declarations + have_kernel() + the launch table (myosim_engine.hip).
+#pragma once
+#define MM_KERNELS_A(X) X(4, 4, 0, 0) X(8, 4, 0, 0) X(16, 4, 0, 0) X(32, 4, 0, 0) X(64, 4, 0, 0)
+#define MM_KERNELS_B(X) X(32, 24, 0, 0) X(64, 24, 0, 0) X(32, 32, 0, 0)
+#define MM_KERNELS_C(X) X(64, 32, 0, 0) X(64, 40, 0, 0) X(16, 4, 1, 0)
+#define MM_KERNELS_D(X) X(32, 24, 1, 0) X(64, 32, 1, 0)
+#define MM_KERNELS_E(X) X(64, 40, 1, 0) X(4, 4, 0, 1) X(32, 24, 0, 1)
+#define MM_KERNELS_F(X) X(32, 32, 0, 1) X(64, 40, 0, 1) X(16, 4, 1, 1) X(32, 24, 1, 1)
+#define MM_KERNELS_G(X) X(64, 32, 1, 1) X(64, 40, 1, 1)
+#define MM_KERNEL_LIST(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X)
+#define MM_INSTANTIATE(G_, N_, GN_, RK_)                                        \
+  template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_ != 0>(KArgs);   \
+  template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_ != 0>(KArgs);
+#define MM_DECLARE(G_, N_, GN_, RK_)                                                   \
+  extern template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_ != 0>(KArgs);   \
+  extern template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_ != 0>(KArgs);

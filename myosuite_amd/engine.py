@@ -19,7 +19,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("MYOSIM_LIB", os.path.join(CSRC, "libmyosim_hip.so"))   # override only for A/B experiments
-_SOURCES = ["myosim_engine.hip"]
+# sources: every *.hip under csrc/ (see build())
 _lib = None
 
 MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK = 0, 1, 2, 3, 4
@@ -35,14 +35,32 @@ class EngineError(RuntimeError):
     pass
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in _SOURCES]
-    deps = srcs + [os.path.join(_HERE, "..", "include", h) for h in ("myosim.h", "myosim_model.h")]
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+    """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU).  The kernel instantiations are
+    spread over several translation units (myosim_inst_*.hip) that are compiled in parallel and linked into one .so."""
+    import concurrent.futures
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + \
+           [os.path.join(_HERE, "..", "include", h) for h in ("myosim.h", "myosim_model.h")]
+    deps = srcs + hdrs
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    bdir = os.path.join(CSRC, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+
+    def compile_one(src):
+        obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+            return obj
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
