@@ -159,11 +159,16 @@ register_env_with_variants(
             "reset_type": "init", "target_x_vel": 0.0, "target_y_vel": 1.2, "target_rot": None})
 
 
-# SAR reorient (myobase/__init__.py:703-725): frame_skip 5, horizon 50.  myoHandReorientID / OOD (:727-749, separate
-# test tables) are not registered.
+# SAR reorient (myobase/__init__.py:703-749): frame_skip 5, horizon 50.
 register_env_with_variants(
     id="myoHandReorient8-v0", entry_point=_reorient, max_episode_steps=50,
     kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "8"})
 register_env_with_variants(
     id="myoHandReorient100-v0", entry_point=_reorient, max_episode_steps=50,
     kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "100"})
+register_env_with_variants(
+    id="myoHandReorientID-v0", entry_point=_reorient, max_episode_steps=50,
+    kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "ID"})
+register_env_with_variants(
+    id="myoHandReorientOOD-v0", entry_point=_reorient, max_episode_steps=50,
+    kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "OOD"})

@@ -513,6 +513,10 @@ REORIENT_CYL_100 = [(0.0118, 0.044, 0.0265), (0.0189, 0.0316, 0.0415), (0.0123, 
 
 def reorient_tables(geometries: str):
     """[4][ntab][3] size tables in geom-type order capsule(3), ellipsoid(4), cylinder(5), box(6)"""
+    if str(geometries) in ("ID", "OOD"):      # 4 x 250 rows of the reference's test envs (tools/extract_reorient_tables.py)
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "envs", "data", "reorient_tables.npz")
+        return np.load(path)[str(geometries)].astype(np.float32)
     if str(geometries) == "8":
         return np.array([REORIENT_CAPS_8, REORIENT_ELLIPS_8, REORIENT_CYL_8, REORIENT_BOX_8], np.float32)
     return np.array([REORIENT_CAPS_100, REORIENT_ELLIPS_100, REORIENT_CYL_100, REORIENT_BOX_100], np.float32)

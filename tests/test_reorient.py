@@ -48,6 +48,9 @@ def test_reorient_model_and_registry():
         s = registry.spec(vid)
         assert s["max_episode_steps"] == 50 and s["kwargs"]["frame_skip"] == 5
     assert len(synth.REORIENT_CAPS_100) == 25 and len(synth.REORIENT_CAPS_8) == 2
+    for vid in ("myoHandReorientID-v0", "myoHandReorientOOD-v0"):
+        assert registry.spec(vid)["max_episode_steps"] == 50
+        assert synth.reorient_tables(registry.spec(vid)["kwargs"]["geometries"]).shape == (4, 250, 3)
 
 
 def test_segment_vs_convex_signed_distance_against_sampling(oracle_lib):
