@@ -198,6 +198,8 @@ static void build_layout(mm_model* m) {
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
+  o = (o + 3) & ~3;
+  L.xvec = take(m->nvp);
   L.efcJ = L.rowtab = 0;
   L.rk_qpos0 = L.rk_act0 = L.rk_adot = 0;
   if (d.integrator == MM_INT_RK4) { L.rk_qpos0 = take(d.nq); L.rk_act0 = take(d.na); L.rk_adot = take(d.na); }

@@ -53,6 +53,7 @@ struct Layout {
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
   int vec;  // nv: joint-transmission actuator forces
+  int xvec; // NVP (16-byte aligned): operand vector of M x products routed through LDS
   int rk_qpos0, rk_act0, rk_adot;   // RK4: state at the start of the step, weighted act_dot sum (RK4 models only)
   int efcJ, rowtab;   // general constraint rows: J [G][NVP+4] (16-byte aligned rows), row table [G][3] (GEN models only)
   int total;
@@ -1053,6 +1054,35 @@ struct Engine {
   }
   __device__ __forceinline__ void factor_core(float (&A)[NVP]) {
     const Layout& L = a.L;
+    if constexpr (G < 64 && NVP >= 8) {
+      // Left-looking form for groups narrower than the wave.  A cross-lane broadcast costs ~5 issue slots there (two
+      // v_readlane + v_mov + v_cndmask + hazard nops), and the right-looking update needs NVP^2/2 of them.  Here row j of L
+      // comes from the LDS tile instead (one 128-bit load per four entries; the tile is written column by column as the
+      // factor proceeds, LDS ops of a wave execute in order) and only the pivot is broadcast: NVP broadcasts in total.
+      float* T = W + L.u1;
+      const int row = g < NVP ? g : 0;
+#pragma unroll
+      for (int j = 0; j < NVP; j++) {
+        float s = A[j];
+#pragma unroll
+        for (int k4 = 0; k4 < (j + 3) / 4; k4++) {
+          const float4 r = *reinterpret_cast<const float4*>(T + j * NVP + 4 * k4);
+          if (4 * k4 + 0 < j) s -= Lrow[4 * k4 + 0] * r.x;
+          if (4 * k4 + 1 < j) s -= Lrow[4 * k4 + 1] * r.y;
+          if (4 * k4 + 2 < j) s -= Lrow[4 * k4 + 2] * r.z;
+          if (4 * k4 + 3 < j) s -= Lrow[4 * k4 + 3] * r.w;
+        }
+        const float piv = bc<G>(s, j);
+        const float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
+        const float lj = (g >= j) ? s * inv : 0.f;
+        Lrow[j] = lj;
+        if (g == j) d_dinv = inv;
+        if (g < NVP) T[row * NVP + j] = lj;
+      }
+      if (g >= NVP) d_dinv = 1.f;
+      GSYNC();
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NVP; j++) {
       float piv = bc<G>(A[j], j);
@@ -1090,6 +1120,17 @@ struct Engine {
   // y_i = sum_j M[i][j] x_j
   __device__ __forceinline__ float mul_m(float x) const {
     float y = 0.f;
+    if constexpr (G < 64 && NVP >= 8) {
+      // x through LDS (one write, NVP/4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts
+      float* X = W + a.L.xvec;
+      if (g < NVP) X[g] = x;
+#pragma unroll
+      for (int k4 = 0; k4 < NVP / 4; k4++) {
+        const float4 r = *reinterpret_cast<const float4*>(X + 4 * k4);
+        y += Mrow[4 * k4] * r.x + Mrow[4 * k4 + 1] * r.y + Mrow[4 * k4 + 2] * r.z + Mrow[4 * k4 + 3] * r.w;
+      }
+      return y;
+    }
 #pragma unroll
     for (int j = 0; j < NVP; j++) y += Mrow[j] * bc<G>(x, j);
     return y;
