@@ -135,11 +135,20 @@ def main():
         # HBM traffic per launch: PMC counters cannot be read from inside the process; the committed rocprofv3 summary
         # of this same command (tools/prof_round.sh -> profiles/*_pmc.json) is reported when it matches the workload
         traffic = None
+        issue = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc.json"))).get(f"{args.env}@{n}")
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc.json"))).get(f"{args.env}@{n}")
             if pm:
                 traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
-        except (OSError, ValueError):
+                # the honest roof of this kernel: fp32 vector issue.  VALU-busy quad-cycles per SIMD over the quad-cycles
+                # the kernel lasts (wave cycles / resident waves per SIMD); 1024 SIMDs on the chip
+                waves_per_simd = pm["sq_waves"] / 1024.0
+                issue = {"valu_busy_frac": pm["sq_active_inst_valu"] / (pm["sq_wave_quadcycles"] / waves_per_simd),
+                         "wave_issue_frac": pm["sq_active_inst_any"] / pm["sq_wave_quadcycles"],
+                         "wave_waitcnt_frac": pm["sq_wait_any"] / pm["sq_wave_quadcycles"],
+                         "valu_insts_per_env_step": pm["sq_insts_valu"] * 64 / n / 64,
+                         "source": "profiles/r01c_pmc.json (rocprofv3 PMC of this command)"}
+        except (OSError, ValueError, KeyError):
             pass
         achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9 if b_alg else None
         out = {
@@ -153,7 +162,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": (b_alg * n) if b_alg else None},
+                         "algorithmic_bytes_per_launch": (b_alg * n) if b_alg else None, "valu_issue": issue},
             "stats": {"mean_episode_return": float(stats[:, 0].mean()), "solved_frac": float(stats[:, 2].mean()),
                       "status_or": int(env.state.status.max())},
         }
