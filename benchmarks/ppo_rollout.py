@@ -2,7 +2,8 @@
 benchmarks/mjx_benchmark_PPO.py:18-66 (brax PPO on 8192 MJX envs) restated in plain torch.
 
 One process per GPU (torch.distributed over RCCL when launched with torch.distributed.run): every rank owns its own env
-shard; the physics never communicates; gradients are all-reduced (bucketed by DDP) during the update; episode statistics
+shard; the physics never communicates; gradients are all-reduced (one flattened buffer per minibatch) during the update;
+episode statistics
 use one all-gather per iteration (myosuite_amd/dist.py).
 
     python benchmarks/ppo_rollout.py --env myoFatiLegWalk-v0 --num-envs 1024 --iters 3
@@ -59,7 +60,9 @@ def main():
     obs_dim, act_dim = env.obs_dim, env.cm.nu
     torch.manual_seed(0)
     net = ActorCritic(obs_dim, act_dim).to(dev)
-    model = nn.parallel.DistributedDataParallel(net, device_ids=[local]) if world > 1 else net
+    if world > 1:                                   # identical initial weights on every rank
+        for p_ in net.parameters():
+            torch.distributed.broadcast(p_.data, src=0)
     opt = torch.optim.Adam(net.parameters(), lr=3e-4)
     obs, _ = env.reset(seed=rank)
     obs = obs.clone()
@@ -94,7 +97,7 @@ def main():
         for _ in range(args.epochs):
             perm = torch.randperm(B, device=dev)
             for mb in perm.chunk(args.minibatches):
-                mean = model.pi(fo[mb]) if world == 1 else model.module.pi(fo[mb])
+                mean = net.pi(fo[mb])
                 dist = torch.distributions.Normal(mean, net.log_std.exp())
                 ratio = (dist.log_prob(fa[mb]).sum(-1) - fl[mb]).exp()
                 pg = -torch.min(ratio * fadv[mb], ratio.clamp(1 - args.clip, 1 + args.clip) * fadv[mb]).mean()
@@ -102,9 +105,12 @@ def main():
                 loss = pg + 0.5 * vl - 1e-2 * dist.entropy().sum(-1).mean()
                 opt.zero_grad(set_to_none=True)
                 loss.backward()
-                if world > 1:                                              # explicit bucket-free all-reduce (tiny MLPs)
-                    for p in net.parameters():
-                        torch.distributed.all_reduce(p.grad); p.grad /= world
+                if world > 1:                      # data-parallel PPO: one flattened gradient all-reduce per minibatch (RCCL)
+                    flat = torch.cat([p_.grad.reshape(-1) for p_ in net.parameters()])
+                    torch.distributed.all_reduce(flat); flat /= world
+                    o_ = 0
+                    for p_ in net.parameters():
+                        n_ = p_.numel(); p_.grad.copy_(flat[o_:o_ + n_].view_as(p_.grad)); o_ += n_
                 opt.step()
         torch.cuda.synchronize(); D.barrier(); t2 = time.perf_counter()
         if it > 0:
