@@ -117,7 +117,8 @@ typedef struct {
   float* ctrl_out;          /* [nenv][nu] optional: ctrl actually applied      */
   int   reaf_src, reaf_dst; /* tendon transfer: ctrl[dst]=ctrl[src]; ctrl[src]=0 (base_v0.py:104-108); -1 = off */
   int   obs_layout;         /* 0: myobase pose  [qpos, qvel*dt, pose_err, act]        (pose_v0.py:17,100-111)
-                               1: MJX pose      [qpos, qvel*timestep, act, pose_err]  (playground_pose_v0.py:119-129) */
+                               1: MJX pose      [qpos, qvel*timestep, act, pose_err]  (playground_pose_v0.py:119-129);
+                                  MJX reach     [qpos, qvel*timestep, act, tip_pos, reach_err] (playground_reach_v0.py:150-165) */
   int   act_reg_mean;       /* 1: act_mag = ||act||/na (pose_v0.py:115-117); 0: ||act|| (playground_pose_v0.py:63) */
   float obs_dt;             /* scale of the qvel observation: env.dt (pose_v0.py:104) or opt.timestep (MJX) */
   /* REACH task (envs/myo/myobase/reach_v0.py:95-151): obs [qpos, qvel*dt, tip_pos, reach_err, act];

@@ -2003,6 +2003,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     if (t.task == MM_TASK_REACH) {
       // obs [qpos, qvel*dt, tip_pos, reach_err, act]; reward dict of reach_v0.py:123-151
       const int n3 = 3 * t.ntip;
+      // obs_layout 1 = MJX order [qpos, qvel, act, tip_pos, reach_err] (playground_reach_v0.py:150-165)
+      const int o_tip = t.obs_layout == 1 ? d.nq + d.nv + d.na : d.nq + d.nv;
+      const int o_ract = t.obs_layout == 1 ? d.nq + d.nv : d.nq + d.nv + 2 * n3;
       float err2 = 0.f, act2 = 0.f;
       float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
       for (int i = g; i < d.nq; i += G) if (ob) ob[i] = W[L.qpos + i];
@@ -2012,12 +2015,12 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         V3 tgt = ld3(t.target_pos + (size_t)e * n3 + 3 * i);
         V3 er = tgt - tip;
         err2 += dot(er, er);
-        if (ob) { st3(ob + d.nq + d.nv + 3 * i, tip); st3(ob + d.nq + d.nv + n3 + 3 * i, er); }
+        if (ob) { st3(ob + o_tip + 3 * i, tip); st3(ob + o_tip + n3 + 3 * i, er); }
       }
       for (int i = g; i < d.na; i += G) {
         float x = W[L.act + i];
         act2 += x * x;
-        if (ob) ob[d.nq + d.nv + 2 * n3 + i] = x;
+        if (ob) ob[o_ract + i] = x;
       }
       err2 = gsum<G>(err2); act2 = gsum<G>(act2);
       if (g == 0) {

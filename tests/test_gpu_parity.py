@@ -358,3 +358,25 @@ def test_rk4_integrator_matches_oracle(oracle_lib, name):
     assert np.median(err) < 5e-5 and err.max() < 2e-3, (np.median(err), err.max())
     np.testing.assert_allclose(st.time.cpu().numpy(), to, rtol=1e-5)
     assert int(st.status.max()) == 0
+
+
+def test_mjx_style_reach_api(models):
+    """mjx_api.MjxReachEnv: obs order / reward of playground_reach_v0.py:71-165."""
+    from myosuite_amd.mjx_api import MjxReachEnv
+    cm = models["hand"]
+    env = MjxReachEnv(num_envs=16, seed=2)
+    st = env.reset(2)
+    n3 = 15
+    assert st.obs["state"].shape == (16, cm.nq + cm.nv + cm.na + 2 * n3)
+    a = torch.rand(16, cm.nu, device="cuda")
+    for _ in range(3):
+        st = env.step(st, a)
+    o = st.obs["state"].cpu().numpy(); q = st.data.qpos.cpu().numpy(); act = st.data.act.cpu().numpy()
+    tgt = st.info["targets"].cpu().numpy()
+    np.testing.assert_allclose(o[:, :cm.nq], q, atol=1e-6)
+    np.testing.assert_allclose(o[:, cm.nq + cm.nv:cm.nq + cm.nv + cm.na], act, atol=1e-6)
+    tip = o[:, cm.nq + cm.nv + cm.na:cm.nq + cm.nv + cm.na + n3]; err = o[:, cm.nq + cm.nv + cm.na + n3:]
+    np.testing.assert_allclose(err, tgt - tip, atol=1e-5)
+    dist = np.linalg.norm(err, axis=1); near = 5 * 0.0125; far = 0.034 * 5
+    ref = -dist + 4.0 * ((dist < 2 * near) * 1.0 + (dist < near) * 1.0) - 50.0 * (dist > far)
+    np.testing.assert_allclose(st.reward.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
