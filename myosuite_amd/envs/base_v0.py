@@ -195,5 +195,27 @@ class BaseV0:
             solved=self.rwd_dict["solved"], done=self.rwd_dict["done"], obs_dict=self.obs_dict, visual_dict={},
             proprio_dict={}, rwd_dict=self.rwd_dict, state=None)
 
+    # ------------------------------------------------------------------ step (env_base.py:377-407, base_v0.py:82-118)
+    def step(self, a, **kwargs):
+        """One fused kernel launch: ctrl map / fatigue, frame_skip x mj_step, final forward, task obs + reward; then the
+        masked auto-reset (always enqueued, no host sync; a no-op for envs that continue).  Subclasses provide
+        ``_task``, ``_refresh_dicts()`` and ``reset(mask=...)``."""
+        a = torch.as_tensor(a, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.expand(self.num_envs, -1)
+        a = a.contiguous()
+        E.env_step(self.hm, self.state, a, self._task)
+        self._refresh_dicts()
+        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
+        terminated = self.done.bool()
+        truncated = self.truncated.bool() & ~terminated
+        info = self.get_env_infos()
+        obs = self.obs
+        if self.autoreset:
+            info["final_obs"] = obs.clone()
+            self.reset(mask=(self.done | self.truncated))
+            obs = self.obs
+        return obs, reward, terminated, truncated, info
+
     def close(self):
         pass

@@ -169,26 +169,3 @@ class PoseEnvV0(BaseV0):
                 torch.where(mask.bool()[:, None], self.get_obs(), self.obs))
         self._refresh_dicts()
         return self.obs, {}
-
-    # ------------------------------------------------------------------ step (base_v0.py:82-118 + env_base.py:403-432)
-    def step(self, a, **kwargs):
-        a = torch.as_tensor(a, dtype=torch.float32, device=self.device)
-        if a.dim() == 1:
-            a = a.expand(self.num_envs, -1)
-        a = a.contiguous()
-        E.env_step(self.hm, self.state, a, self._task)
-        self._refresh_dicts()
-        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
-        terminated = self.done.bool()
-        truncated = self.truncated.bool() & ~terminated
-        info = self.get_env_infos()
-        obs = self.obs
-        if self.autoreset:
-            need = (self.done | self.truncated)
-            info["final_obs"] = None
-            # masked reset is always enqueued (no host sync); it is a no-op for envs that continue
-            final_obs = obs.clone()
-            self.reset(mask=need)
-            info["final_obs"] = final_obs
-            obs = self.obs
-        return obs, reward, terminated, truncated, info

@@ -117,21 +117,3 @@ class WalkEnvV0(BaseV0):
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
         return self.obs, {}
-
-    def step(self, a, **kwargs):
-        a = torch.as_tensor(a, dtype=torch.float32, device=self.device)
-        if a.dim() == 1:
-            a = a.expand(self.num_envs, -1)
-        a = a.contiguous()
-        E.env_step(self.hm, self.state, a, self._task)
-        self._refresh_dicts()
-        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
-        terminated = self.done.bool()
-        truncated = self.truncated.bool() & ~terminated
-        info = self.get_env_infos()
-        obs = self.obs
-        if self.autoreset:
-            info["final_obs"] = obs.clone()
-            self.reset(mask=(self.done | self.truncated))
-            obs = self.obs
-        return obs, reward, terminated, truncated, info
