@@ -195,6 +195,23 @@ class BaseV0:
             solved=self.rwd_dict["solved"], done=self.rwd_dict["done"], obs_dict=self.obs_dict, visual_dict={},
             proprio_dict={}, rwd_dict=self.rwd_dict, state=None)
 
+    def _new_task(self, task_id: int, do_forward: bool = True) -> "E.mm_task":
+        """mm_task with the fields every task shares (frame_skip, ctrl map, fatigue state, output buffers, counters).
+        Call after self.obs / self.rwd exist."""
+        t = E.mm_task()
+        t.task = task_id; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
+        t.do_forward = int(do_forward); t.fatigue = int(self.muscle_condition == "fatigue")
+        t.max_episode_steps = self.max_episode_steps
+        if self.fat_MA is not None:
+            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
+        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15          # fatigue.py:9-11
+        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
+        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
+        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
+        t.reaf_src, t.reaf_dst = self.reaf
+        t.obs_dt = self.dt
+        return t
+
     # ------------------------------------------------------------------ step (env_base.py:377-407, base_v0.py:82-118)
     def step(self, a, **kwargs):
         """One fused kernel launch: ctrl map / fatigue, frame_skip x mj_step, final forward, task obs + reward; then the

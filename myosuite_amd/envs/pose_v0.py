@@ -66,22 +66,12 @@ class PoseEnvV0(BaseV0):
         self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
                                      dtype=np.float32)
         w = self.rwd_keys_wt
-        t = E.mm_task()
-        t.task = E.MM_TASK_POSE; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
-        t.do_forward = int(do_forward); t.fatigue = int(self.muscle_condition == "fatigue")
-        t.max_episode_steps = self.max_episode_steps
+        t = self._new_task(E.MM_TASK_POSE, do_forward)
         t.pose_thd = self.pose_thd; t.far_th = 4 * math.pi / 2
         t.w_pose = float(w.get("pose", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
         t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
         t.target_jnt_value = self.target_jnt_value.data_ptr()
-        if self.fat_MA is not None:
-            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
-        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15          # fatigue.py:9-11
-        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
-        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
-        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
-        t.reaf_src, t.reaf_dst = self.reaf
-        t.obs_layout = 0; t.act_reg_mean = 1; t.obs_dt = self.dt
+        t.obs_layout = 0; t.act_reg_mean = 1
         self._task = t
         self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
         self.reset()

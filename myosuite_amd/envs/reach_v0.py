@@ -60,19 +60,9 @@ class ReachEnvV0(BaseV0):
         self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
                                      dtype=np.float32)
         w = self.rwd_keys_wt
-        t = E.mm_task()
-        t.task = E.MM_TASK_REACH; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
-        t.do_forward = 1; t.fatigue = int(self.muscle_condition == "fatigue"); t.max_episode_steps = self.max_episode_steps
+        t = self._new_task(E.MM_TASK_REACH)
         t.w_pose = float(w.get("reach", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
         t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
-        if self.fat_MA is not None:
-            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
-        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15
-        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
-        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
-        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
-        t.reaf_src, t.reaf_dst = self.reaf
-        t.obs_dt = self.dt
         t.tip_sites = self._tip_sites.data_ptr(); t.ntip = self.ntip; t.target_pos = self.target_pos.data_ptr()
         t.reach_far_th = self.far_th
         self._task = t

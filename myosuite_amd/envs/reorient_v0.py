@@ -57,17 +57,7 @@ class ReorientEnvV0(BaseV0):
         self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
                                      dtype=np.float32)
         w = self.rwd_keys_wt
-        t = E.mm_task()
-        t.task = E.MM_TASK_REORIENT; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
-        t.do_forward = 1; t.fatigue = int(self.muscle_condition == "fatigue"); t.max_episode_steps = self.max_episode_steps
-        if self.fat_MA is not None:
-            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
-        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15
-        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
-        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
-        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
-        t.reaf_src, t.reaf_dst = self.reaf
-        t.obs_dt = self.dt
+        t = self._new_task(E.MM_TASK_REORIENT)
         t.reor_obj_body = cm.body_id("Object"); t.reor_eps_site = cm.site_id("eps_ball"); t.reor_pen_length = self.pen_length
         t.reor_axis_half = self.axis_half.data_ptr(); t.reor_des_rot = self.des_rot.data_ptr()
         for i, k in enumerate(("pos_align", "rot_align", "act_reg", "drop", "bonus")):

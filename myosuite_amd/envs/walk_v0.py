@@ -52,17 +52,7 @@ class WalkEnvV0(BaseV0):
         self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
                                      dtype=np.float32)
         w = self.rwd_keys_wt
-        t = E.mm_task()
-        t.task = E.MM_TASK_WALK; t.nsubsteps = self.frame_skip; t.normalize_act = int(self.normalize_act)
-        t.do_forward = 1; t.fatigue = int(self.muscle_condition == "fatigue"); t.max_episode_steps = self.max_episode_steps
-        if self.fat_MA is not None:
-            t.fat_MA, t.fat_MR, t.fat_MF = self.fat_MA.data_ptr(), self.fat_MR.data_ptr(), self.fat_MF.data_ptr()
-        t.fat_F, t.fat_R, t.fat_r = 0.00912, 0.1 * 0.00094, 10 * 15
-        t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
-        t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
-        t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
-        t.reaf_src, t.reaf_dst = self.reaf
-        t.obs_dt = self.dt
+        t = self._new_task(E.MM_TASK_WALK)
         for i, b in enumerate(("pelvis", "torso", "talus_l", "talus_r")):
             t.walk_body[i] = cm.body_id(b)
         qadr = cm.arrays["JNT_QPOSADR"]
