@@ -172,7 +172,8 @@ void mm_model_destroy(mm_model* m);
 int  mm_model_info(const mm_model* m, int which);
 /* lanes_per_env in {4,8,16,32,64}; 0 = engine default for the model size. */
 int  mm_model_set_lanes(mm_model* m, int lanes_per_env);
-/* tuning knobs: "lds_model" (1: stage model tables in LDS), "waves_per_block" (0 = auto) */
+/* tuning knobs: "lds_model" (1 = stage the model tables in LDS unless that costs resident waves the batch needs,
+   0 = never, 2 = always), "waves_per_block" (0 = auto) */
 int  mm_model_set_option(mm_model* m, const char* name, int value);
 
 /* ---- physics -------------------------------------------------------------- */

@@ -481,9 +481,9 @@ static unsigned long long* g_prof = nullptr;
 extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_ptr; }
 
 template <int G, int NVP, bool GEN, bool RK4>
-static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st, int lm) {
   static bool attr_done[2] = {false, false};
-  const int lm = m->lds_model ? 1 : 0;
+  (void)m;
   if (!attr_done[lm]) {
     if (lm) HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, true, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -509,16 +509,26 @@ static int launch(const mm_model* m, KArgs& a, void* stream) {
   }
   const int epw = 64 / G;
   const size_t kLds = 160 * 1024;
-  const size_t model_bytes = m->lds_model ? (size_t)((m->blob_words + 3) & ~3) * 4 : 0;
+  const size_t blob_bytes = (size_t)((m->blob_words + 3) & ~3) * 4;
   const int waves_needed = (a.s.nenv + epw - 1) / epw;
+  auto fit_waves = [&](size_t model_bytes) {   // waves of one block that fit in LDS next to the model copy (<= 8)
+    int fit = 8;                               // __launch_bounds__(512)
+    while (fit > 1 && model_bytes + (size_t)fit * epw * m->lds_per_env > kLds) fit--;
+    return fit;
+  };
+  // lds_model: 1 = stage the model tables in LDS unless that costs resident waves the batch needs (then read them through
+  // L2 instead: a graceful step instead of an occupancy cliff when a model grows past the LDS budget), 0 = never, 2 = always
+  int want = (waves_needed + 255) / 256;       // waves per CU that spread the batch over all 256 CUs in one round
+  if (want < 1) want = 1;
+  if (want > 8) want = 8;
+  int lm = m->lds_model ? 1 : 0;
+  if (m->lds_model == 1 && fit_waves(blob_bytes) < want && fit_waves(0) > fit_waves(blob_bytes)) lm = 0;
+  const size_t model_bytes = lm ? blob_bytes : 0;
   int wpb = m->waves_per_block;
   if (wpb <= 0) {
-    // one block per CU sharing one model copy: as many waves as fit in LDS (<= 16), but no fatter than
-    // needed to spread the batch over all 256 CUs
-    int fit = 8;   // __launch_bounds__(512): 8 waves per block
-    while (fit > 1 && model_bytes + (size_t)fit * epw * m->lds_per_env > kLds) fit--;
-    wpb = (waves_needed + 255) / 256;
-    if (wpb < 1) wpb = 1;
+    // one block per CU sharing one model copy: as many waves as fit in LDS, but no fatter than needed
+    wpb = want;
+    const int fit = fit_waves(model_bytes);
     if (wpb > fit) wpb = fit;
   }
   const int epb = epw * wpb;
@@ -530,7 +540,7 @@ static int launch(const mm_model* m, KArgs& a, void* stream) {
   a.prof = g_prof;
   const int rk4 = m->d.integrator == MM_INT_RK4 ? 1 : 0;
 #define X(G_, N_, GN_, RK_) \
-  if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_t<G_, N_, GN_ != 0, RK_ != 0>(m, a, grid, block, lds, st);
+  if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_t<G_, N_, GN_ != 0, RK_ != 0>(m, a, grid, block, lds, st, lm);
   MM_KERNEL_LIST(X)
 #undef X
   return fail(MM_EUNSUPPORTED, "no compiled kernel for this (lanes_per_env, nv) combination");
