@@ -184,6 +184,7 @@ static bool have_kernel(int G, int nvp, int gen, int rk4 = 0) {
 }
 
 static void build_layout(mm_model* m) {
+  m->d.efc_rows = std::min(m->lanes, (m->d.njmax + 3) & ~3);
   const Dims& d = m->d;
   Layout& L = m->L;
   int o = 0;
@@ -203,7 +204,7 @@ static void build_layout(mm_model* m) {
   L.efcJ = L.rowtab = 0;
   L.rk_qpos0 = L.rk_act0 = L.rk_adot = 0;
   if (d.integrator == MM_INT_RK4) { L.rk_qpos0 = take(d.nq); L.rk_act0 = take(d.na); L.rk_adot = take(d.na); }
-  if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(m->lanes * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
+  if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(d.efc_rows * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
   o = (o + 3) & ~3;

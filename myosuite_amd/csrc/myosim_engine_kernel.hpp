@@ -42,6 +42,7 @@ struct Dims {
   int iterations, ls_iterations, eulerdamp, any_damping;
   int gen;   // model has equality / contact rows: general (dense-J) constraint path
   int integrator;   // MM_INT_EULER | MM_INT_RK4
+  int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
 };
 
@@ -1299,7 +1300,7 @@ struct Engine {
   // (D, aref, jar).  Row order: equalities, active joint
   // limits (compacted), contact pyramid edges (compacted).  Restates mmo_make_constraint / mmo_collision.inc.
   static constexpr int RS = NVP + 4;
-  __device__ __forceinline__ float* Jrow(int r) const { return W + a.L.efcJ + r * RS; }
+  __device__ __forceinline__ float* Jrow(int r) const { return W + a.L.efcJ + (r < a.d.efc_rows ? r : 0) * RS; }
   __device__ __forceinline__ int gscan_excl(int v) const {
     int incl = v;
 #pragma unroll
@@ -1358,7 +1359,7 @@ struct Engine {
     float* RT = W + L.rowtab;
     {
       float4* Jz = reinterpret_cast<float4*>(W + L.efcJ);
-      for (int e = g; e < G * RS / 4; e += G) Jz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = g; e < a.d.efc_rows * RS / 4; e += G) Jz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     GSYNC();
     const int neq = a.d.neq;
@@ -1399,7 +1400,7 @@ struct Engine {
     int over = 0;
     if (lim) {
       const int r = neq + lrank;
-      if (r < G) {
+      if (r < a.d.efc_rows) {
         Jrow(r)[ldof] = lsign;
         RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 2)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
       } else over = 1;
@@ -1481,7 +1482,7 @@ struct Engine {
     const int ncrows = gsum_i(myrows);
     for (int c = 0; c < 2; c++) {
       if (!(c < nc && cdist[c] < incl)) continue;
-      if (base + rowsper > G) { over = 1; continue; }
+      if (base + rowsper > a.d.efc_rows) { over = 1; continue; }
       // contact frame (mmo_collision.inc: make_frame)
       V3 n = cn[c];
       V3 y = (n.y < 0.5f && n.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
@@ -1499,7 +1500,7 @@ struct Engine {
     }
     if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
     nefc = neq + nlim + ncrows;
-    if (nefc > G) nefc = G;
+    if (nefc > a.d.efc_rows) nefc = a.d.efc_rows;
     {
       int w = nefc;
 #pragma unroll
