@@ -1,0 +1,126 @@
+"""MJCF subset importer / exporter: round trips of the synthetic models and hand-written feature snippets."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from myosuite_amd.model import mjcf, synth
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize("name", ["elbow", "hand", "leg", "contact_toy", "hand_reorient"])
+def test_dump_load_round_trip_is_physically_identical(oracle_lib, name):
+    mk = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg, "contact_toy": synth.make_contact_toy,
+          "hand_reorient": synth.make_hand_reorient}[name]
+    spec = mk()
+    cm0 = spec.compile()
+    spec2 = mjcf.load(mjcf.dump(spec))
+    cm1 = spec2.compile()
+    for k in ("nq", "nv", "nu", "nbody", "njnt", "ngeom", "nsite", "ntendon", "neq", "npair", "njmax"):
+        assert getattr(cm0, k) == getattr(cm1, k), k
+    assert list(cm0.names["joint"]) == list(cm1.names["joint"]) and list(cm0.names["actuator"]) == list(cm1.names["actuator"])
+    d0, d1 = O.OracleData(O.OracleModel(cm0)), O.OracleData(O.OracleModel(cm1))
+    rng = np.random.default_rng(0)
+    q = np.asarray(spec.keys[2][0], float) if hasattr(spec, "keys") else cm0.qpos0.astype(np.float64)
+    v = rng.standard_normal(cm0.nv) * 0.3; act = rng.random(cm0.na); ctrl = rng.random(cm0.nu)
+    for d in (d0, d1):
+        d.qpos[:] = q; d.qvel[:] = v; d.act[:] = act; d.ctrl[:] = ctrl
+        d.step(20)
+    assert np.abs(d0.qpos - d1.qpos).max() == 0.0 and d0.nefc == d1.nefc
+    if hasattr(spec, "keys"):
+        np.testing.assert_array_equal(np.array([k[0] for k in spec2.keys]), np.array([k[0] for k in spec.keys]))
+
+
+_ARM = """
+<mujoco model="arm">
+  <compiler angle="degree" eulerseq="xyz" autolimits="true"/>
+  <option timestep="0.001" integrator="RK4" gravity="0 0 -9.81"/>
+  <default>
+    <joint damping="0.2" armature="0.01"/>
+    <geom contype="0" conaffinity="0"/>
+    <default class="seg"><geom type="capsule" size="0.03" density="1100"/></default>
+    <default class="coll"><geom contype="1" conaffinity="1" friction="0.7 0.005 0.0001"/></default>
+    <muscle ctrllimited="true" ctrlrange="0 1" force="500" scale="200"/>
+  </default>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 1" class="coll"/>
+    <body name="upper" pos="0 0 1" euler="0 90 0" childclass="seg">
+      <joint name="shoulder" axis="0 1 0" range="-90 90"/>
+      <geom name="upper_g" fromto="0 0 0 0 0 -0.3"/>
+      <site name="o1" pos="0.03 0 -0.05"/>
+      <body name="lower" pos="0 0 -0.3">
+        <joint name="elbow" axis="0 1 0" range="0 150" damping="0.5"/>
+        <inertial pos="0 0 -0.12" mass="1.2" fullinertia="0.01 0.012 0.002 0.001 0 0"/>
+        <geom name="lower_g" fromto="0 0 0 0 0 -0.25"/>
+        <geom name="tip" type="sphere" size="0.035" pos="0 0 -0.25" class="coll"/>
+        <site name="i1" pos="0.03 0 -0.05"/>
+      </body>
+    </body>
+  </worldbody>
+  <tendon><spatial name="t1"><site site="o1"/><site site="i1"/></spatial></tendon>
+  <actuator><muscle name="m1" tendon="t1" timeconst="0.02 0.05"/><motor name="mot" joint="shoulder" gear="3" ctrlrange="-1 1"/></actuator>
+  <keyframe><key qpos="0.1 0.2"/></keyframe>
+</mujoco>
+"""
+
+
+def test_defaults_degrees_fromto_inertia_and_generated_pairs(oracle_lib):
+    s = mjcf.load(_ARM)
+    assert s.timestep == 0.001 and s.integrator == 1
+    up, lo = s.bodies[s._bname["upper"]], s.bodies[s._bname["lower"]]
+    np.testing.assert_allclose(up.quat, [math.cos(math.pi / 4), 0, math.sin(math.pi / 4), 0], atol=1e-12)      # euler 0 90 0 (degrees)
+    # joint defaults + override, degrees -> radians, autolimits
+    sh, el = s.joints[s._jname["shoulder"]], s.joints[s._jname["elbow"]]
+    assert sh.limited and abs(sh.range[1] - math.pi / 2) < 1e-12 and sh.damping == 0.2 and sh.armature == 0.01
+    assert el.damping == 0.5 and abs(el.range[1] - math.radians(150)) < 1e-12
+    # fromto capsule: centre, half length, axis
+    g = s.geoms[s._gname["upper_g"]]
+    np.testing.assert_allclose(g["pos"], [0, 0, -0.15]); assert abs(g["size"][1] - 0.15) < 1e-12 and g["size"][0] == 0.03
+    # inertia from the capsule geom (density 1100): mass = rho * (pi r^2 2h + 4/3 pi r^3)
+    vol = math.pi * 0.03 ** 2 * 0.3 + 4.0 / 3.0 * math.pi * 0.03 ** 3
+    assert abs(up.mass - 1100 * vol) < 1e-9 and abs(up.ipos[2] + 0.15) < 1e-12
+    # fullinertia diagonalised: eigenvalues of the given tensor
+    w = np.sort(np.linalg.eigvalsh(np.array([[0.01, 0.001, 0], [0.001, 0.012, 0], [0, 0, 0.002]])))[::-1]
+    np.testing.assert_allclose(np.sort(lo.inertia)[::-1], w, atol=1e-12)
+    # only the two "coll" geoms collide: one generated pair with mixed friction max(1.0 default? no: 0.7, 0.7)
+    assert len(s.pairs) == 1 and {s.pairs[0]["g1"], s.pairs[0]["g2"]} == {"floor", "tip"} and s.pairs[0]["friction"][0] == 0.7
+    # muscle shortcut + general defaults, motor
+    m1, mot = s.actuators
+    assert m1.dynprm[:2] == (0.02, 0.05) and m1.gainprm[2] == 500.0 and m1.ctrllimited and mot.gear == 3.0 and mot.ctrlrange == (-1.0, 1.0)
+    assert np.allclose(s.keys[0][0], [0.1, 0.2])
+    cm = s.compile()
+    d = O.OracleData(O.OracleModel(cm))
+    d.step(50)
+    assert np.isfinite(d.qpos).all() and cm.nq == 2 and cm.nu == 2
+
+
+def test_include_and_unsupported_features_fail_loudly(tmp_path):
+    (tmp_path / "chain.xml").write_text('<mujocoinclude><body name="b" pos="0 0 1"><joint name="j"/><inertial pos="0 0 0" mass="1" diaginertia="0.1 0.1 0.1"/></body></mujocoinclude>')
+    (tmp_path / "main.xml").write_text('<mujoco><compiler angle="radian"/><worldbody><include file="chain.xml"/></worldbody></mujoco>')
+    s = mjcf.load(str(tmp_path / "main.xml"))
+    assert "b" in s._bname and "j" in s._jname
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.load('<mujoco><worldbody><include file="/nonexistent/x.xml"/></worldbody></mujoco>')
+    assert mjcf.load('<mujoco><worldbody><include file="/nonexistent/x.xml"/></worldbody></mujoco>', missing_include="skip").bodies
+    for bad in ('<mujoco><option integrator="implicitfast"/></mujoco>', '<mujoco><option cone="elliptic"/></mujoco>',
+                '<mujoco><worldbody><body><geom type="mesh" mesh="m"/></body></worldbody></mujoco>',
+                '<mujoco><worldbody><body name="a"><joint name="j"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/></body></worldbody>'
+                '<equality><weld body1="a"/></equality></mujoco>'):
+        with pytest.raises(mjcf.MjcfError):
+            mjcf.load(bad)
+
+
+def test_reference_task_xml_parses_up_to_the_missing_submodule():
+    """The reference's task XMLs only <include> the empty myo_sim submodule: with missing includes skipped, what is in-repo
+    (object / target bodies of myohand_sar.xml) imports; convex / mesh content would raise instead of being dropped."""
+    path = "/root/reference/myosuite/envs/myo/assets/hand/myohand_sar.xml"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present (GPU box)")
+    s = mjcf.load(path, missing_include="skip")
+    assert [s.joints[j].name for j in s.bodies[s._bname["Object"]].joints] == ["OBJTx", "OBJTy", "OBJTz", "OBJRx", "OBJRy", "OBJRz"]
+    obj = s.geoms[s._gname["obj"]]
+    assert obj["type"] == 4 and np.allclose(obj["size"], [0.015, 0.015, 0.045])
+    # euler="0 1.27 0": without the (missing) asset include that sets the compiler angle, MJCF's default unit is degrees
+    h = math.radians(1.27) / 2
+    np.testing.assert_allclose(s.bodies[s._bname["Object"]].quat, [math.cos(h), 0, math.sin(h), 0], atol=1e-12)

@@ -1,0 +1,97 @@
+"""Pin the engine against libmujoco where it is available (NOT runnable in the authoring container or on
+the GPU boxes of this project: `mujoco` is not installed and there is no network).
+
+    python tools/validate_against_mujoco.py [--model hand|elbow|leg|contact_toy|hand_reorient | --xml path.xml] [--steps 200] [--gpu]
+
+1. writes the model as MJCF (`myosuite_amd.model.mjcf.dump`) or takes an MJCF file (e.g. the real myo_sim models) and imports it
+   with `mjcf.load`;
+2. loads the SAME XML with `mujoco.MjModel.from_xml_path`, copies the derived constants MuJoCo computes at compile time into the
+   report (actuator_lengthrange / acc0, dof_invweight0, body_invweight0, tendon_invweight0, stat.meaninertia) next to ours;
+3. steps both from identical (qpos, qvel, act, ctrl) with a fixed random ctrl sequence and reports per-stage differences after
+   mj_forward (xpos, ten_length, actuator_force, qfrc_bias, qacc_smooth, efc count, qacc) and the state divergence over `--steps`
+   mj_step calls: mujoco (fp64) vs oracle (fp64) vs, with --gpu, the HIP engine (fp32).
+The report is what would turn "PARITY UNPINNED"  into pinned parity.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="hand")
+    ap.add_argument("--xml", default=None)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--gpu", action="store_true")
+    args = ap.parse_args()
+    try:
+        import mujoco
+    except ImportError:
+        print("mujoco is not installed: nothing to validate against (see module docstring)")
+        return 2
+    from myosuite_amd.model import mjcf, synth
+    from oracle import oracle as O
+    if args.xml:
+        path = args.xml
+        spec = mjcf.load(path)
+    else:
+        spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg, "contact_toy": synth.make_contact_toy,
+                "hand_reorient": synth.make_hand_reorient}[args.model]()
+        path = os.path.join(tempfile.mkdtemp(), f"{args.model}.xml")
+        open(path, "w").write(mjcf.dump(spec))
+    cm = spec.compile()
+    mjm = mujoco.MjModel.from_xml_path(path); mjd = mujoco.MjData(mjm)
+    rep = {"xml": path, "dims": {"nq": [cm.nq, mjm.nq], "nv": [cm.nv, mjm.nv], "nu": [cm.nu, mjm.nu], "ntendon": [cm.ntendon, mjm.ntendon]}}
+    A = cm.arrays
+    rep["compile_constants_maxabs_diff"] = {
+        "dof_invweight0": float(np.abs(A["DOF_INVWEIGHT0"] - mjm.dof_invweight0).max()),
+        "body_invweight0": float(np.abs(A["BODY_INVWEIGHT0"].reshape(-1, 2) - mjm.body_invweight0).max()),
+        "tendon_invweight0": float(np.abs(A["TENDON_INVWEIGHT0"] - mjm.tendon_invweight0).max()) if cm.ntendon else 0.0,
+        "actuator_acc0": float(np.abs(A["ACT_ACC0"] - mjm.actuator_acc0).max()) if cm.nu else 0.0,
+        "actuator_lengthrange": float(np.abs(A["ACT_LENGTHRANGE"].reshape(-1, 2) - mjm.actuator_lengthrange).max()) if cm.nu else 0.0,
+        "meaninertia": float(abs(A["OPT_F"][2] - mjm.stat.meaninertia))}
+    om = O.OracleModel(cm); d = O.OracleData(om)
+    rng = np.random.default_rng(0)
+    q0 = np.asarray(spec.keys[2][0], float) if hasattr(spec, "keys") and len(spec.keys) > 2 else cm.qpos0.astype(np.float64)
+    v0 = rng.standard_normal(cm.nv) * 0.2
+    a0 = rng.random(cm.na)
+    ctrl = rng.random((args.steps, cm.nu))
+    mjd.qpos[:] = q0; mjd.qvel[:] = v0; mjd.act[:] = a0; mjd.ctrl[:] = ctrl[0]
+    d.qpos[:] = q0; d.qvel[:] = v0; d.act[:] = a0; d.ctrl[:] = ctrl[0]
+    mujoco.mj_forward(mjm, mjd); d.forward()
+    fw = {}
+    for ours, theirs in (("xpos", "xpos"), ("ten_length", "ten_length"), ("actuator_force", "actuator_force"),
+                         ("qfrc_bias", "qfrc_bias"), ("qacc_smooth", "qacc_smooth"), ("qacc", "qacc")):
+        x, y = np.asarray(getattr(d, ours)).ravel(), np.asarray(getattr(mjd, theirs)).ravel()
+        fw[ours] = float(np.abs(x - y).max() / max(1e-12, np.abs(y).max())) if x.size else 0.0
+    fw["nefc"] = [int(d.nefc), int(mjd.nefc)]
+    rep["forward_rel_diff"] = fw
+    hip = None
+    if args.gpu:
+        import torch
+        from myosuite_amd import engine as E
+        hm = E.HipModel(cm); st = E.BatchState(hm, 1)
+        st.qpos.copy_(torch.from_numpy(q0.astype(np.float32))[None]); st.qvel.copy_(torch.from_numpy(v0.astype(np.float32))[None])
+        st.act.copy_(torch.from_numpy(a0.astype(np.float32))[None])
+        hip = (hm, st, E, torch)
+    div = {"oracle_vs_mujoco": [], "hip_vs_mujoco": []}
+    for s in range(args.steps):
+        mjd.ctrl[:] = ctrl[s]; d.ctrl[:] = ctrl[s]
+        mujoco.mj_step(mjm, mjd); d.step()
+        div["oracle_vs_mujoco"].append(float(np.abs(d.qpos - mjd.qpos).max()))
+        if hip:
+            hm, st, E, torch = hip
+            E.step(hm, st, torch.from_numpy(ctrl[s].astype(np.float32))[None].cuda().contiguous(), 1)
+            div["hip_vs_mujoco"].append(float(np.abs(st.qpos[0].cpu().numpy() - mjd.qpos).max()))
+    rep["qpos_divergence"] = {k: {"after_10": v[9] if len(v) > 9 else None, "final": v[-1], "max": max(v)} for k, v in div.items() if v}
+    print(json.dumps(rep, indent=1))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
