@@ -149,6 +149,8 @@ typedef struct {
   const float* reor_axis_half; /* [nenv]                                        */
   const float* reor_des_rot;   /* [nenv][3] obj_des_rot of the episode (target body quat applied, / tar_length) */
   float reor_w[5];          /* weights of pos_align, rot_align, act_reg, drop, bonus (reorient_sar_v0.py:38-44) */
+  int   reor_obs_muscle;    /* 1: obs carries mlen / mvel / mforce (reorient_sar_v0.py); 0: PenTwirl's obs (pen_v0.py:16-26:
+                               hand_jnt, obj_pos, obj_vel, obj_rot, obj_des_rot, obj_err_pos, obj_err_rot, act)          */
   /* reset observation support (all tasks) */
   const uint8_t* env_mask;  /* optional [nenv]: envs with 0 are left untouched  */
   int   obs_only;           /* 1: no substeps, no ctrl map, no counters, no reward write: forward + obs of the CURRENT state
@@ -216,6 +218,11 @@ int  mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, co
 int  mm_reorient_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
                        const float* size_table, int ntab, float* geom_size_env, float* axis_half, float* des_rot,
                        float tar_length, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
+/* Pen-twirl reset (pen_v0.py:171-184): fixed object geometry; des_rot[e] = R(euler2quat([U(lo0,hi0), U(lo1,hi1), 0])) *
+ * (0,0,2*axis_half) / tar_length, with lo = hi = 0 for the Fixed task; state = init_qpos, qvel = act = 0. */
+int  mm_pen_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos, float axis_half,
+                  float lo0, float hi0, float lo1, float hi1, float* des_rot, float tar_length, int32_t* episode,
+                  int32_t* step_count, uint64_t seed, void* stream);
 /* Same with the object TYPE drawn too (reorient_sar_v0.py:388-406): size_tables [4][ntab][3] in the order capsule,
  * ellipsoid, cylinder, box (geom types 3,4,5,6); geom_type_env[e] receives the type; axis_half = 1.3*size[1] (capsule),
  * size[2] (ellipsoid, box), size[1] (cylinder). */

@@ -35,6 +35,7 @@ struct ResetArgs {
   int walk, walk_random; const float *ka_qpos, *ka_qvel, *kb_qpos, *kb_qvel;
   int reor, reor_ntab; const float* reor_tab; float *reor_gsize, *reor_axis_half, *reor_des_rot; float reor_tar_length;
   int32_t* reor_gtype;   // non-null: also draw the object type (tables [4][ntab][3])
+  int pen; float pen_axis_half, pen_lo0, pen_hi0, pen_lo1, pen_hi1;   // pen-twirl reset: fixed geometry, euler ranges
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -91,15 +92,21 @@ __global__ void k_reset(ResetArgs r) {
     if (r.episode) r.episode[e] = ep + 1;
     uint32_t c[4] = {0u, 3u, (uint32_t)e, (uint32_t)ep};
     philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
-    int idx = (int)(u01(c[0]) * (float)r.reor_ntab);
-    if (idx >= r.reor_ntab) idx = r.reor_ntab - 1;
-    int ty = 0;   // 0 capsule, 1 ellipsoid, 2 cylinder, 3 box  (geom types 3..6; word 3 of the counter)
-    if (r.reor_gtype) { ty = (int)(u01(c[3]) * 4.f); if (ty > 3) ty = 3; r.reor_gtype[e] = MM_GEOM_CAPSULE + ty; }
-    const float* sz = r.reor_tab + 3 * (ty * r.reor_ntab + idx);
-    for (int k = 0; k < 3; k++) r.reor_gsize[(size_t)e * 3 + k] = sz[k];
-    const float ah = ty == 0 ? 1.3f * sz[1] : (ty == 2 ? sz[1] : sz[2]);   // reorient_sar_v0.py:390-406
-    r.reor_axis_half[e] = ah;
-    const float e0 = -1.f + 2.f * u01(c[1]), e1 = -0.8f + 2.f * u01(c[2]);
+    float ah, e0, e1;
+    if (r.pen) {   // pen_v0.py:171-184: fixed geometry, desired_orien[0:2] ~ U(lo, hi)
+      ah = r.pen_axis_half;
+      e0 = r.pen_lo0 + (r.pen_hi0 - r.pen_lo0) * u01(c[1]); e1 = r.pen_lo1 + (r.pen_hi1 - r.pen_lo1) * u01(c[2]);
+    } else {
+      int idx = (int)(u01(c[0]) * (float)r.reor_ntab);
+      if (idx >= r.reor_ntab) idx = r.reor_ntab - 1;
+      int ty = 0;   // 0 capsule, 1 ellipsoid, 2 cylinder, 3 box  (geom types 3..6; word 3 of the counter)
+      if (r.reor_gtype) { ty = (int)(u01(c[3]) * 4.f); if (ty > 3) ty = 3; r.reor_gtype[e] = MM_GEOM_CAPSULE + ty; }
+      const float* sz = r.reor_tab + 3 * (ty * r.reor_ntab + idx);
+      for (int k = 0; k < 3; k++) r.reor_gsize[(size_t)e * 3 + k] = sz[k];
+      ah = ty == 0 ? 1.3f * sz[1] : (ty == 2 ? sz[1] : sz[2]);   // reorient_sar_v0.py:390-406
+      r.reor_axis_half[e] = ah;
+      e0 = -1.f + 2.f * u01(c[1]); e1 = -0.8f + 2.f * u01(c[2]);
+    }
     // euler2quat([e0, e1, 0]) (utils/quat_math.py:70-86): ai = 0, aj = -e1/2, ak = e0/2
     const float aj = -0.5f * e1, ak = 0.5f * e0;
     const float sj = sinf(aj), cj = cosf(aj), sk = sinf(ak), ck = cosf(ak);
@@ -692,6 +699,22 @@ extern "C" int mm_reorient_reset_typed(const mm_model* m, const mm_state* s, con
   r.qpos_bcast = init_qpos;
   r.reor = 1; r.reor_ntab = ntab; r.reor_tab = size_tables; r.reor_gsize = geom_size_env; r.reor_axis_half = axis_half;
   r.reor_des_rot = des_rot; r.reor_tar_length = tar_length; r.reor_gtype = geom_type_env;
+  hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_pen_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos, float axis_half,
+                            float lo0, float hi0, float lo1, float hi1, float* des_rot, float tar_length, int32_t* episode,
+                            int32_t* step_count, uint64_t seed, void* stream) {
+  if (!m || !s || !init_qpos || !des_rot || !(tar_length > 0.f) || !(axis_half > 0.f))
+    return fail(MM_EARG, "mm_pen_reset: bad argument");
+  ResetArgs r; memset(&r, 0, sizeof(r));
+  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
+  r.qpos_bcast = init_qpos;
+  r.reor = 1; r.pen = 1; r.pen_axis_half = axis_half; r.pen_lo0 = lo0; r.pen_hi0 = hi0; r.pen_lo1 = lo1; r.pen_hi1 = hi1;
+  r.reor_des_rot = des_rot; r.reor_tar_length = tar_length;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;

@@ -2120,12 +2120,13 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
       const int nh = d.nq - 6;
       const int o_pos = nh, o_vel = o_pos + 3, o_rot = o_vel + 6, o_des = o_rot + 3, o_ep = o_des + 3, o_er = o_ep + 3,
-                o_ml = o_er + 3, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = o_mf + d.nu;
+                o_ml = o_er + 3, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = t.reor_obs_muscle ? o_mf + d.nu : o_ml;
       float act2 = 0.f;
       if (ob) {
         for (int i = g; i < nh; i += G) ob[i] = W[L.qpos + i];
         if (g < d.nv && g >= d.nv - 6) ob[o_vel + g - (d.nv - 6)] = E.d_qvel * t.obs_dt;
-        for (int i = g; i < d.nu; i += G) { ob[o_ml + i] = W[L.actlen + i]; ob[o_mv + i] = W[L.actvel + i]; ob[o_mf + i] = W[L.actfrc + i]; }
+        if (t.reor_obs_muscle)
+          for (int i = g; i < d.nu; i += G) { ob[o_ml + i] = W[L.actlen + i]; ob[o_mv + i] = W[L.actvel + i]; ob[o_mf + i] = W[L.actfrc + i]; }
       }
       for (int i = g; i < d.na; i += G) {
         float x = W[L.act + i];
@@ -2137,7 +2138,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         const int bo = t.reor_obj_body;
         V3 opos = ld3(W + L.xpos + 3 * bo);
         const float* R = W + L.xmat + 9 * bo;
-        const float sc_ = 2.f * t.reor_axis_half[e] / t.reor_pen_length;
+        const float sc_ = 2.f * t.reor_axis_half[e] / t.reor_pen_length;   // pen_v0.py: the same vector through the top / bottom sites
         V3 orot = v3(R[2] * sc_, R[5] * sc_, R[8] * sc_);
         V3 odes = ld3(t.reor_des_rot + (size_t)e * 3);
         V3 epos = opos - E.site_pos(t.reor_eps_site), erot = orot - odes;

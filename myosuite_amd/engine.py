@@ -98,6 +98,7 @@ class mm_task(C.Structure):
                 ("walk_target_y_vel", C.c_float), ("walk_target_rot", C.c_float * 4), ("walk_w", C.c_float * 5),
                 ("reor_obj_body", C.c_int), ("reor_eps_site", C.c_int), ("reor_pen_length", C.c_float),
                 ("reor_axis_half", C.c_void_p), ("reor_des_rot", C.c_void_p), ("reor_w", C.c_float * 5),
+                ("reor_obs_muscle", C.c_int),
                 ("env_mask", C.c_void_p), ("obs_only", C.c_int)]
 
 
@@ -133,6 +134,8 @@ def lib():
         L.mm_reorient_reset_typed.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                               C.c_void_p, C.c_uint64, C.c_void_p]
+        L.mm_pen_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
@@ -329,6 +332,14 @@ def reorient_reset_typed(model: HipModel, state: BatchState, mask, init_qpos, si
                                        int(size_tables.shape[1]), _ptr(state.geom_size_env), _ptr(state.geom_type_env),
                                        _ptr(axis_half), _ptr(des_rot), C.c_float(tar_length), _ptr(episode),
                                        _ptr(step_count), C.c_uint64(seed), _stream()), "mm_reorient_reset_typed")
+
+
+def pen_reset(model: HipModel, state: BatchState, mask, init_qpos, axis_half: float, ranges, des_rot, tar_length: float,
+              episode, step_count, seed: int):
+    """ranges = (lo0, hi0, lo1, hi1) of desired_orien[0:2] (pen_v0.py:175-178); zeros for the Fixed task"""
+    _chk(lib().mm_pen_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), C.c_float(axis_half), *[C.c_float(x) for x in ranges],
+                            _ptr(des_rot), C.c_float(tar_length), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()),
+         "mm_pen_reset")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

@@ -35,7 +35,7 @@ def _compiled_model(name: str, muscle_condition: str):
             _MODEL_CACHE[key] = synth.get_model(name)
         else:
             spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg,
-                    "hand_reorient": synth.make_hand_reorient}[name]()
+                    "hand_reorient": synth.make_hand_reorient, "hand_pen": synth.make_hand_pen}[name]()
             for a in spec.actuators:
                 g = list(a.gainprm)
                 g[2] = 0.5 * g[2]

@@ -85,6 +85,11 @@ def _reorient(**kw):
     return ReorientEnvV0(**kw)
 
 
+def _pen(**kw):
+    from .reorient_v0 import PenTwirlEnvV0
+    return PenTwirlEnvV0(**kw)
+
+
 def _walk(**kw):
     from .walk_v0 import WalkEnvV0
     return WalkEnvV0(**kw)
@@ -172,3 +177,11 @@ register_env_with_variants(
 register_env_with_variants(
     id="myoHandReorientOOD-v0", entry_point=_reorient, max_episode_steps=50,
     kwargs={"model": "hand_reorient", "normalize_act": True, "frame_skip": 5, "geometries": "OOD"})
+
+# Pen twirl (myobase/__init__.py:615-634): frame_skip 5, horizon 50
+register_env_with_variants(
+    id="myoHandPenTwirlFixed-v0", entry_point=_pen, max_episode_steps=50,
+    kwargs={"model": "hand_pen", "normalize_act": True, "frame_skip": 5, "random_target": False})
+register_env_with_variants(
+    id="myoHandPenTwirlRandom-v0", entry_point=_pen, max_episode_steps=50,
+    kwargs={"model": "hand_pen", "normalize_act": True, "frame_skip": 5, "random_target": True})

@@ -62,6 +62,7 @@ class ReorientEnvV0(BaseV0):
         t.reor_axis_half = self.axis_half.data_ptr(); t.reor_des_rot = self.des_rot.data_ptr()
         for i, k in enumerate(("pos_align", "rot_align", "act_reg", "drop", "bonus")):
             t.reor_w[i] = float(w.get(k, 0.0))
+        t.reor_obs_muscle = 1
         self._task = t
         self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
         self.reset()
@@ -70,7 +71,10 @@ class ReorientEnvV0(BaseV0):
         cm = self.cm
         o = self.obs
         sizes = [("hand_jnt", cm.nq - 6), ("obj_pos", 3), ("obj_vel", 6), ("obj_rot", 3), ("obj_des_rot", 3), ("obj_err_pos", 3),
-                 ("obj_err_rot", 3), ("mlen", cm.nu), ("mvel", cm.nu), ("mforce", cm.nu), ("act", cm.na)]
+                 ("obj_err_rot", 3)]
+        if self._task.reor_obs_muscle:
+            sizes += [("mlen", cm.nu), ("mvel", cm.nu), ("mforce", cm.nu)]
+        sizes += [("act", cm.na)]
         od = collections.OrderedDict(time=self.state.time)
         k0 = 0
         for k, sz in sizes:
@@ -91,6 +95,58 @@ class ReorientEnvV0(BaseV0):
         self._fatigue_reset(mask)
         E.reorient_reset_typed(self.hm, self.state, mask, self._init_qpos_dev, self._size_tables, self.axis_half,
                                self.des_rot, self.tar_length, self.episode, self.step_count, self._seed_u64)
+        E.reset_observation(self.hm, self.state, self._task, mask)
+        self._refresh_dicts()
+        return self.obs, {}
+
+
+class PenTwirlEnvV0(ReorientEnvV0):
+    """Batched PenTwirl{Fixed,Random}EnvV0 -- mirror of myosuite/envs/myo/myobase/pen_v0.py:15-184.  Same observation /
+    reward arithmetic as the SAR reorient env (which was derived from it) without the muscle length / velocity / force
+    blocks: obs keys ``hand_jnt, obj_pos, obj_vel, obj_rot, obj_des_rot, obj_err_pos, obj_err_rot`` (+ ``act``) = 83; the pen
+    geometry is fixed, ``random_target`` re-draws the desired orientation euler2quat([U(-1,1), U(-1,1), 0]) at reset."""
+    DEFAULT_OBS_KEYS = ["hand_jnt", "obj_pos", "obj_vel", "obj_rot", "obj_des_rot", "obj_err_pos", "obj_err_rot"]   # pen_v0.py:16-26
+
+    def _setup(self, random_target: bool = False, obs_keys=DEFAULT_OBS_KEYS,
+               weighted_reward_keys=ReorientEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS, **kwargs):
+        BaseV0._setup(self, obs_keys=list(obs_keys), weighted_reward_keys=weighted_reward_keys, **kwargs)
+        cm, n, dev = self.cm, self.num_envs, self.device
+        f = dict(dtype=torch.float32, device=dev)
+        sp = {nm: p for nm, _, p in [(k, 0, cm.arrays["SITE_POS"].reshape(-1, 3)[i]) for k, i in cm.names["site"].items()]}
+        self.pen_length = float(np.linalg.norm(sp["object_top"] - sp["object_bottom"]))     # pen_v0.py:71-78
+        self.tar_length = float(np.linalg.norm(sp["target_top"] - sp["target_bottom"]))
+        self.random_target = bool(random_target)
+        self.init_qpos = cm.qpos0.astype(np.float32).copy()
+        self.init_qpos[:-6] *= 0; self.init_qpos[0] = -1.5                                  # pen_v0.py:85-86
+        self._init_qpos_dev = torch.from_numpy(self.init_qpos).to(dev)
+        self._axis_half = 0.5 * self.pen_length
+        self.axis_half = torch.full((n,), self._axis_half, **f); self.des_rot = torch.zeros(n, 3, **f)
+        self.obs_dim = (cm.nq - 6) + 3 + 6 + 3 + 3 + 3 + 3 + cm.na
+        self.obs = torch.zeros(n, self.obs_dim, **f)
+        self.rwd = torch.zeros(n, len(E.RWD_KEYS_REORIENT), **f)
+        self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
+                                     dtype=np.float32)
+        w = self.rwd_keys_wt
+        t = self._new_task(E.MM_TASK_REORIENT)
+        t.reor_obj_body = cm.body_id("Object"); t.reor_eps_site = cm.site_id("eps_ball"); t.reor_pen_length = self.pen_length
+        t.reor_axis_half = self.axis_half.data_ptr(); t.reor_des_rot = self.des_rot.data_ptr()
+        for i, k in enumerate(("pos_align", "rot_align", "act_reg", "drop", "bonus")):
+            t.reor_w[i] = float(w.get(k, 0.0))
+        t.reor_obs_muscle = 0
+        self._task = t
+        self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
+        self.reset()
+
+    def reset(self, seed=None, mask: Optional[torch.Tensor] = None, **kwargs):
+        if seed is not None:
+            self.seed(seed)
+            self._seed_u64 = int(seed)
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
+        self._fatigue_reset(mask)
+        rng = (-1.0, 1.0, -1.0, 1.0) if self.random_target else (0.0, 0.0, 0.0, 0.0)         # pen_v0.py:175-178
+        E.pen_reset(self.hm, self.state, mask, self._init_qpos_dev, self._axis_half, rng, self.des_rot, self.tar_length,
+                    self.episode, self.step_count, self._seed_u64)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
         return self.obs, {}

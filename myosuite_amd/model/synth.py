@@ -532,14 +532,14 @@ def _quat_z_to(v):
     return (math.cos(ang / 2),) + tuple(math.sin(ang / 2) * ax)
 
 
-def make_hand_reorient() -> ModelSpec:
+def _make_hand_with_object(kind: str) -> ModelSpec:
     """myoHand + free-moving object (3 slide + 3 hinge joints, NOT a free joint) + static target, the structure of
     myosuite/envs/myo/assets/hand/myohand_sar.xml:22-57: nq = nv = 29, 39 muscles, obs 200.  The forearm is mounted so that
     init_qpos[0] = pro_sup = -1.5 (reorient_sar_v0.py:113-114) turns the palm up; collision capsules along metacarpals,
     phalanges and the carpal row catch the object.  Object geom: compiled as a capsule; type (capsule / ellipsoid /
     cylinder / box) and size are per-env model deltas re-drawn every episode from the reference's tables."""
     s = make_hand()
-    s.name = "myohand_sar"
+    s.name = "myohand_sar" if kind == "reorient" else "myohand_pen"
     s.nconmax = 8
     phi = -(math.pi - 1.5)                         # base roll: pro_sup = -1.5 then sums to -pi, palm (local -z) up
     s.bodies[s._bname["ulna"]].quat = np.array([math.cos(phi / 2), math.sin(phi / 2), 0.0, 0.0])
@@ -573,17 +573,40 @@ def make_hand_reorient() -> ModelSpec:
     for nm, typ, ax in (("OBJTx", "slide", (1, 0, 0)), ("OBJTy", "slide", (0, 1, 0)), ("OBJTz", "slide", (0, 0, 1)),
                         ("OBJRx", "hinge", (1, 0, 0)), ("OBJRy", "hinge", (0, 1, 0)), ("OBJRz", "hinge", (0, 0, 1))):
         s.add_joint(nm, "Object", typ, axis=ax, armature=0.0)
-    s.add_geom("obj", "Object", "capsule", REORIENT_CAPS_100[0][:2])
-    s.add_geom("top", "Object", "sphere", (0.002,), pos=(0, 0, -0.035))     # xml:36-37 (names as in the reference)
-    s.add_geom("bot", "Object", "sphere", (0.002,), pos=(0, 0, 0.035))
+    if kind == "reorient":
+        s.add_geom("obj", "Object", "capsule", REORIENT_CAPS_100[0][:2])
+        s.add_geom("top", "Object", "sphere", (0.002,), pos=(0, 0, -0.035))     # xml:36-37 (names as in the reference)
+        s.add_geom("bot", "Object", "sphere", (0.002,), pos=(0, 0, 0.035))
+    else:   # the pen: cylinder .015 x .065, density 1500; orientation markers are sites (myohand_pen.xml:34,40-41)
+        mp = 1500.0 * math.pi * 0.015 ** 2 * 0.13
+        ob = s.bodies[s._bname["Object"]]
+        ob.mass = mp; ob.inertia = np.array([mp * (3 * 0.015 ** 2 + 0.13 ** 2) / 12.0] * 2 + [0.5 * mp * 0.015 ** 2])
+        s.add_geom("obj", "Object", "cylinder", (0.015, 0.065))
+        s.add_site("object_top", "Object", (0, 0, 0.065)); s.add_site("object_bottom", "Object", (0, 0, -0.065))
     s.add_site("eps_ball", "world", (OX, 0.004, OZ - 0.005))               # xml:24 vs :26: 5 mm below the object origin
     s.add_site("success", "world", (OX, -0.004, OZ + 0.2))
     s.add_body("target", "world", pos=(OX, -0.004, OZ + 0.2), quat=oq, mass=0.0)
-    s.add_geom("t_top", "target", "sphere", (0.002,), pos=(0, 0, -0.035))
-    s.add_geom("t_bot", "target", "sphere", (0.002,), pos=(0, 0, 0.035))
+    if kind == "reorient":
+        s.add_geom("t_top", "target", "sphere", (0.002,), pos=(0, 0, -0.035))
+        s.add_geom("t_bot", "target", "sphere", (0.002,), pos=(0, 0, 0.035))
+    else:
+        s.bodies[s._bname["target"]].quat = np.array([1.0, 0, 0, 0])            # myohand_pen.xml:44: no euler on the target
+        s.add_site("target_top", "target", (0, 0, 0.065)); s.add_site("target_bottom", "target", (0, 0, -0.065))
     for c in caps:
         s.add_contact_pair("obj", c, condim=3, friction=(1.0, 0.005, 0.0001))
     return s
+
+
+
+def make_hand_reorient() -> ModelSpec:
+    return _make_hand_with_object("reorient")
+
+
+def make_hand_pen() -> ModelSpec:
+    """myoHand + pen (myosuite/envs/myo/assets/hand/myohand_pen.xml:22-52): cylinder .015 x .065 on 3 slide + 3 hinge joints,
+    orientation read through the object_top / object_bottom sites; collides with the hand capsules through the
+    segment-vs-cylinder narrow phase."""
+    return _make_hand_with_object("pen")
 
 
 # ----------------------------------------------------------------------------- contact toy
@@ -645,7 +668,7 @@ def get_model(name: str) -> CompiledModel:
     """Compiled synthetic model by short name: 'elbow' | 'hand' | 'leg'."""
     if name not in _CACHE:
         spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
-                "hand_reorient": make_hand_reorient}[name]()
+                "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen}[name]()
         cm = spec.compile()
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob

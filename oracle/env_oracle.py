@@ -388,14 +388,18 @@ def reorient_reset_draws(size_tables, env: int, episode: int, seed: int, tar_len
 
 
 def reorient_obs_reward(qpos, qvel, act, obj_xpos, obj_xmat, eps_pos, axis_half, des_rot, actuator_length,
-                        actuator_velocity, actuator_force, dt, pen_length, rwd_keys_wt):
-    """get_obs_dict + obsdict2obsvec + get_reward_dict of reorient_sar_v0.py:116-174 on raw arrays."""
+                        actuator_velocity, actuator_force, dt, pen_length, rwd_keys_wt, obs_muscle=True):
+    """get_obs_dict + obsdict2obsvec + get_reward_dict of reorient_sar_v0.py:116-174 (obs_muscle=False: pen_v0.py:88-169,
+    the same arithmetic without the mlen / mvel / mforce observation blocks) on raw arrays."""
     R = np.asarray(obj_xmat, np.float64).reshape(3, 3)
     obj_rot = R[:, 2] * 2 * axis_half / pen_length          # (geom_xpos[top] - geom_xpos[bot]) / pen_length
     od = collections.OrderedDict(
         hand_jnt=qpos[:-6].copy(), obj_pos=np.asarray(obj_xpos, np.float64).copy(), obj_vel=qvel[-6:] * dt, obj_rot=obj_rot,
         obj_des_rot=np.asarray(des_rot, np.float64), obj_err_pos=obj_xpos - eps_pos, obj_err_rot=obj_rot - des_rot,
         mlen=actuator_length.copy(), mvel=actuator_velocity.copy(), mforce=actuator_force.copy(), act=act.copy())
+    if not obs_muscle:
+        for k in ("mlen", "mvel", "mforce"):
+            del od[k]
     obs = np.concatenate([np.asarray(v, np.float64).ravel() for v in od.values()])
     pos_align = np.linalg.norm(od["obj_err_pos"])
     nrm = np.linalg.norm(obj_rot) * np.linalg.norm(des_rot)
@@ -452,3 +456,43 @@ class ReorientEnvOracle(PoseEnvOracle):
         self.steps += 1
         self.rwd_dict = rwd
         return obs, float(rwd["dense"]), bool(rwd["done"]), rwd
+
+
+def pen_reset_draws(env: int, episode: int, seed: int, axis_half: float, tar_length: float, ranges=(-1.0, 1.0, -1.0, 1.0)):
+    """des_rot[3] of the device-side pen reset (k_reset, pen branch): words 1 / 2 of counter (0, 3, env, episode)."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    c = philox4x32_10(0, 3, env, episode, k0, k1)
+    u = [float(u01(x)) for x in c]
+    e0 = ranges[0] + (ranges[1] - ranges[0]) * u[1]; e1 = ranges[2] + (ranges[3] - ranges[2]) * u[2]
+    w, x, y, z = euler2quat([e0, e1, 0.0])
+    col = np.array([2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)])
+    return col * 2 * axis_half / tar_length
+
+
+class PenTwirlEnvOracle(ReorientEnvOracle):
+    """Single-env CPU restatement of PenTwirl{Fixed,Random}EnvV0 (pen_v0.py) on the fp64 oracle engine."""
+
+    def __init__(self, compiled, frame_skip=5, normalize_act=True, muscle_condition=""):
+        PoseEnvOracle.__init__(self, compiled, 0.0, frame_skip, normalize_act, muscle_condition, dict(self.RWD_KEYS_WT))
+        cm = compiled
+        sp = cm.arrays["SITE_POS"].reshape(-1, 3).astype(np.float64); sn = cm.names["site"]
+        self.pen_length = float(np.linalg.norm(sp[sn["object_top"]] - sp[sn["object_bottom"]]))
+        self.tar_length = float(np.linalg.norm(sp[sn["target_top"]] - sp[sn["target_bottom"]]))
+        self.obj_b = cm.body_id("Object"); self.eps_s = cm.site_id("eps_ball")
+        self.init_qpos = cm.qpos0.astype(np.float64).copy(); self.init_qpos[:-6] *= 0; self.init_qpos[0] = -1.5
+        self.axis_half = 0.5 * self.pen_length
+
+    def reset(self, des_rot):
+        self.d.reset()
+        self.d.qpos[:] = self.init_qpos
+        self.des_rot = np.asarray(des_rot, np.float64)
+        self.steps = 0
+        self.d.ctrl[:] = 0
+        self.d.forward()
+        return self._obs_rwd()[0]
+
+    def _obs_rwd(self):
+        d = self.d
+        return reorient_obs_reward(d.qpos, d.qvel, d.act, d.xpos[self.obj_b], d.xmat[self.obj_b], d.site_xpos[self.eps_s],
+                                   self.axis_half, self.des_rot, d.actuator_length, d.actuator_velocity, d.actuator_force,
+                                   self.dt, self.pen_length, self.rwd_keys_wt, obs_muscle=False)

@@ -11,6 +11,7 @@ What can be executed from /root/reference without `mujoco`/`gym` (both absent he
   * myosuite/envs/myo/myobase/reach_v0.py   get_obs_dict / get_reward_dict    -> ref_reach_env.npz
   * myosuite/envs/myo/myobase/walk_v0.py    get_obs_dict / get_reward_dict    -> ref_walk_env.npz
   * myosuite/envs/myo/myobase/reorient_sar_v0.py  get_obs_dict / get_reward_dict -> ref_reorient_env.npz
+  * myosuite/envs/myo/myobase/pen_v0.py     get_obs_dict / get_reward_dict    -> ref_pen_env.npz
   * myosuite/utils/quat_math.py, vector_math.py                               -> ref_math.npz
 `mujoco` and `myosuite.utils.gym` are replaced by stubs that only provide the names those files
 touch at import time (mjtDyn.mjDYN_MUSCLE, gym.utils.seeding.np_random, EzPickle); no arithmetic
@@ -269,6 +270,48 @@ def gen_reorient_env():
     np.savez(os.path.join(OUT, "ref_reorient_env.npz"), **out)
 
 
+def gen_pen_env():
+    """PenTwirlFixedEnvV0.get_obs_dict / get_reward_dict (pen_v0.py:116-169) on synthetic mjData-like arrays."""
+    st = _stubs()
+    st["myosuite.utils.quat_math"] = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
+    st["myosuite.utils.vector_math"] = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
+    pen = _load("ref_pen_v0", f"{REF}/envs/myo/myobase/pen_v0.py", st)
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(31)
+    n, nq, nu, nb, ns = 40, 29, 39, 32, 6
+    obj_bid, eps_sid, ot, ob_, tt, tb = 30, 0, 1, 2, 3, 4
+    qpos = rng.uniform(-1, 1, (n, nq)); qvel = rng.standard_normal((n, nq)) * 3; act = rng.random((n, nu))
+    xpos = rng.uniform(-0.5, 0.5, (n, nb, 3)); site = rng.uniform(-0.5, 0.5, (n, ns, 3))
+    site[:14, eps_sid] = xpos[:14, obj_bid] + rng.uniform(-0.02, 0.02, (14, 3))
+    d1 = rng.standard_normal((n, 3)); d1 *= 0.13 / np.linalg.norm(d1, axis=1, keepdims=True)
+    d2 = d1 + rng.standard_normal((n, 3)) * 0.03; d2[20:] = rng.standard_normal((n - 20, 3)) * 0.1
+    site[:, ot] = site[:, ob_] + d1; site[:, tt] = site[:, tb] + d2
+    dt = 0.01
+    keys = list(pen.PenTwirlFixedEnvV0.DEFAULT_OBS_KEYS) + ["act"]
+    rk = ("pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense")
+    obs = []; rwd = {k: [] for k in rk}
+    for i in range(n):
+        model = types.SimpleNamespace(na=nu)
+        data = types.SimpleNamespace(time=0.1 * i, qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(), xpos=xpos[i],
+                                     site_xpos=site[i])
+        env = object.__new__(pen.PenTwirlFixedEnvV0)
+        env.mj_model = model; env.dt = dt; env.obj_bid = obj_bid; env.eps_ball_sid = eps_sid; env.obj_t_sid = ot
+        env.obj_b_sid = ob_; env.tar_t_sid = tt; env.tar_b_sid = tb; env.pen_length = 0.13; env.tar_length = 0.13
+        env.rwd_keys_wt = pen.PenTwirlFixedEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS
+        od = env.get_obs_dict(model, data)
+        _, vec = ovd.ObsVecDict().obsdict2obsvec(od, keys)
+        env.obs_dict = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+        rd = env.get_reward_dict(env.obs_dict)
+        obs.append(vec)
+        for k in rk:
+            rwd[k].append(np.squeeze(rd[k]))
+    out = dict(qpos=qpos, qvel=qvel, act=act, obj_xpos=xpos[:, obj_bid], eps_pos=site[:, eps_sid], top_minus_bot=d1,
+               ttop_minus_tbot=d2, dt=np.array(dt), obs=np.array(obs), keys=np.array(keys))
+    for k in rk:
+        out[f"rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    np.savez(os.path.join(OUT, "ref_pen_env.npz"), **out)
+
+
 def gen_math():
     qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
     vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
@@ -291,5 +334,6 @@ if __name__ == "__main__":
     gen_reach_env()
     gen_walk_env()
     gen_reorient_env()
+    gen_pen_env()
     gen_math()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))

@@ -154,3 +154,71 @@ def test_gpu_reorient_drop_terminates_and_autoresets(oracle_lib):
         assert torch.isfinite(obs).all() and torch.isfinite(r).all()
     assert float(dropped.float().mean()) > 0.5
     assert int((env.state.status & 0xA).max()) == 0       # no row overflow / no solver failure (bit0 = gimbal auto-reset is legal)
+
+
+# ----------------------------------------------------------------------------------- PenTwirl (pen_v0.py)
+def test_pen_oracle_arithmetic_matches_reference_vectors():
+    g = np.load(os.path.join(G, "ref_pen_env.npz"))
+    n = g["qpos"].shape[0]
+    assert list(g["keys"]) == ["hand_jnt", "obj_pos", "obj_vel", "obj_rot", "obj_des_rot", "obj_err_pos", "obj_err_rot", "act"]
+    z39 = np.zeros(39)
+    for i in range(n):
+        d1 = g["top_minus_bot"][i]
+        z = d1 / np.linalg.norm(d1)
+        x = np.cross(z, [0.3, 0.5, 0.8]); x /= np.linalg.norm(x); y = np.cross(z, x)
+        obs, rwd = EO.reorient_obs_reward(g["qpos"][i], g["qvel"][i], g["act"][i], g["obj_xpos"][i], np.stack([x, y, z], 1),
+                                          g["eps_pos"][i], 0.5 * np.linalg.norm(d1), g["ttop_minus_tbot"][i] / 0.13, z39, z39, z39,
+                                          float(g["dt"]), 0.13, WT, obs_muscle=False)
+        assert obs.shape == (83,)
+        np.testing.assert_allclose(obs, g["obs"][i], rtol=2e-6, atol=2e-6)
+        for k in RK:
+            np.testing.assert_allclose(float(rwd[k]), g[f"rwd_{k}"][i], rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoHandPenTwirlRandom-v0", "myoHandPenTwirlFixed-v0"])
+def test_gpu_pen_twirl_env_matches_oracle_env(oracle_lib, env_id):
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    cm = synth.get_model("hand_pen")
+    n, nsteps = 8, 6
+    env = registry.make(env_id, num_envs=n, seed=4, autoreset=False)
+    obs0, _ = env.reset(seed=4)
+    assert obs0.shape == (n, 83) and list(env.obs_dict.keys())[1:8] == ["hand_jnt", "obj_pos", "obj_vel", "obj_rot", "obj_des_rot",
+                                                                       "obj_err_pos", "obj_err_rot"]
+    ep = env.episode.cpu().numpy()
+    orc = []
+    for e in range(n):
+        rng = (-1.0, 1.0, -1.0, 1.0) if "Random" in env_id else (0.0, 0.0, 0.0, 0.0)
+        des = EO.pen_reset_draws(e, int(ep[e]) - 1, 4, 0.065, env.tar_length, rng)
+        np.testing.assert_allclose(env.des_rot[e].cpu().numpy(), des, atol=2e-6)
+        w = EO.PenTwirlEnvOracle(cm)
+        o = w.reset(env.des_rot[e].cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), o, rtol=1e-4, atol=3e-5)
+        orc.append(w)
+    if "Fixed" in env_id:
+        np.testing.assert_allclose(env.des_rot.cpu().numpy(), np.tile([0, 0, 1.0], (n, 1)), atol=1e-7)
+    a = torch.empty(n, cm.nu, device="cuda")
+    for s in range(nsteps):
+        st = env.get_env_state()
+        for e in range(n):
+            d = orc[e].d
+            for k in ("qpos", "qvel", "act", "qacc_warmstart"):
+                v = getattr(d, k).astype(np.float32); getattr(d, k)[:] = v
+                st[k][e] = torch.from_numpy(v)
+        env.set_env_state(st)
+        E.uniform(a, 21, s)
+        act = (0.3 + 0.5 * a).contiguous()
+        obs, r, term, trunc, info = env.step(act)
+        an = act.cpu().numpy()
+        for e in range(n):
+            o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
+            got = obs[e].cpu().numpy()
+            tol = np.full(83, 2e-3); tol[26:32] = 2e-2
+            bad = np.abs(got - o) / np.maximum(1.0, np.abs(o)) > tol
+            assert not bad.any(), (s, e, np.nonzero(bad)[0][:5])
+            for i, k in enumerate(E.RWD_KEYS_REORIENT):
+                ref = float(rd[k])
+                assert abs(float(env.rwd[e, i]) - ref) < 5e-3 * max(1.0, abs(ref)), (k, s, e)
+            assert bool(term[e]) == done
