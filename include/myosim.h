@@ -48,7 +48,7 @@ extern "C" {
 typedef struct mm_model mm_model;
 
 /* task ids for the fused obs/reward stage */
-enum { MM_TASK_NONE = 0, MM_TASK_POSE = 1, MM_TASK_REACH = 2, MM_TASK_REORIENT = 3, MM_TASK_WALK = 4 };
+enum { MM_TASK_NONE = 0, MM_TASK_POSE = 1, MM_TASK_REACH = 2, MM_TASK_REORIENT = 3, MM_TASK_WALK = 4, MM_TASK_OBJHOLD = 5 };
 
 /* mm_model_info selectors */
 enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INFO_NSITE, MM_INFO_NTENDON,
@@ -151,6 +151,10 @@ typedef struct {
   float reor_w[5];          /* weights of pos_align, rot_align, act_reg, drop, bonus (reorient_sar_v0.py:38-44) */
   int   reor_obs_muscle;    /* 1: obs carries mlen / mvel / mforce (reorient_sar_v0.py); 0: PenTwirl's obs (pen_v0.py:16-26:
                                hand_jnt, obj_pos, obj_vel, obj_rot, obj_des_rot, obj_err_pos, obj_err_rot, act)          */
+  /* OBJHOLD task (envs/myo/myobase/obj_hold_v0.py:60-131; free-joint object = the last 7 qpos / 6 qvel): obs
+     [hand_qpos = qpos[:-7], hand_qvel = qvel[:-6]*dt, obj_pos, obj_err = goal - obj_pos, act]; reuses tip_sites[0] (the
+     "object" site), target_pos [nenv][3] (the per-episode "goal" site position), w_pose (goal_dist weight), w_bonus,
+     w_penalty, w_act_reg and the MM_RWD_* columns (POSE := goal_dist). */
   /* reset observation support (all tasks) */
   const uint8_t* env_mask;  /* optional [nenv]: envs with 0 are left untouched  */
   int   obs_only;           /* 1: no substeps, no ctrl map, no counters, no reward write: forward + obs of the CURRENT state
@@ -230,6 +234,12 @@ int  mm_reorient_reset_typed(const mm_model* m, const mm_state* s, const uint8_t
                              const float* size_tables, int ntab, float* geom_size_env, int32_t* geom_type_env,
                              float* axis_half, float* des_rot, float tar_length, int32_t* episode, int32_t* step_count,
                              uint64_t seed, void* stream);
+/* Object-hold reset (obj_hold_v0.py:134-145): goal[e] = goal_center + U(-goal_half, goal_half)^3, object size[e] ~
+ * U(size_lo, size_hi)^3 -> geom_size_env (skipped when goal_half == 0 / geom_size_env == NULL: the Fixed task); state =
+ * init_qpos, qvel = act = 0. */
+int  mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
+                      const float* goal_center, float goal_half, float size_lo, float size_hi, float* goal,
+                      float* geom_size_env, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

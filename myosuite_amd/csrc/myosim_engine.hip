@@ -36,6 +36,7 @@ struct ResetArgs {
   int reor, reor_ntab; const float* reor_tab; float *reor_gsize, *reor_axis_half, *reor_des_rot; float reor_tar_length;
   int32_t* reor_gtype;   // non-null: also draw the object type (tables [4][ntab][3])
   int pen; float pen_axis_half, pen_lo0, pen_hi0, pen_lo1, pen_hi1;   // pen-twirl reset: fixed geometry, euler ranges
+  int hold; const float* hold_center; float hold_half, hold_slo, hold_shi; float* hold_goal; float* hold_gsize;
 };
 
 __global__ void k_reset(ResetArgs r) {
@@ -83,6 +84,20 @@ __global__ void k_reset(ResetArgs r) {
       for (int i = 0; i < r.nq; i++) ob[i] = qpos0[i];
       for (int i = 0; i < r.nv; i++) ob[r.nq + i] = 0.f;
       for (int i = 0; i < r.na; i++) ob[r.nq + r.nv + 2 * n3 + i] = 0.f;
+    }
+  }
+  if (r.hold) {
+    // obj_hold_v0.py:134-145: goal ~ center + U(-half, half)^3 (counter (0,4,env,episode)), object size ~ U(lo, hi)^3
+    // (counter (1,4,env,episode)); Fixed task: half = 0, no size table
+    int ep = r.episode ? r.episode[e] : 0;
+    if (r.episode) r.episode[e] = ep + 1;
+    uint32_t c[4] = {0u, 4u, (uint32_t)e, (uint32_t)ep};
+    philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    for (int k = 0; k < 3; k++) r.hold_goal[(size_t)e * 3 + k] = r.hold_center[k] + r.hold_half * (2.f * u01(c[k]) - 1.f);
+    if (r.hold_gsize) {
+      uint32_t c2[4] = {1u, 4u, (uint32_t)e, (uint32_t)ep};
+      philox4x32_10(c2, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+      for (int k = 0; k < 3; k++) r.hold_gsize[(size_t)e * 3 + k] = r.hold_slo + (r.hold_shi - r.hold_slo) * u01(c2[k]);
     }
   }
   if (r.reor) {
@@ -595,8 +610,12 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
         !t->reor_axis_half || !t->reor_des_rot || !(t->reor_pen_length > 0.f) || m->d.nq < 7)
       return fail(MM_EARG, "reorient task: bad body/site id or missing per-env buffers");
   }
+  if (t->task == MM_TASK_OBJHOLD) {
+    if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "object-hold task needs do_forward");
+    if (!t->tip_sites || !t->target_pos || m->d.nq < 8) return fail(MM_EARG, "object-hold task needs tip_sites[0], target_pos and a free-joint object");
+  }
   if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH && t->task != MM_TASK_WALK &&
-      t->task != MM_TASK_REORIENT)
+      t->task != MM_TASK_REORIENT && t->task != MM_TASK_OBJHOLD)
     return fail(MM_EUNSUPPORTED, "task not implemented");
   if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "fatigue needs MA/MR/MF");
   KArgs a; fill_common(m, a, s);
@@ -715,6 +734,21 @@ extern "C" int mm_pen_reset(const mm_model* m, const mm_state* s, const uint8_t*
   r.qpos_bcast = init_qpos;
   r.reor = 1; r.pen = 1; r.pen_axis_half = axis_half; r.pen_lo0 = lo0; r.pen_hi0 = hi0; r.pen_lo1 = lo1; r.pen_hi1 = hi1;
   r.reor_des_rot = des_rot; r.reor_tar_length = tar_length;
+  hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
+                                const float* goal_center, float goal_half, float size_lo, float size_hi, float* goal,
+                                float* geom_size_env, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
+  if (!m || !s || !init_qpos || !goal_center || !goal) return fail(MM_EARG, "mm_objhold_reset: bad argument");
+  ResetArgs r; memset(&r, 0, sizeof(r));
+  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
+  r.qpos_bcast = init_qpos;
+  r.hold = 1; r.hold_center = goal_center; r.hold_half = goal_half; r.hold_slo = size_lo; r.hold_shi = size_hi;
+  r.hold_goal = goal; r.hold_gsize = geom_size_env;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
   return MM_OK;

@@ -2115,6 +2115,38 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
       }
     }
+    if (t.task == MM_TASK_OBJHOLD) {
+      // obs / reward of ObjHoldFixedEnvV0 (obj_hold_v0.py:82-131)
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      const int nh = d.nq - 7, nhv = d.nv - 6;
+      float act2 = 0.f;
+      if (ob) {
+        for (int i = g; i < nh; i += G) ob[i] = W[L.qpos + i];
+        if (g < nhv) ob[nh + g] = E.d_qvel * t.obs_dt;
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[nh + nhv + 6 + i] = x;
+      }
+      act2 = gsum<G>(act2);
+      if (g == 0) {
+        const V3 op = E.site_pos(t.tip_sites[0]);
+        const V3 er = ld3(t.target_pos + (size_t)e * 3) - op;
+        if (ob) { st3(ob + nh + nhv, op); st3(ob + nh + nhv + 3, er); }
+        const float goal_dist = sqrtf(dot(er, er)), act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        const float goal_th = 0.010f;
+        const bool drop = goal_dist > 0.300f;
+        const float bonus = (goal_dist < 2.f * goal_th ? 1.f : 0.f) + (goal_dist < goal_th ? 1.f : 0.f);
+        if (t.rwd && !obs_only) {
+          float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
+          r[MM_RWD_POSE] = -goal_dist; r[MM_RWD_BONUS] = bonus; r[MM_RWD_PENALTY] = drop ? -1.f : 0.f; r[MM_RWD_ACT_REG] = -act_mag;
+          r[MM_RWD_SPARSE] = -goal_dist; r[MM_RWD_SOLVED] = goal_dist < goal_th ? 1.f : 0.f; r[MM_RWD_DONE] = drop ? 1.f : 0.f;
+          r[MM_RWD_DENSE] = t.w_pose * -goal_dist + t.w_bonus * bonus + t.w_act_reg * -act_mag + t.w_penalty * (drop ? -1.f : 0.f);
+        }
+        if (t.done && !obs_only) t.done[e] = drop ? 1 : 0;
+      }
+    }
     if (t.task == MM_TASK_REORIENT) {
       // obs / reward of ProprioceptiveEnvV0 (reorient_sar_v0.py:116-174)
       float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;

@@ -5,7 +5,7 @@
 #define MM_KERNELS_A(X) X(4, 4, 0, 0) X(8, 4, 0, 0) X(16, 4, 0, 0) X(32, 4, 0, 0) X(64, 4, 0, 0)
 #define MM_KERNELS_B(X) X(32, 24, 0, 0) X(64, 24, 0, 0) X(32, 32, 0, 0)
 #define MM_KERNELS_C(X) X(64, 32, 0, 0) X(64, 40, 0, 0) X(16, 4, 1, 0)
-#define MM_KERNELS_D(X) X(32, 24, 1, 0) X(64, 32, 1, 0)
+#define MM_KERNELS_D(X) X(32, 24, 1, 0) X(64, 32, 1, 0) X(32, 32, 1, 0)
 #define MM_KERNELS_E(X) X(64, 40, 1, 0) X(4, 4, 0, 1) X(32, 24, 0, 1)
 #define MM_KERNELS_F(X) X(32, 32, 0, 1) X(64, 40, 0, 1) X(16, 4, 1, 1) X(32, 24, 1, 1)
 #define MM_KERNELS_G(X) X(64, 32, 1, 1) X(64, 40, 1, 1)

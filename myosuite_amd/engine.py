@@ -22,9 +22,10 @@ LIB_PATH = os.environ.get("MYOSIM_LIB", os.path.join(CSRC, "libmyosim_hip.so")) 
 # sources: every *.hip under csrc/ (see build())
 _lib = None
 
-MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK = 0, 1, 2, 3, 4
+MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK, MM_TASK_OBJHOLD = 0, 1, 2, 3, 4, 5
 RWD_KEYS_POSE = ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 RWD_KEYS_REACH = ["reach", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+RWD_KEYS_OBJHOLD = ["goal_dist", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense"]
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
@@ -136,6 +137,8 @@ def lib():
                                               C.c_void_p, C.c_uint64, C.c_void_p]
         L.mm_pen_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.mm_objhold_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.mm_last_error.restype = C.c_char_p
         L.mm_version.restype = C.c_char_p
         L.mm_debug_layout.argtypes = [C.c_void_p, C.c_char_p]
@@ -340,6 +343,16 @@ def pen_reset(model: HipModel, state: BatchState, mask, init_qpos, axis_half: fl
     _chk(lib().mm_pen_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), C.c_float(axis_half), *[C.c_float(x) for x in ranges],
                             _ptr(des_rot), C.c_float(tar_length), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()),
          "mm_pen_reset")
+
+
+def objhold_reset(model: HipModel, state: BatchState, mask, init_qpos, goal_center, goal_half: float, size_range, goal,
+                  episode, step_count, seed: int):
+    """size_range (lo, hi) re-draws the object size into state.geom_size_env (Random task); None keeps the model's size"""
+    gs = state.geom_size_env if size_range is not None else None
+    lo, hi = size_range if size_range is not None else (0.0, 0.0)
+    _chk(lib().mm_objhold_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(goal_center), C.c_float(goal_half),
+                                C.c_float(lo), C.c_float(hi), _ptr(goal), _ptr(gs), _ptr(episode), _ptr(step_count),
+                                C.c_uint64(seed), _stream()), "mm_objhold_reset")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

@@ -35,7 +35,8 @@ def _compiled_model(name: str, muscle_condition: str):
             _MODEL_CACHE[key] = synth.get_model(name)
         else:
             spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg,
-                    "hand_reorient": synth.make_hand_reorient, "hand_pen": synth.make_hand_pen}[name]()
+                    "hand_reorient": synth.make_hand_reorient, "hand_pen": synth.make_hand_pen,
+                    "hand_hold": synth.make_hand_hold}[name]()
             for a in spec.actuators:
                 g = list(a.gainprm)
                 g[2] = 0.5 * g[2]

@@ -90,6 +90,11 @@ def _pen(**kw):
     return PenTwirlEnvV0(**kw)
 
 
+def _objhold(**kw):
+    from .obj_hold_v0 import ObjHoldEnvV0
+    return ObjHoldEnvV0(**kw)
+
+
 def _walk(**kw):
     from .walk_v0 import WalkEnvV0
     return WalkEnvV0(**kw)
@@ -185,3 +190,11 @@ register_env_with_variants(
 register_env_with_variants(
     id="myoHandPenTwirlRandom-v0", entry_point=_pen, max_episode_steps=50,
     kwargs={"model": "hand_pen", "normalize_act": True, "frame_skip": 5, "random_target": True})
+
+# Hold objects (myobase/__init__.py:595-612): horizon 75
+register_env_with_variants(
+    id="myoHandObjHoldFixed-v0", entry_point=_objhold, max_episode_steps=75,
+    kwargs={"model": "hand_hold", "normalize_act": True, "randomize": False})
+register_env_with_variants(
+    id="myoHandObjHoldRandom-v0", entry_point=_objhold, max_episode_steps=75,
+    kwargs={"model": "hand_hold", "normalize_act": True, "randomize": True})

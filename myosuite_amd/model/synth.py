@@ -532,14 +532,11 @@ def _quat_z_to(v):
     return (math.cos(ang / 2),) + tuple(math.sin(ang / 2) * ax)
 
 
-def _make_hand_with_object(kind: str) -> ModelSpec:
-    """myoHand + free-moving object (3 slide + 3 hinge joints, NOT a free joint) + static target, the structure of
-    myosuite/envs/myo/assets/hand/myohand_sar.xml:22-57: nq = nv = 29, 39 muscles, obs 200.  The forearm is mounted so that
-    init_qpos[0] = pro_sup = -1.5 (reorient_sar_v0.py:113-114) turns the palm up; collision capsules along metacarpals,
-    phalanges and the carpal row catch the object.  Object geom: compiled as a capsule; type (capsule / ellipsoid /
-    cylinder / box) and size are per-env model deltas re-drawn every episode from the reference's tables."""
+def _hand_palm_up_with_capsules(name: str):
+    """make_hand() mounted so that pro_sup = -1.5 turns the palm up, plus collision capsules along metacarpals, phalanges and
+    the carpal row.  Returns (spec, capsule geom names)."""
     s = make_hand()
-    s.name = "myohand_sar" if kind == "reorient" else "myohand_pen"
+    s.name = name
     s.nconmax = 8
     phi = -(math.pi - 1.5)                         # base roll: pro_sup = -1.5 then sums to -pi, palm (local -z) up
     s.bodies[s._bname["ulna"]].quat = np.array([math.cos(phi / 2), math.sin(phi / 2), 0.0, 0.0])
@@ -563,6 +560,16 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
         cap(f"col_{body}", body, r, 0.004 * tdir, (L - 0.003) * tdir)
     cap("col_carpal", "capitate", 0.012, (0.008, -0.026, 0), (0.008, 0.028, 0))
 
+    return s, caps
+
+
+def _make_hand_with_object(kind: str) -> ModelSpec:
+    """myoHand + free-moving object (3 slide + 3 hinge joints, NOT a free joint) + static target, the structure of
+    myosuite/envs/myo/assets/hand/myohand_sar.xml:22-57: nq = nv = 29, 39 muscles, obs 200.  The forearm is mounted so that
+    init_qpos[0] = pro_sup = -1.5 (reorient_sar_v0.py:113-114) turns the palm up; collision capsules along metacarpals,
+    phalanges and the carpal row catch the object.  Object geom: compiled as a capsule; type (capsule / ellipsoid /
+    cylinder / box) and size are per-env model deltas re-drawn every episode from the reference's tables."""
+    s, caps = _hand_palm_up_with_capsules("myohand_sar" if kind == "reorient" else "myohand_pen")
     # object above the palm centre (world frame at init: local (x, y, z) -> (x, -y, 1 - z) for the rolled forearm)
     OX, OZ = 0.325, 1.0 + 0.009 + 0.022
     eul = 1.27                                                              # myohand_sar.xml:26  euler="0 1.27 0"
@@ -596,6 +603,25 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
         s.add_contact_pair("obj", c, condim=3, friction=(1.0, 0.005, 0.0001))
     return s
 
+
+
+
+def make_hand_hold() -> ModelSpec:
+    """myoHand + free-floating ellipsoid to hold (myosuite/envs/myo/assets/hand/myohand_hold.xml:14-23): object on a free
+    joint (nq 30 / nv 29), frictionless contacts (condim 1), a world-fixed ``goal`` site and an ``object`` site."""
+    s, caps = _hand_palm_up_with_capsules("myohand_hold")
+    OX, OZ = 0.325, 1.0 + 0.009 + 0.032
+    size = (0.025, 0.036, 0.030)
+    m = 1000.0 * 4.0 / 3.0 * math.pi * size[0] * size[1] * size[2]
+    s.add_body("object", "world", pos=(OX, 0.0, OZ), mass=m,
+               inertia=(m / 5 * (size[1] ** 2 + size[2] ** 2), m / 5 * (size[0] ** 2 + size[2] ** 2), m / 5 * (size[0] ** 2 + size[1] ** 2)))
+    s.add_joint("object_free", "object", "free")
+    s.add_geom("object", "object", "ellipsoid", size)
+    s.add_site("object", "object", (0, 0, 0))
+    s.add_site("goal", "world", (OX - 0.005, -0.010, OZ + 0.020))          # xml:15 vs :18: goal - object = (-.005, -.01, +.02)
+    for c in caps:
+        s.add_contact_pair(c, "object", condim=1, friction=(1.0, 0.005, 0.0001))
+    return s
 
 
 def make_hand_reorient() -> ModelSpec:
@@ -668,7 +694,8 @@ def get_model(name: str) -> CompiledModel:
     """Compiled synthetic model by short name: 'elbow' | 'hand' | 'leg'."""
     if name not in _CACHE:
         spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
-                "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen}[name]()
+                "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen,
+                "hand_hold": make_hand_hold}[name]()
         cm = spec.compile()
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob

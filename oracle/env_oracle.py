@@ -496,3 +496,74 @@ class PenTwirlEnvOracle(ReorientEnvOracle):
         return reorient_obs_reward(d.qpos, d.qvel, d.act, d.xpos[self.obj_b], d.xmat[self.obj_b], d.site_xpos[self.eps_s],
                                    self.axis_half, self.des_rot, d.actuator_length, d.actuator_velocity, d.actuator_force,
                                    self.dt, self.pen_length, self.rwd_keys_wt, obs_muscle=False)
+
+
+# ---------------------------------------------------------------------- ObjHold (obj_hold_v0.py)
+def objhold_reset_draws(env: int, episode: int, seed: int, center, goal_half: float, size_range=None):
+    """(goal[3], size[3] | None) of the device-side object-hold reset (k_reset, hold branch), float32 draws."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    c = philox4x32_10(0, 4, env, episode, k0, k1)
+    u = np.array([u01(x) for x in c[:3]], np.float32).reshape(3)
+    goal = (np.asarray(center, np.float32) + np.float32(goal_half) * (np.float32(2.0) * u - np.float32(1.0))).astype(np.float32)
+    size = None
+    if size_range is not None:
+        c2 = philox4x32_10(1, 4, env, episode, k0, k1)
+        u2 = np.array([u01(x) for x in c2[:3]], np.float32).reshape(3)
+        size = (np.float32(size_range[0]) + np.float32(size_range[1] - size_range[0]) * u2).astype(np.float32)
+    return goal, size
+
+
+def objhold_obs_reward(qpos, qvel, act, obj_pos, goal_pos, dt, rwd_keys_wt):
+    """get_obs_dict + obsdict2obsvec + get_reward_dict of obj_hold_v0.py:82-131 on raw arrays."""
+    od = collections.OrderedDict(hand_qpos=qpos[:-7].copy(), hand_qvel=qvel[:-6] * dt, obj_pos=np.asarray(obj_pos, np.float64),
+                                 obj_err=np.asarray(goal_pos, np.float64) - obj_pos, act=act.copy())
+    obs = np.concatenate([np.asarray(v, np.float64).ravel() for v in od.values()])
+    goal_dist = np.abs(np.linalg.norm(od["obj_err"]))
+    na = act.size
+    act_mag = np.linalg.norm(act) / na if na else 0.0
+    gaol_th = 0.010
+    drop = goal_dist > 0.300
+    rwd = collections.OrderedDict((
+        ("goal_dist", -1.0 * goal_dist), ("bonus", 1.0 * (goal_dist < 2 * gaol_th) + 1.0 * (goal_dist < gaol_th)),
+        ("act_reg", -1.0 * act_mag), ("penalty", -1.0 * drop), ("sparse", -goal_dist), ("solved", goal_dist < gaol_th), ("done", drop)))
+    rwd["dense"] = np.sum([wt * rwd[k] for k, wt in rwd_keys_wt.items()], axis=0)
+    return obs, rwd
+
+
+class ObjHoldEnvOracle(PoseEnvOracle):
+    """Single-env CPU restatement of ObjHold{Fixed,Random}EnvV0 on the fp64 oracle engine."""
+    RWD_KEYS_WT = {"goal_dist": 100.0, "bonus": 4.0, "penalty": 10}
+
+    def __init__(self, compiled, frame_skip=10, normalize_act=True, muscle_condition=""):
+        super().__init__(compiled, 0.0, frame_skip, normalize_act, muscle_condition, dict(self.RWD_KEYS_WT))
+        cm = compiled
+        self.obj_s = cm.site_id("object"); self.obj_g = cm.names["geom"]["object"]
+        self.init_qpos = cm.qpos0.astype(np.float64).copy(); self.init_qpos[:-7] *= 0; self.init_qpos[0] = -1.5
+
+    def reset(self, goal, size=None):
+        self.d.reset()
+        self.d.qpos[:] = self.init_qpos
+        if size is not None:
+            self.d.set_geom_size(self.obj_g, size)
+        self.goal = np.asarray(goal, np.float64)
+        self.steps = 0
+        self.d.ctrl[:] = 0
+        self.d.forward()
+        return self._obs_rwd()[0]
+
+    def _obs_rwd(self):
+        d = self.d
+        return objhold_obs_reward(d.qpos, d.qvel, d.act, d.site_xpos[self.obj_s], self.goal, self.dt, self.rwd_keys_wt)
+
+    def step(self, a):
+        a = np.asarray(a, np.float64)
+        ctrl = a.copy()
+        if self.cm.na and self.normalize_act:
+            ctrl[self.muscle] = 1.0 / (1.0 + np.exp(-5.0 * (ctrl[self.muscle] - 0.5)))
+        self.d.ctrl[:] = ctrl
+        self.d.step(self.frame_skip)
+        self.d.forward()
+        obs, rwd = self._obs_rwd()
+        self.steps += 1
+        self.rwd_dict = rwd
+        return obs, float(rwd["dense"]), bool(rwd["done"]), rwd

@@ -12,6 +12,7 @@ What can be executed from /root/reference without `mujoco`/`gym` (both absent he
   * myosuite/envs/myo/myobase/walk_v0.py    get_obs_dict / get_reward_dict    -> ref_walk_env.npz
   * myosuite/envs/myo/myobase/reorient_sar_v0.py  get_obs_dict / get_reward_dict -> ref_reorient_env.npz
   * myosuite/envs/myo/myobase/pen_v0.py     get_obs_dict / get_reward_dict    -> ref_pen_env.npz
+  * myosuite/envs/myo/myobase/obj_hold_v0.py get_obs_dict / get_reward_dict   -> ref_objhold_env.npz
   * myosuite/utils/quat_math.py, vector_math.py                               -> ref_math.npz
 `mujoco` and `myosuite.utils.gym` are replaced by stubs that only provide the names those files
 touch at import time (mjtDyn.mjDYN_MUSCLE, gym.utils.seeding.np_random, EzPickle); no arithmetic
@@ -312,6 +313,40 @@ def gen_pen_env():
     np.savez(os.path.join(OUT, "ref_pen_env.npz"), **out)
 
 
+def gen_objhold_env():
+    """ObjHoldFixedEnvV0.get_obs_dict / get_reward_dict (obj_hold_v0.py:82-131) on synthetic mjData-like arrays."""
+    hold = _load("ref_obj_hold_v0", f"{REF}/envs/myo/myobase/obj_hold_v0.py", _stubs())
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(41)
+    n, nq, nv, nu, ns = 40, 30, 29, 39, 4
+    obj_sid, goal_sid = 2, 0
+    qpos = rng.uniform(-1, 1, (n, nq)); qvel = rng.standard_normal((n, nv)) * 3; act = rng.random((n, nu))
+    site = rng.uniform(-0.5, 0.5, (n, ns, 3))
+    site[:12, goal_sid] = site[:12, obj_sid] + rng.uniform(-0.008, 0.008, (12, 3))      # near: bonus / solved
+    site[12:20, goal_sid] = site[12:20, obj_sid] + 0.25                                  # far: drop / done
+    dt = 0.02
+    keys = list(hold.ObjHoldFixedEnvV0.DEFAULT_OBS_KEYS) + ["act"]
+    rk = ("goal_dist", "bonus", "act_reg", "penalty", "sparse", "solved", "done", "dense")
+    obs = []; rwd = {k: [] for k in rk}
+    for i in range(n):
+        model = types.SimpleNamespace(na=nu)
+        data = types.SimpleNamespace(time=0.1 * i, qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(), site_xpos=site[i])
+        env = object.__new__(hold.ObjHoldFixedEnvV0)
+        env.mj_model = model; env.dt = dt; env.object_sid = obj_sid; env.goal_sid = goal_sid
+        env.rwd_keys_wt = hold.ObjHoldFixedEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS
+        od = env.get_obs_dict(model, data)
+        _, vec = ovd.ObsVecDict().obsdict2obsvec(od, keys)
+        env.obs_dict = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+        rd = env.get_reward_dict(env.obs_dict)
+        obs.append(vec)
+        for k in rk:
+            rwd[k].append(np.squeeze(rd[k]))
+    out = dict(qpos=qpos, qvel=qvel, act=act, obj_pos=site[:, obj_sid], goal_pos=site[:, goal_sid], dt=np.array(dt), obs=np.array(obs))
+    for k in rk:
+        out[f"rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    np.savez(os.path.join(OUT, "ref_objhold_env.npz"), **out)
+
+
 def gen_math():
     qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
     vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
@@ -335,5 +370,6 @@ if __name__ == "__main__":
     gen_walk_env()
     gen_reorient_env()
     gen_pen_env()
+    gen_objhold_env()
     gen_math()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))
