@@ -558,13 +558,10 @@ struct Engine {
   float b_cinert[10];
   float b_cvel[6];
   int b_depth, b_parent;
-  // model constants of the owned body and of its first two joints (loaded once per kernel)
-  V3 c_bpos, c_bipos;
-  Q4 c_bquat;
+  // integer model constants of the owned body and of its first two joints (loaded once per kernel); the float constants
+  // (body / joint frames) are read from the LDS-resident model where they are used: holding them cost 23 VGPRs and spills
   int c_jn, c_ja;
   int c_jtype[2], c_jqadr[2], c_jdadr[2];
-  V3 c_jpos[2], c_jaxis[2];
-  float c_jq0[2];
   // ---- dof-lane registers (valid for g < nv)
   float d_cdof[6];
   float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
@@ -591,10 +588,6 @@ struct Engine {
     b_parent = (g > 0 && g < a.d.nbody) ? MI_(BODY_PARENT)[g] : 0;
     {
       const bool isb = g > 0 && g < a.d.nbody;
-      c_bpos = isb ? ld3(MF_(BODY_POS) + 3 * g) : v3(0.f, 0.f, 0.f);
-      c_bipos = isb ? ld3(MF_(BODY_IPOS) + 3 * g) : v3(0.f, 0.f, 0.f);
-      Q4 q1 = {1.f, 0.f, 0.f, 0.f};
-      c_bquat = isb ? ldq(MF_(BODY_QUAT) + 4 * g) : q1;
       c_ja = isb ? MI_(BODY_JNTADR)[g] : 0;
       c_jn = isb ? MI_(BODY_JNTNUM)[g] : 0;
 #pragma unroll
@@ -604,9 +597,6 @@ struct Engine {
         c_jtype[i] = has ? MI_(JNT_TYPE)[j] : -1;
         c_jqadr[i] = has ? MI_(JNT_QPOSADR)[j] : 0;
         c_jdadr[i] = has ? MI_(JNT_DOFADR)[j] : 0;
-        c_jpos[i] = has ? ld3(MF_(JNT_POS) + 3 * j) : v3(0.f, 0.f, 0.f);
-        c_jaxis[i] = has ? ld3(MF_(JNT_AXIS) + 3 * j) : v3(0.f, 0.f, 1.f);
-        c_jq0[i] = has ? MF_(QPOS0)[c_jqadr[i]] : 0.f;
       }
     }
     r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
@@ -642,13 +632,12 @@ struct Engine {
       if (b_depth == lv) {
         const int b = g, p = b_parent;
         M3 pm = ldm(W + L.xmat + 9 * p);
-        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, c_bpos);
-        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), c_bquat);
+        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, ld3(MF_(BODY_POS) + 3 * b));
+        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), ldq(MF_(BODY_QUAT) + 4 * b));
         for (int i = 0; i < c_jn; i++) {
           const int j = c_ja + i;
           int type, qa; V3 jpos, jax; float q0;
-          if (i == 0) { type = c_jtype[0]; qa = c_jqadr[0]; jpos = c_jpos[0]; jax = c_jaxis[0]; q0 = c_jq0[0]; }
-          else if (i == 1) { type = c_jtype[1]; qa = c_jqadr[1]; jpos = c_jpos[1]; jax = c_jaxis[1]; q0 = c_jq0[1]; }
+          if (i < 2) { type = c_jtype[i & 1]; qa = c_jqadr[i & 1]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
           else { type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
           if (type == MM_JNT_FREE) {
             pos = ld3(W + L.qpos + qa);
@@ -682,7 +671,7 @@ struct Engine {
         st3(W + L.xpos + 3 * b, pos);
         W[L.u1 + 4 * b] = quat.w; W[L.u1 + 4 * b + 1] = quat.x; W[L.u1 + 4 * b + 2] = quat.y; W[L.u1 + 4 * b + 3] = quat.z;
         for (int k = 0; k < 9; k++) W[L.xmat + 9 * b + k] = m.m[k];
-        b_xipos = pos + mv(m, c_bipos);
+        b_xipos = pos + mv(m, ld3(MF_(BODY_IPOS) + 3 * b));
       }
       GSYNC();
     }
