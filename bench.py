@@ -12,6 +12,7 @@ reference's env.step does per environment, for 4096 envs per GPU
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -137,7 +138,8 @@ def main():
         traffic = None
         issue = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc.json"))).get(f"{args.env}@{n}")
+            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+            pm = json.load(open(pmc_file)).get(f"{args.env}@{n}")
             if pm:
                 traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
                 # the honest roof of this kernel: fp32 vector issue.  VALU-busy quad-cycles per SIMD over the quad-cycles
@@ -147,8 +149,8 @@ def main():
                          "wave_issue_frac": pm["sq_active_inst_any"] / pm["sq_wave_quadcycles"],
                          "wave_waitcnt_frac": pm["sq_wait_any"] / pm["sq_wave_quadcycles"],
                          "valu_insts_per_env_step": pm["sq_insts_valu"] * 64 / n / 64,
-                         "source": "profiles/r01c_pmc.json (rocprofv3 PMC of this command)"}
-        except (OSError, ValueError, KeyError):
+                         "source": f"profiles/{os.path.basename(pmc_file)} (rocprofv3 PMC of this command)"}
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9 if b_alg else None
         out = {
