@@ -71,6 +71,13 @@ typedef struct {
   const int32_t* geom_type_env; /* [nenv] or NULL: replaces geom_type[geom_env_id] (MM_GEOM_CAPSULE / ELLIPSOID /
                                    CYLINDER / BOX; reorient_sar_v0.py:408); pairs with that geom must be authored
                                    against capsules                                                          */
+  /* per-env model deltas on ONE body each (-1 / NULL = none): mass (pose_v0.py:177-184 `body_mass[carry_weight]`; the
+     inertia tensor is left alone, as the reference leaves it) and frame position in the parent (key_turn_v0.py:163-166
+     `body_pos[-1]`) */
+  const float* body_mass_env; /* [nenv]    */
+  int    body_mass_env_id;
+  const float* body_pos_env;  /* [nenv][3] */
+  int    body_pos_env_id;
 } mm_state;
 
 /* Optional derived outputs of the final forward pass (NULL = not requested). */
@@ -240,6 +247,12 @@ int  mm_reorient_reset_typed(const mm_model* m, const mm_state* s, const uint8_t
 int  mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
                       const float* goal_center, float goal_half, float size_lo, float size_hi, float* goal,
                       float* geom_size_env, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
+/* Per-episode draw of a per-env model delta (pose_v0.py:180-183 weight ~ U(weight_range); key_turn_v0.py:164-166 key
+ * position offset): out[e][k] = base[k] + lo[k] + (hi[k]-lo[k]) * u, u = Philox4x32-10 word k%4 of counter
+ * (k/4, stream_id, e, episode[e]), key = seed; envs with mask[e] == 0 are left untouched.  Call BEFORE the task reset of the
+ * same episode (which increments episode[e]).  base may be NULL (= 0). */
+int  mm_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi, const uint8_t* mask,
+                 const int32_t* episode, uint64_t seed, uint32_t stream_id, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

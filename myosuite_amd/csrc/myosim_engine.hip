@@ -441,6 +441,20 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->lanes = 0;
   const int rk4 = d.integrator == MM_INT_RK4 ? 1 : 0;
   for (int c : {4, 8, 16, 32, 64}) if (check_lanes(m, c) && have_kernel(c, m->nvp, d.gen, rk4)) { m->lanes = c; break; }
+  if (!m->lanes) {
+    // a model whose rows need a wider group than its dofs do (torso: 18 dofs, 33 rows): take the next larger dense tile
+    // that has a kernel at that width (the padding dofs are inert)
+    const int nvp_min = m->nvp;
+    for (int c : {4, 8, 16, 32, 64}) {
+      for (int n : kNvpChoices) {
+        if (n <= nvp_min) continue;
+        m->nvp = n;
+        if (check_lanes(m, c) && have_kernel(c, n, d.gen, rk4)) { m->lanes = c; break; }
+      }
+      if (m->lanes) break;
+    }
+    if (!m->lanes) m->nvp = nvp_min;
+  }
   if (!m->lanes) { delete m; return fail(MM_EUNSUPPORTED, "no compiled kernel owns this model (needs > 64 lanes per env: nbody, nv, njnt or constraint rows > 64)"); }
   if (d.gen || rk4) m->lanes_auto = 0;   // row tables are sized for one group width; RK4 kernels exist for the default width only
   build_layout(m);
@@ -575,6 +589,8 @@ static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
   memcpy(a.sec, m->sec, sizeof(a.sec));
   a.d = m->d; a.L = m->L; a.D = m->D; a.x = m->x; a.s = *s;
   if (!a.s.geom_size_env || a.s.geom_env_id < 0 || a.s.geom_env_id >= m->d.ngeom) { a.s.geom_size_env = nullptr; a.s.geom_type_env = nullptr; a.s.geom_env_id = -1; }
+  if (!a.s.body_mass_env || a.s.body_mass_env_id <= 0 || a.s.body_mass_env_id >= m->d.nbody) { a.s.body_mass_env = nullptr; a.s.body_mass_env_id = -1; }
+  if (!a.s.body_pos_env || a.s.body_pos_env_id <= 0 || a.s.body_pos_env_id >= m->d.nbody) { a.s.body_pos_env = nullptr; a.s.body_pos_env_id = -1; }
 }
 
 extern "C" int mm_step(const mm_model* m, const mm_state* s, const float* ctrl, int nsub, void* stream) {
@@ -657,6 +673,27 @@ extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
   if (!out) return fail(MM_EARG, "mm_uniform: null output");
   size_t n4 = (n + 3) / 4;
   hipLaunchKernelGGL(k_uniform, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+__global__ void k_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi,
+                           const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nenv || (mask && !mask[e])) return;
+  const uint32_t ep = episode ? (uint32_t)episode[e] : 0u;
+  for (int k = 0; k < ncomp; k++) {
+    uint32_t c[4] = {(uint32_t)(k >> 2), stream_id, (uint32_t)e, ep};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[(size_t)e * ncomp + k] = (base ? base[k] : 0.f) + lo[k] + (hi[k] - lo[k]) * u01(c[k & 3]);
+  }
+}
+
+extern "C" int mm_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi,
+                           const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id, void* stream) {
+  if (!out || !lo || !hi || nenv <= 0 || ncomp <= 0) return fail(MM_EARG, "mm_env_draw: bad argument");
+  hipLaunchKernelGGL(k_env_draw, dim3((nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, nenv, ncomp, base, lo, hi,
+                     mask, episode, seed, stream_id);
   HIPCHK(hipGetLastError());
   return MM_OK;
 }

@@ -578,6 +578,7 @@ struct Engine {
   const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
   float rk_v0, rk_vsum, rk_asum;   // RK4: qvel at the start of the step, weighted sums of stage qvel / qacc
   int env_gtype;            // this env's entry of mm_state.geom_type_env (or -1)
+  int env;                  // env index (per-env model deltas on a body: mm_state.body_mass_env / body_pos_env)
 
   __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
       : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
@@ -632,7 +633,8 @@ struct Engine {
       if (b_depth == lv) {
         const int b = g, p = b_parent;
         M3 pm = ldm(W + L.xmat + 9 * p);
-        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, ld3(MF_(BODY_POS) + 3 * b));
+        const V3 bp = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(MF_(BODY_POS) + 3 * b);
+        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, bp);
         Q4 quat = qmul(ldq(W + L.u1 + 4 * p), ldq(MF_(BODY_QUAT) + 4 * b));
         for (int i = 0; i < c_jn; i++) {
           const int j = c_ja + i;
@@ -701,6 +703,7 @@ struct Engine {
     const int nb = a.d.nbody;
     const bool isb = g > 0 && g < nb;
     float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+    if (a.s.body_mass_env && g == a.s.body_mass_env_id) ms = a.s.body_mass_env[env];
     int myslot = isb ? AUXI(body_rootslot)[g] : -1;
     for (int r = 0; r < a.x.nroot; r++) {
       float w = (myslot == r) ? ms : 0.f;
@@ -1838,6 +1841,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   Engine<G, NVP, GEN, RK4> E(a, mb, W, g);
   if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
   if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
+  E.env = e;
 
   // ---- load state (HBM -> LDS tables / owner registers)
   for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
@@ -1856,6 +1860,11 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     const bool mus = MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE;
     if (obs_only) c = 0.f;
     if (a.mode == 2 && !obs_only && t.normalize_act && mus) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
+    // no activation states at all (motorFinger): BaseV0.step hands the normalisation to the robot, which maps [-1, 1] onto
+    // the ctrl range (base_v0.py:94-96, robot.py:786-796)
+    if (a.mode == 2 && !obs_only && t.normalize_act && d.na == 0)
+      c = 0.5f * (MF_(ACT_CTRLRANGE)[2 * u] + MF_(ACT_CTRLRANGE)[2 * u + 1]) +
+          c * 0.5f * (MF_(ACT_CTRLRANGE)[2 * u + 1] - MF_(ACT_CTRLRANGE)[2 * u]);
     if (a.mode == 2 && !obs_only && t.fatigue && mus) {
       // 3CC-r muscle fatigue (fatigue.py:38-76), dt = timestep * frame_skip
       int aa = MI_(ACT_ACTADR)[u];
@@ -2038,7 +2047,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       const int o_qv = nq2, o_cv = o_qv + d.nv, o_tq = o_cv + 2, o_fh = o_tq + 4, o_h = o_fh + 2, o_fr = o_h + 1,
                 o_ph = o_fr + 6, o_ml = o_ph + 1, o_mv = o_ml + d.nu, o_mf = o_mv + d.nu, o_act = o_mf + d.nu;
       const bool isb = g > 0 && g < d.nbody;
-      const float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+      float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
+      if (a.s.body_mass_env && g == a.s.body_mass_env_id) ms = a.s.body_mass_env[e];
       const float mtot = gsum<G>(ms);
       // com velocity with the reference's sign convention: mean of -cvel[:, 3:5]
       const float cvx = gsum<G>(ms * -E.b_cvel[3]) / mtot, cvy = gsum<G>(ms * -E.b_cvel[4]) / mtot;

@@ -71,7 +71,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
 class mm_state(C.Structure):
     _fields_ = [("nenv", C.c_int), ("qpos", C.c_void_p), ("qvel", C.c_void_p), ("act", C.c_void_p),
                 ("qacc_warmstart", C.c_void_p), ("time", C.c_void_p), ("status", C.c_void_p),
-                ("geom_size_env", C.c_void_p), ("geom_env_id", C.c_int), ("geom_type_env", C.c_void_p)]
+                ("geom_size_env", C.c_void_p), ("geom_env_id", C.c_int), ("geom_type_env", C.c_void_p),
+                ("body_mass_env", C.c_void_p), ("body_mass_env_id", C.c_int),
+                ("body_pos_env", C.c_void_p), ("body_pos_env_id", C.c_int)]
 
 
 _DERIVED_FIELDS = ["xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "cvel", "subtree_com", "actuator_length",
@@ -125,6 +127,8 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.mm_env_draw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_uint64, C.c_uint32, C.c_void_p]
         L.mm_reach_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.mm_walk_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -215,14 +219,28 @@ class BatchState:
         self.status = torch.zeros(nenv, dtype=torch.int32, device=dev)
         self.geom_size_env = None
         self._c = mm_state(nenv, _ptr(self.qpos), _ptr(self.qvel), self.act.data_ptr(), _ptr(self.qacc_warmstart),
-                           _ptr(self.time), _ptr(self.status), None, -1, None)
+                           _ptr(self.time), _ptr(self.status), None, -1, None, None, -1, None, -1)
         self.geom_type_env = None
+        self.body_mass_env = None
+        self.body_pos_env = None
 
     def set_geom_size_env(self, geom_id: int, sizes: torch.Tensor):
         """per-env model delta: collision size [nenv][3] of one geom (mm_state.geom_size_env)"""
         assert sizes.shape == (self.nenv, 3) and sizes.dtype == torch.float32 and sizes.is_contiguous() and sizes.is_cuda
         self.geom_size_env = sizes
         self._c.geom_size_env = sizes.data_ptr(); self._c.geom_env_id = int(geom_id)
+
+    def set_body_mass_env(self, body_id: int, mass: torch.Tensor):
+        """per-env model delta: mass [nenv] of one body (mm_state.body_mass_env)"""
+        assert mass.shape == (self.nenv,) and mass.dtype == torch.float32 and mass.is_contiguous()
+        self.body_mass_env = mass
+        self._c.body_mass_env = mass.data_ptr(); self._c.body_mass_env_id = int(body_id)
+
+    def set_body_pos_env(self, body_id: int, pos: torch.Tensor):
+        """per-env model delta: frame position [nenv][3] of one body in its parent (mm_state.body_pos_env)"""
+        assert pos.shape == (self.nenv, 3) and pos.dtype == torch.float32 and pos.is_contiguous()
+        self.body_pos_env = pos
+        self._c.body_pos_env = pos.data_ptr(); self._c.body_pos_env_id = int(body_id)
 
     def set_geom_type_env(self, types: torch.Tensor):
         """per-env model delta: type [nenv] int32 of the geom named in set_geom_size_env (mm_state.geom_type_env)"""
@@ -353,6 +371,17 @@ def objhold_reset(model: HipModel, state: BatchState, mask, init_qpos, goal_cent
     _chk(lib().mm_objhold_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(goal_center), C.c_float(goal_half),
                                 C.c_float(lo), C.c_float(hi), _ptr(goal), _ptr(gs), _ptr(episode), _ptr(step_count),
                                 C.c_uint64(seed), _stream()), "mm_objhold_reset")
+
+
+def env_draw(out: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, mask, episode, seed: int, stream_id: int, base=None):
+    """out[e, k] = base[k] + lo[k] + (hi[k]-lo[k]) * U[0,1): per-episode draw of a per-env model delta (mm_env_draw); call before
+    the task reset of the same episode."""
+    assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+    n, k = out.shape[0], (out.shape[1] if out.dim() > 1 else 1)
+    assert lo.numel() == k and hi.numel() == k and (base is None or base.numel() == k)
+    _chk(lib().mm_env_draw(out.data_ptr(), n, k, _ptr(base), _ptr(lo), _ptr(hi), _ptr(mask), _ptr(episode), C.c_uint64(seed),
+                           C.c_uint32(stream_id), _stream()), "mm_env_draw")
+    return out
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):

@@ -19,6 +19,7 @@ from .spaces import Box
 
 
 class PoseEnvV0(BaseV0):
+    FAR_TH = 4 * math.pi / 2                                               # pose_v0.py:118
     DEFAULT_OBS_KEYS = ["qpos", "qvel", "pose_err"]                        # pose_v0.py:17
     DEFAULT_RWD_KEYS_AND_WEIGHTS = {"pose": 1.0, "bonus": 4.0, "act_reg": 1.0, "penalty": 50}   # pose_v0.py:18-23
 
@@ -34,8 +35,6 @@ class PoseEnvV0(BaseV0):
         self.reset_type = reset_type
         self.target_type = target_type
         self.pose_thd = float(pose_thd)
-        if weight_bodyname is not None:
-            raise NotImplementedError("weight randomisation (Exo variant, pose_v0.py:177-187) is not built yet")
         super()._setup(obs_keys=list(obs_keys), weighted_reward_keys=weighted_reward_keys, sites=viz_site_targets,
                        **kwargs)
         cm, n, dev = self.cm, self.num_envs, self.device
@@ -65,9 +64,15 @@ class PoseEnvV0(BaseV0):
         self.rwd = torch.zeros(n, len(E.RWD_KEYS_POSE), **f)
         self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim),
                                      dtype=np.float32)
+        # per-episode weight of one body (pose_v0.py:177-187): a per-env model delta (mm_state.body_mass_env)
+        self.weight_bodyname, self.weight_range = weight_bodyname, weight_range
+        if weight_bodyname is not None:
+            self.body_mass = torch.full((n,), float(cm.arrays["BODY_MASS"][cm.names["body"][weight_bodyname]]), **f)
+            self.state.set_body_mass_env(cm.names["body"][weight_bodyname], self.body_mass)
+            self._wlo = torch.tensor([float(weight_range[0])], **f); self._whi = torch.tensor([float(weight_range[1])], **f)
         w = self.rwd_keys_wt
         t = self._new_task(E.MM_TASK_POSE, do_forward)
-        t.pose_thd = self.pose_thd; t.far_th = 4 * math.pi / 2
+        t.pose_thd = self.pose_thd; t.far_th = self.FAR_TH
         t.w_pose = float(w.get("pose", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
         t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
         t.target_jnt_value = self.target_jnt_value.data_ptr()
@@ -106,7 +111,7 @@ class PoseEnvV0(BaseV0):
         act_mag = torch.linalg.norm(obs_dict["act"], dim=-1)
         if self.cm.na != 0:
             act_mag = act_mag / self.cm.na
-        far_th = 4 * math.pi / 2
+        far_th = getattr(self, "FAR_TH", PoseEnvV0.FAR_TH)
         rwd = collections.OrderedDict((
             ("pose", -1.0 * pose_dist),
             ("bonus", 1.0 * (pose_dist < self.pose_thd) + 1.0 * (pose_dist < 1.5 * self.pose_thd)),
@@ -134,6 +139,8 @@ class PoseEnvV0(BaseV0):
         if self.reset_type in (None, "none"):
             # no state reset; only targets (and counters) are refreshed
             keep = self.get_env_state()
+        if self.weight_bodyname is not None:     # weight ~ U(weight_range), Philox stream 16 of (seed, env, episode)
+            E.env_draw(self.body_mass, self._wlo, self._whi, mask, self.episode, self._seed_u64, 16)
         generate = self.target_type == "generate"
         random_q = self.reset_type == "random" and reset_qpos is None
         # targets ~ U(target range) and (optionally) qpos ~ U(joint range): Philox keyed by (seed, env, episode)

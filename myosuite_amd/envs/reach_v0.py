@@ -6,7 +6,8 @@ the world positions of the ``*_target`` sites, re-drawn at every reset.  The fus
 
 Synthetic-model note: the reference's target boxes are absolute coordinates of the real myoHand scene
 (myobase/__init__.py:521-575).  Our synthetic hand lives elsewhere, so each box is re-centred on the synthetic tip position
-at qpos0 while keeping the reference's spans (``target_center`` kwarg carries the reference centres).
+at qpos0 while keeping the reference's spans (``target_center`` kwarg carries the reference centres).  The synthetic
+finger is laid out in the reference's coordinates, so its boxes are used as they are (``target_frame="world"``).
 """
 from __future__ import annotations
 
@@ -32,7 +33,8 @@ class ReachEnvV0(BaseV0):
         self._setup(**kwargs)
 
     def _setup(self, target_reach_range: dict, far_th=0.35, obs_keys=DEFAULT_OBS_KEYS,
-               weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS, target_center: Optional[dict] = None, **kwargs):
+               weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS, target_center: Optional[dict] = None,
+               target_frame: str = "tip", **kwargs):
         self.far_th = float(far_th)
         self.target_reach_range = target_reach_range
         super()._setup(obs_keys=list(obs_keys), weighted_reward_keys=weighted_reward_keys,
@@ -47,6 +49,9 @@ class ReachEnvV0(BaseV0):
         lo, hi = [], []
         for i, (site, span) in enumerate(target_reach_range.items()):
             span = np.asarray(span, np.float64)
+            if target_frame == "world":       # the reference's absolute coordinates (models laid out like the reference's)
+                lo.append(span[0]); hi.append(span[1])
+                continue
             c = np.asarray(target_center[site], np.float64) if target_center else 0.5 * (span[0] + span[1])
             lo.append(tip0[i] + (span[0] - c)); hi.append(tip0[i] + (span[1] - c))
         self._tlo = torch.from_numpy(np.concatenate(lo).astype(np.float32)).to(dev)

@@ -75,6 +75,11 @@ def _pose(**kw):
     return PoseEnvV0(**kw)
 
 
+def _torso(**kw):
+    from .torso_v0 import TorsoEnvV0
+    return TorsoEnvV0(**kw)
+
+
 def _reach(**kw):
     from .reach_v0 import ReachEnvV0
     return ReachEnvV0(**kw)
@@ -100,6 +105,29 @@ def _walk(**kw):
     return WalkEnvV0(**kw)
 
 
+# Finger-tip reaching (myobase/__init__.py:55-105); motorFinger = the torque-motor counterpart (no "myo" prefix, so no
+# muscle-condition variants: env_variants / __init__.py:13-49)
+for _pre, _mdl, _h, _kw in (("motor", "motorfinger", 200, {"frame_skip": 5}), ("myo", "finger", 100, {})):
+    register_env_with_variants(
+        id=_pre + "FingerReachFixed-v0", entry_point=_reach, max_episode_steps=_h,
+        kwargs=dict({"model": _mdl, "target_reach_range": {"IFtip": ((0.2, 0.05, 0.20), (0.2, 0.05, 0.20))},
+                     "normalize_act": True, "target_frame": "world"}, **_kw))
+    register_env_with_variants(
+        id=_pre + "FingerReachRandom-v0", entry_point=_reach, max_episode_steps=_h,
+        kwargs=dict({"model": _mdl, "target_reach_range": {"IFtip": ((0.1, -0.1, 0.1), (0.27, 0.1, 0.3))},
+                     "normalize_act": True, "target_frame": "world"}, **_kw))
+    # Finger-joint posing (myobase/__init__.py:188-254)
+    register_env_with_variants(
+        id=_pre + "FingerPoseFixed-v0", entry_point=_pose, max_episode_steps=_h,
+        kwargs=dict({"model": _mdl, "target_jnt_range": {"IFadb": (0, 0), "IFmcp": (0, 0), "IFpip": (0.75, 0.75),
+                                                         "IFdip": (0.75, 0.75)},
+                     "viz_site_targets": ("IFtip",), "normalize_act": True}, **_kw))
+    register_env_with_variants(
+        id=_pre + "FingerPoseRandom-v0", entry_point=_pose, max_episode_steps=_h,
+        kwargs=dict({"model": _mdl, "target_jnt_range": {"IFadb": (-0.2, 0.2), "IFmcp": (-0.4, 1), "IFpip": (0.1, 1),
+                                                         "IFdip": (0.1, 1)},
+                     "viz_site_targets": ("IFtip",), "normalize_act": True}, **_kw))
+
 # Elbow posing (myobase/__init__.py:108-138)
 register_env_with_variants(
     id="myoElbowPose1D6MFixed-v0", entry_point=_pose, max_episode_steps=100,
@@ -109,6 +137,19 @@ register_env_with_variants(
     id="myoElbowPose1D6MRandom-v0", entry_point=_pose, max_episode_steps=100,
     kwargs={"model": "elbow", "target_jnt_range": {"r_elbow_flex": (0, 2.27)}, "viz_site_targets": ("wrist",),
             "normalize_act": True, "pose_thd": 0.175, "reset_type": "random"})
+
+# Elbow + exoskeleton posing (myobase/__init__.py:141-186): one extra torque actuator; the Random variant re-draws the
+# mass of the carried weight per episode (pose_v0.py:177-187)
+_EXO_W = {"pose": 1.0, "bonus": 4.0, "act_reg": 5.0, "penalty": 50}
+register_env_with_variants(
+    id="myoElbowPose1D6MExoFixed-v0", entry_point=_pose, max_episode_steps=100,
+    kwargs={"model": "elbow_exo", "target_jnt_range": {"r_elbow_flex": (2, 2)}, "viz_site_targets": ("wrist",),
+            "normalize_act": True, "pose_thd": 0.175, "reset_type": "random", "weighted_reward_keys": _EXO_W})
+register_env_with_variants(
+    id="myoElbowPose1D6MExoRandom-v0", entry_point=_pose, max_episode_steps=100,
+    kwargs={"model": "elbow_exo", "target_jnt_range": {"r_elbow_flex": (0, 2.27)}, "viz_site_targets": ("wrist",),
+            "normalize_act": True, "pose_thd": 0.175, "reset_type": "random", "weight_bodyname": "carry_weight",
+            "weight_range": (0.1, 2), "weighted_reward_keys": _EXO_W})
 
 # Hand ASL posing (myobase/__init__.py:300-415)
 jnt_namesHand = ["pro_sup", "deviation", "flexion", "cmc_abduction", "cmc_flexion", "mp_flexion", "ip_flexion",
@@ -134,6 +175,13 @@ for k in ASL_qpos:
         id="myoHandPose" + str(k) + "Fixed-v0", entry_point=_pose, max_episode_steps=100,
         kwargs={"model": "hand", "viz_site_targets": _HAND_SITES, "target_jnt_value": ASL_qpos[k],
                 "normalize_act": True, "pose_thd": 0.7, "reset_type": "init", "target_type": "fixed"})
+# myobase/__init__.py:259-297 ("Remove this when the ASL envs stablizes")
+register_env_with_variants(
+    id="myoHandPoseFixed-v0", entry_point=_pose, max_episode_steps=100,
+    kwargs={"model": "hand", "viz_site_targets": _HAND_SITES,
+            "target_jnt_value": np.array([0, 0, 0, -0.0904, 0.0824475, -0.681555, -0.514888, 0, -0.013964, -0.0458132, 0,
+                                          0.67553, -0.020944, 0.76979, 0.65982, 0, 0, 0, 0, 0.479155, -0.099484, 0.95831, 0]),
+            "normalize_act": True, "pose_thd": 0.7, "reset_type": "init", "target_type": "fixed"})
 _m = np.array([ASL_qpos[i] for i in range(10)]).astype(float)
 Rpos = {n: (float(np.min(_m[:, i])), float(np.max(_m[:, i]))) for i, n in enumerate(jnt_namesHand)}
 register_env_with_variants(
@@ -168,6 +216,14 @@ register_env_with_variants(
     kwargs={"model": "leg", "normalize_act": True, "min_height": 0.8, "max_rot": 0.8, "hip_period": 100,
             "reset_type": "init", "target_x_vel": 0.0, "target_y_vel": 1.2, "target_rot": None})
 
+
+# MyoTorso posing (myobase/__init__.py:638-670).  myoTorsoExoPoseFixed-v0 (:671-701) needs the exosuit model
+# (myotorso_exosuit.xml, absent) and is not registered.
+from ..model.synth import TORSO_JOINTS as _TJ
+register_env_with_variants(
+    id="myoTorsoPoseFixed-v0", entry_point=_torso, max_episode_steps=200,
+    kwargs={"model": "torso", "normalize_act": True, "frame_skip": 5,
+            "target_jnt_range": {j: ((-0.1, 0.1) if j == "lat_bending" else (0.0, 0.0)) for j in _TJ}})
 
 # SAR reorient (myobase/__init__.py:703-749): frame_skip 5, horizon 50.
 register_env_with_variants(

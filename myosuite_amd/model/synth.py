@@ -73,6 +73,175 @@ def make_elbow() -> ModelSpec:
     return s
 
 
+# ----------------------------------------------------------------------------- elbow + exo
+def make_elbow_exo() -> ModelSpec:
+    """myoElbow with the 1-DoF exoskeleton of assets/elbow/myoelbow_1dof6muscles_1dofexo.xml: the same arm plus a torque
+    actuator on the elbow joint (after the six muscles: nu = 7, na = 6) and the ``carry_weight`` body whose mass the Random
+    variant re-draws per episode (pose_v0.py:177-187)."""
+    s = make_elbow()
+    s.name = "myoelbow_1dof6muscles_1dofexo"
+    s.add_body("carry_weight", "forearm", pos=(0, 0, -0.27), mass=1.0, inertia=(4e-4, 4e-4, 4e-4))
+    s.add_motor("Exo", "r_elbow_flex", gear=10.0, ctrlrange=(-1.0, 1.0))
+    return s
+
+
+# ----------------------------------------------------------------------------- finger
+FINGER_JOINTS = ["IFadb", "IFmcp", "IFpip", "IFdip"]
+FINGER_MUSCLES = ["EXTN", "adabR", "adabL", "mflx", "dflx"]          # docs/source/suite.rst:48-56
+
+
+def make_finger(motor: bool = False) -> ModelSpec:
+    """myoFinger / motorFinger (simhive/myo_sim/finger, absent from the reference checkout): 4 DoF (IFadb IFmcp IFpip IFdip,
+    names from myobase/__init__.py:196-201) and either 5 simplified antagonistic muscle-tendon units (EXTN adabR adabL mflx
+    dflx) or 4 joint torque motors ("its robotic counterpart with simple torque actuators", suite.rst:39).  +x distal,
+    +z dorsal; positive flexion curls toward -z.  Sites ``IFtip`` / ``IFtip_target`` for the reach task."""
+    s = ModelSpec("motorfinger_v0" if motor else "myofinger_v0")
+    L = (0.070, 0.045, 0.035)
+    s.add_body("metacarpal", "world", pos=(0.0, 0.0, 0.20), mass=0.2, ipos=(0.04, 0, 0),
+               inertia=_cyl_inertia(0.2, 0.012, 0.08, "x"))
+    s.add_body("mcp_link", "metacarpal", pos=(0.08, 0, 0), mass=0.004, inertia=(4e-7, 4e-7, 4e-7))
+    s.add_joint("IFadb", "mcp_link", "hinge", axis=(0, 0, 1), range=(-0.262, 0.262), damping=0.02, armature=0.0008)
+    s.add_body("proximal", "mcp_link", pos=(0, 0, 0), mass=0.030, ipos=(0.5 * L[0], 0, 0),
+               inertia=_cyl_inertia(0.030, 0.009, L[0], "x"))
+    s.add_joint("IFmcp", "proximal", "hinge", axis=(0, 1, 0), range=(-0.785, 1.571), damping=0.02, armature=0.0008)
+    s.add_body("middle", "proximal", pos=(L[0], 0, 0), mass=0.015, ipos=(0.5 * L[1], 0, 0),
+               inertia=_cyl_inertia(0.015, 0.008, L[1], "x"))
+    s.add_joint("IFpip", "middle", "hinge", axis=(0, 1, 0), range=(0.0, 1.571), damping=0.015, armature=0.0006)
+    s.add_body("distal", "middle", pos=(L[1], 0, 0), mass=0.008, ipos=(0.5 * L[2], 0, 0),
+               inertia=_cyl_inertia(0.008, 0.007, L[2], "x"))
+    s.add_joint("IFdip", "distal", "hinge", axis=(0, 1, 0), range=(0.0, 1.571), damping=0.01, armature=0.0005)
+    s.add_site("IFtip", "distal", (L[2], 0, 0))
+    s.add_site("IFtip_target", "world", (0.2, 0.05, 0.20))
+    if motor:
+        for j, gear in zip(FINGER_JOINTS, (0.15, 0.4, 0.25, 0.15)):
+            s.add_motor("A_" + j, j, gear=gear, ctrlrange=(-1.0, 1.0))
+        return s
+    # wrap cylinders on the three flexion axes (axis along y), dorsal / palmar side-sites
+    for nm, body, r in (("mcp", "metacarpal", 0.010), ("pip", "proximal", 0.008), ("dip", "middle", 0.0065)):
+        x = {"mcp": 0.08, "pip": L[0], "dip": L[1]}[nm]
+        s.add_geom(f"{nm}_wrap", body, "cylinder", size=(r, 0.02), pos=(x, 0, 0), quat=QX90N)
+        s.add_site(f"{nm}_dors", body, (x, 0, 0.03))
+        s.add_site(f"{nm}_palm", body, (x, 0, -0.03))
+    # EXTN: dorsal, spans mcp / pip / dip
+    for nm, body, pos in (("EXTN_o", "metacarpal", (0.02, 0, 0.012)), ("EXTN_a", "metacarpal", (0.06, 0, 0.013)),
+                          ("EXTN_b", "proximal", (0.035, 0, 0.011)), ("EXTN_c", "middle", (0.022, 0, 0.009)),
+                          ("EXTN_i", "distal", (0.012, 0, 0.0075))):
+        s.add_site(nm, body, pos)
+    s.add_tendon("EXTN_tendon", [("site", "EXTN_o"), ("site", "EXTN_a"), ("cylinder", "mcp_wrap", "mcp_dors"),
+                                 ("site", "EXTN_b"), ("cylinder", "pip_wrap", "pip_dors"), ("site", "EXTN_c"),
+                                 ("cylinder", "dip_wrap", "dip_dors"), ("site", "EXTN_i")])
+    s.add_muscle("EXTN", "EXTN_tendon", force=120.0)
+    # abduction pair: lateral bands crossing the mcp on either side
+    for nm, y in (("adabR", -0.012), ("adabL", 0.012)):
+        s.add_site(f"{nm}_o", "metacarpal", (0.045, 1.4 * y, -0.002))
+        s.add_site(f"{nm}_i", "proximal", (0.018, y, -0.003))
+        s.add_tendon(f"{nm}_tendon", [("site", f"{nm}_o"), ("site", f"{nm}_i")])
+        s.add_muscle(nm, f"{nm}_tendon", force=60.0)
+    # mflx: palmar, inserts on the middle phalanx (mcp + pip); dflx: palmar, inserts on the distal phalanx
+    for nm, body, pos in (("mflx_o", "metacarpal", (0.02, -0.003, -0.012)), ("mflx_a", "metacarpal", (0.06, -0.003, -0.0135)),
+                          ("mflx_b", "proximal", (0.035, -0.003, -0.011)), ("mflx_i", "middle", (0.015, -0.003, -0.009)),
+                          ("dflx_o", "metacarpal", (0.02, 0.003, -0.014)), ("dflx_a", "metacarpal", (0.06, 0.003, -0.0145)),
+                          ("dflx_b", "proximal", (0.035, 0.003, -0.012)), ("dflx_c", "middle", (0.022, 0.003, -0.0095)),
+                          ("dflx_i", "distal", (0.012, 0.003, -0.0075))):
+        s.add_site(nm, body, pos)
+    s.add_tendon("mflx_tendon", [("site", "mflx_o"), ("site", "mflx_a"), ("cylinder", "mcp_wrap", "mcp_palm"),
+                                 ("site", "mflx_b"), ("cylinder", "pip_wrap", "pip_palm"), ("site", "mflx_i")])
+    s.add_muscle("mflx", "mflx_tendon", force=110.0)
+    s.add_tendon("dflx_tendon", [("site", "dflx_o"), ("site", "dflx_a"), ("cylinder", "mcp_wrap", "mcp_palm"),
+                                 ("site", "dflx_b"), ("cylinder", "pip_wrap", "pip_palm"), ("site", "dflx_c"),
+                                 ("cylinder", "dip_wrap", "dip_palm"), ("site", "dflx_i")])
+    s.add_muscle("dflx", "dflx_tendon", force=110.0)
+    return s
+
+
+# ----------------------------------------------------------------------------- torso
+TORSO_JOINTS = ["flex_extension", "lat_bending", "axial_rotation", "Abs_t1", "Abs_t2", "Abs_r3",
+                "L4_L5_FE", "L4_L5_LB", "L4_L5_AR", "L3_L4_FE", "L3_L4_LB", "L3_L4_AR",
+                "L2_L3_FE", "L2_L3_LB", "L2_L3_AR", "L1_L2_FE", "L1_L2_LB", "L1_L2_AR"]      # myobase/__init__.py:645-664
+TORSO_GROUPS = [("rect_abd", 1), ("IL", 12), ("QL", 18), ("MF", 25), ("LT", 19), ("EO", 6), ("IO", 6), ("PS", 11),
+                ("LD", 7)]                                                                    # fascicles per side: 105
+
+
+def make_torso() -> ModelSpec:
+    """myoTorso: "210 actuators and 18 joints" (docs/source/suite.rst:207), generated from OpenSim's *constrained* lumbar spine
+    model: the pelvis is fixed, the three L5/S1 rotations (flex_extension, lat_bending, axial_rotation) drive the L4-L5 ...
+    L1-L2 rotations and the abdomen's Abs_t1/Abs_t2/Abs_r3 through joint equalities (here: linear couplings).  210 muscle
+    fascicles = 105 per side in the groups of suite.rst:213-224 (rect_abd, IL, QL, MF, LT, EO, IO + psoas / latissimus);
+    straight or one-via-point paths from pelvis / sacrum to the vertebrae and the rib cage.  +x anterior, +y left, +z up."""
+    s = ModelSpec("myotorso")
+    s.timestep = 0.002
+    s.add_body("pelvis", "world", pos=(0, 0, 0.95), mass=10.0, inertia=(0.09, 0.08, 0.09))
+    H = 0.036                                     # vertebral spacing
+    lv = ["lumbar5", "lumbar4", "lumbar3", "lumbar2", "lumbar1"]
+    jn = [("flex_extension", "lat_bending", "axial_rotation")] + [(f"L{5 - k}_L{6 - k}_FE", f"L{5 - k}_L{6 - k}_LB", f"L{5 - k}_L{6 - k}_AR")
+                                                                   for k in range(1, 5)]
+    # joint order must follow TORSO_JOINTS: lumbar5 (3), abdomen (3), then lumbar4..lumbar1
+    def vertebra(k, parent):
+        top = k == 4
+        m = 14.0 if top else 1.8                  # lumbar1 carries the rib cage / thorax
+        s.add_body(lv[k], parent, pos=(0, 0, 0.05 if k == 0 else H), mass=m, ipos=(0.01, 0, 0.20 if top else 0.0),
+                   inertia=(0.55, 0.45, 0.25) if top else (0.006, 0.006, 0.009))
+        lim = (0.5, 0.35, 0.3) if k == 0 else (0.2, 0.12, 0.1)
+        for name, ax, r in zip(jn[k], ((0, 1, 0), (1, 0, 0), (0, 0, 1)), lim):
+            s.add_joint(name, lv[k], "hinge", axis=ax, range=(-r, r), damping=5.0 if k == 0 else 2.0, armature=0.05 if k == 0 else 0.25,
+                        stiffness=150.0 if k == 0 else 25.0)
+    vertebra(0, "pelvis")
+    s.add_body("abdomen", "pelvis", pos=(0.07, 0, 0.12), mass=6.0, inertia=(0.06, 0.05, 0.06))
+    s.add_joint("Abs_t1", "abdomen", "slide", axis=(1, 0, 0), range=(-0.08, 0.08), damping=30.0, armature=0.5)
+    s.add_joint("Abs_t2", "abdomen", "slide", axis=(0, 0, 1), range=(-0.08, 0.08), damping=30.0, armature=0.5)
+    s.add_joint("Abs_r3", "abdomen", "hinge", axis=(0, 1, 0), range=(-0.8, 0.8), damping=1.0, armature=0.05)
+    for k in range(1, 5):
+        vertebra(k, lv[k - 1])
+    assert [j.name for j in s.joints] == TORSO_JOINTS
+    # constrained spine: fixed fractions of the net rotation at each level, abdomen follows the flexion
+    for k, fr in zip(range(1, 5), (0.26, 0.19, 0.14, 0.10)):
+        for c in range(3):
+            s.add_equality_joint(jn[k][c], jn[0][c], (0.0, fr))
+    s.add_equality_joint("Abs_t1", "flex_extension", (0.0, 0.035))
+    s.add_equality_joint("Abs_t2", "flex_extension", (0.0, -0.012))
+    s.add_equality_joint("Abs_r3", "flex_extension", (0.0, 0.45))
+    # ---- 210 fascicles
+    side_sign = {"r": -1.0, "l": 1.0}
+    attach = {  # group: (origin body, origin xyz (right side, y<0 mirrored), insertion bodies cycled, insertion xyz, via?, Fmax)
+        "rect_abd": ("pelvis", (0.085, 0.035, -0.03), ["lumbar1"], (0.125, 0.04, 0.24), ("abdomen", (0.055, 0.04, 0.0)), 410.0),
+        "IL": ("pelvis", (-0.075, 0.07, 0.03), ["lumbar1"], (-0.055, 0.085, 0.16), None, 160.0),
+        "QL": ("pelvis", (-0.045, 0.085, 0.035), ["lumbar4", "lumbar3", "lumbar2", "lumbar1"], (-0.025, 0.04, 0.0), None, 60.0),
+        "MF": ("pelvis", (-0.07, 0.02, 0.01), lv, (-0.045, 0.012, 0.008), None, 70.0),
+        "LT": ("pelvis", (-0.08, 0.045, 0.02), ["lumbar1", "lumbar2", "lumbar3"], (-0.06, 0.05, 0.10), None, 120.0),
+        "EO": ("pelvis", (0.06, 0.115, 0.01), ["lumbar1"], (0.07, 0.12, 0.14), ("abdomen", (0.03, 0.13, 0.0)), 200.0),
+        "IO": ("pelvis", (0.02, 0.12, 0.02), ["lumbar1"], (0.09, 0.07, 0.12), ("abdomen", (0.04, 0.11, 0.01)), 180.0),
+        "PS": ("pelvis", (0.035, 0.075, -0.07), lv, (0.018, 0.028, 0.0), None, 150.0),
+        "LD": ("pelvis", (-0.07, 0.06, 0.03), ["lumbar1"], (-0.02, 0.15, 0.30), None, 110.0),
+    }
+    rng = np.random.default_rng(7)
+    jit_store = {(grp, f): rng.uniform(-1, 1, 6) * 0.006 for grp, cnt in TORSO_GROUPS for f in range(cnt)}   # mirrored l/r
+    nm = 0
+    for side in ("r", "l"):
+        sg = side_sign[side]
+        for grp, cnt in TORSO_GROUPS:
+            ob, op, ins_bodies, ip, via, fmax = attach[grp]
+            for f in range(cnt):
+                name = f"{grp}{f + 1}_{side}" if cnt > 1 else f"{grp}_{side}"
+                jit = jit_store[(grp, f)]
+                ib = ins_bodies[f % len(ins_bodies)]
+                spread = (f / max(cnt - 1, 1) - 0.5)
+                o = (op[0] + jit[0], sg * (op[1] + 0.012 * spread + abs(jit[1])), op[2] + jit[2] + 0.01 * spread)
+                i = (ip[0] + jit[3], sg * (ip[1] + 0.008 * spread + abs(jit[4])), ip[2] + jit[5])
+                s.add_site(name + "_o", ob, o)
+                path = [("site", name + "_o")]
+                if via is not None:
+                    vb, vp = via
+                    s.add_site(name + "_v", vb, (vp[0] + jit[3], sg * (vp[1] + abs(jit[4])), vp[2] + jit[5]))
+                    path.append(("site", name + "_v"))
+                s.add_site(name + "_i", ib, i)
+                path.append(("site", name + "_i"))
+                s.add_tendon(name + "_tendon", path)
+                s.add_muscle(name, name + "_tendon", force=fmax * (0.7 + 0.6 * (f % 3) / 2.0))
+                nm += 1
+    assert nm == 210
+    return s
+
+
 # ----------------------------------------------------------------------------- hand
 HAND_JOINTS = ["pro_sup", "deviation", "flexion", "cmc_abduction", "cmc_flexion", "mp_flexion",
                "ip_flexion", "mcp2_flexion", "mcp2_abduction", "pm2_flexion", "md2_flexion",
@@ -695,7 +864,8 @@ def get_model(name: str) -> CompiledModel:
     if name not in _CACHE:
         spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
                 "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen,
-                "hand_hold": make_hand_hold}[name]()
+                "hand_hold": make_hand_hold, "elbow_exo": make_elbow_exo, "finger": make_finger,
+                "motorfinger": lambda: make_finger(motor=True), "torso": make_torso}[name]()
         cm = spec.compile()
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob

@@ -57,6 +57,15 @@ def pose_reset_draws(nq: int, env: int, episode: int, seed: int):
     return u[i, i & 1], u[i, 2 + (i & 1)]
 
 
+def env_draw(ncomp: int, env: int, episode: int, seed: int, stream_id: int):
+    """u[ncomp] exactly as mm_env_draw draws a per-env model delta (counter = (k/4, stream_id, env, episode), word k%4)."""
+    k = np.arange(ncomp)
+    c = philox4x32_10((k >> 2).astype(np.uint64), np.full(ncomp, stream_id, np.uint64), np.full(ncomp, env, np.uint64),
+                      np.full(ncomp, episode, np.uint64), seed & 0xFFFFFFFF, seed >> 32)
+    u = np.stack([u01(x) for x in c], axis=1)
+    return u[k, k & 3]
+
+
 # ---------------------------------------------------------------------- fatigue (3CC-r)
 class FatigueOracle:
     """myosuite/envs/myo/fatigue.py:6-99, restated (no mujoco dependency: tau values are passed in)."""
@@ -118,6 +127,7 @@ class PoseEnvOracle:
         self.dt = compiled.timestep * frame_skip
         self.target_jnt_value = np.zeros(compiled.nq)
         self.reaf = reaf
+        self.far_th_pose = 4 * np.pi / 2                         # pose_v0.py:118 (torso_v0.py:119 uses pi)
         self.muscle = compiled.arrays["ACT_DYNTYPE"] == 4
         if muscle_condition == "fatigue":
             dyn = compiled.arrays["ACT_DYNPRM"].reshape(-1, 3).astype(np.float64)
@@ -148,14 +158,15 @@ class PoseEnvOracle:
     def get_obs(self):                                           # obs_vec_dict.py:76-88, keys pose_v0.py:17 + act
         od = self.get_obs_dict()
         self.obs_dict = od
-        return np.concatenate([od[k].ravel() for k in ("qpos", "qvel", "pose_err", "act")]).astype(np.float32)
+        keys = ("qpos", "qvel", "pose_err") + (("act",) if self.cm.na > 0 else ())        # base_v0.py:33-37
+        return np.concatenate([od[k].ravel() for k in keys]).astype(np.float32)
 
     def get_reward_dict(self, od):                               # pose_v0.py:113-140
         pose_dist = np.linalg.norm(od["pose_err"], axis=-1)
         act_mag = np.linalg.norm(od["act"], axis=-1)
         if self.cm.na != 0:
             act_mag = act_mag / self.cm.na
-        far_th = 4 * np.pi / 2
+        far_th = self.far_th_pose
         rwd = collections.OrderedDict((
             ("pose", -1.0 * pose_dist),
             ("bonus", 1.0 * (pose_dist < self.pose_thd) + 1.0 * (pose_dist < 1.5 * self.pose_thd)),
@@ -172,6 +183,9 @@ class PoseEnvOracle:
         ctrl = a.copy()
         if self.cm.na and self.normalize_act:                    # base_v0.py:86-90
             ctrl[self.muscle] = 1.0 / (1.0 + np.exp(-5.0 * (ctrl[self.muscle] - 0.5)))
+        elif self.normalize_act:                                 # base_v0.py:94-96 -> robot.py:786-796
+            cr = self.cm.arrays["ACT_CTRLRANGE"].reshape(-1, 2)
+            ctrl = cr.mean(axis=-1) + ctrl * (cr[:, 1] - cr[:, 0]) / 2.0
         if self.muscle_condition == "fatigue":                   # base_v0.py:99-103
             ctrl[self.muscle], _, _ = self.fatigue.compute_act(ctrl[self.muscle])
         elif self.muscle_condition == "reafferentation":         # base_v0.py:104-108
@@ -233,7 +247,8 @@ class ReachEnvOracle(PoseEnvOracle):
     def get_obs(self):
         od = self.get_obs_dict()
         self.obs_dict = od
-        return np.concatenate([od[k].ravel() for k in ("qpos", "qvel", "tip_pos", "reach_err", "act")]).astype(np.float32)
+        keys = ("qpos", "qvel", "tip_pos", "reach_err") + (("act",) if self.cm.na > 0 else ())
+        return np.concatenate([od[k].ravel() for k in keys]).astype(np.float32)
 
     def get_reward_dict(self, od):                               # reach_v0.py:123-151
         reach_dist = np.linalg.norm(od["reach_err"], axis=-1)

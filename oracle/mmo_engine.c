@@ -120,6 +120,8 @@ typedef struct {
   real *qfrc_constraint, *qacc;
   /* per-env model delta: size override of one geom (mm_state.geom_size_env) */
   int gsize_id, gtype; real gsize_val[3];
+  /* per-env model deltas on one body each (mm_state.body_mass_env / body_pos_env) */
+  int bmass_id, bpos_id; real bmass_val, bpos_val[3];
   /* contacts */
   int* con_pair;
   real *con_dist, *con_pos, *con_frame;
@@ -166,7 +168,7 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   }
   d->cacc = ralloc(6 * nb); d->cfrc = ralloc(6 * nb); d->tmp_nv = ralloc(nv);
   d->qH = ralloc(m->nM); d->qHDiagInv = ralloc(nv);
-  d->gsize_id = -1; d->gtype = -1;
+  d->gsize_id = -1; d->gtype = -1; d->bmass_id = -1; d->bpos_id = -1;
   mmo_reset(m, d);
   return d;
 }
@@ -282,7 +284,7 @@ static void mmo_kinematics(const mmo_model* m, mmo_data* d) {
   for (int b = 1; b < m->nbody; b++) {
     int p = MI(m, BODY_PARENT)[b];
     real pos[3], quat[4], v[3];
-    mat_vec(v, d->xmat + 9 * p, MF(m, BODY_POS) + 3 * b);
+    mat_vec(v, d->xmat + 9 * p, b == d->bpos_id ? d->bpos_val : MF(m, BODY_POS) + 3 * b);
     for (int k = 0; k < 3; k++) pos[k] = d->xpos[3 * p + k] + v[k];
     quat_mul(quat, d->xquat + 4 * p, MF(m, BODY_QUAT) + 4 * b);
     int ja = MI(m, BODY_JNTADR)[b], jn = MI(m, BODY_JNTNUM)[b];
@@ -358,7 +360,7 @@ static void mmo_com_pos(const mmo_model* m, mmo_data* d) {
   real* sm = (real*)calloc(nb, sizeof(real));
   (void)mass;
   for (int b = 0; b < nb; b++) {
-    sm[b] = MF(m, BODY_MASS)[b];
+    sm[b] = b == d->bmass_id ? d->bmass_val : MF(m, BODY_MASS)[b];
     for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = sm[b] * d->xipos[3 * b + k];
   }
   for (int b = nb - 1; b > 0; b--) {
@@ -375,7 +377,7 @@ static void mmo_com_pos(const mmo_model* m, mmo_data* d) {
     const real* c = d->subtree_com + 3 * MI(m, BODY_ROOTID)[b];
     const real* R = d->ximat + 9 * b;
     const real* I = MF(m, BODY_INERTIA) + 3 * b;
-    real ms = MF(m, BODY_MASS)[b];
+    real ms = b == d->bmass_id ? d->bmass_val : MF(m, BODY_MASS)[b];
     real r[3] = {d->xipos[3 * b] - c[0], d->xipos[3 * b + 1] - c[1], d->xipos[3 * b + 2] - c[2]};
     real* ci = d->cinert + 10 * b;
     /* R diag(I) R^T */
@@ -1385,6 +1387,8 @@ real* mmo_field(mmo_data* d, const char* name) {
 }
 void mmo_set_geom_size(mmo_data* d, int geom, double a, double b, double c) { d->gsize_id = geom; d->gsize_val[0] = a; d->gsize_val[1] = b; d->gsize_val[2] = c; }
 void mmo_set_geom_type(mmo_data* d, int type) { d->gtype = type; }
+void mmo_set_body_mass(mmo_data* d, int body, double mass) { d->bmass_id = body; d->bmass_val = mass; }
+void mmo_set_body_pos(mmo_data* d, int body, double x, double y, double z) { d->bpos_id = body; d->bpos_val[0] = x; d->bpos_val[1] = y; d->bpos_val[2] = z; }
 /* test hook: capsule-axis segment vs convex primitive in the primitive's frame -> signed distance, t, outward normal */
 double mmo_test_seg_shape(int type, const double* size, const double* a, const double* u, double h, double* t, double* grad);
 double mmo_time(const mmo_data* d) { return d->time; }

@@ -47,6 +47,8 @@ def lib():
         L.mmo_set_time.argtypes = [C.c_void_p, C.c_double]
         L.mmo_set_geom_size.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         L.mmo_set_geom_type.argtypes = [C.c_void_p, C.c_int]
+        L.mmo_set_body_mass.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.mmo_set_body_pos.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         L.mmo_test_seg_shape.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double, C.c_void_p, C.c_void_p]
         L.mmo_test_seg_shape.restype = C.c_double
         for f in ("mmo_nefc", "mmo_ncon", "mmo_solver_niter", "mmo_warn"):
@@ -159,6 +161,14 @@ class OracleData:
         mj_model.geom_size / geom_type at reset)"""
         lib().mmo_set_geom_size(self.ptr, int(geom), float(size[0]), float(size[1]), float(size[2]))
         lib().mmo_set_geom_type(self.ptr, int(gtype))
+
+    def set_body_mass(self, body: int, mass: float):
+        """per-env model delta (pose_v0.py:183): mass of one body; its inertia tensor is untouched"""
+        lib().mmo_set_body_mass(self.ptr, int(body), float(mass))
+
+    def set_body_pos(self, body: int, pos):
+        """per-env model delta (key_turn_v0.py:164): frame position of one body in its parent"""
+        lib().mmo_set_body_pos(self.ptr, int(body), float(pos[0]), float(pos[1]), float(pos[2]))
 
     def forward(self):
         lib().mmo_forward(self.model.ptr, self.ptr)

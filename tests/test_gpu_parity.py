@@ -380,3 +380,80 @@ def test_mjx_style_reach_api(models):
     dist = np.linalg.norm(err, axis=1); near = 5 * 0.0125; far = 0.034 * 5
     ref = -dist + 4.0 * ((dist < 2 * near) * 1.0 + (dist < near) * 1.0) - 50.0 * (dist > far)
     np.testing.assert_allclose(st.reward.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoFingerPoseRandom-v0", "motorFingerPoseRandom-v0", "myoElbowPose1D6MExoRandom-v0",
+                                    "myoElbowPose1D6MExoFixed-v0", "myoTorsoPoseFixed-v0", "myoHandPoseFixed-v0"])
+def test_more_pose_family_envs_match_env_oracle(oracle_lib, env_id):
+    """The rest of the myobase Pose family (finger / motor finger / exo elbow with per-episode carried weight / torso with
+    joint equalities and 210 muscles / fixed-target hand): reset draws, ctrl map (incl. the [-1,1] -> ctrlrange map of the
+    activation-free motor finger), frame_skip substeps + forward, obs vector, reward terms."""
+    nenv, nsteps = 4, 8
+    env = registry.make(env_id, num_envs=nenv, seed=5, autoreset=False)
+    cm = env.cm
+    obs0, _ = env.reset(seed=5)
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    oracles = []
+    for e in range(nenv):
+        uq, ut = EO.pose_reset_draws(cm.nq, e, 1, 5)
+        q0 = (lo + (hi - lo) * uq).astype(np.float32) if env.reset_type == "random" else env.init_qpos
+        if env.target_type == "generate":
+            tr = env.target_jnt_range
+            tg = (tr[:, 0] + (tr[:, 1] - tr[:, 0]) * ut).astype(np.float32)
+        else:
+            tg = env.target_jnt_value[e].cpu().numpy()
+        o = EO.PoseEnvOracle(cm, pose_thd=env.pose_thd, frame_skip=env.frame_skip, weighted_reward_keys=env.rwd_keys_wt)
+        o.far_th_pose = env.FAR_TH
+        if env.weight_bodyname is not None:
+            w = np.float32(env.weight_range[0] + (env.weight_range[1] - env.weight_range[0]) * EO.env_draw(1, e, 1, 5, 16)[0])
+            assert abs(float(env.body_mass[e]) - float(w)) < 1e-6
+            o.d.set_body_mass(cm.names["body"][env.weight_bodyname], float(env.body_mass[e]))
+        ob = o.reset(q0, tg)
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), ob, rtol=1e-6, atol=1e-6)
+        oracles.append(o)
+    assert obs0.shape[1] == 2 * cm.nq + cm.nv + cm.na
+    if env.weight_bodyname is not None:
+        assert float(env.body_mass.max() - env.body_mass.min()) > 0.05
+    rng = np.random.default_rng(0)
+    for s in range(nsteps):
+        a = rng.uniform(-1, 1, (nenv, cm.nu)).astype(np.float32)
+        obs, rwd, term, trunc, info = env.step(torch.from_numpy(a))
+        for e, o in enumerate(oracles):
+            ob, r, done, rd = o.step(a[e])
+            np.testing.assert_allclose(env.last_ctrl[e].cpu().numpy(), o.last_ctrl, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(obs[e].cpu().numpy(), ob, rtol=0, atol=5e-4)
+            assert abs(float(rwd[e]) - r) < 2e-3 * max(1.0, abs(r))
+            assert bool(term[e]) == done
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoFingerReachRandom-v0", "motorFingerReachRandom-v0", "myoFingerReachFixed-v0"])
+def test_finger_reach_envs_match_env_oracle(oracle_lib, env_id):
+    nenv, nsteps = 4, 8
+    env = registry.make(env_id, num_envs=nenv, seed=11, autoreset=False)
+    cm = env.cm
+    obs0, _ = env.reset(seed=11)
+    tlo, thi = env._tlo.cpu().numpy(), env._thi.cpu().numpy()
+    if "Random" in env_id:     # the reference's absolute box (myobase/__init__.py:75,100)
+        np.testing.assert_allclose(tlo, [0.1, -0.1, 0.1], atol=1e-7); np.testing.assert_allclose(thi, [0.27, 0.1, 0.3], atol=1e-7)
+    oracles = []
+    for e in range(nenv):
+        u = EO.reach_reset_draws(3 * env.ntip, e, 1, 11)
+        tg = (tlo + (thi - tlo) * u).astype(np.float32)
+        np.testing.assert_allclose(env.target_pos[e].cpu().numpy(), tg, rtol=0, atol=1e-7)
+        o = EO.ReachEnvOracle(cm, tip_sids=env.tip_sids, far_th=env.far_th, frame_skip=env.frame_skip)
+        ob = o.reset(tg)
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), ob, rtol=0, atol=2e-6)
+        oracles.append(o)
+    assert obs0.shape == (nenv, cm.nq + cm.nv + 6 + cm.na)
+    rng = np.random.default_rng(1)
+    for s in range(nsteps):
+        a = rng.uniform(-1, 1, (nenv, cm.nu)).astype(np.float32)
+        obs, rwd, term, trunc, info = env.step(torch.from_numpy(a))
+        for e, o in enumerate(oracles):
+            ob, r, done, rd = o.step(a[e])
+            np.testing.assert_allclose(obs[e].cpu().numpy(), ob, rtol=0, atol=5e-4)
+            for i, k in enumerate(E.RWD_KEYS_REACH):
+                assert abs(float(env.rwd[e, i]) - float(rd[k])) < 2e-3 * max(1.0, abs(float(rd[k]))), k
+            assert bool(term[e]) == done
