@@ -48,7 +48,8 @@ extern "C" {
 typedef struct mm_model mm_model;
 
 /* task ids for the fused obs/reward stage */
-enum { MM_TASK_NONE = 0, MM_TASK_POSE = 1, MM_TASK_REACH = 2, MM_TASK_REORIENT = 3, MM_TASK_WALK = 4, MM_TASK_OBJHOLD = 5 };
+enum { MM_TASK_NONE = 0, MM_TASK_POSE = 1, MM_TASK_REACH = 2, MM_TASK_REORIENT = 3, MM_TASK_WALK = 4, MM_TASK_OBJHOLD = 5,
+       MM_TASK_KEYTURN = 6 };
 
 /* mm_model_info selectors */
 enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INFO_NSITE, MM_INFO_NTENDON,
@@ -162,6 +163,11 @@ typedef struct {
      [hand_qpos = qpos[:-7], hand_qvel = qvel[:-6]*dt, obj_pos, obj_err = goal - obj_pos, act]; reuses tip_sites[0] (the
      "object" site), target_pos [nenv][3] (the per-episode "goal" site position), w_pose (goal_dist weight), w_bonus,
      w_penalty, w_act_reg and the MM_RWD_* columns (POSE := goal_dist). */
+  /* KEYTURN task (envs/myo/myobase/key_turn_v0.py:84-150; the key's hinge is the last qpos / qvel): obs [hand_qpos =
+     qpos[:-1], hand_qvel = qvel[:-1]*dt, key_qpos, key_qvel*dt, IFtip_approach = keyhead - IFtip, THtip_approach = keyhead -
+     THtip, act]; tip_sites[0..2] = the keyhead, IFtip, THtip site ids; reward columns MM_RWDK_*.  Needs do_forward = 1. */
+  float key_goal_th;        /* key_turn_v0.py:59,138                            */
+  float key_w[6];           /* weights of key_turn, IFtip_approach, THtip_approach, act_reg, bonus, penalty (key_turn_v0.py:24-31) */
   /* reset observation support (all tasks) */
   const uint8_t* env_mask;  /* optional [nenv]: envs with 0 are left untouched  */
   int   obs_only;           /* 1: no substeps, no ctrl map, no counters, no reward write: forward + obs of the CURRENT state
@@ -174,6 +180,10 @@ enum { MM_RWD_POSE = 0, MM_RWD_BONUS, MM_RWD_PENALTY, MM_RWD_ACT_REG, MM_RWD_SPA
 /* columns of mm_task.rwd for MM_TASK_WALK (walk_v0.py:305-325) */
 enum { MM_RWDW_VEL = 0, MM_RWDW_CYCLIC_HIP, MM_RWDW_REF_ROT, MM_RWDW_JOINT_ANGLE, MM_RWDW_ACT_MAG, MM_RWDW_SPARSE,
        MM_RWDW_SOLVED, MM_RWDW_DONE, MM_RWDW_DENSE, MM_RWDW_COUNT };
+
+/* columns of mm_task.rwd for MM_TASK_KEYTURN (key_turn_v0.py:116-150) */
+enum { MM_RWDK_KEY_TURN = 0, MM_RWDK_IF_APPROACH, MM_RWDK_TH_APPROACH, MM_RWDK_ACT_REG, MM_RWDK_BONUS, MM_RWDK_PENALTY,
+       MM_RWDK_SPARSE, MM_RWDK_SOLVED, MM_RWDK_DONE, MM_RWDK_DENSE, MM_RWDK_COUNT };
 
 /* columns of mm_task.rwd for MM_TASK_REORIENT (reorient_sar_v0.py:136-166) */
 enum { MM_RWDR_POS_ALIGN = 0, MM_RWDR_ROT_ALIGN, MM_RWDR_ACT_REG, MM_RWDR_DROP, MM_RWDR_BONUS, MM_RWDR_SPARSE,

@@ -28,7 +28,7 @@
 #define MYOSIM_MODEL_H_
 
 #define MM_MAGIC   0x424F594D  /* "MYOB" little endian */
-#define MM_VERSION 3
+#define MM_VERSION 4
 #define MM_HEADER_WORDS 4
 
 /* ---- integer options / dimensions: indices into section OPT_I ------------ */
@@ -73,7 +73,7 @@ enum { MM_EQ_JOINT = 2 };
 enum { MM_INT_EULER = 0, MM_INT_RK4 = 1 };
 /* constraint row types (oracle + engine internal) */
 enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
-       MM_CON_CONTACT = 3 };
+       MM_CON_CONTACT = 3, MM_CON_FRICTION_DOF = 4 };
 
 #define MM_MINVAL 1e-15  /* MuJoCo mjMINVAL */
 
@@ -116,6 +116,9 @@ enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
   MM_SEC(DOF_DAMPING,      'f', 1)                                               \
   MM_SEC(DOF_ARMATURE,     'f', 1)                                               \
   MM_SEC(DOF_INVWEIGHT0,   'f', 1)                                               \
+  MM_SEC(DOF_FRICTIONLOSS, 'f', 1)   /* dry friction (joint frictionloss)    */ \
+  MM_SEC(DOF_SOLREF,       'f', 2)   /* solreffriction                       */ \
+  MM_SEC(DOF_SOLIMP,       'f', 5)   /* solimpfriction                       */ \
   MM_SEC(QPOS0,            'f', 1)   /* [nq] */                                  \
   MM_SEC(QPOS_SPRING,      'f', 1)   /* [nq] */                                  \
   /* sites */                                                                    \

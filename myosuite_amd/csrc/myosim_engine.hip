@@ -272,7 +272,12 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
   d.integrator = oi[MM_OI_INTEGRATOR];
   if (d.integrator != MM_INT_EULER && d.integrator != MM_INT_RK4) { delete m; return fail(MM_EUNSUPPORTED, "integrator must be Euler (0) or RK4 (1)"); }
-  d.gen = (d.neq > 0 || d.npair > 0) ? 1 : 0;
+  d.nfric = 0;
+  {
+    const float* fl = (const float*)(blob + m->sec[MM_SEC_DOF_FRICTIONLOSS]);
+    for (int i = 0; i < d.nv; i++) if (fl[i] > 0.f) d.nfric++;
+  }
+  d.gen = (d.neq > 0 || d.npair > 0 || d.nfric > 0) ? 1 : 0;
   {
     const int32_t* et = (const int32_t*)(blob + m->sec[MM_SEC_EQ_TYPE]);
     for (int e = 0; e < d.neq; e++)
@@ -630,8 +635,12 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
     if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "object-hold task needs do_forward");
     if (!t->tip_sites || !t->target_pos || m->d.nq < 8) return fail(MM_EARG, "object-hold task needs tip_sites[0], target_pos and a free-joint object");
   }
+  if (t->task == MM_TASK_KEYTURN) {
+    if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "key-turn task needs do_forward");
+    if (!t->tip_sites || t->ntip != 3 || m->d.nq < 2) return fail(MM_EARG, "key-turn task needs tip_sites = {keyhead, IFtip, THtip}");
+  }
   if (t->task != MM_TASK_NONE && t->task != MM_TASK_POSE && t->task != MM_TASK_REACH && t->task != MM_TASK_WALK &&
-      t->task != MM_TASK_REORIENT && t->task != MM_TASK_OBJHOLD)
+      t->task != MM_TASK_REORIENT && t->task != MM_TASK_OBJHOLD && t->task != MM_TASK_KEYTURN)
     return fail(MM_EUNSUPPORTED, "task not implemented");
   if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "fatigue needs MA/MR/MF");
   KArgs a; fill_common(m, a, s);

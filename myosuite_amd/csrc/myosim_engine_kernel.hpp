@@ -40,7 +40,8 @@
 struct Dims {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, njmax, ntenJ;
   int iterations, ls_iterations, eulerdamp, any_damping;
-  int gen;   // model has equality / contact rows: general (dense-J) constraint path
+  int gen;   // model has equality / friction-loss / contact rows: general (dense-J) constraint path
+  int nfric; // dofs with frictionloss > 0 (one friction-loss row each, behind the equalities)
   int integrator;   // MM_INT_EULER | MM_INT_RK4
   int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
@@ -225,7 +226,7 @@ __device__ __forceinline__ float sh(float v, int src) { return __shfl(v, src, G)
 // Stages: xor 1 / xor 2 inside quads (quad_perm), quads -> 8 lanes (row_half_mirror), 8 -> 16 lanes (row_mirror); rows of
 // 16 are combined through v_readlane.  Every stage is symmetric (lane i and its partner compute a op b and b op a), so
 // the result is BITWISE IDENTICAL in every lane of the group -- group-uniform decisions (line-search alpha, loop exits)
-// rely on that.  The adds are explicit (__fadd_rn): a contracted fma(a_i, b_i, partner) would differ between partners.
+// rely on that.  The reduced value is made opaque first (gsum): a contracted fma(a_i, b_i, partner) would differ between partners.
 #define DPP_QUAD_XOR1 0xB1
 #define DPP_QUAD_XOR2 0x4E
 #define DPP_ROW_HALF_MIRROR 0x141
@@ -242,6 +243,10 @@ __device__ __forceinline__ float rl(float v, int lane) {
 
 template <int G>
 __device__ __forceinline__ float gsum(float v) {
+  // the first stage must add the ROUNDED operand: __fadd_rn is a plain `+` in this toolchain, so a product passed in would be
+  // contracted to fma(a_i, b_i, partner), which differs from the partner's fma(a_j, b_j, mine) in the last bit -- enough to
+  // split a group's line search at a kink of the cost (seen with friction-loss rows: even / odd lanes took different alpha)
+  asm("" : "+v"(v));
   v = __fadd_rn(v, dppf<DPP_QUAD_XOR1>(v));
   v = __fadd_rn(v, dppf<DPP_QUAD_XOR2>(v));
   if constexpr (G >= 8) v = __fadd_rn(v, dppf<DPP_ROW_HALF_MIRROR>(v));
@@ -574,6 +579,7 @@ struct Engine {
   int r_dof;
   // ---- general rows (GEN): lane r owns row r of efc_J (LDS); equality rows are always active
   bool r_eq;
+  float r_floss;    // friction-loss row: bound of the row force (0 on every other row)
   int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
   const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
   float rk_v0, rk_vsum, rk_asum;   // RK4: qvel at the start of the step, weighted sums of stage qvel / qacc
@@ -600,7 +606,7 @@ struct Engine {
         c_jdadr[i] = has ? MI_(JNT_DOFADR)[j] : 0;
       }
     }
-    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; r_floss = 0.f; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
     b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
@@ -1371,7 +1377,21 @@ struct Engine {
         Jrow(e)[d2] = -deriv;
       } else res = pos1 - c[0];
       Jrow(e)[d1] = 1.f;
-      RT[3 * e] = __int_as_float(MM_CON_EQUALITY | (e << 2)); RT[3 * e + 1] = res; RT[3 * e + 2] = dA;
+      RT[3 * e] = __int_as_float(MM_CON_EQUALITY | (e << 3)); RT[3 * e + 1] = res; RT[3 * e + 2] = dA;
+    }
+    // ---- dof friction loss (MuJoCo row order: equality, friction loss, limits, contacts): J = e_dof at pos 0
+    int nfr = 0;
+    if (a.d.nfric) {
+      const int fr = (g < a.d.nv && MF_(DOF_FRICTIONLOSS)[g] > 0.f) ? 1 : 0;
+      const int frank = gscan_excl(fr);
+      nfr = gsum_i(fr);
+      if (fr) {
+        const int r = neq + frank;
+        if (r < a.d.efc_rows) {
+          Jrow(r)[g] = 1.f;
+          RT[3 * r] = __int_as_float(MM_CON_FRICTION_DOF | (g << 3)); RT[3 * r + 1] = 0.f; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[g];
+        }
+      }
     }
     // ---- joint limits, compacted behind the equalities
     int lim = 0, ldof = 0;
@@ -1391,10 +1411,10 @@ struct Engine {
     const int lrank = gscan_excl(lim), nlim = gsum_i(lim);
     int over = 0;
     if (lim) {
-      const int r = neq + lrank;
+      const int r = neq + nfr + lrank;
       if (r < a.d.efc_rows) {
         Jrow(r)[ldof] = lsign;
-        RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 2)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
+        RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 3)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
       } else over = 1;
     }
     // ---- contacts: lane p handles explicit pair p (up to two contacts for plane-capsule)
@@ -1470,7 +1490,7 @@ struct Engine {
     if (a.prof) pf[PF_IO] += clock64() - tc0_;   // narrow phase only (reported as 'io' = collide)
     int myrows = 0;
     for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
-    int base = neq + nlim + gscan_excl(myrows);
+    int base = neq + nfr + nlim + gscan_excl(myrows);
     const int ncrows = gsum_i(myrows);
     for (int c = 0; c < 2; c++) {
       if (!(c < nc && cdist[c] < incl)) continue;
@@ -1484,14 +1504,14 @@ struct Engine {
       contact_rows(base, rowsper, b1, b2, cpos[c], n, y, z, mu);
       const float tran = MF_(BODY_INVWEIGHT0)[2 * b1] + MF_(BODY_INVWEIGHT0)[2 * b2];
       for (int k = 0; k < rowsper; k++) {
-        RT[3 * (base + k)] = __int_as_float(MM_CON_CONTACT | (g << 2));
+        RT[3 * (base + k)] = __int_as_float(MM_CON_CONTACT | (g << 3));
         RT[3 * (base + k) + 1] = cdist[c] - incl;
         RT[3 * (base + k) + 2] = rowsper == 1 ? tran : tran + mu * mu * tran;
       }
       base += rowsper;
     }
     if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
-    nefc = neq + nlim + ncrows;
+    nefc = neq + nfr + nlim + ncrows;
     if (nefc > a.d.efc_rows) nefc = a.d.efc_rows;
     {
       int w = nefc;
@@ -1501,9 +1521,9 @@ struct Engine {
     }
     GSYNC();
     // ---- owner stage: impedance / reference acceleration of row g (mmo_reference_constraint + pyramid R)
-    r_active = g < nefc; r_eq = false; r_D = 0.f; r_aref = 0.f; r_jar = 0.f;
+    r_active = g < nefc; r_eq = false; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_floss = 0.f;
     if (r_active) {
-      const int desc = __float_as_int(RT[3 * g]), kind = desc & 3, id = desc >> 2;
+      const int desc = __float_as_int(RT[3 * g]), kind = desc & 7, id = desc >> 3;
       const float x = RT[3 * g + 1], dA = RT[3 * g + 2];
       float vel = 0.f;
       const float* J = Jrow(g);
@@ -1511,6 +1531,7 @@ struct Engine {
       const float *si, *sr;
       if (kind == MM_CON_EQUALITY) { si = MF_(EQ_SOLIMP) + 5 * id; sr = MF_(EQ_SOLREF) + 2 * id; }
       else if (kind == MM_CON_LIMIT_JOINT) { si = MF_(JNT_SOLIMP) + 5 * id; sr = MF_(JNT_SOLREF) + 2 * id; }
+      else if (kind == MM_CON_FRICTION_DOF) { si = MF_(DOF_SOLIMP) + 5 * id; sr = MF_(DOF_SOLREF) + 2 * id; r_floss = MF_(DOF_FRICTIONLOSS)[id]; }
       else { si = MF_(PAIR_SOLIMP) + 5 * id; sr = MF_(PAIR_SOLREF) + 2 * id; }
       impedance(si, sr, x, dA, vel, r_D, r_aref);
       if (kind == MM_CON_CONTACT && MI_(PAIR_CONDIM)[id] > 1) {
@@ -1539,10 +1560,25 @@ struct Engine {
     for (int r = 0; r < nrows_wave; r++) s += Jc[r * RS] * bc<G>(f, r);
     return g < a.d.nv ? s : 0.f;
   }
+  // force -s'(x) of the row owned by this lane at x = J a - aref; quad = the row is in its quadratic state (contributes
+  // D J'J to the Hessian).  Equality rows are quadratic everywhere, limit / contact rows for x < 0, friction-loss rows are
+  // Huber: the force -D x saturates at +-frictionloss (mmo_engine.c: row_cost)
+  __device__ __forceinline__ float row_force(float x, bool& quad) const {
+    // branch-free on purpose: the callers feed the result straight into wave-collective reductions
+    const float f = -r_D * x;
+    const bool fr = r_floss > 0.f;
+    quad = r_active && (fr ? fabsf(f) < r_floss : (r_eq || x < 0.f));
+    const float v = fr ? clampf(f, -r_floss, r_floss) : (quad ? f : 0.f);
+    return r_active ? v : 0.f;
+  }
   __device__ __forceinline__ float cost_gen(float x, float Ma) {
     float c = 0.5f * (x - d_qaccsm) * (Ma - d_smooth);
     r_jar = jac_mul(x) - r_aref;
-    if (r_active && (r_eq || r_jar < 0.f)) c += 0.5f * r_D * r_jar * r_jar;
+    bool quad;
+    const float f = row_force(r_jar, quad);
+    if (quad) c += 0.5f * r_D * r_jar * r_jar;
+    else if (r_floss > 0.f && r_active) c += r_floss * (fabsf(r_jar) - 0.5f * r_floss / r_D);
+    (void)f;
     return gsum<G>(c);
   }
 
@@ -1559,22 +1595,24 @@ struct Engine {
     if (cost_ws < cost_sm) { d_qacc = d_warm; Ma = Ma_ws; (void)cost_gen(d_qacc, Ma); }
     else { d_qacc = d_qaccsm; Ma = d_smooth; }
     float alpha_prev = 0.f;
-    unsigned long long set_prev = 0ull;
+    unsigned long long set_prev = 0ull, sat_prev = 0ull;
     bool done = nefc == 0;     // envs of the wave that have no rows idle through the loop (wave-collective code below)
     for (int iter = 0; iter < a.d.iterations; iter++) {
-      const bool on = r_active && (r_eq || r_jar < 0.f);
-      const unsigned long long set_now = __ballot(on);
-      d_qfrccon = jacT_mul(on ? -r_D * r_jar : 0.f);
+      bool on;
+      const float rf = row_force(r_jar, on);
+      // active-set signature: quadratic rows, plus the sign of saturated friction rows
+      const unsigned long long set_now = __ballot(on), sat_now = a.d.nfric ? __ballot(rf > 0.f && !on) : 0ull;
+      d_qfrccon = jacT_mul(rf);
       float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
       float gn = sqrtf(gsum<G>(grad * grad));
       if (scale * gn < a.d.tolerance) done = true;
       if (!done && iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
         const int lane = threadIdx.x & 63;
         const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
-        if (((set_now ^ set_prev) & gm) == 0ull) done = true;
+        if ((((set_now ^ set_prev) | (sat_now ^ sat_prev)) & gm) == 0ull) done = true;
       }
       if (__ballot(!done) == 0ull) break;
-      set_prev = set_now;
+      set_prev = set_now; sat_prev = sat_now;
       // H = M + J_A' D J_A : lane i accumulates row i, the J row is an LDS broadcast
       float A[NVP];
 #pragma unroll
@@ -1610,7 +1648,12 @@ struct Engine {
       for (int it = 0; it < a.d.ls_iterations; it++) {
         float x = r_jar + alpha * jv;
         float d1 = 0.f, d2 = 0.f;
-        if (r_active && (r_eq || x < 0.f)) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
+        {
+          bool q;
+          const float f = row_force(x, q);
+          d1 = -f * jv;
+          if (q) d2 = r_D * jv * jv;
+        }
         d1 = gsum<G>(d1) + q1 + 2.f * alpha * q2;
         d2 = gsum<G>(d2) + 2.f * q2;
         if (!lsdone) {
@@ -1638,8 +1681,8 @@ struct Engine {
       }
       if (iter == a.d.iterations - 1 && !done) status |= 4;
     }
-    const bool on2 = r_active && (r_eq || r_jar < 0.f);
-    d_qfrccon = jacT_mul(on2 ? -r_D * r_jar : 0.f);
+    bool on2;
+    d_qfrccon = jacT_mul(row_force(r_jar, on2));
   }
 
   // ------------------------------------------------------------------ pipeline
@@ -1951,6 +1994,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     for (int i = g; i < d.na; i += G) D[a.D.actdot + i] = W[L.actdot + i];
     D[a.D.efc_active + g] = E.r_active ? 1.f : 0.f; D[a.D.efc_D + g] = E.r_D; D[a.D.efc_aref + g] = E.r_aref;
     if (g == 0) D[a.D.scal] = (float)E.niter;
+    if (g < 15) { D[a.D.scal + 1 + g] = E.r_jar; D[a.D.scal + 16 + g] = E.r_floss; }   // rows of small test models
   }
   if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
     E.pf[PF_TOTAL] = clock64() - t_start;
@@ -2144,6 +2188,45 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
           r[MM_RWD_DENSE] = t.w_pose * -goal_dist + t.w_bonus * bonus + t.w_act_reg * -act_mag + t.w_penalty * (drop ? -1.f : 0.f);
         }
         if (t.done && !obs_only) t.done[e] = drop ? 1 : 0;
+      }
+    }
+    if (t.task == MM_TASK_KEYTURN) {
+      // obs / reward of KeyTurnEnvV0 (key_turn_v0.py:101-150)
+      float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+      const int nh = d.nq - 1, nhv = d.nv - 1;
+      const int o_kq = nh + nhv, o_if = o_kq + 2, o_th = o_if + 3, o_act = o_th + 3;
+      float act2 = 0.f;
+      if (ob) {
+        for (int i = g; i < nh; i += G) ob[i] = W[L.qpos + i];
+        if (g < nhv) ob[nh + g] = E.d_qvel * t.obs_dt;
+        if (g == nhv) ob[o_kq + 1] = E.d_qvel * t.obs_dt;
+      }
+      for (int i = g; i < d.na; i += G) {
+        float x = W[L.act + i];
+        act2 += x * x;
+        if (ob) ob[o_act + i] = x;
+      }
+      act2 = gsum<G>(act2);
+      if (g == 0) {
+        const V3 kh = E.site_pos(t.tip_sites[0]);
+        const V3 ifa = kh - E.site_pos(t.tip_sites[1]), tha = kh - E.site_pos(t.tip_sites[2]);
+        const float key_pos = W[L.qpos + nh];
+        if (ob) { ob[o_kq] = key_pos; st3(ob + o_if, ifa); st3(ob + o_th, tha); }
+        const float ifd = fabsf(sqrtf(dot(ifa, ifa)) - 0.030f), thd = fabsf(sqrtf(dot(tha, tha)) - 0.030f);
+        const float act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
+        const float far_th = 0.1f, pi_ = 3.14159265358979f;
+        const float bonus = (key_pos > 0.5f * pi_ ? 1.f : 0.f) + (key_pos > pi_ ? 1.f : 0.f);
+        const float penalty = -(ifd > 0.5f * far_th ? 1.f : 0.f) - (thd > 0.5f * far_th ? 1.f : 0.f);
+        const bool done = ifd > far_th || thd > far_th;
+        if (t.rwd && !obs_only) {
+          float* r = t.rwd + (size_t)e * MM_RWDK_COUNT;
+          r[MM_RWDK_KEY_TURN] = key_pos; r[MM_RWDK_IF_APPROACH] = -ifd; r[MM_RWDK_TH_APPROACH] = -thd; r[MM_RWDK_ACT_REG] = -act_mag;
+          r[MM_RWDK_BONUS] = bonus; r[MM_RWDK_PENALTY] = penalty; r[MM_RWDK_SPARSE] = key_pos;
+          r[MM_RWDK_SOLVED] = key_pos > t.key_goal_th ? 1.f : 0.f; r[MM_RWDK_DONE] = done ? 1.f : 0.f;
+          r[MM_RWDK_DENSE] = t.key_w[0] * key_pos + t.key_w[1] * -ifd + t.key_w[2] * -thd + t.key_w[3] * -act_mag +
+                             t.key_w[4] * bonus + t.key_w[5] * penalty;
+        }
+        if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
       }
     }
     if (t.task == MM_TASK_REORIENT) {

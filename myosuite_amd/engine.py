@@ -22,10 +22,12 @@ LIB_PATH = os.environ.get("MYOSIM_LIB", os.path.join(CSRC, "libmyosim_hip.so")) 
 # sources: every *.hip under csrc/ (see build())
 _lib = None
 
-MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK, MM_TASK_OBJHOLD = 0, 1, 2, 3, 4, 5
+MM_TASK_NONE, MM_TASK_POSE, MM_TASK_REACH, MM_TASK_REORIENT, MM_TASK_WALK, MM_TASK_OBJHOLD, MM_TASK_KEYTURN = 0, 1, 2, 3, 4, 5, 6
 RWD_KEYS_POSE = ["pose", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 RWD_KEYS_REACH = ["reach", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
 RWD_KEYS_OBJHOLD = ["goal_dist", "bonus", "penalty", "act_reg", "sparse", "solved", "done", "dense"]
+RWD_KEYS_KEYTURN = ["key_turn", "IFtip_approach", "THtip_approach", "act_reg", "bonus", "penalty", "sparse", "solved", "done",
+                    "dense"]
 RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense"]
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
@@ -102,6 +104,7 @@ class mm_task(C.Structure):
                 ("reor_obj_body", C.c_int), ("reor_eps_site", C.c_int), ("reor_pen_length", C.c_float),
                 ("reor_axis_half", C.c_void_p), ("reor_des_rot", C.c_void_p), ("reor_w", C.c_float * 5),
                 ("reor_obs_muscle", C.c_int),
+                ("key_goal_th", C.c_float), ("key_w", C.c_float * 6),
                 ("env_mask", C.c_void_p), ("obs_only", C.c_int)]
 
 

@@ -100,6 +100,11 @@ def _objhold(**kw):
     return ObjHoldEnvV0(**kw)
 
 
+def _keyturn(**kw):
+    from .key_turn_v0 import KeyTurnEnvV0
+    return KeyTurnEnvV0(**kw)
+
+
 def _walk(**kw):
     from .walk_v0 import WalkEnvV0
     return WalkEnvV0(**kw)
@@ -216,6 +221,14 @@ register_env_with_variants(
     kwargs={"model": "leg", "normalize_act": True, "min_height": 0.8, "max_rot": 0.8, "hip_period": 100,
             "reset_type": "init", "target_x_vel": 0.0, "target_y_vel": 1.2, "target_rot": None})
 
+
+# Hand key turn (myobase/__init__.py:572-592)
+register_env_with_variants(
+    id="myoHandKeyTurnFixed-v0", entry_point=_keyturn, max_episode_steps=200,
+    kwargs={"model": "hand_keyturn", "normalize_act": True})
+register_env_with_variants(
+    id="myoHandKeyTurnRandom-v0", entry_point=_keyturn, max_episode_steps=200,
+    kwargs={"model": "hand_keyturn", "normalize_act": True, "key_init_range": (-np.pi / 2, np.pi / 2), "goal_th": 2 * np.pi})
 
 # MyoTorso posing (myobase/__init__.py:638-670).  myoTorsoExoPoseFixed-v0 (:671-701) needs the exosuit model
 # (myotorso_exosuit.xml, absent) and is not registered.

@@ -384,9 +384,10 @@ def load(source: str, missing_include: str = "error") -> ModelSpec:
                       ref=ctx.ang(float(ja.get("ref", "0"))) if angular else float(ja.get("ref", "0")),
                       springref=ctx.ang(float(ja.get("springref", "0"))) if angular else float(ja.get("springref", "0")),
                       solref=tuple(_floats(ja.get("solreflimit"), 2, list(DEFAULT_SOLREF))),
-                      solimp=tuple(_floats(ja.get("solimplimit"), 5, list(DEFAULT_SOLIMP))))
-            if float(ja.get("frictionloss", "0")) != 0:
-                raise MjcfError("joint frictionloss is not implemented")
+                      solimp=tuple(_floats(ja.get("solimplimit"), 5, list(DEFAULT_SOLIMP))),
+                      frictionloss=float(ja.get("frictionloss", "0")),
+                      solreffriction=tuple(_floats(ja.get("solreffriction"), 2, list(DEFAULT_SOLREF))),
+                      solimpfriction=tuple(_floats(ja.get("solimpfriction"), 5, list(DEFAULT_SOLIMP))))
             s.add_joint(ja.get("name") or uname("jnt"), name, jt, **kw)
         for g in el.findall("geom"):
             add_geom(g, name, cc)
@@ -623,6 +624,8 @@ def dump(spec: ModelSpec) -> str:
                       limited="true" if j.limited else "false")
             if j.limited:
                 at["range"] = _f(j.range)
+            if j.frictionloss > 0:
+                at.update(frictionloss=repr(j.frictionloss), solreffriction=_f(j.solreffriction), solimpfriction=_f(j.solimpfriction))
             ET.SubElement(node, "joint", **at)
         emit_attached(bi, node)
     if spec.tendons:

@@ -62,6 +62,9 @@ class _Joint:
     margin: float
     solref: Tuple[float, float]
     solimp: Tuple[float, ...]
+    frictionloss: float = 0.0
+    solreffriction: Tuple[float, float] = DEFAULT_SOLREF
+    solimpfriction: Tuple[float, ...] = DEFAULT_SOLIMP
 
 
 @dataclasses.dataclass
@@ -188,7 +191,8 @@ class ModelSpec:
 
     def add_joint(self, name, body, type="hinge", pos=(0, 0, 0), axis=(0, 0, 1), range=None,
                   stiffness=0.0, damping=0.0, armature=0.0, ref=0.0, springref=0.0, margin=0.0,
-                  solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP) -> int:
+                  solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP, frictionloss=0.0, solreffriction=DEFAULT_SOLREF,
+                  solimpfriction=DEFAULT_SOLIMP) -> int:
         assert name not in self._jname, name
         b = self._bname[body]
         # MuJoCo requires joints of a body to be contiguous: enforce authoring order
@@ -203,7 +207,8 @@ class ModelSpec:
         rng = (float(range[0]), float(range[1])) if lim else (0.0, 0.0)
         self.joints.append(_Joint(name, b, t, _v(pos, 3), ax, lim, rng, float(stiffness), float(damping),
                                   float(armature), float(ref), float(springref), float(margin),
-                                  tuple(solref), tuple(solimp)))
+                                  tuple(solref), tuple(solimp), float(frictionloss), tuple(solreffriction),
+                                  tuple(solimpfriction)))
         jid = len(self.joints) - 1
         self.bodies[b].joints.append(jid)
         self._jname[name] = jid
@@ -316,6 +321,7 @@ class ModelSpec:
 
         dof_bodyid = np.zeros(nv, i32); dof_jntid = np.zeros(nv, i32)
         dof_damping = np.zeros(nv, f32); dof_armature = np.zeros(nv, f32)
+        dof_floss = np.zeros(nv, f32); dof_solref = np.zeros((nv, 2), f32); dof_solimp = np.zeros((nv, 5), f32)
         qpos0 = np.zeros(nq, f32); qpos_spring = np.zeros(nq, f32)
         for ji, j in enumerate(self.joints):
             dv = {0: 6, 1: 3, 2: 1, 3: 1}[j.type]
@@ -323,6 +329,7 @@ class ModelSpec:
                 d = dofadr[ji] + k
                 dof_bodyid[d] = j.body; dof_jntid[d] = ji
                 dof_damping[d] = j.damping; dof_armature[d] = j.armature
+                dof_floss[d] = j.frictionloss; dof_solref[d] = j.solreffriction; dof_solimp[d] = j.solimpfriction
             qa = qposadr[ji]
             if j.type == C["MM_JNT_FREE"]:
                 qpos0[qa:qa + 3] = self.bodies[j.body].pos; qpos0[qa + 3:qa + 7] = self.bodies[j.body].quat
@@ -354,6 +361,7 @@ class ModelSpec:
         A["DOF_BODYID"] = dof_bodyid; A["DOF_JNTID"] = dof_jntid
         A["DOF_PARENTID"] = dof_parent; A["DOF_MADR"] = dof_madr
         A["DOF_DAMPING"] = dof_damping; A["DOF_ARMATURE"] = dof_armature
+        A["DOF_FRICTIONLOSS"] = dof_floss; A["DOF_SOLREF"] = dof_solref; A["DOF_SOLIMP"] = dof_solimp
         A["QPOS0"] = qpos0; A["QPOS_SPRING"] = qpos_spring
 
         nsite = len(self.sites)
@@ -517,7 +525,8 @@ class ModelSpec:
         ncon_bound = sum(2 if (self.geoms[self._gname[p["g1"]]]["type"] == 0
                                and self.geoms[self._gname[p["g2"]]]["type"] == 3) else 1 for p in self.pairs)
         nconmax = self.nconmax if self.nconmax else ncon_bound
-        njmax = neq + nlim_j + nlim_t + nconmax * con_rows
+        nfric = int(np.count_nonzero(dof_floss > 0))
+        njmax = neq + nfric + nlim_j + nlim_t + nconmax * con_rows
 
         oi = np.zeros(C["MM_OI_COUNT"], i32)
         oi[C["MM_OI_NQ"]] = nq; oi[C["MM_OI_NV"]] = nv; oi[C["MM_OI_NU"]] = nu; oi[C["MM_OI_NA"]] = na

@@ -709,10 +709,17 @@ def _hand_palm_up_with_capsules(name: str):
     s.nconmax = 8
     phi = -(math.pi - 1.5)                         # base roll: pro_sup = -1.5 then sums to -pi, palm (local -z) up
     s.bodies[s._bname["ulna"]].quat = np.array([math.cos(phi / 2), math.sin(phi / 2), 0.0, 0.0])
-    ZX = (math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0)      # capsule axis (local z) -> body x
+    return s, _add_hand_capsules(s)
+
+
+def _add_hand_capsules(s: ModelSpec, only=None):
+    """Collision capsules along metacarpals, phalanges and the carpal row of make_hand() (``only``: restrict to these bodies).
+    Returns the capsule geom names."""
     caps = []
 
     def cap(name, body, r, p0, p1):
+        if only is not None and body not in only:
+            return
         p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
         s.add_geom(name, body, "capsule", (r, 0.5 * np.linalg.norm(p1 - p0)), pos=tuple(0.5 * (p0 + p1)), quat=_quat_z_to(p1 - p0))
         caps.append(name)
@@ -728,8 +735,7 @@ def _hand_palm_up_with_capsules(name: str):
     for body, L, r in (("firstmc", 0.044, 0.009), ("proximal_thumb", 0.032, 0.008), ("distal_thumb", 0.026, 0.007)):
         cap(f"col_{body}", body, r, 0.004 * tdir, (L - 0.003) * tdir)
     cap("col_carpal", "capitate", 0.012, (0.008, -0.026, 0), (0.008, 0.028, 0))
-
-    return s, caps
+    return caps
 
 
 def _make_hand_with_object(kind: str) -> ModelSpec:
@@ -773,6 +779,31 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
     return s
 
 
+
+
+def make_hand_keyturn() -> ModelSpec:
+    """myoHand + key (myosuite/envs/myo/assets/hand/myohand_keyturn.xml:22-32, "Index Thumb Model for turning key task"):
+    the key is the LAST body, one hinge about its shaft (``keyjoint``: frictionloss 0.02, damping 0.1 -- xml:29) = the last
+    qpos / qvel (key_turn_v0.py:86-91), geoms ellipsoid head .030 .030 .004, capsule shaft .005 x .070, box bit .015 .010 .004
+    (xml:25-28), site ``keyhead`` at the body origin.  nq = nv = 24, 39 muscles, obs 93.  The key is placed between the open
+    synthetic hand's index and thumb tips with the shaft pointing away from the wrist; index / thumb phalanx capsules collide
+    with the three key geoms."""
+    s = make_hand()
+    s.name = "myohand_keyturn"
+    s.nconmax = 6
+    caps = _add_hand_capsules(s, only=("proxph2", "midph2", "distph2", "proximal_thumb", "distal_thumb"))
+    KP = (0.388, -0.056, 0.970)
+    s.add_body("key", "world", pos=KP, quat=(math.cos(math.pi / 2), 0.0, 0.0, math.sin(math.pi / 2)),   # key x = world -x
+               mass=0.031, ipos=(-0.03, 0.001, 0), inertia=(4.0e-6, 6.0e-5, 6.2e-5))
+    s.add_joint("keyjoint", "key", "hinge", axis=(1, 0, 0), damping=0.1, frictionloss=0.02)
+    s.add_geom("keyhead", "key", "ellipsoid", (0.030, 0.030, 0.004))
+    s.add_geom("keyshaft", "key", "capsule", (0.005, 0.070), pos=(-0.045, 0, 0), quat=(math.cos(1.57 / 2), 0.0, math.sin(1.57 / 2), 0.0))
+    s.add_geom("keybit", "key", "box", (0.015, 0.010, 0.004), pos=(-0.1, 0.008, 0))
+    s.add_site("keyhead", "key", (0, 0, 0))
+    for c in caps:
+        for kg in ("keyhead", "keyshaft", "keybit"):
+            s.add_contact_pair(c, kg, condim=3, friction=(1.0, 0.005, 0.0001))
+    return s
 
 
 def make_hand_hold() -> ModelSpec:
@@ -835,6 +866,27 @@ def make_contact_toy() -> ModelSpec:
     return s
 
 
+def make_friction_toy() -> ModelSpec:
+    """Two-link arm with dry joint friction (``frictionloss``), limits, damping and torque motors, plus a slider coupled to the
+    elbow by a joint equality.  Test model for the friction-loss constraint rows (Huber cost); not a reference asset."""
+    s = ModelSpec("friction_toy", timestep=0.002)
+    s.add_body("upper", "world", pos=(0, 0, 1.0), mass=1.2, ipos=(0.15, 0, 0), inertia=(0.002, 0.012, 0.012))
+    s.add_joint("shoulder", "upper", "hinge", axis=(0, 1, 0), range=(-1.5, 1.5), damping=0.05, armature=0.005,
+                frictionloss=0.6)
+    s.add_body("fore", "upper", pos=(0.3, 0, 0), mass=0.8, ipos=(0.12, 0, 0), inertia=(0.001, 0.006, 0.006))
+    s.add_joint("elbow", "fore", "hinge", axis=(0, 1, 0), range=(-0.2, 2.0), damping=0.02, armature=0.003,
+                frictionloss=0.15, solreffriction=(0.01, 1.0), solimpfriction=(0.95, 0.99, 0.001, 0.5, 2.0))
+    s.add_body("knob", "fore", pos=(0.25, 0, 0), mass=0.05, inertia=(2e-5, 2e-5, 2e-5))
+    s.add_joint("knob_turn", "knob", "hinge", axis=(1, 0, 0), damping=0.001, armature=0.0005, frictionloss=0.02)
+    s.add_body("slider", "world", pos=(0.5, 0.3, 0.5), mass=0.3, inertia=(3e-4, 3e-4, 3e-4))
+    s.add_joint("slide_z", "slider", "slide", axis=(0, 0, 1), damping=0.2, armature=0.01)
+    s.add_equality_joint("slide_z", "elbow", (0.0, 0.05))
+    s.add_motor("m_shoulder", "shoulder", gear=4.0, ctrlrange=(-1.0, 1.0))
+    s.add_motor("m_elbow", "elbow", gear=1.5, ctrlrange=(-1.0, 1.0))
+    s.add_motor("m_knob", "knob_turn", gear=0.05, ctrlrange=(-1.0, 1.0))
+    return s
+
+
 def _ground_keyframes(cm):
     """Shift the root height of every keyframe so that the lowest foot sphere just touches the floor (z = 0)."""
     from . import kin_np as K
@@ -865,7 +917,8 @@ def get_model(name: str) -> CompiledModel:
         spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
                 "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen,
                 "hand_hold": make_hand_hold, "elbow_exo": make_elbow_exo, "finger": make_finger,
-                "motorfinger": lambda: make_finger(motor=True), "torso": make_torso}[name]()
+                "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
+                "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn}[name]()
         cm = spec.compile()
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob

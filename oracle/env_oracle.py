@@ -582,3 +582,66 @@ class ObjHoldEnvOracle(PoseEnvOracle):
         self.steps += 1
         self.rwd_dict = rwd
         return obs, float(rwd["dense"]), bool(rwd["done"]), rwd
+
+
+# ---------------------------------------------------------------------- KeyTurn (key_turn_v0.py)
+def keyturn_obs_reward(qpos, qvel, act, keyhead, iftip, thtip, dt, goal_th, rwd_keys_wt):
+    """get_obs_dict + obsdict2obsvec + get_reward_dict of key_turn_v0.py:101-150 on raw arrays."""
+    od = collections.OrderedDict(hand_qpos=qpos[:-1].copy(), hand_qvel=qvel[:-1] * dt, key_qpos=np.array([qpos[-1]]),
+                                 key_qvel=np.array([qvel[-1]]) * dt, IFtip_approach=np.asarray(keyhead, np.float64) - iftip,
+                                 THtip_approach=np.asarray(keyhead, np.float64) - thtip, act=act.copy())
+    obs = np.concatenate([np.asarray(v, np.float64).ravel() for v in od.values()])
+    IF_d = np.abs(np.linalg.norm(od["IFtip_approach"]) - 0.030)
+    TH_d = np.abs(np.linalg.norm(od["THtip_approach"]) - 0.030)
+    key_pos = od["key_qpos"][0]
+    na = act.size
+    act_mag = np.linalg.norm(act) / na if na else 0.0
+    far_th = 0.1
+    rwd = collections.OrderedDict((
+        ("key_turn", key_pos), ("IFtip_approach", -1.0 * IF_d), ("THtip_approach", -1.0 * TH_d), ("act_reg", -1.0 * act_mag),
+        ("bonus", 1.0 * (key_pos > np.pi / 2) + 1.0 * (key_pos > np.pi)),
+        ("penalty", -1.0 * (IF_d > far_th / 2) - 1.0 * (TH_d > far_th / 2)),
+        ("sparse", key_pos), ("solved", key_pos > goal_th), ("done", (IF_d > far_th) or (TH_d > far_th))))
+    rwd["dense"] = np.sum([wt * rwd[k] for k, wt in rwd_keys_wt.items()], axis=0)
+    return obs, rwd
+
+
+class KeyTurnEnvOracle(PoseEnvOracle):
+    """Single-env CPU restatement of KeyTurnEnvV0 on the fp64 oracle engine."""
+    RWD_KEYS_WT = {"key_turn": 1.0, "IFtip_approach": 10.0, "THtip_approach": 10.0, "act_reg": 1.0, "bonus": 4.0, "penalty": 25.0}
+
+    def __init__(self, compiled, goal_th=3.14, frame_skip=10, normalize_act=True, muscle_condition=""):
+        super().__init__(compiled, 0.0, frame_skip, normalize_act, muscle_condition, dict(self.RWD_KEYS_WT))
+        cm = compiled
+        self.goal_th = goal_th
+        self.kh, self.IF, self.TH = cm.site_id("keyhead"), cm.site_id("IFtip"), cm.site_id("THtip")
+        self.init_qpos = cm.qpos0.astype(np.float64).copy(); self.init_qpos[:-1] *= 0
+
+    def reset(self, key_q0, key_pos=None):
+        self.d.reset()
+        self.d.qpos[:] = self.init_qpos
+        self.d.qpos[-1] = key_q0
+        if key_pos is not None:
+            self.d.set_body_pos(self.cm.nbody - 1, key_pos)
+        self.steps = 0
+        self.d.ctrl[:] = 0
+        self.d.forward()
+        return self._obs_rwd()[0]
+
+    def _obs_rwd(self):
+        d = self.d
+        return keyturn_obs_reward(d.qpos, d.qvel, d.act, d.site_xpos[self.kh], d.site_xpos[self.IF], d.site_xpos[self.TH],
+                                  self.dt, self.goal_th, self.rwd_keys_wt)
+
+    def step(self, a):
+        a = np.asarray(a, np.float64)
+        ctrl = a.copy()
+        if self.cm.na and self.normalize_act:
+            ctrl[self.muscle] = 1.0 / (1.0 + np.exp(-5.0 * (ctrl[self.muscle] - 0.5)))
+        self.d.ctrl[:] = ctrl
+        self.d.step(self.frame_skip)
+        self.d.forward()
+        obs, rwd = self._obs_rwd()
+        self.steps += 1
+        self.rwd_dict = rwd
+        return obs, float(rwd["dense"]), bool(rwd["done"]), rwd

@@ -116,6 +116,7 @@ typedef struct {
   int nefc, ncon;
   int *efc_type, *efc_id;
   real *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_solref, *efc_solimp;
+  real* efc_floss;   /* friction-loss rows: the dry-friction bound (0 on every other row) */
   real *efc_R, *efc_D, *efc_vel, *efc_aref, *efc_force;
   real *qfrc_constraint, *qacc;
   /* per-env model delta: size override of one geom (mm_state.geom_size_env) */
@@ -159,7 +160,7 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   d->efc_J = ralloc(nj * nv); d->efc_pos = ralloc(nj); d->efc_margin = ralloc(nj);
   d->efc_diagApprox = ralloc(nj); d->efc_solref = ralloc(2 * nj); d->efc_solimp = ralloc(5 * nj);
   d->efc_R = ralloc(nj); d->efc_D = ralloc(nj); d->efc_vel = ralloc(nj); d->efc_aref = ralloc(nj);
-  d->efc_force = ralloc(nj);
+  d->efc_force = ralloc(nj); d->efc_floss = ralloc(nj);
   d->qfrc_constraint = ralloc(nv); d->qacc = ralloc(nv);
   {
     int nc = m->nconmax > 0 ? m->nconmax : 1;
@@ -183,7 +184,7 @@ void mmo_data_free(mmo_data* d) {
                 &d->actuator_force, &d->qfrc_actuator, &d->qfrc_smooth, &d->qacc_smooth, &d->efc_J,
                 &d->efc_pos, &d->efc_margin, &d->efc_diagApprox, &d->efc_solref, &d->efc_solimp, &d->efc_R,
                 &d->efc_D, &d->efc_vel, &d->efc_aref, &d->efc_force, &d->qfrc_constraint, &d->qacc, &d->cacc,
-                &d->cfrc, &d->tmp_nv, &d->qH, &d->qHDiagInv, &d->con_dist, &d->con_pos, &d->con_frame};
+                &d->cfrc, &d->tmp_nv, &d->qH, &d->qHDiagInv, &d->con_dist, &d->con_pos, &d->con_frame, &d->efc_floss};
   for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
   free(d->efc_type); free(d->efc_id); free(d->con_pair);
   free(d);
@@ -931,7 +932,7 @@ static int add_row(const mmo_model* m, mmo_data* d, int type, int id, real pos, 
   int r = d->nefc;
   if (r >= m->njmax) { d->warn_bad |= 2; return -1; }
   d->efc_type[r] = type; d->efc_id[r] = id; d->efc_pos[r] = pos; d->efc_margin[r] = margin;
-  d->efc_diagApprox[r] = diagApprox;
+  d->efc_diagApprox[r] = diagApprox; d->efc_floss[r] = 0;
   memcpy(d->efc_solref + 2 * r, solref, 2 * sizeof(real));
   memcpy(d->efc_solimp + 5 * r, solimp, 5 * sizeof(real));
   memset(d->efc_J + r * m->nv, 0, sizeof(real) * m->nv);
@@ -964,6 +965,16 @@ static void mmo_make_constraint(const mmo_model* m, mmo_data* d) {
     if (r < 0) continue;
     d->efc_J[r * nv + d1] = 1;
     if (j2 >= 0) d->efc_J[r * nv + MI(m, JNT_DOFADR)[j2]] = -deriv;
+  }
+  /* dof friction loss (MuJoCo order: equality, friction loss, limits, contacts): a row J = e_dof at pos 0 whose force is
+     bounded by +-frictionloss (Huber cost, see row_cost) */
+  for (int i = 0; i < nv; i++) {
+    real f = MF(m, DOF_FRICTIONLOSS)[i];
+    if (!(f > 0)) continue;
+    int r = add_row(m, d, MM_CON_FRICTION_DOF, i, 0, 0, MF(m, DOF_INVWEIGHT0)[i], MF(m, DOF_SOLREF) + 2 * i,
+                    MF(m, DOF_SOLIMP) + 5 * i);
+    if (r < 0) continue;
+    d->efc_J[r * nv + i] = 1; d->efc_floss[r] = f;
   }
   /* joint limits (hinge / slide) */
   for (int j = 0; j < m->njnt; j++) {
@@ -1037,17 +1048,30 @@ static void mmo_reference_constraint(const mmo_model* m, mmo_data* d) {
 /* ---- Newton solver on  1/2 (a-a0)'M(a-a0) + sum_i s_i(J_i a - aref_i) ------- */
 typedef struct { real cost, d1, d2; } lspoint;
 
+/* cost s_i(x) of row i at x = J_i a - aref_i, its force -s' and curvature s'' (MuJoCo constraint model: equality rows are
+   quadratic everywhere, limit / contact rows only for x < 0, friction-loss rows are Huber: quadratic for |x| < R f, linear
+   with slope -+f outside, so that the force saturates at +-f) */
+static inline real row_cost(const mmo_data* d, int i, real x, real* force, real* curv) {
+  real D = d->efc_D[i];
+  if (d->efc_type[i] == MM_CON_FRICTION_DOF) {
+    real f = d->efc_floss[i], rf = f / D;
+    if (x <= -rf) { *force = f; *curv = 0; return f * (-0.5 * rf - x); }
+    if (x >= rf) { *force = -f; *curv = 0; return f * (-0.5 * rf + x); }
+    *force = -D * x; *curv = D; return 0.5 * D * x * x;
+  }
+  if (d->efc_type[i] == MM_CON_EQUALITY || x < 0) { *force = -D * x; *curv = D; return 0.5 * D * x * x; }
+  *force = 0; *curv = 0; return 0;
+}
+
 static lspoint ls_eval(const mmo_data* d, int nefc, const real* jar, const real* jv, const real* quadg, real alpha) {
   lspoint p;
   p.cost = quadg[0] + alpha * (quadg[1] + alpha * quadg[2]);
   p.d1 = quadg[1] + 2 * alpha * quadg[2];
   p.d2 = 2 * quadg[2];
   for (int i = 0; i < nefc; i++) {
-    real x = jar[i] + alpha * jv[i];
-    if (d->efc_type[i] == MM_CON_EQUALITY || x < 0) {
-      real D = d->efc_D[i];
-      p.cost += 0.5 * D * x * x; p.d1 += D * x * jv[i]; p.d2 += D * jv[i] * jv[i];
-    }
+    real x = jar[i] + alpha * jv[i], f, c;
+    p.cost += row_cost(d, i, x, &f, &c);
+    p.d1 -= f * jv[i]; p.d2 += c * jv[i] * jv[i];
   }
   return p;
 }
@@ -1076,7 +1100,7 @@ static void mmo_solve(const mmo_model* m, mmo_data* d) {
       real x_ = -d->efc_aref[r_];                                                     \
       for (int i_ = 0; i_ < nv; i_++) x_ += d->efc_J[r_ * nv + i_] * qa[i_];          \
       jar[r_] = x_;                                                                   \
-      if (d->efc_type[r_] == MM_CON_EQUALITY || x_ < 0) c_ += 0.5 * d->efc_D[r_] * x_ * x_; \
+      { real f_, h_; c_ += row_cost(d, r_, x_, &f_, &h_); }                           \
     }                                                                                 \
     out = c_;                                                                         \
   } while (0)
@@ -1094,9 +1118,10 @@ static void mmo_solve(const mmo_model* m, mmo_data* d) {
     /* active set, forces, gradient */
     for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
     for (int r = 0; r < nefc; r++) {
-      active[r] = (d->efc_type[r] == MM_CON_EQUALITY || jar[r] < 0);
-      d->efc_force[r] = active[r] ? -d->efc_D[r] * jar[r] : 0;
-      if (active[r]) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
+      real curv;
+      (void)row_cost(d, r, jar[r], &d->efc_force[r], &curv);
+      active[r] = curv > 0;      /* quadratic state: contributes D J'J to the Hessian */
+      if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
     }
     real gnorm = 0;
     for (int i = 0; i < nv; i++) {
@@ -1183,9 +1208,9 @@ static void mmo_solve(const mmo_model* m, mmo_data* d) {
       /* refresh forces for the final state before exiting */
       for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0;
       for (int r = 0; r < nefc; r++) {
-        int act = (d->efc_type[r] == MM_CON_EQUALITY || jar[r] < 0);
-        d->efc_force[r] = act ? -d->efc_D[r] * jar[r] : 0;
-        if (act) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
+        real curv;
+        (void)row_cost(d, r, jar[r], &d->efc_force[r], &curv);
+        if (d->efc_force[r] != 0) for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
       }
       break;
     }

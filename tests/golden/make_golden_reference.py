@@ -13,6 +13,7 @@ What can be executed from /root/reference without `mujoco`/`gym` (both absent he
   * myosuite/envs/myo/myobase/reorient_sar_v0.py  get_obs_dict / get_reward_dict -> ref_reorient_env.npz
   * myosuite/envs/myo/myobase/pen_v0.py     get_obs_dict / get_reward_dict    -> ref_pen_env.npz
   * myosuite/envs/myo/myobase/obj_hold_v0.py get_obs_dict / get_reward_dict   -> ref_objhold_env.npz
+  * myosuite/envs/myo/myobase/key_turn_v0.py get_obs_dict / get_reward_dict   -> ref_keyturn_env.npz
   * myosuite/utils/quat_math.py, vector_math.py                               -> ref_math.npz
 `mujoco` and `myosuite.utils.gym` are replaced by stubs that only provide the names those files
 touch at import time (mjtDyn.mjDYN_MUSCLE, gym.utils.seeding.np_random, EzPickle); no arithmetic
@@ -347,6 +348,46 @@ def gen_objhold_env():
     np.savez(os.path.join(OUT, "ref_objhold_env.npz"), **out)
 
 
+def gen_keyturn_env():
+    """KeyTurnEnvV0.get_obs_dict / get_reward_dict (key_turn_v0.py:101-150) on synthetic mjData-like arrays."""
+    kt = _load("ref_key_turn_v0", f"{REF}/envs/myo/myobase/key_turn_v0.py", _stubs())
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(43)
+    n, nq, nu, ns = 48, 24, 39, 5
+    kh, IF, TH = 4, 1, 0
+    qpos = rng.uniform(-1, 1, (n, nq)); qvel = rng.standard_normal((n, nq)) * 3; act = rng.random((n, nu))
+    qpos[:, -1] = rng.uniform(-2.0, 7.0, n)                                            # key angle: below / above pi/2, pi, 2 pi
+    site = rng.uniform(-0.5, 0.5, (n, ns, 3))
+    dirs = rng.standard_normal((n, 2, 3)); dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    rad = rng.uniform(0.0, 0.16, (n, 2))                                               # around the 0.03 shell, the 0.05 / 0.1 bounds
+    site[:, IF] = site[:, kh] - dirs[:, 0] * rad[:, :1]; site[:, TH] = site[:, kh] - dirs[:, 1] * rad[:, 1:]
+    dt = 0.02
+    keys = list(kt.KeyTurnEnvV0.DEFAULT_OBS_KEYS) + ["act"]
+    rk = ("key_turn", "IFtip_approach", "THtip_approach", "act_reg", "bonus", "penalty", "sparse", "solved", "done", "dense")
+    out = {}
+    for goal_th in (3.14, 2 * np.pi):
+        obs = []; rwd = {k: [] for k in rk}
+        for i in range(n):
+            model = types.SimpleNamespace(na=nu)
+            data = types.SimpleNamespace(time=0.1 * i, qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(), site_xpos=site[i])
+            env = object.__new__(kt.KeyTurnEnvV0)
+            env.mj_model = model; env.dt = dt; env.keyhead_sid = kh; env.IF_sid = IF; env.TH_sid = TH; env.goal_th = goal_th
+            env.rwd_keys_wt = kt.KeyTurnEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS
+            od = env.get_obs_dict(model, data)
+            _, vec = ovd.ObsVecDict().obsdict2obsvec(od, keys)
+            env.obs_dict = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+            rd = env.get_reward_dict(env.obs_dict)
+            obs.append(vec)
+            for k in rk:
+                rwd[k].append(np.squeeze(rd[k]))
+        tag = "a" if goal_th == 3.14 else "b"
+        out[f"{tag}_goal_th"] = np.array(goal_th); out[f"{tag}_obs"] = np.array(obs)
+        for k in rk:
+            out[f"{tag}_rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    out.update(qpos=qpos, qvel=qvel, act=act, keyhead=site[:, kh], iftip=site[:, IF], thtip=site[:, TH], dt=np.array(dt))
+    np.savez(os.path.join(OUT, "ref_keyturn_env.npz"), **out)
+
+
 def gen_math():
     qm = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
     vm = _load("ref_vector_math", f"{REF}/utils/vector_math.py", {})
@@ -371,5 +412,6 @@ if __name__ == "__main__":
     gen_reorient_env()
     gen_pen_env()
     gen_objhold_env()
+    gen_keyturn_env()
     gen_math()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.startswith("ref_")))

@@ -149,3 +149,73 @@ def test_gpu_general_rows_forward_and_rollout_match_oracle(oracle_lib, name):
     err = np.abs(st.qpos.cpu().numpy() - qo).max(axis=1)
     assert int(st.status.cpu().max()) == 0 and max(d.warn for d in ds) == 0
     assert np.median(err) < 2e-5 and err.max() < 1e-3, (np.median(err), err.max())
+
+
+def test_friction_loss_rows_oracle(oracle_lib):
+    """Dry joint friction (MuJoCo `frictionloss`): the row force saturates at +-frictionloss, holds a load below the bound
+    (up to the soft-constraint creep) and dissipates energy."""
+    from myosuite_amd.model.spec import ModelSpec
+
+    def toy(f):
+        s = ModelSpec("fric_pendulum")
+        s.add_body("arm", "world", pos=(0, 0, 1), mass=1.0, ipos=(0.1, 0, 0), inertia=(1e-3, 1e-3, 1e-3))
+        s.add_joint("hinge", "arm", "hinge", axis=(0, 1, 0), frictionloss=f)
+        return s.compile()
+    tau_g = 1.0 * 9.81 * 0.1
+    for f in (0.5, 1.2):
+        cm = toy(f)
+        assert cm.njmax == 1
+        d = O.OracleData(O.OracleModel(cm)); d.reset(); d.forward()
+        assert d.nefc == 1
+        if f < tau_g:      # saturated: force = -f exactly
+            assert abs(d.qfrc_constraint[0] + f) < 1e-12
+            assert abs(d.qacc[0] - (tau_g - f) / (1e-3 + 0.01)) < 1e-4      # model constants are stored as f32
+        else:              # below the bound: held, up to the impedance (d0 = 0.9 -> at least 85 % of the load)
+            assert -tau_g < d.qfrc_constraint[0] < -0.85 * tau_g
+            d.step(500)
+            assert abs(d.qpos[0]) < 0.12 and abs(d.qvel[0]) < 0.12
+    # free swing with friction loses energy monotonically (sampled at velocity zero crossings via |q| peaks)
+    cm = toy(0.2)
+    d = O.OracleData(O.OracleModel(cm)); d.reset(); d.qpos[0] = -1.0
+    peaks, prev_v = [], 0.0
+    for k in range(4000):
+        d.step(1)
+        if prev_v * d.qvel[0] < 0:
+            peaks.append(abs(d.qpos[0] - np.pi / 2))
+        prev_v = d.qvel[0]
+    assert len(peaks) >= 3 and all(b < a for a, b in zip(peaks, peaks[1:]))
+
+
+@pytest.mark.gpu
+def test_friction_loss_gpu_matches_oracle(oracle_lib):
+    """friction_toy (three friction-loss dofs with different solref/solimp, limits, an equality, motors): teacher-forced
+    per-substep parity of the fused kernel against the oracle, and a short free run."""
+    import torch
+    from myosuite_amd import engine as E
+    cm = synth.get_model("friction_toy")
+    assert cm.njmax == 1 + 3 + 2
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    n = 16
+    rng = np.random.default_rng(4)
+    q = rng.uniform(-0.5, 0.8, (n, cm.nq)); q[:, 3] = 0.05 * q[:, 1]
+    v = rng.standard_normal((n, cm.nv)) * np.array([1.0, 1.0, 3.0, 0.05])
+    v[: n // 4] = 0.0                                            # some envs start at rest: stick regime
+    st = E.BatchState(hm, n)
+    ds = [O.OracleData(om) for _ in range(n)]
+    worst = 0.0
+    for k in range(60):
+        ctrl = rng.uniform(-1, 1, (n, cm.nu)).astype(np.float32)
+        if k % 3 == 0:
+            ctrl[:, :] *= 0.05                                   # small torques: below the friction bounds
+        st.qpos.copy_(torch.from_numpy(q.astype(np.float32))); st.qvel.copy_(torch.from_numpy(v.astype(np.float32)))
+        E.step(hm, st, torch.from_numpy(ctrl).cuda(), 1)
+        qg, vg = st.qpos.cpu().numpy().astype(np.float64), st.qvel.cpu().numpy().astype(np.float64)
+        for e, d in enumerate(ds):
+            d.qpos[:] = q[e].astype(np.float32); d.qvel[:] = v[e].astype(np.float32); d.ctrl[:] = ctrl[e]
+            d.qacc_warmstart[:] = 0 if k == 0 else d.qacc_warmstart
+            d.step(1)
+            worst = max(worst, float(np.abs(vg[e] - d.qvel).max() / max(1.0, np.abs(d.qvel).max())))
+            assert d.nefc >= 4
+            q[e] = d.qpos; v[e] = d.qvel
+    assert worst < 2e-4, worst
+    assert int(st.status.max()) == 0
