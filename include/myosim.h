@@ -135,6 +135,8 @@ typedef struct {
   int   ntip;
   const float* target_pos;  /* [nenv][3*ntip] world positions of the *_target sites */
   float reach_far_th;       /* far_th (per tip), reach_v0.py:57,131-135         */
+  int   reach_stand;        /* 1: the leg-stand variant of the reach task (walk_v0.py:17-128, `ReachEnvV0` of walk_v0): reach =
+                               10 - reach_dist - 10*||qvel*dt||, act_reg = -100*act_mag, near_th = 0.050 per tip */
   /* WALK task (envs/myo/myobase/walk_v0.py:189-480): obs [qpos[2:], qvel*dt, com_vel(2), torso xquat(4),
      feet_heights(2), height(1), feet_rel_positions(6), phase_var(1), muscle_length, muscle_velocity, muscle_force, act];
      reward columns MM_RWDW_* (row stride MM_RWDW_COUNT).  Needs do_forward = 1. */

@@ -2053,6 +2053,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
       for (int i = g; i < d.nq; i += G) if (ob) ob[i] = W[L.qpos + i];
       if (ob && g < d.nv) ob[d.nq + g] = E.d_qvel * t.obs_dt;
+      const float vs = g < d.nv ? E.d_qvel * t.obs_dt : 0.f;
+      const float vel2 = t.reach_stand ? gsum<G>(vs * vs) : 0.f;
       for (int i = g; i < t.ntip; i += G) {
         V3 tip = E.site_pos(t.tip_sites[i]);
         V3 tgt = ld3(t.target_pos + (size_t)e * n3 + 3 * i);
@@ -2069,19 +2071,20 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       if (g == 0) {
         float reach_dist = sqrtf(err2), act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
         float far_th = time > 2.f * t.obs_dt ? t.reach_far_th * (float)t.ntip : INFINITY;
-        float near_th = (float)t.ntip * 0.0125f;
+        float near_th = (float)t.ntip * (t.reach_stand ? 0.050f : 0.0125f);
         float r_reach = -reach_dist;
+        if (t.reach_stand) { r_reach = 10.f - reach_dist - 10.f * sqrtf(vel2); act_mag *= 100.f; }   // walk_v0.py:100-111
         float r_bonus = (reach_dist < 2.f * near_th ? 1.f : 0.f) + (reach_dist < near_th ? 1.f : 0.f);
         float r_pen = reach_dist > far_th ? -1.f : 0.f;
         bool done = reach_dist > far_th;
-        if (t.rwd) {
+        if (t.rwd && !obs_only) {
           float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
           r[MM_RWD_POSE] = r_reach; r[MM_RWD_BONUS] = r_bonus; r[MM_RWD_PENALTY] = r_pen; r[MM_RWD_ACT_REG] = -act_mag;
           r[MM_RWD_SPARSE] = -reach_dist; r[MM_RWD_SOLVED] = reach_dist < near_th ? 1.f : 0.f;
           r[MM_RWD_DONE] = done ? 1.f : 0.f;
           r[MM_RWD_DENSE] = t.w_pose * r_reach + t.w_bonus * r_bonus + t.w_act_reg * (-act_mag) + t.w_penalty * r_pen;
         }
-        if (t.done) t.done[e] = done ? 1 : 0;
+        if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
       }
     }
     if (t.task == MM_TASK_WALK) {

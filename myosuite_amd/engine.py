@@ -97,7 +97,7 @@ class mm_task(C.Structure):
                 ("obs", C.c_void_p), ("obs_dim", C.c_int), ("rwd", C.c_void_p), ("done", C.c_void_p),
                 ("truncated", C.c_void_p), ("step_count", C.c_void_p), ("ctrl_out", C.c_void_p),
                 ("reaf_src", C.c_int), ("reaf_dst", C.c_int), ("obs_layout", C.c_int), ("act_reg_mean", C.c_int), ("obs_dt", C.c_float),
-                ("tip_sites", C.c_void_p), ("ntip", C.c_int), ("target_pos", C.c_void_p), ("reach_far_th", C.c_float),
+                ("tip_sites", C.c_void_p), ("ntip", C.c_int), ("target_pos", C.c_void_p), ("reach_far_th", C.c_float), ("reach_stand", C.c_int),
                 ("walk_body", C.c_int * 4), ("walk_qadr", C.c_int * 6), ("walk_min_height", C.c_float),
                 ("walk_max_rot", C.c_float), ("walk_hip_period", C.c_int), ("walk_target_x_vel", C.c_float),
                 ("walk_target_y_vel", C.c_float), ("walk_target_rot", C.c_float * 4), ("walk_w", C.c_float * 5),

@@ -100,6 +100,11 @@ def _objhold(**kw):
     return ObjHoldEnvV0(**kw)
 
 
+def _stand(**kw):
+    from .stand_v0 import StandEnvV0
+    return StandEnvV0(**kw)
+
+
 def _keyturn(**kw):
     from .key_turn_v0 import KeyTurnEnvV0
     return KeyTurnEnvV0(**kw)
@@ -213,6 +218,12 @@ register_env_with_variants(
                 "RFtip": ((-0.148 - 0.040, -0.543 - 0.020, 1.445 - 0.010), (-0.148 + 0.040, -0.543 + 0.020, 1.445 + 0.010)),
                 "LFtip": ((-0.148 - 0.040, -0.528 - 0.020, 1.434 - 0.010), (-0.148 + 0.040, -0.528 + 0.020, 1.434 + 0.010))}})
 
+
+# Leg standing (myobase/__init__.py:422-440): the reach task of walk_v0.py on the leg model
+register_env_with_variants(
+    id="myoLegStandRandom-v0", entry_point=_stand, max_episode_steps=150,
+    kwargs={"model": "leg", "joint_random_range": (-0.2, 0.2), "target_reach_range": {"pelvis": ((-0.05, -0.05, 0), (0.05, 0.05, 0))},
+            "normalize_act": True, "far_th": 0.44})
 
 # Gait: torso walking (myobase/__init__.py:442-458).  The terrain variants (Rough/Hilly/Stair, :460-520) need
 # height-field collision and are not registered.

@@ -502,6 +502,8 @@ def make_leg() -> ModelSpec:
     s.add_joint("root", "pelvis", "free")
     s.add_body("torso", "pelvis", pos=(0, -0.03, 0.08), mass=34.0, ipos=(0, -0.01, 0.27), inertia=(1.47, 1.43, 0.76))
     s.add_site("pelvis_mark", "pelvis", (0, 0, 0))
+    s.add_site("pelvis", "pelvis", (0, 0, 0))            # tip / target pair of myoLegStandRandom-v0 (myobase/__init__.py:434)
+    s.add_site("pelvis_target", "world", (0, 0, PZ))
     for side, sx in (("r", 1.0), ("l", -1.0)):
         def X(p):
             return (sx * p[0], p[1], p[2])

@@ -645,3 +645,72 @@ class KeyTurnEnvOracle(PoseEnvOracle):
         self.steps += 1
         self.rwd_dict = rwd
         return obs, float(rwd["dense"]), bool(rwd["done"]), rwd
+
+
+# ---------------------------------------------------------------------- leg stand (walk_v0.py ReachEnvV0)
+def stand_obs_reward(qpos, qvel, act, tip_pos, target_pos, time, dt, far_th, rwd_keys_wt):
+    """get_obs_dict + obsdict2obsvec + get_reward_dict of walk_v0.py:71-128 on raw arrays (ntip tips concatenated)."""
+    tip_pos = np.asarray(tip_pos, np.float64).ravel(); target_pos = np.asarray(target_pos, np.float64).ravel()
+    ntip = tip_pos.size // 3
+    od = collections.OrderedDict(qpos=qpos.copy(), qvel=qvel * dt, tip_pos=tip_pos, reach_err=target_pos - tip_pos, act=act.copy())
+    obs = np.concatenate([np.asarray(v, np.float64).ravel() for v in od.values()])
+    reach_dist = np.linalg.norm(od["reach_err"])
+    vel_dist = np.linalg.norm(od["qvel"])
+    na = act.size
+    act_mag = np.linalg.norm(act) / na if na else 0.0
+    fth = far_th * ntip if time > 2 * dt else np.inf
+    near_th = ntip * 0.050
+    rwd = collections.OrderedDict((
+        ("reach", 10.0 - 1.0 * reach_dist - 10.0 * vel_dist),
+        ("bonus", 1.0 * (reach_dist < 2 * near_th) + 1.0 * (reach_dist < near_th)),
+        ("act_reg", -100.0 * act_mag), ("penalty", -1.0 * (reach_dist > fth)), ("sparse", -1.0 * reach_dist),
+        ("solved", reach_dist < near_th), ("done", reach_dist > fth)))
+    rwd["dense"] = np.sum([wt * rwd[k] for k, wt in rwd_keys_wt.items()], axis=0)
+    return obs, rwd
+
+
+def stand_generate_qpos(init_qpos, jnt_qposadr, jnt_range, draw):
+    """walk_v0.py:153-168: init + draw on the jnt_qposadr entries, clipped to jnt_range."""
+    q = np.asarray(init_qpos, np.float64).copy()
+    q[jnt_qposadr] += np.asarray(draw)[jnt_qposadr]
+    q[jnt_qposadr] = np.clip(q[jnt_qposadr], jnt_range[:, 0], jnt_range[:, 1])
+    return q
+
+
+class StandEnvOracle(PoseEnvOracle):
+    """Single-env CPU restatement of walk_v0.ReachEnvV0 (myoLegStandRandom-v0) on the fp64 oracle engine."""
+    RWD_KEYS_WT = {"reach": 1.0, "bonus": 4.0, "penalty": 50, "act_reg": 1}
+
+    def __init__(self, compiled, tip_sids, far_th, frame_skip=10, normalize_act=True, muscle_condition=""):
+        super().__init__(compiled, 0.0, frame_skip, normalize_act, muscle_condition, dict(self.RWD_KEYS_WT))
+        self.tip_sids = list(tip_sids); self.far_th = far_th
+        self.target_pos = np.zeros(3 * len(self.tip_sids))
+
+    def tip_pos(self):
+        return np.concatenate([self.d.site_xpos[s] for s in self.tip_sids])
+
+    def place(self, qpos, qvel=None):
+        self.d.reset()
+        self.d.qpos[:] = qpos
+        if qvel is not None:
+            self.d.qvel[:] = qvel
+        self.d.ctrl[:] = 0
+        self.d.forward()
+        self.steps = 0
+
+    def _obs_rwd(self):
+        d = self.d
+        return stand_obs_reward(d.qpos, d.qvel, d.act, self.tip_pos(), self.target_pos, d.time, self.dt, self.far_th, self.rwd_keys_wt)
+
+    def step(self, a):
+        a = np.asarray(a, np.float64)
+        ctrl = a.copy()
+        if self.cm.na and self.normalize_act:
+            ctrl[self.muscle] = 1.0 / (1.0 + np.exp(-5.0 * (ctrl[self.muscle] - 0.5)))
+        self.d.ctrl[:] = ctrl
+        self.d.step(self.frame_skip)
+        self.d.forward()
+        obs, rwd = self._obs_rwd()
+        self.steps += 1
+        self.rwd_dict = rwd
+        return obs, float(rwd["dense"]), bool(rwd["done"]), rwd

@@ -10,6 +10,7 @@ What can be executed from /root/reference without `mujoco`/`gym` (both absent he
   * myosuite/envs/obs_vec_dict.py           obsdict2obsvec                    -> ref_pose_env.npz
   * myosuite/envs/myo/myobase/reach_v0.py   get_obs_dict / get_reward_dict    -> ref_reach_env.npz
   * myosuite/envs/myo/myobase/walk_v0.py    get_obs_dict / get_reward_dict    -> ref_walk_env.npz
+  * myosuite/envs/myo/myobase/walk_v0.py    ReachEnvV0 (leg stand) obs / reward / generate_qpos -> ref_stand_env.npz
   * myosuite/envs/myo/myobase/reorient_sar_v0.py  get_obs_dict / get_reward_dict -> ref_reorient_env.npz
   * myosuite/envs/myo/myobase/pen_v0.py     get_obs_dict / get_reward_dict    -> ref_pen_env.npz
   * myosuite/envs/myo/myobase/obj_hold_v0.py get_obs_dict / get_reward_dict   -> ref_objhold_env.npz
@@ -221,6 +222,55 @@ def gen_walk_env():
     np.savez(os.path.join(OUT, "ref_walk_env.npz"), **out)
 
 
+def gen_stand_env():
+    """walk_v0.ReachEnvV0 (myoLegStandRandom-v0): get_obs_dict / get_reward_dict (walk_v0.py:71-128) and generate_qpos
+    (:153-168) executed on synthetic mjData-like arrays."""
+    st = _stubs()
+    st["myosuite.utils.quat_math"] = _load("ref_quat_math", f"{REF}/utils/quat_math.py", {})
+    walk = _load("ref_walk_v0", f"{REF}/envs/myo/myobase/walk_v0.py", st)
+    ovd = _load("ref_obs_vec_dict", f"{REF}/envs/obs_vec_dict.py", {})
+    rng = np.random.default_rng(19)
+    n, nq, nv, nu, ns = 40, 35, 34, 80, 3
+    tip, tgt = 1, 2
+    qpos = rng.uniform(-1, 1, (n, nq)); qvel = rng.standard_normal((n, nv)) * rng.choice([0.02, 1.0], (n, 1)); act = rng.random((n, nu))
+    site = rng.uniform(-0.5, 0.5, (n, ns, 3))
+    dirs = rng.standard_normal((n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    site[:, tgt] = site[:, tip] + dirs * rng.uniform(0.0, 0.6, (n, 1))                 # around near_th .05 / .1 and far_th .44
+    time = np.where(np.arange(n) % 4 == 0, 0.01, 0.5)                                  # time <= 2 dt: far_th = inf
+    dt = 0.02
+    keys = list(walk.ReachEnvV0.DEFAULT_OBS_KEYS) + ["act"]
+    rk = ("reach", "bonus", "act_reg", "penalty", "sparse", "solved", "done", "dense")
+    obs = []; rwd = {k: [] for k in rk}
+    for i in range(n):
+        model = types.SimpleNamespace(na=nu)
+        data = types.SimpleNamespace(time=time[i], qpos=qpos[i].copy(), qvel=qvel[i].copy(), act=act[i].copy(), site_xpos=site[i])
+        env = object.__new__(walk.ReachEnvV0)
+        env.mj_model = model; env.dt = dt; env.tip_sids = [tip]; env.target_sids = [tgt]; env.far_th = 0.44
+        env.rwd_keys_wt = walk.ReachEnvV0.DEFAULT_RWD_KEYS_AND_WEIGHTS
+        od = env.get_obs_dict(model, data)
+        _, vec = ovd.ObsVecDict().obsdict2obsvec(od, keys)
+        env.obs_dict = {k: np.asarray(v)[None, None, :] for k, v in od.items()}
+        rd = env.get_reward_dict(env.obs_dict)
+        obs.append(vec)
+        for k in rk:
+            rwd[k].append(np.squeeze(rd[k]))
+    out = dict(qpos=qpos, qvel=qvel, act=act, tip=site[:, tip], target=site[:, tgt], time=time, dt=np.array(dt), obs=np.array(obs))
+    for k in rk:
+        out[f"rwd_{k}"] = np.array(rwd[k], dtype=np.float64)
+    # generate_qpos: init + U(range) on the jnt_qposadr entries, clipped to jnt_range (unlimited joints: range (0, 0))
+    njnt = 29
+    adr = np.concatenate([[0], 7 + np.arange(28)])
+    jr = np.stack([-rng.uniform(0.1, 1.5, njnt), rng.uniform(0.1, 1.5, njnt)], 1); jr[[0, 5, 6]] = 0.0
+    init = rng.uniform(-0.3, 0.3, nq)
+    env = object.__new__(walk.ReachEnvV0)
+    env.mj_model = types.SimpleNamespace(jnt_qposadr=adr, jnt_range=jr)
+    env.init_qpos = init.copy(); env.joint_random_range = (-0.2, 0.2)
+    env.np_random = np.random.default_rng(5)
+    u = np.random.default_rng(5).uniform(low=-0.2, high=0.2, size=init.shape)          # the draw generate_qpos makes
+    out.update(gq_adr=adr, gq_range=jr, gq_init=init, gq_draw=u, gq_out=env.generate_qpos())
+    np.savez(os.path.join(OUT, "ref_stand_env.npz"), **out)
+
+
 def gen_reorient_env():
     """ProprioceptiveEnvV0.get_obs_dict / get_reward_dict (reorient_sar_v0.py:116-174) executed on synthetic mjData-like
     arrays (nq 29, 39 muscles), plus the reference's euler2quat on the reset's desired-orientation draws."""
@@ -409,6 +459,7 @@ if __name__ == "__main__":
     gen_pose_env()
     gen_reach_env()
     gen_walk_env()
+    gen_stand_env()
     gen_reorient_env()
     gen_pen_env()
     gen_objhold_env()

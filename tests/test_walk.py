@@ -168,3 +168,75 @@ def test_gpu_walk_free_running_vs_committed_oracle_trajectory():
             np.testing.assert_allclose(r.cpu().numpy(), g["dense"][s], rtol=0.02, atol=0.05)
     assert med[-1] < 2e-2, med
     assert int(env.state.status.max()) == 0
+
+
+# ------------------------------------------------------------------ leg stand (walk_v0.py ReachEnvV0)
+def test_stand_oracle_arithmetic_matches_reference_vectors():
+    g = np.load(os.path.join(G, "ref_stand_env.npz"))
+    wt = EO.StandEnvOracle.RWD_KEYS_WT
+    seen = {"done": 0, "solved": 0}
+    for i in range(g["qpos"].shape[0]):
+        obs, rwd = EO.stand_obs_reward(g["qpos"][i], g["qvel"][i], g["act"][i], g["tip"][i], g["target"][i], float(g["time"][i]),
+                                       float(g["dt"]), 0.44, wt)
+        np.testing.assert_allclose(obs, g["obs"][i], rtol=2e-6, atol=2e-6)
+        for k in ("reach", "bonus", "act_reg", "penalty", "sparse", "solved", "done", "dense"):
+            np.testing.assert_allclose(float(rwd[k]), g[f"rwd_{k}"][i], rtol=1e-9, atol=1e-9, err_msg=k)
+        seen["done"] += int(rwd["done"]); seen["solved"] += int(rwd["solved"])
+    assert seen["done"] > 0 and seen["solved"] > 0
+    q = EO.stand_generate_qpos(g["gq_init"], g["gq_adr"], g["gq_range"], g["gq_draw"])
+    np.testing.assert_allclose(q, g["gq_out"], rtol=0, atol=1e-15)
+    assert q[0] == 0.0 and np.all(q[1:7] == g["gq_init"][1:7])          # unlimited root: clipped to its (0, 0) range; quaternion untouched
+
+
+@pytest.mark.gpu
+def test_gpu_stand_env_matches_oracle_env(oracle_lib):
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    cm = synth.get_model("leg")
+    n, nsteps = 6, 5
+    env = registry.make("myoLegStandRandom-v0", num_envs=n, seed=8, autoreset=False)
+    obs0, _ = env.reset(seed=8)
+    assert obs0.shape == (n, cm.nq + cm.nv + 6 + cm.na) and env.frame_skip == 10 and env.max_episode_steps == 150
+    ep = env.episode.cpu().numpy()
+    adr = cm.arrays["JNT_QPOSADR"].astype(np.int64); jr = cm.jnt_range.astype(np.float32)
+    orc = []
+    for e in range(n):
+        w = EO.StandEnvOracle(cm, env.tip_sids, env.far_th)
+        u1 = np.float32(-0.2) + np.float32(0.4) * EO.env_draw(cm.nq, e, int(ep[e]) - 1, 8, 19)
+        q1 = EO.stand_generate_qpos(env.init_qpos, adr, jr, u1).astype(np.float32)
+        w.place(q1.astype(np.float64))
+        ut = EO.env_draw(3, e, int(ep[e]) - 1, 8, 20)
+        tgt = w.tip_pos() + (np.array([-0.05, -0.05, 0], np.float32) + np.array([0.1, 0.1, 0], np.float32) * ut)
+        np.testing.assert_allclose(env.target_pos[e].cpu().numpy(), tgt, atol=2e-6)
+        w.target_pos = env.target_pos[e].cpu().numpy().astype(np.float64)
+        u2 = np.float32(-0.2) + np.float32(0.4) * EO.env_draw(cm.nq, e, int(ep[e]) - 1, 8, 21)
+        q2 = EO.stand_generate_qpos(env.init_qpos, adr, jr, u2).astype(np.float32)
+        np.testing.assert_allclose(env.state.qpos[e].cpu().numpy(), q2, atol=1e-6)
+        w.place(q2.astype(np.float64), env.init_qvel.astype(np.float64))
+        o, _ = w._obs_rwd()
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), o, rtol=1e-4, atol=5e-5)
+        orc.append(w)
+    assert float(env.state.qpos[:, 0].abs().max()) == 0.0               # root x: clipped to the (0, 0) range of the free joint
+    a = torch.empty(n, cm.nu, device="cuda")
+    for s in range(nsteps):
+        st = env.get_env_state()
+        for e in range(n):                       # teacher-forced per env-step (contact onsets are discontinuous)
+            d = orc[e].d
+            for k in ("qpos", "qvel", "act", "qacc_warmstart"):
+                v = getattr(d, k).astype(np.float32); getattr(d, k)[:] = v
+                st[k][e] = torch.from_numpy(v)
+        env.set_env_state(st)
+        E.uniform(a, 31, s)
+        obs, r, term, trunc, info = env.step(a)
+        an = a.cpu().numpy()
+        for e in range(n):
+            o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
+            got = obs[e].cpu().numpy()
+            tol = np.full(got.shape, 2e-3); tol[cm.nq:cm.nq + cm.nv] = 1e-2
+            bad = np.abs(got - o) / np.maximum(1.0, np.abs(o)) > tol
+            assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], (np.abs(got - o))[bad][:5])
+            for i, k in enumerate(E.RWD_KEYS_REACH):
+                ref = float(rd[k])
+                assert abs(float(env.rwd[e, i]) - ref) < 1e-2 * max(1.0, abs(ref)), (k, s, e, float(env.rwd[e, i]), ref)
+            assert bool(term[e]) == done
