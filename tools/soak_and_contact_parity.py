@@ -12,7 +12,10 @@ from oracle import env_oracle as EO
 
 out = {"soak": {}, "teacher_forced": {}}
 for env_id, n in (("myoElbowPose1D6MRandom-v0", 4096), ("myoHandPoseRandom-v0", 4096), ("myoHandReachRandom-v0", 4096),
-                  ("myoHandReorient100-v0", 2048), ("myoFatiLegWalk-v0", 1024)):
+                  ("myoHandReorient100-v0", 2048), ("myoFatiLegWalk-v0", 1024), ("myoHandPenTwirlRandom-v0", 2048),
+                  ("myoHandObjHoldRandom-v0", 2048), ("myoHandKeyTurnRandom-v0", 2048), ("myoTorsoPoseFixed-v0", 1024),
+                  ("myoFingerReachRandom-v0", 4096), ("motorFingerPoseRandom-v0", 4096), ("myoElbowPose1D6MExoRandom-v0", 4096),
+                  ("myoLegStandRandom-v0", 1024)):
     env = registry.make(env_id, num_envs=n, seed=3)
     env.reset(seed=3)
     a = torch.empty(n, env.cm.nu, device="cuda")
@@ -26,6 +29,11 @@ for env_id, n in (("myoElbowPose1D6MRandom-v0", 4096), ("myoHandPoseRandom-v0", 
     out["soak"][env_id] = dict(envs=n, steps=300, finite=finite, episodes_finished=ndone,
                                bad_state_resets=int((st & 1).sum()), row_overflow=int(((st >> 3) & 1).sum()),
                                solver_cap=int(((st >> 2) & 1).sum()))
+    torch.cuda.synchronize(); t0 = __import__("time").perf_counter()
+    for s in range(20):
+        env.step(a)
+    torch.cuda.synchronize()
+    out["soak"][env_id]["env_steps_per_s"] = round(20 * n / (__import__("time").perf_counter() - t0))
     print(env_id, out["soak"][env_id])
     del env
 
