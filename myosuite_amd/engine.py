@@ -38,6 +38,14 @@ class EngineError(RuntimeError):
     pass
 
 
+# fp32 divide / sqrt as v_rcp / v_sqrt + one refinement (<= 2.5 ulp) instead of the correctly rounded expansions, hardware
+# exp / log / sin / cos, reassociation and contraction: +4 % (hand) .. +5 % (leg-walk) env-steps/s with every parity test
+# unchanged.  Infinities and NaNs stay honoured (far_th = inf, the bad-state check).  Group reductions do not depend on the
+# flags: gsum() hides its operand from the optimiser and its stages are separate instructions.
+EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
+                             "-fno-hip-fp32-correctly-rounded-divide-sqrt -ffast-math -fhonor-infinities -fhonor-nans").split()
+
+
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU).  The kernel instantiations are
     spread over several translation units (myosim_inst_*.hip) that are compiled in parallel and linked into one .so."""
@@ -56,7 +64,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
         obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
             return obj
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", obj, src]
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
