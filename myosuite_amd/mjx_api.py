@@ -93,11 +93,10 @@ class MjxPoseEnv:
         need = (env.done | env.truncated)
         env.step_count.masked_fill_(need.bool(), 0)
         rng = state.info["rng"] + 1
-        if bool(need.any()):
-            new_t = torch.empty_like(env.target_jnt_value)
-            E.uniform(new_t, seed=rng, stream_id=0x7A6)
-            new_t = env._tlo + (env._thi - env._tlo) * new_t
-            env.target_jnt_value.copy_(torch.where(need.bool()[:, None], new_t, env.target_jnt_value))
+        new_t = torch.empty_like(env.target_jnt_value)         # no host sync: draw for everyone, keep where not needed
+        E.uniform(new_t, seed=rng, stream_id=0x7A6)
+        new_t = env._tlo + (env._thi - env._tlo) * new_t
+        env.target_jnt_value.copy_(torch.where(need.bool()[:, None], new_t, env.target_jnt_value))
         info = {**state.info, "rng": rng, "step_count": env.step_count, "target_angles": env.target_jnt_value}
         return State(env.state, {"state": env.obs}, reward, done, metrics, info)
 
@@ -158,10 +157,79 @@ class MjxReachEnv:
         need = (env.done | env.truncated).bool()
         env.step_count.masked_fill_(need, 0)
         rng = state.info["rng"] + 1
-        if bool(need.any()):
-            u = torch.empty_like(env.target_pos)
-            E.uniform(u, seed=rng, stream_id=0x7A7)
-            new_t = env._tlo + (env._thi - env._tlo) * u
-            env.target_pos.copy_(torch.where(need[:, None], new_t, env.target_pos))
+        u = torch.empty_like(env.target_pos)                   # no host sync: draw for everyone, keep where not needed
+        E.uniform(u, seed=rng, stream_id=0x7A7)
+        new_t = env._tlo + (env._thi - env._tlo) * u
+        env.target_pos.copy_(torch.where(need[:, None], new_t, env.target_pos))
         info = {**state.info, "rng": rng, "step_count": env.step_count, "targets": env.target_pos}
         return State(env.state, {"state": env.obs}, reward, done, metrics, info)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# make() of myosuite/envs/myo/mjx/__init__.py:109-199 and the training wrapper of mujoco_playground / brax
+PPO_CONFIG = dict(                                   # myosuite/envs/myo/mjx/__init__.py:43-67
+    num_timesteps=50_000_000, learning_rate=3e-4, discounting=0.97, gae_lambda=0.95, entropy_cost=0.001, clipping_epsilon=0.3,
+    max_grad_norm=1.0, action_repeat=1, num_minibatches=32, num_updates_per_batch=8, batch_size=256, unroll_length=10,
+    reward_scaling=1.0, normalize_observations=True, num_evals=16, num_eval_envs=128, num_resets_per_eval=1,
+    network_factory=dict(policy_hidden_layer_sizes=(64, 64, 64), value_hidden_layer_sizes=(64, 64, 64),
+                         policy_obs_key="state", value_obs_key="state"))
+
+
+def get_default_config(env_name: str) -> dict:
+    base = dict(ctrl_dt=0.02, sim_dt=0.002, num_envs=4096, max_episode_steps=100, impl="hip", norm_actions=True)
+    if "Reach" in env_name:
+        base.update(reward_config=dict(reach_weight=1.0, bonus_scale=4.0, penalty_scale=50.0), far_th=0.35)
+    else:
+        base.update(reward_config=dict(angle_reward_weight=1.0, ctrl_cost_weight=1.0, pose_thd=0.35, far_th=4 * np.pi / 2,
+                                       bonus_weight=4.0))
+    return base
+
+
+def make(env_name: str, config_overrides: dict = None, num_envs: int = None, device=None, seed: int = 0):
+    """``myosuite.envs.myo.mjx.make`` for the ids the reference registers there (Mjx{Elbow,Finger}Pose{Fixed,Random}-v0,
+    MjxHandReach{Fixed,Random}-v0); ``impl`` is always this engine."""
+    from .envs import registry
+    cfg = get_default_config(env_name)
+    cfg.update(config_overrides or {})
+    n = int(num_envs if num_envs is not None else cfg["num_envs"])
+    fixed = "Fixed" in env_name
+    if env_name.startswith("MjxElbowPose") or env_name.startswith("MjxFingerPose"):
+        elbow = env_name.startswith("MjxElbowPose")
+        ref_id = ("myoElbowPose1D6M" if elbow else "myoFingerPose") + ("Fixed" if fixed else "Random") + "-v0"
+        rc = cfg["reward_config"]
+        return MjxPoseEnv(model="elbow" if elbow else "finger", num_envs=n, target_jnt_range=registry.spec(ref_id)["kwargs"]["target_jnt_range"],
+                          ctrl_dt=cfg["ctrl_dt"], max_episode_steps=cfg["max_episode_steps"], norm_actions=cfg["norm_actions"],
+                          angle_reward_weight=rc["angle_reward_weight"], ctrl_cost_weight=rc["ctrl_cost_weight"],
+                          bonus_weight=rc["bonus_weight"], pose_thd=rc["pose_thd"], far_th=rc["far_th"], device=device, seed=seed)
+    if env_name.startswith("MjxHandReach"):
+        rc = cfg["reward_config"]
+        return MjxReachEnv(num_envs=n, env_id="myoHandReach" + ("Fixed" if fixed else "Random") + "-v0", ctrl_dt=cfg["ctrl_dt"],
+                           max_episode_steps=cfg["max_episode_steps"], norm_actions=cfg["norm_actions"],
+                           reach_weight=rc["reach_weight"], bonus_scale=rc["bonus_scale"], penalty_scale=rc["penalty_scale"],
+                           device=device, seed=seed)
+    raise KeyError(f"unknown MJX env {env_name!r}")
+
+
+class TrainingWrapper:
+    """What ``mujoco_playground.wrapper.wrap_for_brax_training`` adds for PPO (benchmarks/mjx_benchmark_PPO.py:59): episode
+    truncation and auto-reset.  Brax's AutoResetWrapper restores the FIRST state of the run on done; here the finished envs
+    are re-drawn from the env's own reset distribution (one masked reset launch), which is the better-mixed equivalent."""
+
+    def __init__(self, env):
+        self.env = env
+        self.num_envs = env.num_envs
+        self.observation_size, self.action_size = env.observation_size, env.action_size
+
+    def reset(self, rng: int) -> State:
+        return self.env.reset(rng)
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        st = self.env.step(state, action)
+        inner = self.env._env
+        need = (inner.done | inner.truncated)
+        done = need.to(torch.float32)
+        truncation = (inner.truncated.bool() & ~inner.done.bool()).to(torch.float32)
+        inner.reset(mask=need)                              # masked reset launch; obs of the reset envs in the env's layout
+        E.reset_observation(inner.hm, inner.state, inner._task, need.to(torch.uint8).contiguous())
+        info = {**st.info, "truncation": truncation}
+        return State(st.data, {"state": inner.obs}, st.reward, done, st.metrics, info)
