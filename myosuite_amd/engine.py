@@ -46,6 +46,13 @@ EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
                              "-fno-hip-fp32-correctly-rounded-divide-sqrt -ffast-math -fhonor-infinities -fhonor-nans").split()
 
 
+# Machine-scheduler strategy per kernel group (measured on MI355X, env-steps/s, default scheduler -> chosen):
+#   hand pose   <32,24>      4.07 M -> 4.15 M  iterative-maxocc
+#   reorient    <64,32,GEN>  1.79 M -> 1.85 M  iterative-maxocc
+#   leg walk    <64,40,GEN>  0.71 M -> 0.79 M  iterative-ilp      (iterative-maxocc: 0.71 M; iterative-minreg loses 10-25 % everywhere)
+SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp"}
+
+
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     """Compile the HIP engine for gfx950 in-tree (hipcc cross-compiles without a GPU).  The kernel instantiations are
     spread over several translation units (myosim_inst_*.hip) that are compiled in parallel and linked into one .so."""
@@ -64,7 +71,10 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
         obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
             return obj
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS + ["-c", "-o", obj, src]
+        sched = SCHED_STRATEGY.get(os.path.basename(src), SCHED_STRATEGY["default"])
+        cmd = (["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS +
+               (["-mllvm", f"-amdgpu-sched-strategy={sched}"] if sched and src.endswith(".hip") and "inst" in os.path.basename(src) else []) +
+               ["-c", "-o", obj, src])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
