@@ -180,10 +180,12 @@ struct mm_model {
   int waves_per_block = 0;   // 0 = auto
   int lds_model = 1;
   int blob_words = 0;
+  int cofs = 0;              // word offset of the ConstBlock behind the blob (device copy only)
   size_t lds_per_env = 0;
   int device = 0;
 };
 
+static int upload_consts(mm_model* m);
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x)                                                                                 \
@@ -441,6 +443,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->x.seg_list = append(seg_list);
   m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
   m->blob_words = (int)dev.size();
+  m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS
+  dev.resize(dev.size() + (sizeof(ConstBlock) + 3) / 4, 0u);
 
   // default group width: the smallest that can own every body / dof / constraint row and has a compiled kernel
   m->lanes = 0;
@@ -466,7 +470,18 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   HIPCHK(hipGetDevice(&m->device));
   HIPCHK(hipMalloc((void**)&m->d_blob, dev.size() * sizeof(uint32_t)));
   HIPCHK(hipMemcpy(m->d_blob, dev.data(), dev.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  { int rc = upload_consts(m); if (rc != MM_OK) return rc; }
   *out = m;
+  return MM_OK;
+}
+
+// dims / LDS layout / aux offsets as the kernel reads them (ConstBlock behind the blob); re-sent when the layout changes
+static int upload_consts(mm_model* m) {
+  ConstBlock cb;
+  memset(&cb, 0, sizeof(cb));
+  cb.d = m->d; cb.L = m->L; cb.x = m->x;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(m->d_blob + m->cofs, &cb, sizeof(cb), hipMemcpyHostToDevice));
   return MM_OK;
 }
 
@@ -484,7 +499,7 @@ extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
   m->lanes = lanes;
   m->lanes_auto = 0;
   build_layout(m);
-  return MM_OK;
+  return upload_consts(m);
 }
 
 extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
@@ -590,7 +605,7 @@ static int launch(const mm_model* m, KArgs& a, void* stream) {
 
 static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
   memset(&a, 0, sizeof(a));
-  a.blob = m->d_blob;
+  a.blob = m->d_blob; a.cofs = m->cofs;
   memcpy(a.sec, m->sec, sizeof(a.sec));
   a.d = m->d; a.L = m->L; a.D = m->D; a.x = m->x; a.s = *s;
   if (!a.s.geom_size_env || a.s.geom_env_id < 0 || a.s.geom_env_id >= m->d.ngeom) { a.s.geom_size_env = nullptr; a.s.geom_type_env = nullptr; a.s.geom_env_id = -1; }

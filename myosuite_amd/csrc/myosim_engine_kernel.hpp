@@ -76,9 +76,13 @@ struct Aux {
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
 };
 
+// model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)
+struct ConstBlock { Dims d; Layout L; Aux x; };
+
 struct KArgs {
   const uint32_t* blob;
-  int sec[MM_NSEC];
+  int cofs;              // word offset of the ConstBlock in the device blob
+  int sec[MM_NSEC];      // host-side copies (the kernel reads the blob header / ConstBlock instead)
   Dims d;
   Layout L;
   DbgLayout D;
@@ -96,9 +100,21 @@ struct KArgs {
 enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_ACT, PF_SOLVE0, PF_NEWTON, PF_EULER,
        PF_IO, PF_TOTAL, NPROF };
 
-#define MI_(S) (reinterpret_cast<const int*>(mb + a.sec[MM_SEC_##S]))
-#define MF_(S) (reinterpret_cast<const float*>(mb + a.sec[MM_SEC_##S]))
-#define AUXI(f) (reinterpret_cast<const int*>(mb + a.x.f))
+// section offsets come from the blob header in global memory through the scalar cache (s_load at use) instead of ~100
+// kernel-argument words that live in (spilled) SGPRs for the whole kernel
+typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+#define SECOFF_(S) ((int)(reinterpret_cast<ConstWords>(reinterpret_cast<uintptr_t>(a.blob))[MM_HEADER_WORDS + 2 * (MM_SEC_##S)]))
+typedef const __attribute__((address_space(4))) ConstBlock ConstBlockC;
+typedef const __attribute__((address_space(4))) Dims ConstDims;
+typedef const __attribute__((address_space(4))) Layout ConstLayout;
+typedef const __attribute__((address_space(4))) Aux ConstAux;
+#define KCB_() (*reinterpret_cast<ConstBlockC*>(reinterpret_cast<uintptr_t>(a.blob + a.cofs)))
+#define KD() (KCB_().d)
+#define KL() (KCB_().L)
+#define KX() (KCB_().x)
+#define MI_(S) (reinterpret_cast<const int*>(mb + SECOFF_(S)))
+#define MF_(S) (reinterpret_cast<const float*>(mb + SECOFF_(S)))
+#define AUXI(f) (reinterpret_cast<const int*>(mb + KX().f))
 
 #define GSYNC()                                           \
   do {                                                    \
@@ -591,10 +607,10 @@ struct Engine {
 #pragma unroll
     for (int i = 0; i < NPROF; i++) pf[i] = 0;
     d_warm = 0.f; d_qvel = 0.f;
-    b_depth = (g < a.d.nbody) ? AUXI(body_depth)[g] : -1;
-    b_parent = (g > 0 && g < a.d.nbody) ? MI_(BODY_PARENT)[g] : 0;
+    b_depth = (g < KD().nbody) ? AUXI(body_depth)[g] : -1;
+    b_parent = (g > 0 && g < KD().nbody) ? MI_(BODY_PARENT)[g] : 0;
     {
-      const bool isb = g > 0 && g < a.d.nbody;
+      const bool isb = g > 0 && g < KD().nbody;
       c_ja = isb ? MI_(BODY_JNTADR)[g] : 0;
       c_jn = isb ? MI_(BODY_JNTNUM)[g] : 0;
 #pragma unroll
@@ -621,11 +637,11 @@ struct Engine {
     for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; }
   }
 
-  __device__ __forceinline__ float com_of_body(int b, int k) const { return W[a.L.com + 3 * AUXI(body_rootslot)[b] + k]; }
+  __device__ __forceinline__ float com_of_body(int b, int k) const { return W[KL().com + 3 * AUXI(body_rootslot)[b] + k]; }
 
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     if (g == 0) {
       b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
       Q4 q = {1.f, 0.f, 0.f, 0.f};
@@ -635,7 +651,7 @@ struct Engine {
       for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
     }
     GSYNC();
-    for (int lv = 1; lv <= a.d.nlevel; lv++) {
+    for (int lv = 1; lv <= KD().nlevel; lv++) {
       if (b_depth == lv) {
         const int b = g, p = b_parent;
         M3 pm = ldm(W + L.xmat + 9 * p);
@@ -687,15 +703,15 @@ struct Engine {
 
   __device__ __forceinline__ V3 site_pos(int s) const {
     int b = MI_(SITE_BODYID)[s];
-    return ld3(W + a.L.xpos + 3 * b) + mv(ldm(W + a.L.xmat + 9 * b), ld3(MF_(SITE_POS) + 3 * s));
+    return ld3(W + KL().xpos + 3 * b) + mv(ldm(W + KL().xmat + 9 * b), ld3(MF_(SITE_POS) + 3 * s));
   }
   __device__ __forceinline__ V3 geom_pos(int gi) const {
     int b = MI_(GEOM_BODYID)[gi];
-    return ld3(W + a.L.xpos + 3 * b) + mv(ldm(W + a.L.xmat + 9 * b), ld3(MF_(GEOM_POS) + 3 * gi));
+    return ld3(W + KL().xpos + 3 * b) + mv(ldm(W + KL().xmat + 9 * b), ld3(MF_(GEOM_POS) + 3 * gi));
   }
   __device__ __forceinline__ M3 geom_mat(int gi) const {  // xmat_body * R(geom_quat)
     int b = MI_(GEOM_BODYID)[gi];
-    M3 A = ldm(W + a.L.xmat + 9 * b), B = q2m(ldq(MF_(GEOM_QUAT) + 4 * gi)), R;
+    M3 A = ldm(W + KL().xmat + 9 * b), B = q2m(ldq(MF_(GEOM_QUAT) + 4 * gi)), R;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -705,13 +721,13 @@ struct Engine {
 
   // subtree COM of each tree root, body inertias about it (registers), dof motion axes (LDS + registers)
   __device__ __forceinline__ void com_pos() {
-    const Layout& L = a.L;
-    const int nb = a.d.nbody;
+    ConstLayout& L = KL();
+    const int nb = KD().nbody;
     const bool isb = g > 0 && g < nb;
     float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
     if (a.s.body_mass_env && g == a.s.body_mass_env_id) ms = a.s.body_mass_env[env];
     int myslot = isb ? AUXI(body_rootslot)[g] : -1;
-    for (int r = 0; r < a.x.nroot; r++) {
+    for (int r = 0; r < KX().nroot; r++) {
       float w = (myslot == r) ? ms : 0.f;
       float sm = gsum<G>(w), sx = gsum<G>(w * b_xipos.x), sy = gsum<G>(w * b_xipos.y), sz = gsum<G>(w * b_xipos.z);
       if (g == 0) {
@@ -744,7 +760,7 @@ struct Engine {
       for (int k = 0; k < 10; k++) b_cinert[k] = 0.f;
     }
     // motion axes of the dof(s) owned by this lane (lane g == dof g)
-    if (g < a.d.nv) {
+    if (g < KD().nv) {
       int j = MI_(DOF_JNTID)[g], b = MI_(JNT_BODYID)[j], type = MI_(JNT_TYPE)[j], da = MI_(JNT_DOFADR)[j];
       V3 off = ld3(W + L.com + 3 * AUXI(dof_rootslot)[g]) - ld3(W + L.xanchor + 3 * j);
       V3 ang, lin;
@@ -769,7 +785,7 @@ struct Engine {
   // ---------------------------------------------------------------- A2 tendons
   // add the contributions of one straight segment (point p0 -> p1, unit direction u) to the sparse J row
   __device__ __forceinline__ void tenj_segment(int l0, int l1, V3 p0, V3 p1, V3 u) {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     const int* lst = AUXI(seg_list);
     for (int e = l0; e < l1; e++) {
       int w = lst[e];
@@ -788,13 +804,13 @@ struct Engine {
   // of G lanes then executes one kind of item, instead of every lane walking its own tendon with divergent item kinds.
   // Lengths and Jacobian entries are accumulated with LDS float atomics (one wave: deterministic lane order).
   __device__ __forceinline__ void tendon() {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     const int *sa = AUXI(sega_adr), *sb = AUXI(segb_adr), *sc = AUXI(segc_adr);
     const int* items = AUXI(item_tab);
-    for (int e = g; e < a.d.ntenJ; e += G) W[L.tenj + e] = 0.f;
-    for (int t = g; t < a.d.ntendon; t += G) W[L.tenlen + t] = 0.f;
+    for (int e = g; e < KD().ntenJ; e += G) W[L.tenj + e] = 0.f;
+    for (int t = g; t < KD().ntendon; t += G) W[L.tenlen + t] = 0.f;
     GSYNC();
-    for (int it = g; it < a.x.nitem; it += G) {
+    for (int it = g; it < KX().nitem; it += G) {
       const int* I = items + 8 * it;
       const int t = I[0], kind = I[1], k0 = I[2];
       const float inv_div = __int_as_float(I[7]);
@@ -859,7 +875,7 @@ struct Engine {
     float R = fmaxf(MINVALF, (1.f - imp) * diagApprox / imp);
     float K, B;
     if (sr[0] > 0.f) {
-      float tc = fmaxf(sr[0], 2.f * a.d.timestep), dr = sr[1];
+      float tc = fmaxf(sr[0], 2.f * KD().timestep), dr = sr[1];
       K = 1.f / fmaxf(MINVALF, dmax * dmax * tc * tc * dr * dr);
       B = 2.f / fmaxf(MINVALF, dmax * tc);
     } else { K = -sr[0] / fmaxf(MINVALF, dmax * dmax); B = -sr[1] / fmaxf(MINVALF, dmax); }
@@ -871,10 +887,10 @@ struct Engine {
   // time (mm_model_create rejects ranges narrower than 2*margin).
   __device__ __forceinline__ void make_constraint() {
     if constexpr (GEN) { make_constraint_gen(); return; }
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     const int j = g;
     r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = 1.f;
-    if (j < a.d.njnt) {
+    if (j < KD().njnt) {
       int type = MI_(JNT_TYPE)[j];
       if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
         r_dof = MI_(JNT_DOFADR)[j];
@@ -895,17 +911,17 @@ struct Engine {
 
   // value of the limit row of the joint that owns dof g (0 for dofs that are not a hinge/slide joint's dof)
   __device__ __forceinline__ float rows_to_dof(float val) const {
-    int j = g < a.d.nv ? MI_(DOF_JNTID)[g] : 0;
+    int j = g < KD().nv ? MI_(DOF_JNTID)[g] : 0;
     float v = sh<G>(val, j);
-    bool mine = g < a.d.nv && MI_(JNT_DOFADR)[j] == g;
+    bool mine = g < KD().nv && MI_(JNT_DOFADR)[j] == g;
     return mine ? v : 0.f;
   }
 
   // ----------------------------------------------------- A5 velocity stage + bias forces
   __device__ __forceinline__ void velocity_bias() {
-    const Layout& L = a.L;
-    const int nb = a.d.nbody;
-    for (int t = g; t < a.d.ntendon; t += G) {
+    ConstLayout& L = KL();
+    const int nb = KD().nbody;
+    for (int t = g; t < KD().ntendon; t += G) {
       float s = 0.f;
       for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) s += W[L.tenj + e] * W[L.qvel + MI_(TENJ_DOF)[e]];
       W[L.tenvel + t] = s;
@@ -917,12 +933,12 @@ struct Engine {
     // parents publish (cvel, cacc) in LDS (u1 region, 12 words per body: three 128-bit accesses instead of twelve
     // cross-lane permutes per level)
     if (g == 0) {
-      ca[3] = -a.d.gx; ca[4] = -a.d.gy; ca[5] = -a.d.gz;
+      ca[3] = -KD().gx; ca[4] = -KD().gy; ca[5] = -KD().gz;
 #pragma unroll
       for (int k = 0; k < 6; k++) { W[L.u1 + k] = 0.f; W[L.u1 + 6 + k] = ca[k]; }
     }
     GSYNC();
-    for (int lv = 1; lv <= a.d.nlevel; lv++) {
+    for (int lv = 1; lv <= KD().nlevel; lv++) {
       if (b_depth == lv) {
 #pragma unroll
         for (int k = 0; k < 6; k++) { cv[k] = W[L.u1 + 12 * b_parent + k]; ca[k] = W[L.u1 + 12 * b_parent + 6 + k]; }
@@ -974,7 +990,7 @@ struct Engine {
 #pragma unroll
       for (int k = 0; k < 6; k++) W[L.u1 + 6 * g + k] = 0.f;
     GSYNC();
-    for (int lv = a.d.nlevel; lv >= 1; lv--) {
+    for (int lv = KD().nlevel; lv >= 1; lv--) {
       if (b_depth == lv) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -986,7 +1002,7 @@ struct Engine {
       GSYNC();
     }
     d_bias = 0.f;
-    if (g < a.d.nv) {
+    if (g < KD().nv) {
       int b = MI_(DOF_BODYID)[g];
 #pragma unroll
       for (int k = 0; k < 6; k++) d_bias += d_cdof[k] * W[L.u1 + 6 * b + k];
@@ -996,15 +1012,15 @@ struct Engine {
 
   // ---------------------------------------------------------------- A4 CRB -> dense M rows
   __device__ __forceinline__ void crb() {
-    const Layout& L = a.L;
-    const int nb = a.d.nbody, nv = a.d.nv;
+    ConstLayout& L = KL();
+    const int nb = KD().nbody, nv = KD().nv;
     if (g < nb)
 #pragma unroll
       for (int k = 0; k < 10; k++) W[L.crb + 10 * g + k] = b_cinert[k];
     // zero the dense tile (u1 region; cfrc is dead now) and put 1 on the padded diagonal
     for (int e = g; e < NVP * NVP; e += G) W[L.u1 + e] = 0.f;
     GSYNC();
-    for (int lv = a.d.nlevel; lv >= 2; lv--) {
+    for (int lv = KD().nlevel; lv >= 2; lv--) {
       if (b_depth == lv && b_parent > 0)
 #pragma unroll
         for (int k = 0; k < 10; k++) atomicAdd(&W[L.crb + 10 * b_parent + k], W[L.crb + 10 * g + k]);
@@ -1052,7 +1068,7 @@ struct Engine {
     factor_core(A);
   }
   __device__ __forceinline__ void factor_core(float (&A)[NVP]) {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     if constexpr (G < 64 && NVP >= 8) {
       // Left-looking form for groups narrower than the wave.  A cross-lane broadcast costs ~5 issue slots there (two
       // v_readlane + v_mov + v_cndmask + hazard nops), and the right-looking update needs NVP^2/2 of them.  Here row j of L
@@ -1107,7 +1123,7 @@ struct Engine {
       float yj = bc<G>(x * d_dinv, j);
       x = (g == j) ? yj : (g > j ? x - Lrow[j] * yj : x);
     }
-    const float* LT = W + a.L.u1 + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
+    const float* LT = W + KL().u1 + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
 #pragma unroll
     for (int i = NVP - 1; i >= 0; i--) {
       float zi = bc<G>(x * d_dinv, i);
@@ -1121,7 +1137,7 @@ struct Engine {
     float y = 0.f;
     if constexpr (G < 64 && NVP >= 8) {
       // x through LDS (one write, NVP/4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts
-      float* X = W + a.L.xvec;
+      float* X = W + KL().xvec;
       if (g < NVP) X[g] = x;
 #pragma unroll
       for (int k4 = 0; k4 < NVP / 4; k4++) {
@@ -1137,8 +1153,8 @@ struct Engine {
 
   // ------------------------------------------- A5/A6 passive + actuation -> qfrc_smooth
   __device__ __forceinline__ void passive_actuation() {
-    const Layout& L = a.L;
-    for (int t = g; t < a.d.ntendon; t += G) {
+    ConstLayout& L = KL();
+    for (int t = g; t < KD().ntendon; t += G) {
       float k = MF_(TENDON_STIFFNESS)[t], bd = MF_(TENDON_DAMPING)[t], f = 0.f;
       if (k != 0.f || bd != 0.f) {
         float len = W[L.tenlen + t], lo = MF_(TENDON_LENGTHSPRING)[2 * t], hi = MF_(TENDON_LENGTHSPRING)[2 * t + 1];
@@ -1148,9 +1164,9 @@ struct Engine {
       }
       W[L.tenfrc + t] = f;
     }
-    if (g < a.d.nv) W[L.vec + g] = 0.f;
+    if (g < KD().nv) W[L.vec + g] = 0.f;
     GSYNC();
-    for (int u = g; u < a.d.nu; u += G) {
+    for (int u = g; u < KD().nu; u += G) {
       float ctrl = W[L.ctrl + u];
       if (MI_(ACT_CTRLLIMITED)[u]) ctrl = clampf(ctrl, MF_(ACT_CTRLRANGE)[2 * u], MF_(ACT_CTRLRANGE)[2 * u + 1]);
       int aa = MI_(ACT_ACTADR)[u], id = MI_(ACT_TRNID)[u];
@@ -1177,14 +1193,14 @@ struct Engine {
     GSYNC();
     // J' f: every tendon lane scatters its (<= 8) Jacobian entries into the per-dof accumulator with LDS float
     // atomics (one wave => deterministic lane order); shorter critical path than gathering ~25 entries per wrist dof
-    for (int t = g; t < a.d.ntendon; t += G) {
+    for (int t = g; t < KD().ntendon; t += G) {
       float f = W[L.tenfrc + t];
       if (f != 0.f)
         for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) atomicAdd(&W[L.vec + MI_(TENJ_DOF)[e]], W[L.tenj + e] * f);
     }
     GSYNC();
     d_smooth = 0.f;
-    if (g < a.d.nv) {
+    if (g < KD().nv) {
       float s = -MF_(DOF_DAMPING)[g] * d_qvel - d_bias + W[L.vec + g];
       int j = MI_(DOF_JNTID)[g];
       float ks = MF_(JNT_STIFFNESS)[j];
@@ -1209,11 +1225,11 @@ struct Engine {
 
   __device__ __forceinline__ void solve_constraints() {
     if constexpr (GEN) { solve_constraints_gen(); return; }
-    const int nv = a.d.nv;
+    const int nv = KD().nv;
     niter = 0;
     d_qfrccon = 0.f;
     if (nefc == 0) { d_qacc = d_qaccsm; return; }
-    const float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
+    const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
     // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_of(d_warm, Ma_ws);
@@ -1227,14 +1243,14 @@ struct Engine {
     // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull;
-    for (int iter = 0; iter < a.d.iterations; iter++) {
+    for (int iter = 0; iter < KD().iterations; iter++) {
       const bool on = r_active && r_jar < 0.f;
       const unsigned long long set_now = __ballot(on);
       float f = on ? -r_D * r_jar : 0.f;
       d_qfrccon = rows_to_dof(r_sign * f);
       float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
       float gn = sqrtf(gsum<G>(grad * grad));
-      if (scale * gn < a.d.tolerance) break;
+      if (scale * gn < KD().tolerance) break;
       if (iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
         // compare the active sets of THIS group only
         const int lane = threadIdx.x & 63;
@@ -1252,10 +1268,10 @@ struct Engine {
       float jv = r_sign * sh<G>(search, r_dof);
       float dm = Ma - d_smooth;
       float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
-      const float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
+      const float gtol = KD().tolerance * KD().ls_tolerance * sn / scale;
       // exact line search on the convex piecewise-quadratic phi(alpha): safeguarded Newton on phi'(alpha) = 0
       float alpha = 1.f, lo = 0.f, hi = -1.f;
-      for (int it = 0; it < a.d.ls_iterations; it++) {
+      for (int it = 0; it < KD().ls_iterations; it++) {
         float x = r_jar + alpha * jv;
         float d1 = 0.f, d2 = 0.f;
         if (r_active && x < 0.f) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
@@ -1283,7 +1299,7 @@ struct Engine {
           break;
         }
       }
-      if (iter == a.d.iterations - 1) {
+      if (iter == KD().iterations - 1) {
         const bool on2 = r_active && r_jar < 0.f;
         d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
         status |= 4;
@@ -1298,7 +1314,7 @@ struct Engine {
   // (D, aref, jar).  Row order: equalities, active joint
   // limits (compacted), contact pyramid edges (compacted).  Restates mmo_make_constraint / mmo_collision.inc.
   static constexpr int RS = NVP + 4;
-  __device__ __forceinline__ float* Jrow(int r) const { return W + a.L.efcJ + (r < a.d.efc_rows ? r : 0) * RS; }
+  __device__ __forceinline__ float* Jrow(int r) const { return W + KL().efcJ + (r < KD().efc_rows ? r : 0) * RS; }
   __device__ __forceinline__ int gscan_excl(int v) const {
     int incl = v;
 #pragma unroll
@@ -1312,7 +1328,7 @@ struct Engine {
   }
   // Jacobian entries of one contact: rows r0.. get  +-(edge . (J_b2 - J_b1))  over the two kinematic chains
   __device__ __forceinline__ void contact_rows(int r0, int nrow, int b1, int b2, V3 pos, V3 n, V3 t1, V3 t2, float mu) {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     for (int side = 0; side < 2; side++) {
       int b = side ? b2 : b1;
       const float sg = side ? 1.f : -1.f;
@@ -1353,14 +1369,14 @@ struct Engine {
   }
 
   __device__ __forceinline__ void make_constraint_gen() {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     float* RT = W + L.rowtab;
     {
       float4* Jz = reinterpret_cast<float4*>(W + L.efcJ);
-      for (int e = g; e < a.d.efc_rows * RS / 4; e += G) Jz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = g; e < KD().efc_rows * RS / 4; e += G) Jz[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     GSYNC();
-    const int neq = a.d.neq;
+    const int neq = KD().neq;
     // ---- equality rows: joint coupling q1 - q1_0 = poly(q2 - q2_0)
     if (g < neq) {
       const int e = g, j1 = MI_(EQ_OBJ1ID)[e], j2 = MI_(EQ_OBJ2ID)[e];
@@ -1381,13 +1397,13 @@ struct Engine {
     }
     // ---- dof friction loss (MuJoCo row order: equality, friction loss, limits, contacts): J = e_dof at pos 0
     int nfr = 0;
-    if (a.d.nfric) {
-      const int fr = (g < a.d.nv && MF_(DOF_FRICTIONLOSS)[g] > 0.f) ? 1 : 0;
+    if (KD().nfric) {
+      const int fr = (g < KD().nv && MF_(DOF_FRICTIONLOSS)[g] > 0.f) ? 1 : 0;
       const int frank = gscan_excl(fr);
       nfr = gsum_i(fr);
       if (fr) {
         const int r = neq + frank;
-        if (r < a.d.efc_rows) {
+        if (r < KD().efc_rows) {
           Jrow(r)[g] = 1.f;
           RT[3 * r] = __int_as_float(MM_CON_FRICTION_DOF | (g << 3)); RT[3 * r + 1] = 0.f; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[g];
         }
@@ -1396,7 +1412,7 @@ struct Engine {
     // ---- joint limits, compacted behind the equalities
     int lim = 0, ldof = 0;
     float ldist = 0.f, lsign = 1.f, lmargin = 0.f;
-    if (g < a.d.njnt) {
+    if (g < KD().njnt) {
       const int j = g, type = MI_(JNT_TYPE)[j];
       if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
         ldof = MI_(JNT_DOFADR)[j];
@@ -1412,7 +1428,7 @@ struct Engine {
     int over = 0;
     if (lim) {
       const int r = neq + nfr + lrank;
-      if (r < a.d.efc_rows) {
+      if (r < KD().efc_rows) {
         Jrow(r)[ldof] = lsign;
         RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 3)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
       } else over = 1;
@@ -1423,7 +1439,7 @@ struct Engine {
     float cdist[2] = {0.f, 0.f}, mu = 0.f, incl = 0.f;
     V3 cpos[2], cn[2];
     cpos[0] = cpos[1] = cn[0] = cn[1] = v3(0.f, 0.f, 0.f);
-    if (g < a.d.npair) {
+    if (g < KD().npair) {
       const int p = g, g1 = MI_(PAIR_GEOM1)[p], g2 = MI_(PAIR_GEOM2)[p];
       int t1 = MI_(GEOM_TYPE)[g1], t2 = MI_(GEOM_TYPE)[g2];
       if (env_gtype >= 0) {   // per-env model delta: type of one geom (mm_state.geom_type_env)
@@ -1494,7 +1510,7 @@ struct Engine {
     const int ncrows = gsum_i(myrows);
     for (int c = 0; c < 2; c++) {
       if (!(c < nc && cdist[c] < incl)) continue;
-      if (base + rowsper > a.d.efc_rows) { over = 1; continue; }
+      if (base + rowsper > KD().efc_rows) { over = 1; continue; }
       // contact frame (mmo_collision.inc: make_frame)
       V3 n = cn[c];
       V3 y = (n.y < 0.5f && n.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
@@ -1512,7 +1528,7 @@ struct Engine {
     }
     if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
     nefc = neq + nfr + nlim + ncrows;
-    if (nefc > a.d.efc_rows) nefc = a.d.efc_rows;
+    if (nefc > KD().efc_rows) nefc = KD().efc_rows;
     {
       int w = nefc;
 #pragma unroll
@@ -1527,7 +1543,7 @@ struct Engine {
       const float x = RT[3 * g + 1], dA = RT[3 * g + 2];
       float vel = 0.f;
       const float* J = Jrow(g);
-      for (int k = 0; k < a.d.nv; k++) vel += J[k] * W[L.qvel + k];
+      for (int k = 0; k < KD().nv; k++) vel += J[k] * W[L.qvel + k];
       const float *si, *sr;
       if (kind == MM_CON_EQUALITY) { si = MF_(EQ_SOLIMP) + 5 * id; sr = MF_(EQ_SOLREF) + 2 * id; }
       else if (kind == MM_CON_LIMIT_JOINT) { si = MF_(JNT_SOLIMP) + 5 * id; sr = MF_(JNT_SOLREF) + 2 * id; }
@@ -1555,10 +1571,10 @@ struct Engine {
   }
   // (J' f)_i for the dof owned by this lane; f lives in the row lanes
   __device__ __forceinline__ float jacT_mul(float f) const {
-    const float* Jc = W + a.L.efcJ + (g < NVP ? g : 0);
+    const float* Jc = W + KL().efcJ + (g < NVP ? g : 0);
     float s = 0.f;
     for (int r = 0; r < nrows_wave; r++) s += Jc[r * RS] * bc<G>(f, r);
-    return g < a.d.nv ? s : 0.f;
+    return g < KD().nv ? s : 0.f;
   }
   // force -s'(x) of the row owned by this lane at x = J a - aref; quad = the row is in its quadratic state (contributes
   // D J'J to the Hessian).  Equality rows are quadratic everywhere, limit / contact rows for x < 0, friction-loss rows are
@@ -1583,11 +1599,11 @@ struct Engine {
   }
 
   __device__ __forceinline__ void solve_constraints_gen() {
-    const int nv = a.d.nv;
+    const int nv = KD().nv;
     niter = 0;
     d_qfrccon = 0.f;
     if (nrows_wave == 0) { d_qacc = d_qaccsm; return; }
-    const float scale = 1.f / (a.d.meaninertia * (float)(nv > 1 ? nv : 1));
+    const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_gen(d_warm, Ma_ws);
     float cost_sm = cost_gen(d_qaccsm, d_smooth);
@@ -1597,15 +1613,15 @@ struct Engine {
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull, sat_prev = 0ull;
     bool done = nefc == 0;     // envs of the wave that have no rows idle through the loop (wave-collective code below)
-    for (int iter = 0; iter < a.d.iterations; iter++) {
+    for (int iter = 0; iter < KD().iterations; iter++) {
       bool on;
       const float rf = row_force(r_jar, on);
       // active-set signature: quadratic rows, plus the sign of saturated friction rows
-      const unsigned long long set_now = __ballot(on), sat_now = a.d.nfric ? __ballot(rf > 0.f && !on) : 0ull;
+      const unsigned long long set_now = __ballot(on), sat_now = KD().nfric ? __ballot(rf > 0.f && !on) : 0ull;
       d_qfrccon = jacT_mul(rf);
       float grad = g < nv ? Ma - d_smooth - d_qfrccon : 0.f;
       float gn = sqrtf(gsum<G>(grad * grad));
-      if (scale * gn < a.d.tolerance) done = true;
+      if (scale * gn < KD().tolerance) done = true;
       if (!done && iter > 0 && fabsf(alpha_prev - 1.f) < 1e-3f) {
         const int lane = threadIdx.x & 63;
         const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
@@ -1623,7 +1639,7 @@ struct Engine {
         for (int r = 0; r < nrows_wave; r++) {
           const float sD = bc<G>(dr, r);
           if (__ballot(sD != 0.f) == 0ull) continue;
-          const float* Jr = W + a.L.efcJ + r * RS;
+          const float* Jr = W + KL().efcJ + r * RS;
           const float c = g < NVP ? sD * Jr[col] : 0.f;
           const float4* Jr4 = reinterpret_cast<const float4*>(Jr);
 #pragma unroll
@@ -1642,10 +1658,10 @@ struct Engine {
       float jv = jac_mul(search);
       float dm = Ma - d_smooth;
       float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
-      const float gtol = a.d.tolerance * a.d.ls_tolerance * sn / scale;
+      const float gtol = KD().tolerance * KD().ls_tolerance * sn / scale;
       float alpha = 1.f, lo = 0.f, hi = -1.f;
       bool lsdone = done;
-      for (int it = 0; it < a.d.ls_iterations; it++) {
+      for (int it = 0; it < KD().ls_iterations; it++) {
         float x = r_jar + alpha * jv;
         float d1 = 0.f, d2 = 0.f;
         {
@@ -1679,7 +1695,7 @@ struct Engine {
         float stepmax = gmax<G>(fabsf(alpha * search)), qmax = gmax<G>(fabsf(d_qacc));
         if (!done && stepmax <= 2e-7f * fmaxf(qmax, 1.f)) done = true;
       }
-      if (iter == a.d.iterations - 1 && !done) status |= 4;
+      if (iter == KD().iterations - 1 && !done) status |= 4;
     }
     bool on2;
     d_qfrccon = jacT_mul(row_force(r_jar, on2));
@@ -1706,42 +1722,42 @@ struct Engine {
   }
 
   __device__ __forceinline__ bool bad_state(bool check_acc) {
-    const Layout& L = a.L;
+    ConstLayout& L = KL();
     int bad = 0;
-    for (int i = g; i < a.d.nq; i += G) bad |= !(fabsf(W[L.qpos + i]) < 1e10f);
-    if (g < a.d.nv) {
+    for (int i = g; i < KD().nq; i += G) bad |= !(fabsf(W[L.qpos + i]) < 1e10f);
+    if (g < KD().nv) {
       bad |= !(fabsf(d_qvel) < 1e10f);
       if (check_acc) bad |= !(fabsf(d_qacc) < 1e10f);
     }
     return gor<G>(bad) != 0;
   }
   __device__ __forceinline__ void reset_data() {
-    const Layout& L = a.L;
-    for (int i = g; i < a.d.nq; i += G) W[L.qpos + i] = MF_(QPOS0)[i];
+    ConstLayout& L = KL();
+    for (int i = g; i < KD().nq; i += G) W[L.qpos + i] = MF_(QPOS0)[i];
     d_qvel = 0.f; d_warm = 0.f;
-    if (g < a.d.nv) W[L.qvel + g] = 0.f;
-    for (int i = g; i < a.d.na; i += G) W[L.act + i] = 0.f;
+    if (g < KD().nv) W[L.qvel + g] = 0.f;
+    for (int i = g; i < KD().na; i += G) W[L.act + i] = 0.f;
     GSYNC();
   }
 
   // A9 semi-implicit Euler with implicit joint damping
   __device__ __forceinline__ void euler(float& time) {
-    const Layout& L = a.L;
-    const float h = a.d.timestep;
+    ConstLayout& L = KL();
+    const float h = KD().timestep;
     d_warm = d_qacc;
     float qa_ = d_qacc;
-    if (a.d.any_damping && a.d.eulerdamp) {
-      factor(g < a.d.nv ? h * MF_(DOF_DAMPING)[g] : 0.f);
-      qa_ = solve(g < a.d.nv ? d_smooth + d_qfrccon : 0.f);
+    if (KD().any_damping && KD().eulerdamp) {
+      factor(g < KD().nv ? h * MF_(DOF_DAMPING)[g] : 0.f);
+      qa_ = solve(g < KD().nv ? d_smooth + d_qfrccon : 0.f);
     }
-    for (int u = g; u < a.d.nu; u += G) {
+    for (int u = g; u < KD().nu; u += G) {
       int aa = MI_(ACT_ACTADR)[u];
       if (aa < 0) continue;
       float x = W[L.act + aa] + h * W[L.actdot + aa];
       if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
       W[L.act + aa] = x;
     }
-    if (g < a.d.nv) {
+    if (g < KD().nv) {
       d_qvel += h * qa_;
       W[L.qvel + g] = d_qvel;
     }
@@ -1753,8 +1769,8 @@ struct Engine {
 
   // qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos); vel = LDS vector at word offset `voff`
   __device__ __forceinline__ void integrate_pos(int voff, float hh) {
-    const Layout& L = a.L;
-    for (int j = g; j < a.d.njnt; j += G) {
+    ConstLayout& L = KL();
+    for (int j = g; j < KD().njnt; j += G) {
       int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j], da = MI_(JNT_DOFADR)[j];
       if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[L.qpos + qa] += hh * W[voff + da]; continue; }
       if (type == MM_JNT_FREE) {
@@ -1777,30 +1793,30 @@ struct Engine {
   // One stage of classical RK4 (mj_RungeKutta, N = 4; oracle: mmo_rk4).  Called after the forward pass of stage `i`
   // (i = 0 is mj_step's own forward).  Stages 0..2 move the state to X0 + h a_i F_i; stage 3 applies the weighted update.
   __device__ __forceinline__ void rk4_stage(int i, float& time, float t0) {
-    const Layout& L = a.L;
-    const float h = a.d.timestep;
+    ConstLayout& L = KL();
+    const float h = KD().timestep;
     const float A_ = i == 2 ? 1.f : 0.5f;
     const float B_ = (i == 0 || i == 3) ? (1.f / 6.f) : (1.f / 3.f);
     d_warm = d_qacc;
     if (i == 0) {
       rk_v0 = d_qvel; rk_vsum = 0.f; rk_asum = 0.f;
-      for (int k = g; k < a.d.nq; k += G) W[L.rk_qpos0 + k] = W[L.qpos + k];
-      for (int k = g; k < a.d.na; k += G) { W[L.rk_act0 + k] = W[L.act + k]; W[L.rk_adot + k] = 0.f; }
+      for (int k = g; k < KD().nq; k += G) W[L.rk_qpos0 + k] = W[L.qpos + k];
+      for (int k = g; k < KD().na; k += G) { W[L.rk_act0 + k] = W[L.act + k]; W[L.rk_adot + k] = 0.f; }
     }
     rk_vsum += B_ * d_qvel; rk_asum += B_ * d_qacc;
-    for (int k = g; k < a.d.na; k += G) W[L.rk_adot + k] += B_ * W[L.actdot + k];
+    for (int k = g; k < KD().na; k += G) W[L.rk_adot + k] += B_ * W[L.actdot + k];
     GSYNC();
     // velocity used for the position update of this stage goes through the (free) L.vec scratch vector
     const float hh = i < 3 ? h * A_ : h;
-    if (g < a.d.nv) W[L.vec + g] = i < 3 ? d_qvel : rk_vsum;
-    for (int k = g; k < a.d.nq; k += G) W[L.qpos + k] = W[L.rk_qpos0 + k];
+    if (g < KD().nv) W[L.vec + g] = i < 3 ? d_qvel : rk_vsum;
+    for (int k = g; k < KD().nq; k += G) W[L.qpos + k] = W[L.rk_qpos0 + k];
     GSYNC();
     integrate_pos(L.vec, hh);
-    if (g < a.d.nv) {
+    if (g < KD().nv) {
       d_qvel = i < 3 ? rk_v0 + hh * d_qacc : rk_v0 + h * rk_asum;
       W[L.qvel + g] = d_qvel;
     }
-    for (int u = g; u < a.d.nu; u += G) {
+    for (int u = g; u < KD().nu; u += G) {
       int aa = MI_(ACT_ACTADR)[u];
       if (aa < 0) continue;
       float x = i < 3 ? W[L.rk_act0 + aa] + hh * W[L.actdot + aa] : W[L.rk_act0 + aa] + h * W[L.rk_adot + aa];
@@ -1878,9 +1894,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (a.mode == 2 && a.t.env_mask && !a.t.env_mask[e]) dup = true;   // masked-out envs are left untouched
   const bool obs_only = a.mode == 2 && a.t.obs_only;
   if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
-  float* W = wsbase + (size_t)(wave * EPW + lane / G) * a.L.total;
-  const Layout& L = a.L;
-  const Dims& d = a.d;
+  float* W = wsbase + (size_t)(wave * EPW + lane / G) * KL().total;
+  ConstLayout& L = KL();
+  ConstDims& d = KD();
   Engine<G, NVP, GEN, RK4> E(a, mb, W, g);
   if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
   if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
