@@ -108,6 +108,10 @@ typedef const __attribute__((address_space(4))) ConstBlock ConstBlockC;
 typedef const __attribute__((address_space(4))) Dims ConstDims;
 typedef const __attribute__((address_space(4))) Layout ConstLayout;
 typedef const __attribute__((address_space(4))) Aux ConstAux;
+// per-call arguments used late in the kernel (task description, state / derived pointers) are read from the kernarg segment
+// at the point of use instead of living in SGPRs from kernel entry
+typedef const __attribute__((address_space(4))) KArgs ConstKArgs;
+#define KA() (*(ConstKArgs*)(__builtin_amdgcn_kernarg_segment_ptr()))
 #define KCB_() (*reinterpret_cast<ConstBlockC*>(reinterpret_cast<uintptr_t>(a.blob + a.cofs)))
 #define KD() (KCB_().d)
 #define KL() (KCB_().L)
@@ -1891,8 +1895,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if ((blockIdx.x * wpb + wave) * EPW >= nenv) return;  // whole wave idle
   bool dup = e >= nenv;
   if (dup) e = nenv - 1;  // surplus groups recompute the last env (they never store)
-  if (a.mode == 2 && a.t.env_mask && !a.t.env_mask[e]) dup = true;   // masked-out envs are left untouched
-  const bool obs_only = a.mode == 2 && a.t.obs_only;
+  if (a.mode == 2 && KA().t.env_mask && !KA().t.env_mask[e]) dup = true;   // masked-out envs are left untouched
+  const bool obs_only = a.mode == 2 && KA().t.obs_only;
   if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * KL().total;
   ConstLayout& L = KL();
@@ -1912,7 +1916,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   for (int i = g; i < d.na; i += G) W[L.act + i] = a.s.act[(size_t)e * d.na + i];
   float time = a.s.time[e];
   E.status = a.s.status ? a.s.status[e] : 0;
-  const mm_task& t = a.t;
+  const __attribute__((address_space(4))) mm_task& t = KA().t;
   // ---- action -> ctrl (BaseV0.step: base_v0.py:82-108)
   for (int u = g; u < d.nu; u += G) {
     float c = a.ctrl ? a.ctrl[(size_t)e * d.nu + u] : 0.f;
