@@ -17,7 +17,10 @@ from myosuite_amd import engine as E
 from myosuite_amd.mjx_api import MjxPoseEnv
 
 
-def measure_num_env_simulation_steps(model="hand", seed=0, loop_iterations=16):
+def measure_num_env_simulation_steps(model="hand", seed=0, loop_iterations=16, graph=True):
+    """graph=True: the 16-step loop is captured once into a HIP graph and replayed -- the counterpart of the reference's
+    jitted ``jax.lax.scan`` over 16 steps (mjx_benchmark.py:24-33); actions are drawn inside the graph (torch's graph-safe
+    Philox), as the reference draws them inside the scan.  graph=False launches every step eagerly."""
     res = {}
     for e in [64, 512, 1024, 2048, 4096, 8192]:
         env = MjxPoseEnv(model=model, num_envs=e, seed=seed)
@@ -26,16 +29,31 @@ def measure_num_env_simulation_steps(model="hand", seed=0, loop_iterations=16):
 
         def loop(state, key):
             for i in range(loop_iterations):
-                E.uniform(act, seed=key, stream_id=i)
+                if graph:
+                    act.uniform_()
+                else:
+                    E.uniform(act, seed=key, stream_id=i)
                 state = env.step(state, act)
             return state
 
         state = loop(state, 0)          # preheat
         torch.cuda.synchronize()
+        if graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                state = loop(state, 0)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                state = loop(state, 1)
 
         def run_benchmark():
             nonlocal state
-            state = loop(state, 1)
+            if graph:
+                g.replay()
+            else:
+                state = loop(state, 1)
             torch.cuda.synchronize()
 
         results = timeit.repeat(run_benchmark, number=8192 // e, repeat=3)
@@ -48,5 +66,6 @@ def measure_num_env_simulation_steps(model="hand", seed=0, loop_iterations=16):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="hand")
+    ap.add_argument("--eager", action="store_true", help="launch every step instead of replaying a captured 16-step HIP graph")
     a = ap.parse_args()
-    print(measure_num_env_simulation_steps(a.model))
+    print(measure_num_env_simulation_steps(a.model, graph=not a.eager))

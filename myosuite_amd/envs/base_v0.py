@@ -235,5 +235,25 @@ class BaseV0:
             obs = self.obs
         return obs, reward, terminated, truncated, info
 
+    def capture_step_graph(self, warmup: int = 2):
+        """Capture ``step()`` (fused env-step launch + masked auto-reset + the few tensor ops between them) into a HIP graph.
+
+        Returns ``(graph, action, outputs)``: fill ``action`` ([num_envs, nu], in place), call ``graph.replay()``; ``outputs`` is
+        the ``(obs, reward, terminated, truncated, info)`` tuple of the captured call, whose tensors are rewritten by every
+        replay.  One replay costs one launch instead of ~10, which is what bounds small models (elbow: 0.2 ms per eager step).
+        The warm-up steps advance the envs (call ``reset()`` afterwards if that matters); host-side draws (random fatigue
+        reset) are frozen into the graph."""
+        action = torch.zeros(self.num_envs, self.cm.nu, dtype=torch.float32, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                      # first launches set kernel attributes: keep them out of the capture
+            for _ in range(max(1, warmup)):
+                self.step(action)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outputs = self.step(action)
+        return graph, action, outputs
+
     def close(self):
         pass

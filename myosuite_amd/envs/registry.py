@@ -65,8 +65,8 @@ def make(id: str, num_envs: int = 1, device=None, seed=None, **overrides):
     s = _SPECS[id]
     kw = copy.deepcopy(s["kwargs"])
     kw.update(overrides)
-    return s["entry_point"](env_id=id, num_envs=num_envs, device=device, seed=seed,
-                            max_episode_steps=s["max_episode_steps"], **kw)
+    horizon = kw.pop("max_episode_steps", s["max_episode_steps"])      # gym.make(id, max_episode_steps=...) override
+    return s["entry_point"](env_id=id, num_envs=num_envs, device=device, seed=seed, max_episode_steps=horizon, **kw)
 
 
 # ------------------------------------------------------------------ registrations

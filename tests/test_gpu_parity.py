@@ -484,3 +484,32 @@ def test_mjx_make_registry_names():
         assert st.obs["state"].shape == (8, obs)
     with pytest.raises(KeyError):
         mjx_api.make("MjxNope-v0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoElbowPose1D6MRandom-v0", "myoHandKeyTurnRandom-v0"])
+def test_hip_graph_step_replays_bitwise(env_id):
+    """env.capture_step_graph(): replaying the captured step (+ auto-reset) gives bit-identical observations, rewards and
+    flags to the eager path, including across episode boundaries."""
+    n = 64
+    outs = []
+    for graphed in (False, True):
+        env = registry.make(env_id, num_envs=n, seed=3, max_episode_steps=7)
+        a = torch.empty(n, env.cm.nu, device="cuda")
+        if graphed:
+            g, a_static, (obs, rew, term, trunc, info) = env.capture_step_graph(warmup=2)
+        else:
+            for _ in range(2):                              # the capture path runs 2 warm-up steps (capturing executes nothing)
+                env.step(torch.zeros(n, env.cm.nu, device="cuda"))
+        rec = []
+        for s in range(12):
+            E.uniform(a, 17, s)
+            if graphed:
+                a_static.copy_(a); g.replay()
+            else:
+                obs, rew, term, trunc, info = env.step(a)
+            rec.append((obs.clone(), rew.clone(), term.clone(), trunc.clone()))
+        outs.append(rec)
+    assert any(bool(t[3].any()) for t in outs[0])           # a time-limit boundary was crossed
+    for (o0, r0, t0, u0), (o1, r1, t1, u1) in zip(*outs):
+        assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(t0, t1) and torch.equal(u0, u1)
