@@ -513,3 +513,31 @@ def test_hip_graph_step_replays_bitwise(env_id):
     assert any(bool(t[3].any()) for t in outs[0])           # a time-limit boundary was crossed
     for (o0, r0, t0, u0), (o1, r1, t1, u1) in zip(*outs):
         assert torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(t0, t1) and torch.equal(u0, u1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,n_full,lanes", [("myoHandPoseRandom-v0", 4096, 32), ("myoHandReorient100-v0", 2048, 0),
+                                                 ("myoFatiLegWalk-v0", 1024, 0)])
+def test_full_size_batch_properties(env_id, n_full, lanes):
+    """BASELINE.json's per-GPU batch sizes, through size-independent properties: the trajectory of an env inside the full
+    batch is bit-identical to the same env stepped in a 48-env batch (same group width), everything stays finite and no
+    status bit (bad state / row overflow / solver cap) is raised."""
+    pick = torch.arange(0, n_full, n_full // 48, device="cuda")[:48]
+    big = registry.make(env_id, num_envs=n_full, seed=21, autoreset=False, lanes_per_env=lanes)
+    small = registry.make(env_id, num_envs=48, seed=99, autoreset=False, lanes_per_env=big.hm.info(E.INFO_LANES))
+    big.reset(seed=21)
+    st = big.get_env_state()
+    small.set_env_state({k: (v[pick].contiguous() if v is not None else None) for k, v in st.items()})
+    # per-episode task data that lives outside the physics state
+    for name in ("target_jnt_value", "target_pos", "geom_size", "geom_type", "axis_half", "des_rot", "fat_MA", "fat_MR", "fat_MF"):
+        if getattr(big, name, None) is not None and torch.is_tensor(getattr(big, name)):
+            getattr(small, name).copy_(getattr(big, name)[pick])
+    small.step_count.copy_(big.step_count[pick])
+    a = torch.empty(n_full, big.cm.nu, device="cuda")
+    for s in range(6):
+        E.uniform(a, 77, s)
+        ob, rb, tb, ub, _ = big.step(a)
+        osm, rs, ts, us, _ = small.step(a[pick].contiguous())
+        assert bool(torch.isfinite(ob).all()) and bool(torch.isfinite(rb).all())
+        assert torch.equal(ob[pick], osm) and torch.equal(rb[pick], rs) and torch.equal(tb[pick], ts)
+    assert int(big.state.status.max()) == 0
