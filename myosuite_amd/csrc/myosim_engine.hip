@@ -274,12 +274,23 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
   d.integrator = oi[MM_OI_INTEGRATOR];
   if (d.integrator != MM_INT_EULER && d.integrator != MM_INT_RK4) { delete m; return fail(MM_EUNSUPPORTED, "integrator must be Euler (0) or RK4 (1)"); }
+  d.ntlim = 0;
+  {
+    const int32_t* tlim = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_LIMITED]);
+    const float* trng = (const float*)(blob + m->sec[MM_SEC_TENDON_RANGE]);
+    const float* tmar = (const float*)(blob + m->sec[MM_SEC_TENDON_MARGIN]);
+    for (int t = 0; t < d.ntendon; t++) {
+      if (!tlim[t]) continue;
+      d.ntlim++;
+      if (trng[2 * t + 1] - trng[2 * t] < 2.f * tmar[t]) { delete m; return fail(MM_EUNSUPPORTED, "tendon range narrower than 2*margin"); }
+    }
+  }
   d.nfric = 0;
   {
     const float* fl = (const float*)(blob + m->sec[MM_SEC_DOF_FRICTIONLOSS]);
     for (int i = 0; i < d.nv; i++) if (fl[i] > 0.f) d.nfric++;
   }
-  d.gen = (d.neq > 0 || d.npair > 0 || d.nfric > 0) ? 1 : 0;
+  d.gen = (d.neq > 0 || d.npair > 0 || d.nfric > 0 || d.ntlim > 0) ? 1 : 0;
   {
     const int32_t* et = (const int32_t*)(blob + m->sec[MM_SEC_EQ_TYPE]);
     for (int e = 0; e < d.neq; e++)
@@ -297,9 +308,6 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
       if (pc[p] != 1 && pc[p] != 3) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1 or 3"); }
     }
   }
-  const int32_t* tlim = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_LIMITED]);
-  for (int t = 0; t < d.ntendon; t++)
-    if (tlim[t]) { delete m; return fail(MM_EUNSUPPORTED, "tendon limits not implemented in this build"); }
   if (d.nv > 255) { delete m; return fail(MM_EUNSUPPORTED, "nv > 255"); }
   {
     const int32_t* jlim = (const int32_t*)(blob + m->sec[MM_SEC_JNT_LIMITED]);

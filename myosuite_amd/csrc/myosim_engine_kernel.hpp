@@ -42,6 +42,7 @@ struct Dims {
   int iterations, ls_iterations, eulerdamp, any_damping;
   int gen;   // model has equality / friction-loss / contact rows: general (dense-J) constraint path
   int nfric; // dofs with frictionloss > 0 (one friction-loss row each, behind the equalities)
+  int ntlim; // limited tendons (at most one limit row each, behind the joint-limit rows)
   int integrator;   // MM_INT_EULER | MM_INT_RK4
   int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
@@ -1437,6 +1438,32 @@ struct Engine {
         RT[3 * r] = __int_as_float(MM_CON_LIMIT_JOINT | (g << 3)); RT[3 * r + 1] = ldist - lmargin; RT[3 * r + 2] = MF_(DOF_INVWEIGHT0)[ldof];
       } else over = 1;
     }
+    // ---- tendon limits, compacted behind the joint limits (MuJoCo row order); J = -+ the tendon's Jacobian row
+    int ntl = 0;
+    if (KD().ntlim) {
+      for (int t0 = 0; t0 < KD().ntendon; t0 += G) {
+        const int t = t0 + g;
+        int tl = 0;
+        float tdist = 0.f, tsign = 1.f, tmargin = 0.f;
+        if (t < KD().ntendon && MI_(TENDON_LIMITED)[t]) {
+          const float len = W[L.tenlen + t];
+          tmargin = MF_(TENDON_MARGIN)[t];
+          const float dlo = len - MF_(TENDON_RANGE)[2 * t], dhi = MF_(TENDON_RANGE)[2 * t + 1] - len;
+          tdist = dlo;
+          if (!(dlo < tmargin) && dhi < tmargin) { tdist = dhi; tsign = -1.f; }
+          tl = tdist < tmargin ? 1 : 0;
+        }
+        const int trank = gscan_excl(tl), tcnt = gsum_i(tl);
+        if (tl) {
+          const int r = neq + nfr + nlim + ntl + trank;
+          if (r < KD().efc_rows) {
+            for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) Jrow(r)[MI_(TENJ_DOF)[e]] = tsign * W[L.tenj + e];
+            RT[3 * r] = __int_as_float(MM_CON_LIMIT_TENDON | (t << 3)); RT[3 * r + 1] = tdist - tmargin; RT[3 * r + 2] = MF_(TENDON_INVWEIGHT0)[t];
+          } else over = 1;
+        }
+        ntl += tcnt;
+      }
+    }
     // ---- contacts: lane p handles explicit pair p (up to two contacts for plane-capsule)
     const unsigned long long tc0_ = a.prof ? clock64() : 0;
     int nc = 0, rowsper = 0, b1 = 0, b2 = 0;
@@ -1510,7 +1537,7 @@ struct Engine {
     if (a.prof) pf[PF_IO] += clock64() - tc0_;   // narrow phase only (reported as 'io' = collide)
     int myrows = 0;
     for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
-    int base = neq + nfr + nlim + gscan_excl(myrows);
+    int base = neq + nfr + nlim + ntl + gscan_excl(myrows);
     const int ncrows = gsum_i(myrows);
     for (int c = 0; c < 2; c++) {
       if (!(c < nc && cdist[c] < incl)) continue;
@@ -1531,7 +1558,7 @@ struct Engine {
       base += rowsper;
     }
     if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
-    nefc = neq + nfr + nlim + ncrows;
+    nefc = neq + nfr + nlim + ntl + ncrows;
     if (nefc > KD().efc_rows) nefc = KD().efc_rows;
     {
       int w = nefc;
@@ -1551,6 +1578,7 @@ struct Engine {
       const float *si, *sr;
       if (kind == MM_CON_EQUALITY) { si = MF_(EQ_SOLIMP) + 5 * id; sr = MF_(EQ_SOLREF) + 2 * id; }
       else if (kind == MM_CON_LIMIT_JOINT) { si = MF_(JNT_SOLIMP) + 5 * id; sr = MF_(JNT_SOLREF) + 2 * id; }
+      else if (kind == MM_CON_LIMIT_TENDON) { si = MF_(TENDON_SOLIMP) + 5 * id; sr = MF_(TENDON_SOLREF) + 2 * id; }
       else if (kind == MM_CON_FRICTION_DOF) { si = MF_(DOF_SOLIMP) + 5 * id; sr = MF_(DOF_SOLREF) + 2 * id; r_floss = MF_(DOF_FRICTIONLOSS)[id]; }
       else { si = MF_(PAIR_SOLIMP) + 5 * id; sr = MF_(PAIR_SOLREF) + 2 * id; }
       impedance(si, sr, x, dA, vel, r_D, r_aref);

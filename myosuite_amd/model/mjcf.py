@@ -413,8 +413,7 @@ def load(source: str, missing_include: str = "error") -> ModelSpec:
             name = a.get("name") or uname("tendon")
             rng = _floats(a.get("range"), 2)
             limited = a.get("limited", "auto")
-            if limited == "true" or (limited == "auto" and ctx.autolimits and rng is not None):
-                raise MjcfError(f"tendon limits are not implemented (tendon {name})")
+            tlim = limited == "true" or (limited == "auto" and ctx.autolimits and rng is not None)
             path = []
             if el.tag == "spatial":
                 for p in el:
@@ -434,7 +433,10 @@ def load(source: str, missing_include: str = "error") -> ModelSpec:
             sl = _floats(a.get("springlength"), None)
             sl = (-1.0, -1.0) if sl is None else ((sl[0], sl[0]) if len(sl) == 1 else (sl[0], sl[1]))
             s.add_tendon(name, path, stiffness=float(a.get("stiffness", "0")), damping=float(a.get("damping", "0")),
-                         springlength=sl)
+                         springlength=sl, limited=tlim, range=tuple(rng) if tlim else (0.0, 0.0),
+                         margin=float(a.get("margin", "0")),
+                         solref=tuple(_floats(a.get("solreflimit"), 2, list(DEFAULT_SOLREF))),
+                         solimp=tuple(_floats(a.get("solimplimit"), 5, list(DEFAULT_SOLIMP))))
 
     # ---- actuators
     for ac in root.findall("actuator"):
@@ -633,7 +635,10 @@ def dump(spec: ModelSpec) -> str:
         for t in spec.tendons:
             fixed = any(p[0] == "joint" for p in t.path)
             el = ET.SubElement(tn, "fixed" if fixed else "spatial", name=t.name, stiffness=repr(t.stiffness),
-                               damping=repr(t.damping), limited="false")
+                               damping=repr(t.damping), limited="true" if t.limited else "false")
+            if t.limited:
+                el.set("range", _f(t.range)); el.set("margin", repr(t.margin))
+                el.set("solreflimit", _f(t.solref)); el.set("solimplimit", _f(t.solimp))
             if t.springlength[0] >= 0:
                 el.set("springlength", _f(t.springlength))
             for p in t.path:

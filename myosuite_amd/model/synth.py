@@ -868,6 +868,23 @@ def make_contact_toy() -> ModelSpec:
     return s
 
 
+def make_tendon_limit_toy() -> ModelSpec:
+    """myoElbow with length limits on two of its muscle tendons (one reaches its lower, one its upper bound inside the joint
+    range) and a limited fixed tendon on the joint.  Test model for the tendon-limit constraint rows; not a reference asset."""
+    s = make_elbow()
+    s.name = "tendon_limit_toy"
+    cm = make_elbow().compile()
+    lr = cm.arrays["ACT_LENGTHRANGE"].reshape(-1, 2).astype(float)
+    tid = {t.name: i for i, t in enumerate(s.tendons)}
+    for name, lo_f, hi_f in (("TRIlong_tendon", 0.0, 0.7), ("BIClong_tendon", 0.35, 1.0)):
+        i = cm.names["actuator"][name.replace("_tendon", "")]
+        L0, L1 = lr[i]
+        t = s.tendons[tid[name]]
+        t.limited = True; t.range = (L0 + lo_f * (L1 - L0), L0 + hi_f * (L1 - L0)); t.margin = 0.001
+    s.add_tendon("flex_stop", [("joint", "r_elbow_flex", 1.0)], limited=True, range=(0.3, 1.9), solref=(0.01, 1.0))
+    return s
+
+
 def make_friction_toy() -> ModelSpec:
     """Two-link arm with dry joint friction (``frictionloss``), limits, damping and torque motors, plus a slider coupled to the
     elbow by a joint equality.  Test model for the friction-loss constraint rows (Huber cost); not a reference asset."""
@@ -920,7 +937,8 @@ def get_model(name: str) -> CompiledModel:
                 "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen,
                 "hand_hold": make_hand_hold, "elbow_exo": make_elbow_exo, "finger": make_finger,
                 "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
-                "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn}[name]()
+                "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
+                "tendon_limit_toy": make_tendon_limit_toy}[name]()
         cm = spec.compile()
         keys = getattr(spec, "keys", None)
         if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob

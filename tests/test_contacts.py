@@ -219,3 +219,42 @@ def test_friction_loss_gpu_matches_oracle(oracle_lib):
             q[e] = d.qpos; v[e] = d.qvel
     assert worst < 2e-4, worst
     assert int(st.status.max()) == 0
+
+
+@pytest.mark.gpu
+def test_tendon_limit_rows_gpu_match_oracle(oracle_lib):
+    """tendon_limit_toy (two length-limited spatial tendons + a limited fixed tendon on the elbow): teacher-forced per-substep
+    parity of the fused kernel against the oracle; all three limits become active somewhere in the sweep."""
+    import torch
+    from myosuite_amd import engine as E
+    cm = synth.get_model("tendon_limit_toy")
+    assert cm.njmax == 4 and int(cm.arrays["TENDON_LIMITED"].sum()) == 3
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    n = 32
+    rng = np.random.default_rng(6)
+    q = rng.uniform(0.0, 2.27, (n, 1)); v = rng.standard_normal((n, 1)) * 2.0
+    act = rng.random((n, cm.na))
+    st = E.BatchState(hm, n)
+    ds = [O.OracleData(om) for _ in range(n)]
+    dv = E.Derived(hm, n, ["nefc"])
+    worst, rows = 0.0, set()
+    for k in range(40):
+        ctrl = rng.random((n, cm.nu)).astype(np.float32)
+        st.qpos.copy_(torch.from_numpy(q.astype(np.float32))); st.qvel.copy_(torch.from_numpy(v.astype(np.float32)))
+        st.act.copy_(torch.from_numpy(act.astype(np.float32)))
+        c = torch.from_numpy(ctrl).cuda()
+        E.forward(hm, st, c, dv)
+        E.step(hm, st, c, 1)
+        vg = st.qvel.cpu().numpy().astype(np.float64)
+        for e, d in enumerate(ds):
+            d.qpos[:] = q[e].astype(np.float32); d.qvel[:] = v[e].astype(np.float32); d.act[:] = act[e].astype(np.float32); d.ctrl[:] = ctrl[e]
+            d.forward()
+            assert int(dv["nefc"][e]) == d.nefc
+            rows.add(d.nefc)
+            d.step(1)
+            worst = max(worst, float(np.abs(vg[e] - d.qvel).max() / max(1.0, np.abs(d.qvel).max())))
+            q[e] = d.qpos; v[e] = d.qvel; act[e] = d.act
+        if k % 10 == 9:                                  # re-spread the states over the joint range
+            q = rng.uniform(0.0, 2.27, (n, 1)); v = rng.standard_normal((n, 1)) * 2.0
+    assert worst < 2e-4, worst
+    assert max(rows) >= 2 and int(st.status.max()) == 0

@@ -10,12 +10,12 @@ from oracle import oracle as O
 
 
 @pytest.mark.parametrize("name", ["elbow", "hand", "leg", "contact_toy", "hand_reorient", "friction_toy", "hand_keyturn", "finger",
-                                  "motorfinger", "elbow_exo"])
+                                  "motorfinger", "elbow_exo", "tendon_limit_toy"])
 def test_dump_load_round_trip_is_physically_identical(oracle_lib, name):
     mk = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg, "contact_toy": synth.make_contact_toy,
           "hand_reorient": synth.make_hand_reorient, "friction_toy": synth.make_friction_toy,       # frictionloss / solreffriction
           "hand_keyturn": synth.make_hand_keyturn, "finger": synth.make_finger, "motorfinger": lambda: synth.make_finger(motor=True),
-          "elbow_exo": synth.make_elbow_exo}[name]
+          "elbow_exo": synth.make_elbow_exo, "tendon_limit_toy": synth.make_tendon_limit_toy}[name]
     spec = mk()
     cm0 = spec.compile()
     spec2 = mjcf.load(mjcf.dump(spec))
