@@ -66,7 +66,7 @@ enum { MM_GEOM_PLANE = 0, MM_GEOM_HFIELD = 1, MM_GEOM_SPHERE = 2, MM_GEOM_CAPSUL
 enum { MM_TRN_JOINT = 0, MM_TRN_TENDON = 3 };
 enum { MM_DYN_NONE = 0, MM_DYN_MUSCLE = 4 };
 enum { MM_GAIN_FIXED = 0, MM_GAIN_MUSCLE = 2 };
-enum { MM_BIAS_NONE = 0, MM_BIAS_MUSCLE = 2 };
+enum { MM_BIAS_NONE = 0, MM_BIAS_AFFINE = 1, MM_BIAS_MUSCLE = 2 };   /* affine: biasprm0 + biasprm1*length + biasprm2*velocity */
 /* equality types */
 enum { MM_EQ_JOINT = 2 };
 /* mjtIntegrator values carried in MM_OI_INTEGRATOR */

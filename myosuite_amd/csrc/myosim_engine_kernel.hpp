@@ -1189,6 +1189,8 @@ struct Engine {
       if (MI_(ACT_GAINTYPE)[u] == MM_GAIN_MUSCLE) gain = muscle_gain(len, vel, lr0, lr1, acc0, MF_(ACT_GAINPRM) + 9 * u);
       else gain = MF_(ACT_GAINPRM)[9 * u];
       if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_MUSCLE) bias = muscle_bias(len, lr0, lr1, acc0, MF_(ACT_BIASPRM) + 9 * u);
+      else if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_AFFINE)   // position / velocity servos
+        bias = MF_(ACT_BIASPRM)[9 * u] + MF_(ACT_BIASPRM)[9 * u + 1] * len + MF_(ACT_BIASPRM)[9 * u + 2] * vel;
       float f = gain * input + bias;
       if (MI_(ACT_FORCELIMITED)[u]) f = clampf(f, MF_(ACT_FORCERANGE)[2 * u], MF_(ACT_FORCERANGE)[2 * u + 1]);
       W[L.actfrc + u] = f; W[L.actlen + u] = len; W[L.actvel + u] = vel;

@@ -483,14 +483,27 @@ def load(source: str, missing_include: str = "error") -> ModelSpec:
             else:
                 if a.get("dyntype", "none") != "none":
                     raise MjcfError(f"actuator {name}: dyntype {a.get('dyntype')!r} is not implemented")
-                if el.tag == "motor" or (a.get("gaintype", "fixed") == "fixed" and a.get("biastype", "none") == "none"):
+                if el.tag == "motor" or (el.tag == "general" and a.get("gaintype", "fixed") == "fixed" and a.get("biastype", "none") == "none"):
                     gp = _floats(a.get("gainprm"), None, [1.0])
                     s.actuators.append(_Actuator(name, trn, target, float(gear), C["MM_DYN_NONE"], C["MM_GAIN_FIXED"],
                                                  C["MM_BIAS_NONE"], (1.0, 0.0, 0.0), tuple(([gp[0]] + z9)[:9]), tuple(z9),
                                                  ctrllimited, tuple(cr) if cr else (0.0, 0.0), forcelimited,
                                                  tuple(fr) if fr else (0.0, 0.0), tuple(lr) if lr else None))
-                else:
-                    raise MjcfError(f"actuator {name}: <{el.tag}> with affine bias is not implemented")
+                else:   # position / velocity shortcuts and <general biastype="affine">: fixed gain + affine bias
+                    if a.get("gaintype", "fixed") != "fixed" or a.get("biastype", "affine" if el.tag != "general" else "none") not in ("affine", "none"):
+                        raise MjcfError(f"actuator {name}: gaintype / biastype combination is not implemented")
+                    if el.tag == "position":
+                        kp = float(a.get("kp", "1")); kv = float(a.get("kv", "0"))
+                        gp, bp = [kp], [0.0, -kp, -kv]
+                    elif el.tag == "velocity":
+                        kv = float(a.get("kv", "1"))
+                        gp, bp = [kv], [0.0, 0.0, -kv]
+                    else:
+                        gp = _floats(a.get("gainprm"), None, [1.0]); bp = (_floats(a.get("biasprm"), None, [0.0]) + [0.0] * 3)[:3]
+                    s.actuators.append(_Actuator(name, trn, target, float(gear), C["MM_DYN_NONE"], C["MM_GAIN_FIXED"],
+                                                 C["MM_BIAS_AFFINE"], (1.0, 0.0, 0.0), tuple(([gp[0]] + z9)[:9]),
+                                                 tuple((list(bp) + z9)[:9]), ctrllimited, tuple(cr) if cr else (0.0, 0.0),
+                                                 forcelimited, tuple(fr) if fr else (0.0, 0.0), tuple(lr) if lr else None))
 
     # ---- equalities
     for eq in root.findall("equality"):
@@ -667,6 +680,8 @@ def dump(spec: ModelSpec) -> str:
             if a.dyntype == C["MM_DYN_MUSCLE"]:
                 at.update(dyntype="muscle", gaintype="muscle", biastype="muscle", dynprm=_f(a.dynprm), gainprm=_f(a.gainprm),
                           biasprm=_f(a.biasprm))
+            elif a.biastype == C["MM_BIAS_AFFINE"]:
+                at.update(dyntype="none", gaintype="fixed", biastype="affine", gainprm=_f(a.gainprm[:1]), biasprm=_f(a.biasprm[:3]))
             else:
                 at.update(dyntype="none", gaintype="fixed", biastype="none", gainprm=_f(a.gainprm[:1]))
             ET.SubElement(ac, "general", **at)

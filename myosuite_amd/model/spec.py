@@ -257,6 +257,22 @@ class ModelSpec:
                                         tuple(ctrlrange) if ctrlrange else (0.0, 0.0), False, (0.0, 0.0), None))
         return len(self.actuators) - 1
 
+    def add_general(self, name, joint=None, tendon=None, gear=1.0, gainprm=(1.0,), biasprm=(0.0, 0.0, 0.0), ctrlrange=None,
+                    forcerange=None) -> int:
+        """<general> / <position> / <velocity> without activation dynamics: force = gainprm0 * ctrl + biasprm0 +
+        biasprm1 * length + biasprm2 * velocity (position servo kp: gainprm0 = kp, biasprm1 = -kp; velocity servo kv:
+        gainprm0 = kv, biasprm2 = -kv)."""
+        assert (joint is None) != (tendon is None)
+        z9 = (0.0,) * 9
+        gp = (tuple(float(x) for x in gainprm) + z9)[:9]; bp = (tuple(float(x) for x in biasprm) + z9)[:9]
+        affine = any(x != 0.0 for x in bp)
+        self.actuators.append(_Actuator(name, C["MM_TRN_JOINT"] if joint is not None else C["MM_TRN_TENDON"],
+                                        joint if joint is not None else tendon, float(gear), C["MM_DYN_NONE"], C["MM_GAIN_FIXED"],
+                                        C["MM_BIAS_AFFINE"] if affine else C["MM_BIAS_NONE"], (1.0, 0.0, 0.0), gp, bp,
+                                        ctrlrange is not None, tuple(ctrlrange) if ctrlrange else (0.0, 0.0),
+                                        forcerange is not None, tuple(forcerange) if forcerange else (0.0, 0.0), None))
+        return len(self.actuators) - 1
+
     def add_equality_joint(self, joint1, joint2, polycoef, solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP):
         pc = np.zeros(5); pc[:len(polycoef)] = polycoef
         self.equalities.append(dict(j1=joint1, j2=joint2, data=pc, solref=tuple(solref), solimp=tuple(solimp)))

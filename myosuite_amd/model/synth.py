@@ -903,6 +903,9 @@ def make_friction_toy() -> ModelSpec:
     s.add_motor("m_shoulder", "shoulder", gear=4.0, ctrlrange=(-1.0, 1.0))
     s.add_motor("m_elbow", "elbow", gear=1.5, ctrlrange=(-1.0, 1.0))
     s.add_motor("m_knob", "knob_turn", gear=0.05, ctrlrange=(-1.0, 1.0))
+    # a position servo and a velocity servo (affine bias: force = kp (ctrl - q) resp. kv (ctrl - qdot))
+    s.add_general("p_elbow", joint="elbow", gainprm=(2.0,), biasprm=(0.0, -2.0, -0.05), ctrlrange=(-0.2, 2.0), forcerange=(-3.0, 3.0))
+    s.add_general("v_slider", joint="slide_z", gainprm=(0.5,), biasprm=(0.0, 0.0, -0.5), ctrlrange=(-1.0, 1.0))
     return s
 
 

@@ -916,6 +916,10 @@ static void mmo_actuation(const mmo_model* m, mmo_data* d) {
     else gain = MF(m, ACT_GAINPRM)[9 * a];
     if (MI(m, ACT_BIASTYPE)[a] == MM_BIAS_MUSCLE)
       bias = muscle_bias(d->actuator_length[a], lr, MF(m, ACT_ACC0)[a], MF(m, ACT_BIASPRM) + 9 * a);
+    else if (MI(m, ACT_BIASTYPE)[a] == MM_BIAS_AFFINE) {   /* position / velocity servos: mjBIAS_AFFINE */
+      const real* bp = MF(m, ACT_BIASPRM) + 9 * a;
+      bias = bp[0] + bp[1] * d->actuator_length[a] + bp[2] * d->actuator_velocity[a];
+    }
     real f = gain * input + bias;
     if (MI(m, ACT_FORCELIMITED)[a]) {
       real lo = MF(m, ACT_FORCERANGE)[2 * a], hi = MF(m, ACT_FORCERANGE)[2 * a + 1];

@@ -127,3 +127,31 @@ def test_reference_task_xml_parses_up_to_the_missing_submodule():
     # euler="0 1.27 0": without the (missing) asset include that sets the compiler angle, MJCF's default unit is degrees
     h = math.radians(1.27) / 2
     np.testing.assert_allclose(s.bodies[s._bname["Object"]].quat, [math.cos(h), 0, math.sin(h), 0], atol=1e-12)
+
+
+def test_position_and_velocity_servos_import(oracle_lib):
+    """<position kp kv> / <velocity kv> / <general biastype="affine">: fixed gain + affine bias (force = kp (ctrl - q) - kv qdot)."""
+    xml = """
+<mujoco model="servo">
+  <option timestep="0.002"/>
+  <worldbody>
+    <body name="arm" pos="0 0 1">
+      <inertial pos="0.1 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+      <joint name="j" type="hinge" axis="0 1 0" damping="0.1"/>
+    </body>
+  </worldbody>
+  <actuator>
+    <position name="p" joint="j" kp="5" kv="0.5" ctrlrange="-1 1"/>
+    <velocity name="v" joint="j" kv="0.3"/>
+    <general name="g" joint="j" gainprm="2" biastype="affine" biasprm="0.1 -2 0"/>
+  </actuator>
+</mujoco>"""
+    cm = mjcf.load(xml).compile()
+    assert cm.nu == 3 and cm.na == 0
+    d = O.OracleData(O.OracleModel(cm)); d.reset()
+    d.qpos[0] = 0.3; d.qvel[0] = -0.4; d.ctrl[:] = [0.5, 0.2, 1.0]
+    d.forward()
+    f = d.actuator_force
+    np.testing.assert_allclose(f, [5 * (0.5 - 0.3) - 0.5 * (-0.4), 0.3 * (0.2 + 0.4), 2 * 1.0 + 0.1 - 2 * 0.3], rtol=1e-6)
+    spec2 = mjcf.load(mjcf.dump(mjcf.load(xml)))
+    assert np.array_equal(spec2.compile().blob, cm.blob)
