@@ -64,7 +64,7 @@ enum { MM_GEOM_PLANE = 0, MM_GEOM_HFIELD = 1, MM_GEOM_SPHERE = 2, MM_GEOM_CAPSUL
        MM_GEOM_ELLIPSOID = 4, MM_GEOM_CYLINDER = 5, MM_GEOM_BOX = 6 };
 /* actuator enums */
 enum { MM_TRN_JOINT = 0, MM_TRN_TENDON = 3 };
-enum { MM_DYN_NONE = 0, MM_DYN_MUSCLE = 4 };
+enum { MM_DYN_NONE = 0, MM_DYN_INTEGRATOR = 1, MM_DYN_FILTER = 2, MM_DYN_MUSCLE = 4 };   /* mjtDyn; filter: act_dot = (ctrl - act) / dynprm0 */
 enum { MM_GAIN_FIXED = 0, MM_GAIN_MUSCLE = 2 };
 enum { MM_BIAS_NONE = 0, MM_BIAS_AFFINE = 1, MM_BIAS_MUSCLE = 2 };   /* affine: biasprm0 + biasprm1*length + biasprm2*velocity */
 /* equality types */

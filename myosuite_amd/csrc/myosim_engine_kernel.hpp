@@ -1183,6 +1183,11 @@ struct Engine {
         float act = W[L.act + aa];
         W[L.actdot + aa] = muscle_dynamics(ctrl, act, MF_(ACT_DYNPRM) + 3 * u);
         input = act;
+      } else if (MI_(ACT_DYNTYPE)[u] == MM_DYN_INTEGRATOR) {
+        W[L.actdot + aa] = ctrl; input = W[L.act + aa];
+      } else if (MI_(ACT_DYNTYPE)[u] == MM_DYN_FILTER) {
+        const float act = W[L.act + aa];
+        W[L.actdot + aa] = (ctrl - act) / fmaxf(MINVALF, MF_(ACT_DYNPRM)[3 * u]); input = act;
       }
       float lr0 = MF_(ACT_LENGTHRANGE)[2 * u], lr1 = MF_(ACT_LENGTHRANGE)[2 * u + 1], acc0 = MF_(ACT_ACC0)[u];
       float gain, bias = 0.f;

@@ -481,12 +481,15 @@ def load(source: str, missing_include: str = "error") -> ModelSpec:
                                              tuple(cr) if cr else (0.0, 0.0), forcelimited, tuple(fr) if fr else (0.0, 0.0),
                                              tuple(lr) if lr else None))
             else:
-                if a.get("dyntype", "none") != "none":
-                    raise MjcfError(f"actuator {name}: dyntype {a.get('dyntype')!r} is not implemented")
+                dyn_name = a.get("dyntype", "none")
+                if dyn_name not in ("none", "integrator", "filter"):
+                    raise MjcfError(f"actuator {name}: dyntype {dyn_name!r} is not implemented")
+                dynt = {"none": C["MM_DYN_NONE"], "integrator": C["MM_DYN_INTEGRATOR"], "filter": C["MM_DYN_FILTER"]}[dyn_name]
+                dynp = tuple((_floats(a.get("dynprm"), None, [1.0, 0.0, 0.0]) + [0.0, 0.0])[:3])
                 if el.tag == "motor" or (el.tag == "general" and a.get("gaintype", "fixed") == "fixed" and a.get("biastype", "none") == "none"):
                     gp = _floats(a.get("gainprm"), None, [1.0])
-                    s.actuators.append(_Actuator(name, trn, target, float(gear), C["MM_DYN_NONE"], C["MM_GAIN_FIXED"],
-                                                 C["MM_BIAS_NONE"], (1.0, 0.0, 0.0), tuple(([gp[0]] + z9)[:9]), tuple(z9),
+                    s.actuators.append(_Actuator(name, trn, target, float(gear), dynt, C["MM_GAIN_FIXED"],
+                                                 C["MM_BIAS_NONE"], dynp, tuple(([gp[0]] + z9)[:9]), tuple(z9),
                                                  ctrllimited, tuple(cr) if cr else (0.0, 0.0), forcelimited,
                                                  tuple(fr) if fr else (0.0, 0.0), tuple(lr) if lr else None))
                 else:   # position / velocity shortcuts and <general biastype="affine">: fixed gain + affine bias
@@ -500,8 +503,8 @@ def load(source: str, missing_include: str = "error") -> ModelSpec:
                         gp, bp = [kv], [0.0, 0.0, -kv]
                     else:
                         gp = _floats(a.get("gainprm"), None, [1.0]); bp = (_floats(a.get("biasprm"), None, [0.0]) + [0.0] * 3)[:3]
-                    s.actuators.append(_Actuator(name, trn, target, float(gear), C["MM_DYN_NONE"], C["MM_GAIN_FIXED"],
-                                                 C["MM_BIAS_AFFINE"], (1.0, 0.0, 0.0), tuple(([gp[0]] + z9)[:9]),
+                    s.actuators.append(_Actuator(name, trn, target, float(gear), dynt, C["MM_GAIN_FIXED"],
+                                                 C["MM_BIAS_AFFINE"], dynp, tuple(([gp[0]] + z9)[:9]),
                                                  tuple((list(bp) + z9)[:9]), ctrllimited, tuple(cr) if cr else (0.0, 0.0),
                                                  forcelimited, tuple(fr) if fr else (0.0, 0.0), tuple(lr) if lr else None))
 
@@ -680,10 +683,13 @@ def dump(spec: ModelSpec) -> str:
             if a.dyntype == C["MM_DYN_MUSCLE"]:
                 at.update(dyntype="muscle", gaintype="muscle", biastype="muscle", dynprm=_f(a.dynprm), gainprm=_f(a.gainprm),
                           biasprm=_f(a.biasprm))
-            elif a.biastype == C["MM_BIAS_AFFINE"]:
-                at.update(dyntype="none", gaintype="fixed", biastype="affine", gainprm=_f(a.gainprm[:1]), biasprm=_f(a.biasprm[:3]))
             else:
-                at.update(dyntype="none", gaintype="fixed", biastype="none", gainprm=_f(a.gainprm[:1]))
+                dn = {C["MM_DYN_NONE"]: "none", C["MM_DYN_INTEGRATOR"]: "integrator", C["MM_DYN_FILTER"]: "filter"}[a.dyntype]
+                at.update(dyntype=dn, gaintype="fixed", gainprm=_f(a.gainprm[:1]), dynprm=_f(a.dynprm))
+                if a.biastype == C["MM_BIAS_AFFINE"]:
+                    at.update(biastype="affine", biasprm=_f(a.biasprm[:3]))
+                else:
+                    at.update(biastype="none")
             ET.SubElement(ac, "general", **at)
     if spec.equalities:
         eq = ET.SubElement(root, "equality")

@@ -258,7 +258,7 @@ class ModelSpec:
         return len(self.actuators) - 1
 
     def add_general(self, name, joint=None, tendon=None, gear=1.0, gainprm=(1.0,), biasprm=(0.0, 0.0, 0.0), ctrlrange=None,
-                    forcerange=None) -> int:
+                    forcerange=None, dyntype="none", dynprm=(1.0, 0.0, 0.0)) -> int:
         """<general> / <position> / <velocity> without activation dynamics: force = gainprm0 * ctrl + biasprm0 +
         biasprm1 * length + biasprm2 * velocity (position servo kp: gainprm0 = kp, biasprm1 = -kp; velocity servo kv:
         gainprm0 = kv, biasprm2 = -kv)."""
@@ -267,8 +267,10 @@ class ModelSpec:
         gp = (tuple(float(x) for x in gainprm) + z9)[:9]; bp = (tuple(float(x) for x in biasprm) + z9)[:9]
         affine = any(x != 0.0 for x in bp)
         self.actuators.append(_Actuator(name, C["MM_TRN_JOINT"] if joint is not None else C["MM_TRN_TENDON"],
-                                        joint if joint is not None else tendon, float(gear), C["MM_DYN_NONE"], C["MM_GAIN_FIXED"],
-                                        C["MM_BIAS_AFFINE"] if affine else C["MM_BIAS_NONE"], (1.0, 0.0, 0.0), gp, bp,
+                                        joint if joint is not None else tendon, float(gear),
+                                        {"none": C["MM_DYN_NONE"], "integrator": C["MM_DYN_INTEGRATOR"], "filter": C["MM_DYN_FILTER"]}[dyntype],
+                                        C["MM_GAIN_FIXED"], C["MM_BIAS_AFFINE"] if affine else C["MM_BIAS_NONE"],
+                                        (tuple(float(x) for x in dynprm) + (0.0, 0.0))[:3], gp, bp,
                                         ctrlrange is not None, tuple(ctrlrange) if ctrlrange else (0.0, 0.0),
                                         forcerange is not None, tuple(forcerange) if forcerange else (0.0, 0.0), None))
         return len(self.actuators) - 1

@@ -906,6 +906,9 @@ def make_friction_toy() -> ModelSpec:
     # a position servo and a velocity servo (affine bias: force = kp (ctrl - q) resp. kv (ctrl - qdot))
     s.add_general("p_elbow", joint="elbow", gainprm=(2.0,), biasprm=(0.0, -2.0, -0.05), ctrlrange=(-0.2, 2.0), forcerange=(-3.0, 3.0))
     s.add_general("v_slider", joint="slide_z", gainprm=(0.5,), biasprm=(0.0, 0.0, -0.5), ctrlrange=(-1.0, 1.0))
+    # activation states without muscle dynamics: first-order filter and integrator
+    s.add_general("f_shoulder", joint="shoulder", gainprm=(1.5,), ctrlrange=(-1.0, 1.0), dyntype="filter", dynprm=(0.03,))
+    s.add_general("i_knob", joint="knob_turn", gainprm=(0.01,), ctrlrange=(-1.0, 1.0), dyntype="integrator")
     return s
 
 

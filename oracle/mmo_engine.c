@@ -907,6 +907,10 @@ static void mmo_actuation(const mmo_model* m, mmo_data* d) {
     if (MI(m, ACT_DYNTYPE)[a] == MM_DYN_MUSCLE) {
       d->act_dot[aa] = muscle_dynamics(ctrl, d->act[aa], MF(m, ACT_DYNPRM) + 3 * a);
       input = d->act[aa];
+    } else if (MI(m, ACT_DYNTYPE)[a] == MM_DYN_INTEGRATOR) {
+      d->act_dot[aa] = ctrl; input = d->act[aa];
+    } else if (MI(m, ACT_DYNTYPE)[a] == MM_DYN_FILTER) {
+      d->act_dot[aa] = (ctrl - d->act[aa]) / fmax(MINVAL, MF(m, ACT_DYNPRM)[3 * a]); input = d->act[aa];
     }
     real gain, bias = 0;
     const real* lr = MF(m, ACT_LENGTHRANGE) + 2 * a;

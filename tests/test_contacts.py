@@ -219,6 +219,10 @@ def test_friction_loss_gpu_matches_oracle(oracle_lib):
             q[e] = d.qpos; v[e] = d.qvel
     assert worst < 2e-4, worst
     assert int(st.status.max()) == 0
+    # activation states of the filter / integrator actuators ran free on both sides for 60 steps
+    assert cm.na == 2
+    np.testing.assert_allclose(st.act.cpu().numpy(), np.array([d.act for d in ds]), rtol=0, atol=2e-5)
+    assert float(np.abs(st.act.cpu().numpy()).max()) > 1e-3
 
 
 @pytest.mark.gpu

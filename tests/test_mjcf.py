@@ -144,14 +144,19 @@ def test_position_and_velocity_servos_import(oracle_lib):
     <position name="p" joint="j" kp="5" kv="0.5" ctrlrange="-1 1"/>
     <velocity name="v" joint="j" kv="0.3"/>
     <general name="g" joint="j" gainprm="2" biastype="affine" biasprm="0.1 -2 0"/>
+    <general name="f" joint="j" gainprm="3" dyntype="filter" dynprm="0.05"/>
+    <general name="i" joint="j" gainprm="1" dyntype="integrator"/>
   </actuator>
 </mujoco>"""
     cm = mjcf.load(xml).compile()
-    assert cm.nu == 3 and cm.na == 0
+    assert cm.nu == 5 and cm.na == 2
     d = O.OracleData(O.OracleModel(cm)); d.reset()
-    d.qpos[0] = 0.3; d.qvel[0] = -0.4; d.ctrl[:] = [0.5, 0.2, 1.0]
+    d.qpos[0] = 0.3; d.qvel[0] = -0.4; d.ctrl[:] = [0.5, 0.2, 1.0, 0.8, -0.5]; d.act[:] = [0.2, 0.1]
     d.forward()
     f = d.actuator_force
-    np.testing.assert_allclose(f, [5 * (0.5 - 0.3) - 0.5 * (-0.4), 0.3 * (0.2 + 0.4), 2 * 1.0 + 0.1 - 2 * 0.3], rtol=1e-6)
+    np.testing.assert_allclose(f, [5 * (0.5 - 0.3) - 0.5 * (-0.4), 0.3 * (0.2 + 0.4), 2 * 1.0 + 0.1 - 2 * 0.3, 3 * 0.2, 1 * 0.1], rtol=1e-6)
+    np.testing.assert_allclose(d.act_dot, [(0.8 - 0.2) / 0.05, -0.5], rtol=1e-6)      # first-order filter, integrator
+    d.step(1)
+    np.testing.assert_allclose(d.act, [0.2 + 0.002 * 12.0, 0.1 - 0.002 * 0.5], rtol=1e-6)
     spec2 = mjcf.load(mjcf.dump(mjcf.load(xml)))
     assert np.array_equal(spec2.compile().blob, cm.blob)
