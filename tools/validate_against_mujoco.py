@@ -1,7 +1,7 @@
 """Pin the engine against libmujoco where it is available (NOT runnable in the authoring container or on
 the GPU boxes of this project: `mujoco` is not installed and there is no network).
 
-    python tools/validate_against_mujoco.py [--model hand|elbow|leg|contact_toy|hand_reorient | --xml path.xml] [--steps 200] [--gpu]
+    python tools/validate_against_mujoco.py [--model hand|elbow|leg|contact_toy|hand_reorient|hand_keyturn|friction_toy|tendon_limit_toy|finger|torso|... | --xml path.xml] [--steps 200] [--gpu]
 
 1. writes the model as MJCF (`myosuite_amd.model.mjcf.dump`) or takes an MJCF file (e.g. the real myo_sim models) and imports it
    with `mjcf.load`;
@@ -41,7 +41,10 @@ def main():
         spec = mjcf.load(path)
     else:
         spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg, "contact_toy": synth.make_contact_toy,
-                "hand_reorient": synth.make_hand_reorient}[args.model]()
+                "hand_reorient": synth.make_hand_reorient, "hand_pen": synth.make_hand_pen, "hand_hold": synth.make_hand_hold,
+                "hand_keyturn": synth.make_hand_keyturn, "friction_toy": synth.make_friction_toy,
+                "tendon_limit_toy": synth.make_tendon_limit_toy, "finger": synth.make_finger, "torso": synth.make_torso,
+                "elbow_exo": synth.make_elbow_exo}[args.model]()
         path = os.path.join(tempfile.mkdtemp(), f"{args.model}.xml")
         open(path, "w").write(mjcf.dump(spec))
     cm = spec.compile()
