@@ -656,54 +656,103 @@ struct Engine {
       for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
     }
     GSYNC();
-    for (int lv = 1; lv <= KD().nlevel; lv++) {
-      if (b_depth == lv) {
-        const int b = g, p = b_parent;
-        M3 pm = ldm(W + L.xmat + 9 * p);
-        const V3 bp = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(MF_(BODY_POS) + 3 * b);
-        V3 pos = ld3(W + L.xpos + 3 * p) + mv(pm, bp);
-        Q4 quat = qmul(ldq(W + L.u1 + 4 * p), ldq(MF_(BODY_QUAT) + 4 * b));
-        for (int i = 0; i < c_jn; i++) {
-          const int j = c_ja + i;
-          int type, qa; V3 jpos, jax; float q0;
-          if (i < 2) { type = c_jtype[i & 1]; qa = c_jqadr[i & 1]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
-          else { type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
-          if (type == MM_JNT_FREE) {
-            pos = ld3(W + L.qpos + qa);
-            quat = qnorm(ldq(W + L.qpos + qa + 3));
-            st3(W + L.xanchor + 3 * j, pos);
-            M3 m = q2m(quat);
-            st3(W + L.xaxis + 3 * j, v3(m.m[2], m.m[5], m.m[8]));
-            continue;
-          }
+    // Phase A (all bodies at once): transform of every body in its PARENT's frame, its joints applied; joint anchors / axes
+    // are left in LDS in that frame.  Phase B: pointer jumping -- every body composes its transform with the one of the
+    // ancestor it currently points at and then points at that ancestor's target: ceil(log2(depth)) rounds instead of one
+    // round per tree level (4 instead of 9 for the hand).  Phase C: world anchors / axes from the parent's final frame.
+    const int nb = KD().nbody;
+    const bool isb = g > 0 && g < nb;
+    V3 tp = v3(0.f, 0.f, 0.f);
+    Q4 tq = {1.f, 0.f, 0.f, 0.f};
+    if (isb) {
+      const int b = g;
+      V3 pos = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(MF_(BODY_POS) + 3 * b);
+      Q4 quat = ldq(MF_(BODY_QUAT) + 4 * b);
+      for (int i = 0; i < c_jn; i++) {
+        const int j = c_ja + i;
+        int type, qa; V3 jpos, jax; float q0;
+        if (i < 2) { type = c_jtype[i & 1]; qa = c_jqadr[i & 1]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
+        else { type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
+        if (type == MM_JNT_FREE) {      // child of the world: its frame is the world frame
+          pos = ld3(W + L.qpos + qa);
+          quat = qnorm(ldq(W + L.qpos + qa + 3));
+          st3(W + L.xanchor + 3 * j, pos);
           M3 m = q2m(quat);
-          V3 anchor = pos + mv(m, jpos), axis = mv(m, jax);
-          st3(W + L.xanchor + 3 * j, anchor);
-          st3(W + L.xaxis + 3 * j, axis);
-          if (type == MM_JNT_SLIDE) {
-            pos = pos + (W[L.qpos + qa] - q0) * axis;
-          } else if (type == MM_JNT_HINGE) {
-            float ang = W[L.qpos + qa] - q0;
-            float sn, cs;
-            sincos_small(0.5f * ang, &sn, &cs);
-            Q4 ql = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
-            quat = qmul(quat, ql);
-            pos = anchor - mv(q2m(quat), jpos);
-          } else {  // ball
-            quat = qmul(quat, qnorm(ldq(W + L.qpos + qa)));
-            pos = anchor - mv(q2m(quat), jpos);
-          }
+          st3(W + L.xaxis + 3 * j, v3(m.m[2], m.m[5], m.m[8]));
+          continue;
         }
-        quat = qnorm(quat);
         M3 m = q2m(quat);
-        b_xpos = pos; b_xquat = quat;
-        st3(W + L.xpos + 3 * b, pos);
-        W[L.u1 + 4 * b] = quat.w; W[L.u1 + 4 * b + 1] = quat.x; W[L.u1 + 4 * b + 2] = quat.y; W[L.u1 + 4 * b + 3] = quat.z;
-        for (int k = 0; k < 9; k++) W[L.xmat + 9 * b + k] = m.m[k];
-        b_xipos = pos + mv(m, ld3(MF_(BODY_IPOS) + 3 * b));
+        V3 anchor = pos + mv(m, jpos), axis = mv(m, jax);
+        st3(W + L.xanchor + 3 * j, anchor);
+        st3(W + L.xaxis + 3 * j, axis);
+        if (type == MM_JNT_SLIDE) {
+          pos = pos + (W[L.qpos + qa] - q0) * axis;
+        } else if (type == MM_JNT_HINGE) {
+          float ang = W[L.qpos + qa] - q0;
+          float sn, cs;
+          sincos_small(0.5f * ang, &sn, &cs);
+          Q4 ql = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
+          quat = qmul(quat, ql);
+          pos = anchor - mv(q2m(quat), jpos);
+        } else {  // ball
+          quat = qmul(quat, qnorm(ldq(W + L.qpos + qa)));
+          pos = anchor - mv(q2m(quat), jpos);
+        }
+      }
+      tp = pos; tq = qnorm(quat);
+    }
+    int up = isb ? b_parent : 0;
+    int* UP = reinterpret_cast<int*>(W + L.xmat);     // scratch: xmat is written last
+    int nround = 0;
+    for (int s_ = 1; s_ < KD().nlevel; s_ <<= 1) nround++;
+    for (int r = 0; r < nround; r++) {
+      if (g < nb) {
+        st3(W + L.xpos + 3 * g, tp);
+        W[L.u1 + 4 * g] = tq.w; W[L.u1 + 4 * g + 1] = tq.x; W[L.u1 + 4 * g + 2] = tq.y; W[L.u1 + 4 * g + 3] = tq.z;
+        UP[g] = up;
+      }
+      GSYNC();
+      if (up > 0) {
+        const V3 pp = ld3(W + L.xpos + 3 * up);
+        const Q4 pq = ldq(W + L.u1 + 4 * up);
+        const int uu = UP[up];
+        tp = pp + mv(q2m(pq), tp);
+        tq = qmul(pq, tq);
+        up = uu;
       }
       GSYNC();
     }
+    // final frames
+    if (isb) {
+      tq = qnorm(tq);
+      st3(W + L.xpos + 3 * g, tp);
+      W[L.u1 + 4 * g] = tq.w; W[L.u1 + 4 * g + 1] = tq.x; W[L.u1 + 4 * g + 2] = tq.y; W[L.u1 + 4 * g + 3] = tq.z;
+      b_xpos = tp; b_xquat = tq;
+    }
+    GSYNC();
+    if (isb) {
+      const M3 m = q2m(tq);
+      b_xipos = tp + mv(m, ld3(MF_(BODY_IPOS) + 3 * g));
+      // joint anchors / axes: parent frame -> world (a free joint's parent is the world: nothing to do)
+      const int p = b_parent;
+      if (p > 0) {
+        const V3 pp = ld3(W + L.xpos + 3 * p);
+        const M3 pm = q2m(ldq(W + L.u1 + 4 * p));
+        for (int i = 0; i < c_jn; i++) {
+          const int j = c_ja + i;
+          st3(W + L.xanchor + 3 * j, pp + mv(pm, ld3(W + L.xanchor + 3 * j)));
+          st3(W + L.xaxis + 3 * j, mv(pm, ld3(W + L.xaxis + 3 * j)));
+        }
+      }
+    }
+    GSYNC();   // UP scratch (xmat region) is dead for everybody: write the rotation matrices
+    if (g == 0)
+      for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+    if (isb) {
+      const M3 m = q2m(tq);
+      for (int k = 0; k < 9; k++) W[L.xmat + 9 * g + k] = m.m[k];
+    }
+    GSYNC();
   }
 
   __device__ __forceinline__ V3 site_pos(int s) const {
