@@ -217,7 +217,7 @@ static void build_layout(mm_model* m) {
   L.xpos = take(3 * d.nbody); L.xmat = take(9 * d.nbody);
   L.com = take(3 * m->x.nroot); L.cdof = take(6 * d.nv);
   o = (o + 3) & ~3;
-  L.u1 = take(std::max(12 * d.nbody, m->nvp * m->nvp));
+  L.u1 = take(std::max(13 * d.nbody, m->nvp * m->nvp));   // 12 words (cvel, cacc) + 1 pointer-jumping word per body | dense tile
   L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
   L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);

@@ -980,54 +980,104 @@ struct Engine {
       for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) s += W[L.tenj + e] * W[L.qvel + MI_(TENJ_DOF)[e]];
       W[L.tenvel + t] = s;
     }
-    // forward pass over tree levels; parent values come straight from the parent's lane
+    // Forward pass by pointer jumping (see kinematics): cvel of a body is the SUM of cdof * qvel over the dofs of its
+    // ancestors and itself (everything is expressed about the subtree COM: no frame change along the chain), so it is a
+    // prefix sum over the chain: ceil(log2(depth)) rounds of "add what my pointer holds, point where it points".  The bias
+    // acceleration cacc is the same kind of sum of (cvel before the dof) x cdof * qvel, plus -gravity at the root, and is
+    // summed the same way once cvel is final.
     float cv[6], ca[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) { cv[k] = 0.f; ca[k] = 0.f; }
-    // parents publish (cvel, cacc) in LDS (u1 region, 12 words per body: three 128-bit accesses instead of twelve
-    // cross-lane permutes per level)
-    if (g == 0) {
-      ca[3] = -KD().gx; ca[4] = -KD().gy; ca[5] = -KD().gz;
+    const bool isb = g > 0 && g < nb;
+    int nround = 0;
+    for (int s_ = 1; s_ < KD().nlevel; s_ <<= 1) nround++;
+    int* UP = reinterpret_cast<int*>(W + L.u1 + 12 * nb);   // pointer scratch behind the (cvel, cacc) slots: u1 holds >= 13 nbody words
+    if (isb) {      // own dofs: local velocity contribution
+      for (int i = 0; i < c_jn; i++) {
+        int type, da;
+        if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
+        else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
+        else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
+        const int nd = type == MM_JNT_FREE ? 6 : (type == MM_JNT_BALL ? 3 : 1);
+        for (int d3 = 0; d3 < nd; d3++) {
+          const float qv = W[L.qvel + da + d3];
 #pragma unroll
-      for (int k = 0; k < 6; k++) { W[L.u1 + k] = 0.f; W[L.u1 + 6 + k] = ca[k]; }
-    }
-    GSYNC();
-    for (int lv = 1; lv <= KD().nlevel; lv++) {
-      if (b_depth == lv) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) { cv[k] = W[L.u1 + 12 * b_parent + k]; ca[k] = W[L.u1 + 12 * b_parent + 6 + k]; }
-        for (int i = 0; i < c_jn; i++) {
-          int type, da;
-          if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
-          else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
-          else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
-          if (type == MM_JNT_FREE) {
-            for (int d3 = 0; d3 < 3; d3++) {
-              float qv = W[L.qvel + da + d3];
-              for (int k = 0; k < 6; k++) cv[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
-            }
-            da += 3;
-            type = MM_JNT_BALL;
-          }
-          int nd = type == MM_JNT_BALL ? 3 : 1;
-          float base[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) base[k] = cv[k];
-          for (int d3 = 0; d3 < nd; d3++) {
-            float cd[6], cdd[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) cd[k] = W[L.cdof + 6 * (da + d3) + k];
-            cross_motion(cdd, base, cd);
-            float qv = W[L.qvel + da + d3];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { cv[k] += cd[k] * qv; ca[k] += cdd[k] * qv; }
-          }
+          for (int k = 0; k < 6; k++) cv[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
         }
-#pragma unroll
-        for (int k = 0; k < 6; k++) { W[L.u1 + 12 * g + k] = cv[k]; W[L.u1 + 12 * g + 6 + k] = ca[k]; }
       }
-      GSYNC();
     }
+    float own[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) own[k] = cv[k];
+    {
+      int up = isb ? b_parent : 0;
+      for (int r = 0; r < nround; r++) {
+        if (g < nb) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) W[L.u1 + 12 * g + k] = cv[k];
+          UP[g] = up;
+        }
+        GSYNC();
+        if (up > 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) cv[k] += W[L.u1 + 12 * up + k];
+          up = UP[up];
+        }
+        GSYNC();
+      }
+    }
+    // local acceleration contribution: walk the own dofs again with the running velocity (parent's cvel first)
+    if (isb) {
+      float run[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) run[k] = cv[k] - own[k];
+      for (int i = 0; i < c_jn; i++) {
+        int type, da;
+        if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
+        else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
+        else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
+        if (type == MM_JNT_FREE) {     // translational dofs: cdof_dot = 0, they only move the running velocity
+          for (int d3 = 0; d3 < 3; d3++) {
+            const float qv = W[L.qvel + da + d3];
+#pragma unroll
+            for (int k = 0; k < 6; k++) run[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
+          }
+          da += 3;
+          type = MM_JNT_BALL;
+        }
+        const int nd = type == MM_JNT_BALL ? 3 : 1;
+        float base[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) base[k] = run[k];
+        for (int d3 = 0; d3 < nd; d3++) {
+          float cd[6], cdd[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) cd[k] = W[L.cdof + 6 * (da + d3) + k];
+          cross_motion(cdd, base, cd);
+          const float qv = W[L.qvel + da + d3];
+#pragma unroll
+          for (int k = 0; k < 6; k++) { run[k] += cd[k] * qv; ca[k] += cdd[k] * qv; }
+        }
+      }
+    }
+    {
+      int up = isb ? b_parent : 0;
+      for (int r = 0; r < nround; r++) {
+        if (g < nb) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) W[L.u1 + 12 * g + 6 + k] = ca[k];
+          UP[g] = up;
+        }
+        GSYNC();
+        if (up > 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) ca[k] += W[L.u1 + 12 * up + 6 + k];
+          up = UP[up];
+        }
+        GSYNC();
+      }
+    }
+    if (g < nb) { ca[3] -= KD().gx; ca[4] -= KD().gy; ca[5] -= KD().gz; }   // the world body's cacc = -gravity reaches everybody
 #pragma unroll
     for (int k = 0; k < 6; k++) b_cvel[k] = cv[k];
     // cfrc_body = I*cacc + cvel x* (I*cvel)
