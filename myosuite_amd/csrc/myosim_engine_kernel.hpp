@@ -1166,12 +1166,14 @@ struct Engine {
   // (instruction-level parallelism) instead of one serial dot-product chain per column.
   // Leaves Lrow (L[g][k]) and d_dinv (1/L[g][g]) in registers and L in the LDS tile (for the L' solve).
   __device__ __forceinline__ void factor(float dadd) {
+    if constexpr (G < 64 && NVP >= 8) { factor_core<true>(Mrow, dadd); return; }   // left-looking: reads M[g][j] once, no copy
     float A[NVP];
 #pragma unroll
     for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == g ? dadd : 0.f);
-    factor_core(A);
+    factor_core<false>(A, 0.f);
   }
-  __device__ __forceinline__ void factor_core(float (&A)[NVP]) {
+  template <bool DIAG>
+  __device__ __forceinline__ void factor_core(float (&A)[NVP], float dadd = 0.f) {
     ConstLayout& L = KL();
     if constexpr (G < 64 && NVP >= 8) {
       // Left-looking form for groups narrower than the wave.  A cross-lane broadcast costs ~5 issue slots there (two
@@ -1183,6 +1185,7 @@ struct Engine {
 #pragma unroll
       for (int j = 0; j < NVP; j++) {
         float s = A[j];
+        if constexpr (DIAG) s += (g == j) ? dadd : 0.f;
 #pragma unroll
         for (int k4 = 0; k4 < (j + 3) / 4; k4++) {
           const float4 r = *reinterpret_cast<const float4*>(T + j * NVP + 4 * k4);
@@ -1787,7 +1790,7 @@ struct Engine {
           }
         }
       }
-      factor_core(A);
+      factor_core<false>(A);
       float search = -solve(grad);
       if (g >= nv || done) search = 0.f;
       float sn = sqrtf(gsum<G>(search * search));
