@@ -97,7 +97,8 @@ def main():
     env = registry.make(args.env, num_envs=n, seed=1000 * rank, lanes_per_env=args.lanes)
     cm = env.cm
     act = torch.empty(n, cm.nu, device="cuda")
-    ep_ret = torch.zeros(n, device="cuda"); ep_len = torch.zeros(n, device="cuda"); solved = torch.zeros(n, device="cuda")
+    ep_stats = torch.zeros(n, 3, device="cuda")        # (episode return, length, solved) per env
+    need = torch.zeros(n, dtype=torch.uint8, device="cuda")
     dense_col = env.rwd.shape[1] - 1     # reward rows end with ..., sparse, solved, done, dense (MM_RWD_* / MM_RWDW_*)
 
     def one_step(s, ev=None):
@@ -108,9 +109,7 @@ def main():
         if ev is not None:
             ev[1].record()
         # episode statistics + masked auto-reset (device side, no host sync)
-        r = env.rwd[:, dense_col]
-        ep_ret.add_(r); ep_len.add_(1); solved.copy_(torch.maximum(solved, env.rwd[:, dense_col - 2]))
-        need = env.done | env.truncated
+        E.episode_stats(ep_stats, need, env.rwd, dense_col, dense_col - 2, env.done, env.truncated)
         env.reset(mask=need)
 
     for s in range(args.warmup):
@@ -122,7 +121,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(args.warmup + s, evs[s])
-    stats = D.gather_episode_stats(torch.stack([ep_ret, ep_len, solved], dim=1))   # the one collective of a rollout
+    stats = D.gather_episode_stats(ep_stats)   # the one collective of a rollout
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0

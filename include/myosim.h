@@ -265,6 +265,11 @@ int  mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask,
  * same episode (which increments episode[e]).  base may be NULL (= 0). */
 int  mm_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi, const uint8_t* mask,
                  const int32_t* episode, uint64_t seed, uint32_t stream_id, void* stream);
+/* Rollout bookkeeping in one launch (what a gym vector wrapper's RecordEpisodeStatistics + autoreset mask do with a handful
+ * of elementwise ops): stats[e] = {return += rwd[e][dense_col], length += 1, solved = max(solved, rwd[e][solved_col])},
+ * reset_mask[e] = done[e] | truncated[e].  stats is [nenv][3] float32, rwd has row stride rwd_cols. */
+int  mm_episode_stats(float* stats, uint8_t* reset_mask, const float* rwd, int rwd_cols, int dense_col, int solved_col,
+                      const uint8_t* done, const uint8_t* truncated, int nenv, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

@@ -709,6 +709,26 @@ extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
   return MM_OK;
 }
 
+__global__ void k_episode_stats(float* stats, uint8_t* mask, const float* rwd, int cols, int dense_col, int solved_col,
+                                const uint8_t* done, const uint8_t* trunc, int nenv) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nenv) return;
+  const float* r = rwd + (size_t)e * cols;
+  float* s = stats + (size_t)e * 3;
+  s[0] += r[dense_col]; s[1] += 1.f; s[2] = fmaxf(s[2], r[solved_col]);
+  if (mask) mask[e] = (uint8_t)((done && done[e]) || (trunc && trunc[e]));
+}
+
+extern "C" int mm_episode_stats(float* stats, uint8_t* reset_mask, const float* rwd, int rwd_cols, int dense_col, int solved_col,
+                                const uint8_t* done, const uint8_t* truncated, int nenv, void* stream) {
+  if (!stats || !rwd || nenv <= 0 || dense_col < 0 || dense_col >= rwd_cols || solved_col < 0 || solved_col >= rwd_cols)
+    return fail(MM_EARG, "mm_episode_stats: bad argument");
+  hipLaunchKernelGGL(k_episode_stats, dim3((nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, reset_mask, rwd, rwd_cols,
+                     dense_col, solved_col, done, truncated, nenv);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
 __global__ void k_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi,
                            const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;

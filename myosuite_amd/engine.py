@@ -148,6 +148,8 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                     C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.mm_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p]
         L.mm_env_draw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_uint32, C.c_void_p]
         L.mm_reach_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -403,6 +405,14 @@ def env_draw(out: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, mask, episod
     _chk(lib().mm_env_draw(out.data_ptr(), n, k, _ptr(base), _ptr(lo), _ptr(hi), _ptr(mask), _ptr(episode), C.c_uint64(seed),
                            C.c_uint32(stream_id), _stream()), "mm_env_draw")
     return out
+
+
+def episode_stats(stats: torch.Tensor, reset_mask: torch.Tensor, rwd: torch.Tensor, dense_col: int, solved_col: int,
+                  done: torch.Tensor, truncated: torch.Tensor):
+    """stats[e] = (return, length, solved) accumulated with this step's reward row; reset_mask = done | truncated (one launch)."""
+    assert stats.shape == (rwd.shape[0], 3) and stats.dtype == torch.float32 and reset_mask.dtype == torch.uint8
+    _chk(lib().mm_episode_stats(_ptr(stats), _ptr(reset_mask), _ptr(rwd), int(rwd.shape[1]), int(dense_col), int(solved_col),
+                                _ptr(done), _ptr(truncated), int(rwd.shape[0]), _stream()), "mm_episode_stats")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int):
