@@ -587,7 +587,6 @@ struct Engine {
   // integer model constants of the owned body and of its first two joints (loaded once per kernel); the float constants
   // (body / joint frames) are read from the LDS-resident model where they are used: holding them cost 23 VGPRs and spills
   int c_jn, c_ja;
-  int c_jtype[2], c_jqadr[2], c_jdadr[2];
   // ---- dof-lane registers (valid for g < nv)
   float d_cdof[6];
   float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
@@ -618,14 +617,6 @@ struct Engine {
       const bool isb = g > 0 && g < KD().nbody;
       c_ja = isb ? MI_(BODY_JNTADR)[g] : 0;
       c_jn = isb ? MI_(BODY_JNTNUM)[g] : 0;
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const bool has = i < c_jn;
-        const int j = has ? c_ja + i : 0;
-        c_jtype[i] = has ? MI_(JNT_TYPE)[j] : -1;
-        c_jqadr[i] = has ? MI_(JNT_QPOSADR)[j] : 0;
-        c_jdadr[i] = has ? MI_(JNT_DOFADR)[j] : 0;
-      }
     }
     r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; r_floss = 0.f; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
@@ -671,8 +662,7 @@ struct Engine {
       for (int i = 0; i < c_jn; i++) {
         const int j = c_ja + i;
         int type, qa; V3 jpos, jax; float q0;
-        if (i < 2) { type = c_jtype[i & 1]; qa = c_jqadr[i & 1]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
-        else { type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa]; }
+        type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa];
         if (type == MM_JNT_FREE) {      // child of the world: its frame is the world frame
           pos = ld3(W + L.qpos + qa);
           quat = qnorm(ldq(W + L.qpos + qa + 3));
@@ -995,9 +985,7 @@ struct Engine {
     if (isb) {      // own dofs: local velocity contribution
       for (int i = 0; i < c_jn; i++) {
         int type, da;
-        if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
-        else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
-        else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
+        type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i];
         const int nd = type == MM_JNT_FREE ? 6 : (type == MM_JNT_BALL ? 3 : 1);
         for (int d3 = 0; d3 < nd; d3++) {
           const float qv = W[L.qvel + da + d3];
@@ -1033,9 +1021,7 @@ struct Engine {
       for (int k = 0; k < 6; k++) run[k] = cv[k] - own[k];
       for (int i = 0; i < c_jn; i++) {
         int type, da;
-        if (i == 0) { type = c_jtype[0]; da = c_jdadr[0]; }
-        else if (i == 1) { type = c_jtype[1]; da = c_jdadr[1]; }
-        else { type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i]; }
+        type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i];
         if (type == MM_JNT_FREE) {     // translational dofs: cdof_dot = 0, they only move the running velocity
           for (int d3 = 0; d3 < 3; d3++) {
             const float qv = W[L.qvel + da + d3];
