@@ -541,3 +541,31 @@ def test_full_size_batch_properties(env_id, n_full, lanes):
         assert bool(torch.isfinite(ob).all()) and bool(torch.isfinite(rb).all())
         assert torch.equal(ob[pick], osm) and torch.equal(rb[pick], rs) and torch.equal(tb[pick], ts)
     assert int(big.state.status.max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,lanes", [("myoHandPoseRandom-v0", 32), ("myoElbowPose1D6MRandom-v0", 8), ("myoHandKeyTurnRandom-v0", 0)])
+def test_ragged_and_single_env_batches(env_id, lanes):
+    """Batch sizes that do not fill a wave / a block (1, 3, 33 envs): the surplus lane groups recompute the last env and never
+    store, so every env matches the same env inside a 64-env batch bit for bit (same, pinned, group width: the launcher
+    otherwise picks the width from the batch size)."""
+    ref = registry.make(env_id, num_envs=64, seed=13, autoreset=False, lanes_per_env=lanes)
+    lanes = ref.hm.info(E.INFO_LANES)
+    ref.reset(seed=13)
+    st = ref.get_env_state()
+    a = torch.empty(64, ref.cm.nu, device="cuda")
+    outs = {}
+    for n in (1, 3, 33):
+        env = registry.make(env_id, num_envs=n, seed=5, autoreset=False, lanes_per_env=lanes)
+        env.set_env_state({k: (v[:n].contiguous() if v is not None else None) for k, v in st.items()})
+        for name in ("target_jnt_value", "body_pos", "key_q0"):
+            if getattr(ref, name, None) is not None and torch.is_tensor(getattr(ref, name)):
+                getattr(env, name).copy_(getattr(ref, name)[:n])
+        env.step_count.copy_(ref.step_count[:n])
+        outs[n] = env
+    for s in range(4):
+        E.uniform(a, 3, s)
+        ob, rb, *_ = ref.step(a)
+        for n, env in outs.items():
+            o, r, *_ = env.step(a[:n].contiguous())
+            assert torch.equal(o, ob[:n]) and torch.equal(r, rb[:n]), (n, s)
