@@ -197,7 +197,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mm_version(void) { return "myosim-hip 0.2 (gfx950, lane=item engine)"; }
 
-static const int kNvpChoices[] = {4, 24, 32, 40};
+static const int kNvpChoices[] = {4, 24, 32, 36, 40};
 
 // is (lanes_per_env, padded nv, general-rows, integrator) a compiled instantiation?  (myosim_inst_list.hpp)
 static bool have_kernel(int G, int nvp, int gen, int rk4 = 0) {

@@ -50,7 +50,7 @@ EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
 #   hand pose   <32,24>      4.07 M -> 4.15 M  iterative-maxocc
 #   reorient    <64,32,GEN>  1.79 M -> 1.85 M  iterative-maxocc
 #   leg walk    <64,40,GEN>  0.71 M -> 0.79 M  iterative-ilp      (iterative-maxocc: 0.71 M; iterative-minreg loses 10-25 % everywhere)
-SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp"}
+SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp", "myosim_inst_H.hip": "iterative-ilp"}
 
 
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
