@@ -10,7 +10,8 @@
 #define MM_KERNELS_F(X) X(32, 32, 0, 1) X(64, 40, 0, 1) X(16, 4, 1, 1) X(32, 24, 1, 1)
 #define MM_KERNELS_G(X) X(64, 32, 1, 1) X(64, 40, 1, 1)
 #define MM_KERNELS_H(X) X(64, 36, 1, 0)   /* leg models: 34 dofs (the 40-wide tile wastes 20 % of the dense linear algebra) */
-#define MM_KERNEL_LIST(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X) MM_KERNELS_H(X)
+#define MM_KERNELS_I(X) X(64, 24, 1, 0)   /* row-rich models with <= 24 dofs (key turn, torso) */
+#define MM_KERNEL_LIST(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X) MM_KERNELS_H(X) MM_KERNELS_I(X)
 #define MM_INSTANTIATE(G_, N_, GN_, RK_)                                        \
   template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_ != 0>(KArgs);   \
   template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_ != 0>(KArgs);
