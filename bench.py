@@ -2,46 +2,66 @@
 """bench.py -- throughput of the fused batched env-step on MI355X.
 
     python bench.py --gpus 1 --steps 64 --warmup 8
+    python bench.py --gpus 8                       # no launcher: re-executes itself under torch.distributed.run, 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one env.step over the whole per-GPU batch: sample actions U[0,1) on the device
-(benchmarks/mjx_benchmark.py:29), ctrl map, frame_skip=10 physics substeps, the post-step
-mj_forward, obs/reward, TimeLimit bookkeeping and the masked auto-reset -- exactly what the
-reference's env.step does per environment, for 4096 envs per GPU.
+One "step" = one env.step over the whole per-GPU batch, as ONE kernel launch (mm_rollout_step): draw actions U[0,1) on the
+device (benchmarks/mjx_benchmark.py:29), muscle ctrl map, frame_skip physics substeps, the post-step mj_forward, obs /
+reward, TimeLimit bookkeeping, episode statistics and the masked auto-reset -- exactly what the reference's env.step (+ a
+gym autoreset / RecordEpisodeStatistics wrapper) does per environment, for 4096 envs per GPU.  Tasks whose
+reset is not folded into the launch (everything but the Pose family) add their masked reset launch.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes... per the microarch guide), dense, no MFMA
 
-# algorithmic HBM bytes per env-step (fp32; state read+written once, ctrl, target, obs, 4 reward scalars):
-# SURVEY.md 8(d)  B_alg = 4*[(nq+nv+na) + nu + n_task_in + (nq+nv+na) + obs_dim + 4]
+# BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288) reported next to the headline line
+EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
+                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"})]
+
+
 def algorithmic_bytes(env) -> int:
-    """144 B (elbow pose), 1 376 B (hand pose), 4 600 B (leg walk; +1 920 B with the fatigue state)."""
+    """fp32, state read + written once per env-step (substeps are fused on chip), constant model excluded:
+    B_alg = 4*[(nq+nv+na) + nu + n_task_in + n_aux + (nq+nv+na) + n_aux + obs_dim + 4], n_aux = the fatigue state (3 na) and,
+    for models with a constraint solve that is warm started across steps (contacts / equalities), qacc_warmstart (nv).
+    144 B (elbow pose), 1 376 B (hand pose), 2 012 B (reorient), 5 336 B (leg walk + fatigue)."""
     cm = env.cm
-    # per-step task inputs: pose targets [nq] | reach targets [3 ntip] | reorient des_rot 3 + axis_half 1 + geom_size 3
-    n_task_in = {1: cm.nq, 2: 3 * getattr(env, "ntip", 0), 3: 7}.get(int(env._task.task), 0)
-    b = 4 * (2 * (cm.nq + cm.nv + cm.na) + cm.nu + n_task_in + env.obs_dim + 4)
+    # per-step task inputs: pose targets [nq] | reach targets [3 ntip] | reorient geom type 1 + size 3 + axis_half 1 + des_rot 3 |
+    # walk step counter 1
+    n_task_in = {1: cm.nq, 2: 3 * getattr(env, "ntip", 0), 3: 8, 4: 1}.get(int(env._task.task), 0)
+    n_aux = 0
     if env.muscle_condition == "fatigue":
-        b += 4 * 6 * cm.na          # MA/MR/MF read + written
-    return b
+        n_aux += 3 * cm.na          # MA / MR / MF
+    if cm.npair > 0 or cm.neq > 0:
+        n_aux += cm.nv              # qacc_warmstart
+    return 4 * (2 * (cm.nq + cm.nv + cm.na) + cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
 
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+def algorithmic_flops(env_id: str):
+    """fp operations of ONE env-step of the reference algorithm, counted by the instrumented oracle (tests/tools/count_flops.py
+    -> profiles/flops_per_env_step.json); None when the table has no entry for the workload."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "flops_per_env_step.json")))
+        return tab.get(env_id)
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(env_id: str, nenv: int, nsteps: int):
     """fp64 oracle ("port": CPU restatement, NOT libmujoco) on the host cores, bounded sample."""
+    import numpy as np
     from myosuite_amd.envs import registry
     from myosuite_amd.model import synth
     from oracle import oracle as O
@@ -73,6 +93,80 @@ def cpu_baseline(env_id: str, nenv: int, nsteps: int):
             "sample": f"{nenv} envs x {nsteps} env-steps of {env_id} (fp64 C oracle, {cores} threads, {dt:.1f} s)"}
 
 
+def respawn_under_launcher(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: run the N ranks ourselves (one process per GPU,
+    torch.distributed.run, RCCL rendezvous on 127.0.0.1) and pass their output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=None):
+    """W untimed + K timed rollout steps of `env_id` with n envs on this rank; returns (elapsed_s max over ranks,
+    mean kernel ms, env, gathered stats)."""
+    import numpy as np
+    import torch
+    from myosuite_amd import dist as D
+    from myosuite_amd.envs import registry
+    # every rank owns the envs [rank*n, (rank+1)*n) of the global batch; all Philox streams (reset draws, actions) are keyed by
+    # the GLOBAL env index (mm_state.env_index_base), so the rollout does not depend on how the envs are spread over ranks
+    env = registry.make(env_id, num_envs=n, seed=seed, lanes_per_env=lanes, env_index_base=rank * n, **(overrides or {}))
+    ep_stats = env.rollout_setup(action_seed=seed)     # (episode return, length, solved) per env, accumulated in the launch
+    for s in range(warmup):
+        env.rollout_step(None, stream_id=s)
+    torch.cuda.synchronize()
+    D.barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        env.rollout_step(None, stream_id=warmup + s, events=evs[s])   # events bracket the fused env-step kernel alone
+    stats = D.gather_episode_stats(ep_stats)   # the one collective of a rollout
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, device="cuda" if world > 1 else None)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    return elapsed, kern_ms, env, stats
+
+
+def roofline(env, env_id, n, kern_ms):
+    """HBM roofline of the fused kernel (the contract's definition) + the views that actually bound it: fp32 vector issue
+    (PMC counters of the committed profile of this command) and algorithmic flops against the fp32 vector peak."""
+    from myosuite_amd import engine as E
+    b_alg = algorithmic_bytes(env)
+    achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9
+    traffic = issue = None
+    try:   # PMC counters cannot be read in-process: the committed rocprofv3 summary of this same command is reported
+        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+        pm = json.load(open(pmc_file)).get(f"{env_id}@{n}")
+        if pm:
+            traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
+            waves_per_simd = pm["sq_waves"] / 1024.0
+            issue = {"valu_busy_frac": pm["sq_active_inst_valu"] / (pm["sq_wave_quadcycles"] / waves_per_simd),
+                     "wave_issue_frac": pm["sq_active_inst_any"] / pm["sq_wave_quadcycles"],
+                     "wave_waitcnt_frac": pm["sq_wait_any"] / pm["sq_wave_quadcycles"],
+                     "valu_insts_per_env_step": pm["sq_insts_valu"] * 64 / n / 64,
+                     "source": f"profiles/{os.path.basename(pmc_file)} (rocprofv3 PMC of this command)"}
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
+           "algorithmic_bytes_per_launch": b_alg * n, "valu_issue": issue}
+    fl = algorithmic_flops(env_id)
+    if fl:
+        tf = fl["flops"] * n / (kern_ms * 1e-3) / 1e12
+        out["flops"] = {"algorithmic_flops_per_env_step": fl["flops"], "achieved_tflops": tf, "peak_tflops": FP32_PEAK_TFLOPS,
+                        "frac": tf / FP32_PEAK_TFLOPS, "source": fl.get("source", "instrumented oracle")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,91 +176,60 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs lines (elbow / reorient / leg-walk / self-contact hand)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_launcher(args))
+
+    import torch
     from myosuite_amd import dist as D
     from myosuite_amd import engine as E
-    from myosuite_amd.envs import registry
 
     rank, world, local = D.init_from_env()
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        # never print a line whose n_gpus differs from the request
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local)
     n = args.envs_per_gpu
-    start, _ = D.shard_envs(n * world, rank, world)
-    # every rank owns its own shard of envs; Philox streams are keyed by the GLOBAL env index via the seed
-    env = registry.make(args.env, num_envs=n, seed=1000 * rank, lanes_per_env=args.lanes)
+    elapsed, kern_ms, env, stats = measure(args.env, n, args.steps, args.warmup, rank, world, args.lanes)
     cm = env.cm
-    act = torch.empty(n, cm.nu, device="cuda")
-    ep_stats = torch.zeros(n, 3, device="cuda")        # (episode return, length, solved) per env
-    need = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    dense_col = env.rwd.shape[1] - 1     # reward rows end with ..., sparse, solved, done, dense (MM_RWD_* / MM_RWDW_*)
-
-    def one_step(s, ev=None):
-        E.uniform(act, seed=rank, stream_id=s)
-        if ev is not None:
-            ev[0].record()
-        E.env_step(env.hm, env.state, act, env._task)
-        if ev is not None:
-            ev[1].record()
-        # episode statistics + masked auto-reset (device side, no host sync)
-        E.episode_stats(ep_stats, need, env.rwd, dense_col, dense_col - 2, env.done, env.truncated)
-        env.reset(mask=need)
-
-    for s in range(args.warmup):
-        one_step(s)
-    torch.cuda.synchronize()
-    D.barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        one_step(args.warmup + s, evs[s])
-    stats = D.gather_episode_stats(ep_stats)   # the one collective of a rollout
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, device="cuda" if world > 1 else None)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
-        b_alg = algorithmic_bytes(env)
-        # HBM traffic per launch: PMC counters cannot be read from inside the process; the committed rocprofv3 summary
-        # of this same command (tools/prof_round.sh -> profiles/*_pmc.json) is reported when it matches the workload
-        traffic = None
-        issue = None
-        try:
-            pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
-            pm = json.load(open(pmc_file)).get(f"{args.env}@{n}")
-            if pm:
-                traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
-                # the honest roof of this kernel: fp32 vector issue.  VALU-busy quad-cycles per SIMD over the quad-cycles
-                # the kernel lasts (wave cycles / resident waves per SIMD); 1024 SIMDs on the chip
-                waves_per_simd = pm["sq_waves"] / 1024.0
-                issue = {"valu_busy_frac": pm["sq_active_inst_valu"] / (pm["sq_wave_quadcycles"] / waves_per_simd),
-                         "wave_issue_frac": pm["sq_active_inst_any"] / pm["sq_wave_quadcycles"],
-                         "wave_waitcnt_frac": pm["sq_wait_any"] / pm["sq_wave_quadcycles"],
-                         "valu_insts_per_env_step": pm["sq_insts_valu"] * 64 / n / 64,
-                         "source": f"profiles/{os.path.basename(pmc_file)} (rocprofv3 PMC of this command)"}
-        except (OSError, ValueError, KeyError, IndexError):
-            pass
-        achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9 if b_alg else None
         out = {
             "metric": "env-steps/sec (whole node) at %d envs/GPU" % n,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1), frame_skip {env.frame_skip} + final forward + "
-                                   f"obs/reward + auto-reset (synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
-                       "envs_per_gpu": n, "lanes_per_env": env.hm.info(E.INFO_LANES), "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": (b_alg * n) if b_alg else None, "valu_issue": issue},
+            "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1) drawn in the kernel, frame_skip {env.frame_skip} + final "
+                                   f"forward + obs/reward + episode stats + auto-reset in one launch per step "
+                                   f"(synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
+                       "envs_per_gpu": n, "lanes_per_env": env.hm.launch_lanes(n), "launches_per_step": 1 if env._ro.autoreset else "1 + the task's masked reset",
+                       "parallelism": f"env-shard x{world}"},
+            "roofline": roofline(env, args.env, n, kern_ms),
             "stats": {"mean_episode_return": float(stats[:, 0].mean()), "solved_frac": float(stats[:, 2].mean()),
                       "status_or": int(env.state.status.max())},
         }
+        del env
+        if world == 1 and not args.no_extra:
+            # driver-visible numbers for the other BASELINE.json configs (same timed loop, shorter): not the headline value
+            extra = []
+            for env_id, ne, ov in EXTRA_CONFIGS:
+                tag = f"{env_id}, {ne} envs/GPU" + (f", {ov}" if ov else "")
+                try:
+                    el, km, ev, st = measure(env_id, ne, max(8, args.steps // 2), max(2, args.warmup // 2), 0, 1, overrides=ov)
+                    extra.append({"workload": tag, "value": ne * max(8, args.steps // 2) / el, "unit": "env-steps/s",
+                                  "ms_per_step": 1e3 * el / max(8, args.steps // 2), "lanes_per_env": ev.hm.launch_lanes(ne),
+                                  "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": roofline(ev, env_id, ne, km),
+                                  "status_or": int(ev.state.status.max())})
+                    del ev
+                except Exception as exc:      # an extra line must never take the headline line down
+                    extra.append({"workload": tag, "error": repr(exc)})
+            out["extra_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             # a few seconds of wall time on the host cores
             nb, ns = (8192, 200) if cm.nv <= 4 else ((4096, 60) if cm.nv < 25 else (1024, 40))

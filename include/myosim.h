@@ -79,6 +79,10 @@ typedef struct {
   int    body_mass_env_id;
   const float* body_pos_env;  /* [nenv][3] */
   int    body_pos_env_id;
+  /* global index of env 0 of this shard (multi-GPU env sharding, myosuite_amd/dist.py): every Philox stream of the reset
+     kernels, mm_env_draw and the in-kernel action draw of mm_rollout_step is keyed by env_index_base + e, so a rollout
+     does not depend on how the envs are spread over ranks */
+  int    env_index_base;
 } mm_state;
 
 /* Optional derived outputs of the final forward pass (NULL = not requested). */
@@ -176,6 +180,28 @@ typedef struct {
                                (the observation returned by reset(): env_base.py:560-575) */
 } mm_task;
 
+/* Rollout bookkeeping folded into the env-step launch (mm_rollout_step): what a rollout harness around env.step does per
+ * step -- benchmarks/mjx_benchmark.py:29 draws actions, gym's autoreset wrapper / playground's TrainingWrapper re-arm
+ * finished episodes, RecordEpisodeStatistics accumulates returns -- without extra kernel launches. */
+typedef struct {
+  const float* action;      /* [nenv][nu], or NULL: draw action ~ U[0,1) in the kernel (Philox4x32-10, mm_uniform's scheme:
+                               element i = (env_index_base + e) * nu + u is word i%4 of counter (i/4, action_stream), key action_seed) */
+  uint64_t action_seed, action_stream;
+  float* action_out;        /* optional [nenv][nu]: the actions that were applied (for the learner)                 */
+  float* ep_stats;          /* optional [nenv][3] in/out: return += dense reward, length += 1, solved = max(solved, .) */
+  uint8_t* reset_mask;      /* optional [nenv] out: done | truncated of this step                                  */
+  /* masked auto-reset folded into the same launch, MM_TASK_POSE only (pose_v0.py:174-257; same draws as mm_pose_reset):
+     envs whose episode ended get qpos ~ U(qlo,qhi) (random_qpos) or qpos0, target ~ U(tlo,thi), qvel = act = time = 0,
+     step_count = 0, episode += 1, and their obs row holds the FIRST observation of the new episode (reward / done rows keep
+     the terminal step's values).  Other tasks: autoreset = 0, reset through reset_mask + the task's reset call. */
+  int   autoreset;
+  int   random_qpos;
+  const float *qlo, *qhi, *tlo, *thi;   /* [nq] each */
+  float* target;            /* [nenv][nq]: == mm_task.target_jnt_value                                             */
+  int32_t* episode;         /* [nenv] in/out                                                                        */
+  uint64_t reset_seed;
+} mm_rollout;
+
 /* columns of mm_task.rwd for MM_TASK_POSE (pose_v0.py:120-139) */
 enum { MM_RWD_POSE = 0, MM_RWD_BONUS, MM_RWD_PENALTY, MM_RWD_ACT_REG, MM_RWD_SPARSE, MM_RWD_SOLVED,
        MM_RWD_DONE, MM_RWD_DENSE, MM_RWD_COUNT };
@@ -198,8 +224,12 @@ int  mm_model_info(const mm_model* m, int which);
 /* lanes_per_env in {4,8,16,32,64}; 0 = engine default for the model size. */
 int  mm_model_set_lanes(mm_model* m, int lanes_per_env);
 /* tuning knobs: "lds_model" (1 = stage the model tables in LDS unless that costs resident waves the batch needs,
-   0 = never, 2 = always), "waves_per_block" (0 = auto) */
+   0 = never, 2 = always), "waves_per_block" (0 = auto), "origin_shift" (1 = the kernel works in a frame centred on the
+   model; 0 = raw world coordinates, for the fp32 error study) */
 int  mm_model_set_option(mm_model* m, const char* name, int value);
+/* lanes per env a launch over `nenv` envs will use (the width is picked per launch from the batch size unless pinned
+   with mm_model_set_lanes or fixed by the model's constraint tables) */
+int  mm_model_launch_lanes(const mm_model* m, int nenv);
 
 /* ---- physics -------------------------------------------------------------- */
 /* `nsub` mj_step substeps with ctrl [nenv][nu] applied as-is (engine boundary). */
@@ -209,6 +239,11 @@ int  mm_forward(const mm_model* m, const mm_state* s, const float* ctrl, const m
 /* fused env.step: action [nenv][nu] -> state advanced, obs/reward/done written. */
 int  mm_env_step(const mm_model* m, const mm_state* s, const float* action, const mm_task* t,
                  const mm_derived* out, void* stream);
+
+/* mm_env_step with the rollout bookkeeping of `r` folded into the same launch (in-kernel action draw, episode statistics,
+ * reset mask and -- POSE task -- the masked auto-reset with the first observation of the new episode). */
+int  mm_rollout_step(const mm_model* m, const mm_state* s, const mm_task* t, const mm_rollout* r, const mm_derived* out,
+                     void* stream);
 
 /* ---- reset / RNG ----------------------------------------------------------- */
 /* mj_resetData + (qpos,qvel) overwrite for envs with mask[e]!=0 (mask NULL = all).
@@ -261,10 +296,10 @@ int  mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask,
                       float* geom_size_env, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream);
 /* Per-episode draw of a per-env model delta (pose_v0.py:180-183 weight ~ U(weight_range); key_turn_v0.py:164-166 key
  * position offset): out[e][k] = base[k] + lo[k] + (hi[k]-lo[k]) * u, u = Philox4x32-10 word k%4 of counter
- * (k/4, stream_id, e, episode[e]), key = seed; envs with mask[e] == 0 are left untouched.  Call BEFORE the task reset of the
+ * (k/4, stream_id, env_index_base + e, episode[e]), key = seed; envs with mask[e] == 0 are left untouched.  Call BEFORE the task reset of the
  * same episode (which increments episode[e]).  base may be NULL (= 0). */
 int  mm_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi, const uint8_t* mask,
-                 const int32_t* episode, uint64_t seed, uint32_t stream_id, void* stream);
+                 const int32_t* episode, uint64_t seed, uint32_t stream_id, int env_index_base, void* stream);
 /* Rollout bookkeeping in one launch (what a gym vector wrapper's RecordEpisodeStatistics + autoreset mask do with a handful
  * of elementwise ops): stats[e] = {return += rwd[e][dense_col], length += 1, solved = max(solved, rwd[e][solved_col])},
  * reset_mask[e] = done[e] | truncated[e].  stats is [nenv][3] float32, rwd has row stride rwd_cols. */
@@ -272,6 +307,9 @@ int  mm_episode_stats(float* stats, uint8_t* reset_mask, const float* rwd, int r
                       const uint8_t* done, const uint8_t* truncated, int nenv, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* the same stream from element `first_index` on: out[i] = element first_index + i (a shard of envs draws ITS slice of the
+ * global [nenv_total][nu] action matrix: first_index = env_index_base * nu) */
+int  mm_uniform_at(float* out, size_t n, uint64_t seed, uint64_t stream_id, size_t first_index, void* stream);
 
 const char* mm_last_error(void);
 const char* mm_version(void);

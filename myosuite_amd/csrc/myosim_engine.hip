@@ -1,28 +1,21 @@
 // myosim_engine.hip -- host side of the C ABI (include/myosim.h): model upload, LDS layout, kernel selection / launch,
 // reset and Philox kernels.  The fused physics kernel template is in myosim_engine_kernel.hpp.
+#include <atomic>
 #include "myosim_engine_kernel.hpp"
 #include "myosim_inst_list.hpp"
 MM_KERNEL_LIST(MM_DECLARE)
 
-// ---- Philox4x32-10 (counter based; the oracle side reproduces it in numpy) -----------
-__device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
-  for (int r = 0; r < 10; r++) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-__device__ __host__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
-
-__global__ void k_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id) {
-  size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t i = i4 * 4;
-  if (i >= n) return;
+// Philox4x32-10 / u01: myosim_engine_kernel.hpp
+// out[i] = word (first+i)%4 of Philox counter ((first+i)/4, stream_id): one thread per counter
+__global__ void k_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, size_t first) {
+  const size_t i4 = first / 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 * 4 >= first + n) return;
   uint32_t c[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  for (int k = 0; k < 4 && i + k < n; k++) out[i + k] = u01(c[k]);
+  for (int k = 0; k < 4; k++) {
+    const size_t gi = i4 * 4 + k;
+    if (gi >= first && gi < first + n) out[gi - first] = u01(c[k]);
+  }
 }
 
 struct ResetArgs {
@@ -43,6 +36,7 @@ __global__ void k_reset(ResetArgs r) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= r.nenv) return;
   if (r.mask && !r.mask[e]) return;
+  const uint32_t ge = (uint32_t)(r.s.env_index_base + e);   // global env index: keys every Philox stream below
   const float* qpos0 = reinterpret_cast<const float*>(r.blob + r.qpos0_off);
   int ep = 0;
   if (r.pose && r.episode) { ep = r.episode[e]; r.episode[e] = ep + 1; }
@@ -50,7 +44,7 @@ __global__ void k_reset(ResetArgs r) {
     float q = r.qpos_src ? r.qpos_src[(size_t)e * r.nq + i] : (r.qpos_bcast ? r.qpos_bcast[i] : qpos0[i]);
     if (r.pose) {
       // counter = (i/2, 0, env, episode): words 0/1 -> qpos draw of coordinate i (even/odd), words 2/3 -> target
-      uint32_t c[4] = {(uint32_t)(i >> 1), 0u, (uint32_t)e, (uint32_t)ep};
+      uint32_t c[4] = {(uint32_t)(i >> 1), 0u, ge, (uint32_t)ep};
       philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
       float uq = u01(c[i & 1]), ut = u01(c[2 + (i & 1)]);
       if (r.random_qpos) q = r.qlo[i] + (r.qhi[i] - r.qlo[i]) * uq;
@@ -74,7 +68,7 @@ __global__ void k_reset(ResetArgs r) {
     const int n3 = 3 * r.ntip;
     float* ob = r.obs ? r.obs + (size_t)e * r.obs_dim : nullptr;
     for (int i = 0; i < n3; i++) {
-      uint32_t c[4] = {(uint32_t)(i >> 2), 1u, (uint32_t)e, (uint32_t)ep};
+      uint32_t c[4] = {(uint32_t)(i >> 2), 1u, ge, (uint32_t)ep};
       philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
       float tg = r.tlo[i] + (r.thi[i] - r.tlo[i]) * u01(c[i & 3]);
       r.target[(size_t)e * n3 + i] = tg;
@@ -91,11 +85,11 @@ __global__ void k_reset(ResetArgs r) {
     // (counter (1,4,env,episode)); Fixed task: half = 0, no size table
     int ep = r.episode ? r.episode[e] : 0;
     if (r.episode) r.episode[e] = ep + 1;
-    uint32_t c[4] = {0u, 4u, (uint32_t)e, (uint32_t)ep};
+    uint32_t c[4] = {0u, 4u, ge, (uint32_t)ep};
     philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
     for (int k = 0; k < 3; k++) r.hold_goal[(size_t)e * 3 + k] = r.hold_center[k] + r.hold_half * (2.f * u01(c[k]) - 1.f);
     if (r.hold_gsize) {
-      uint32_t c2[4] = {1u, 4u, (uint32_t)e, (uint32_t)ep};
+      uint32_t c2[4] = {1u, 4u, ge, (uint32_t)ep};
       philox4x32_10(c2, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
       for (int k = 0; k < 3; k++) r.hold_gsize[(size_t)e * 3 + k] = r.hold_slo + (r.hold_shi - r.hold_slo) * u01(c2[k]);
     }
@@ -105,7 +99,7 @@ __global__ void k_reset(ResetArgs r) {
     // words 1 / 2 -> desired_orien[0] ~ U(-1,1), desired_orien[1] ~ U(-0.8,1.2)
     int ep = r.episode ? r.episode[e] : 0;
     if (r.episode) r.episode[e] = ep + 1;
-    uint32_t c[4] = {0u, 3u, (uint32_t)e, (uint32_t)ep};
+    uint32_t c[4] = {0u, 3u, ge, (uint32_t)ep};
     philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
     float ah, e0, e1;
     if (r.pen) {   // pen_v0.py:171-184: fixed geometry, desired_orien[0:2] ~ U(lo, hi)
@@ -139,14 +133,14 @@ __global__ void k_reset(ResetArgs r) {
     if (r.episode) r.episode[e] = ep + 1;
     const float *kq = r.ka_qpos, *kv = r.ka_qvel;
     if (r.walk_random) {
-      uint32_t c[4] = {0xFFFFu, 2u, (uint32_t)e, (uint32_t)ep};
+      uint32_t c[4] = {0xFFFFu, 2u, ge, (uint32_t)ep};
       philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
       if (!(u01(c[0]) < 0.5f)) { kq = r.kb_qpos; kv = r.kb_qvel; }
     }
     for (int i = 0; i < r.nq; i++) {
       float q = kq[i];
       if (r.walk_random && !(i >= 2 && i < 7)) {
-        uint32_t c[4] = {(uint32_t)i, 2u, (uint32_t)e, (uint32_t)ep};
+        uint32_t c[4] = {(uint32_t)i, 2u, ge, (uint32_t)ep};
         philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
         float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = u01(c[1]);
         q += 0.02f * sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -183,6 +177,7 @@ struct mm_model {
   int cofs = 0;              // word offset of the ConstBlock behind the blob (device copy only)
   size_t lds_per_env = 0;
   int device = 0;
+  float origin[3] = {0.f, 0.f, 0.f};   // internal world-frame origin (see Dims::ox)
 };
 
 static int upload_consts(mm_model* m);
@@ -444,6 +439,35 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     if (v.empty()) dev.push_back(0);
     return off;
   };
+  // internal world-frame origin (Dims::ox/oy/oz): mean body position of the reference configuration, on a 1/64 m grid.
+  // Bodies hanging off a free joint start wherever qpos0 puts them, which body_pos already encodes.
+  {
+    const float* bpos = (const float*)(blob + m->sec[MM_SEC_BODY_POS]);
+    const float* bquat = (const float*)(blob + m->sec[MM_SEC_BODY_QUAT]);
+    std::vector<double> xp(3 * d.nbody, 0.0), xq(4 * d.nbody, 0.0);
+    xq[0] = 1.0;
+    double sum[3] = {0, 0, 0};
+    for (int b = 1; b < d.nbody; b++) {
+      const double* pq = &xq[4 * bpar[b]];
+      const double w = pq[0], x = pq[1], y = pq[2], z = pq[3];
+      const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                           2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                           2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+      for (int k = 0; k < 3; k++)
+        xp[3 * b + k] = xp[3 * bpar[b] + k] + R[3 * k] * bpos[3 * b] + R[3 * k + 1] * bpos[3 * b + 1] + R[3 * k + 2] * bpos[3 * b + 2];
+      const double a0 = bquat[4 * b], a1 = bquat[4 * b + 1], a2 = bquat[4 * b + 2], a3 = bquat[4 * b + 3];
+      double q[4] = {w * a0 - x * a1 - y * a2 - z * a3, w * a1 + x * a0 + y * a3 - z * a2,
+                     w * a2 - x * a3 + y * a0 + z * a1, w * a3 + x * a2 - y * a1 + z * a0};
+      const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int k = 0; k < 4; k++) xq[4 * b + k] = n > 0 ? q[k] / n : (k == 0);
+      for (int k = 0; k < 3; k++) sum[k] += xp[3 * b + k];
+    }
+    const int nb1 = d.nbody > 1 ? d.nbody - 1 : 1;
+    m->origin[0] = (float)(std::round(64.0 * sum[0] / nb1) / 64.0);
+    m->origin[1] = (float)(std::round(64.0 * sum[1] / nb1) / 64.0);
+    m->origin[2] = (float)(std::round(64.0 * sum[2] / nb1) / 64.0);
+    d.ox = m->origin[0]; d.oy = m->origin[1]; d.oz = m->origin[2];
+  }
   m->x.body_depth = append(depth); m->x.body_rootslot = append(rootslot); m->x.dof_rootslot = append(dofslot);
   m->x.dofj_adr = append(dj_adr); m->x.dofj_entry = append(dj_entry); m->x.dofj_tendon = append(dj_tendon);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
@@ -514,6 +538,10 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
   if (!m || !name) return MM_EARG;
   if (!strcmp(name, "lds_model")) { m->lds_model = value; return MM_OK; }
   if (!strcmp(name, "waves_per_block")) { m->waves_per_block = value; return MM_OK; }
+  if (!strcmp(name, "origin_shift")) {   // 0: the kernel works in raw world coordinates (A/B of the fp32 error study)
+    m->d.ox = value ? m->origin[0] : 0.f; m->d.oy = value ? m->origin[1] : 0.f; m->d.oz = value ? m->origin[2] : 0.f;
+    return upload_consts(m);
+  }
   return fail(MM_EARG, "unknown option");
 }
 
@@ -547,12 +575,13 @@ extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_pt
 
 template <int G, int NVP, bool GEN, bool RK4>
 static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st, int lm) {
-  static bool attr_done[2] = {false, false};
-  (void)m;
-  if (!attr_done[lm]) {
+  // the dynamic-LDS limit is a per-device attribute of the function: one flag per (device, LM variant) of this instantiation
+  static std::atomic<unsigned> attr_done[2] = {{0u}, {0u}};   // bit d = set on device d (devices >= 32: set on every launch)
+  const unsigned bit = m->device < 32 ? (1u << m->device) : 0u;
+  if (!(attr_done[lm].load(std::memory_order_acquire) & bit) || !bit) {
     if (lm) HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, true, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     else HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[lm] = true;
+    attr_done[lm].fetch_or(bit, std::memory_order_release);
   }
   if (lm) hipLaunchKernelGGL((k_engine<G, NVP, true, GEN, RK4>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((k_engine<G, NVP, false, GEN, RK4>), grid, block, lds, st, a);
@@ -560,18 +589,46 @@ static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t l
   return MM_OK;
 }
 
-static int launch(const mm_model* m, KArgs& a, void* stream) {
+// group width (lanes per env) a launch over `nenv` envs uses: the pinned / default width, or -- for models without general
+// constraint rows, whose LDS tables do not depend on the width -- the narrowest group (most envs per wave) that still yields
+// >= 2 waves per CU, else the widest available
+static int pick_lanes(const mm_model* m, int nenv) {
   int G = m->lanes;
   if (m->lanes_auto && !m->d.gen) {
-    // narrowest group (most envs per wave) that still yields >= 2 waves per CU; else the widest available
     int best = 0;
     for (int c : {4, 8, 16, 32, 64}) {
       if (!check_lanes(m, c) || !have_kernel(c, m->nvp, 0)) continue;
       best = c;
-      if ((a.s.nenv + (64 / c) - 1) / (64 / c) >= 512) break;
+      if ((nenv + (64 / c) - 1) / (64 / c) >= 512) break;
     }
     if (best) G = best;
   }
+  return G;
+}
+
+extern "C" int mm_model_launch_lanes(const mm_model* m, int nenv) {
+  if (!m || nenv <= 0) return MM_EARG;
+  return pick_lanes(m, nenv);
+}
+
+static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int G);
+static int launch(const mm_model* m, KArgs& a, void* stream) {
+  const int G = pick_lanes(m, a.s.nenv);
+  {   // launch on the model's device (the caller's stream must belong to it); restore the caller's current device afterwards
+    int cur = -1;
+    HIPCHK(hipGetDevice(&cur));
+    if (cur != m->device) {
+      HIPCHK(hipSetDevice(m->device));
+      KArgs& a2 = a;
+      const int rc = launch_on_device(m, a2, stream, G);
+      (void)hipSetDevice(cur);
+      return rc;
+    }
+  }
+  return launch_on_device(m, a, stream, G);
+}
+
+static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int G) {
   const int epw = 64 / G;
   const size_t kLds = 160 * 1024;
   const size_t blob_bytes = (size_t)((m->blob_words + 3) & ~3) * 4;
@@ -637,8 +694,7 @@ extern "C" int mm_forward(const mm_model* m, const mm_state* s, const float* ctr
   return launch(m, a, stream);
 }
 
-extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* action, const mm_task* t,
-                           const mm_derived* out, void* stream) {
+static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
   if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
   if (t->task == MM_TASK_REACH && (!t->tip_sites || !t->target_pos || t->ntip <= 0)) return fail(MM_EARG, "reach task needs tip_sites/target_pos");
@@ -666,8 +722,32 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
       t->task != MM_TASK_REORIENT && t->task != MM_TASK_OBJHOLD && t->task != MM_TASK_KEYTURN)
     return fail(MM_EUNSUPPORTED, "task not implemented");
   if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "fatigue needs MA/MR/MF");
+  return MM_OK;
+}
+
+extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* action, const mm_task* t,
+                           const mm_derived* out, void* stream) {
+  { const int rc = check_task(m, s, t); if (rc != MM_OK) return rc; }
   KArgs a; fill_common(m, a, s);
   a.ctrl = action; a.mode = 2; a.t = *t;
+  if (out) { a.o = *out; a.has_derived = 1; }
+  a.dbg = g_dbg;
+  return launch(m, a, stream);
+}
+
+extern "C" int mm_rollout_step(const mm_model* m, const mm_state* s, const mm_task* t, const mm_rollout* r,
+                               const mm_derived* out, void* stream) {
+  { const int rc = check_task(m, s, t); if (rc != MM_OK) return rc; }
+  if (!r) return fail(MM_EARG, "mm_rollout_step: null rollout description");
+  if (t->obs_only) return fail(MM_EARG, "mm_rollout_step: obs_only passes go through mm_env_step");
+  if (r->autoreset) {
+    if (t->task != MM_TASK_POSE) return fail(MM_EUNSUPPORTED, "mm_rollout_step: the folded auto-reset exists for the POSE task only (reset the others through reset_mask)");
+    if (!r->tlo || !r->thi || !r->target || !r->episode || !t->step_count || (r->random_qpos && (!r->qlo || !r->qhi)))
+      return fail(MM_EARG, "mm_rollout_step: autoreset needs tlo/thi/target/episode/step_count (and qlo/qhi for random_qpos)");
+    if (r->target != t->target_jnt_value) return fail(MM_EARG, "mm_rollout_step: rollout.target must be the task's target_jnt_value buffer");
+  }
+  KArgs a; fill_common(m, a, s);
+  a.ctrl = r->action; a.mode = 2; a.t = *t; a.ro = *r; a.has_ro = 1;
   if (out) { a.o = *out; a.has_derived = 1; }
   a.dbg = g_dbg;
   return launch(m, a, stream);
@@ -701,12 +781,18 @@ extern "C" int mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t
   return MM_OK;
 }
 
-extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+extern "C" int mm_uniform_at(float* out, size_t n, uint64_t seed, uint64_t stream_id, size_t first_index, void* stream) {
   if (!out) return fail(MM_EARG, "mm_uniform: null output");
-  size_t n4 = (n + 3) / 4;
-  hipLaunchKernelGGL(k_uniform, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id);
+  if (n == 0) return MM_OK;
+  const size_t ncounter = (first_index + n + 3) / 4 - first_index / 4;
+  hipLaunchKernelGGL(k_uniform, dim3((unsigned)((ncounter + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, stream_id,
+                     first_index);
   HIPCHK(hipGetLastError());
   return MM_OK;
+}
+
+extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  return mm_uniform_at(out, n, seed, stream_id, 0, stream);
 }
 
 __global__ void k_episode_stats(float* stats, uint8_t* mask, const float* rwd, int cols, int dense_col, int solved_col,
@@ -730,22 +816,23 @@ extern "C" int mm_episode_stats(float* stats, uint8_t* reset_mask, const float* 
 }
 
 __global__ void k_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi,
-                           const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id) {
+                           const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id, int env_index_base) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nenv || (mask && !mask[e])) return;
   const uint32_t ep = episode ? (uint32_t)episode[e] : 0u;
   for (int k = 0; k < ncomp; k++) {
-    uint32_t c[4] = {(uint32_t)(k >> 2), stream_id, (uint32_t)e, ep};
+    uint32_t c[4] = {(uint32_t)(k >> 2), stream_id, (uint32_t)(env_index_base + e), ep};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     out[(size_t)e * ncomp + k] = (base ? base[k] : 0.f) + lo[k] + (hi[k] - lo[k]) * u01(c[k & 3]);
   }
 }
 
 extern "C" int mm_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi,
-                           const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id, void* stream) {
+                           const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id, int env_index_base,
+                           void* stream) {
   if (!out || !lo || !hi || nenv <= 0 || ncomp <= 0) return fail(MM_EARG, "mm_env_draw: bad argument");
   hipLaunchKernelGGL(k_env_draw, dim3((nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, nenv, ncomp, base, lo, hi,
-                     mask, episode, seed, stream_id);
+                     mask, episode, seed, stream_id, env_index_base);
   HIPCHK(hipGetLastError());
   return MM_OK;
 }

@@ -36,6 +36,18 @@
 
 #define MINVALF 1e-15f
 
+// ---- Philox4x32-10 (counter based; the oracle side reproduces it in numpy: oracle/env_oracle.py) -----------
+__device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__device__ __host__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
 // ------------------------------------------------------------------ kernel args
 struct Dims {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, nlevel, njmax, ntenJ;
@@ -46,6 +58,11 @@ struct Dims {
   int integrator;   // MM_INT_EULER | MM_INT_RK4
   int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
+  // Origin of the kernel's internal world frame (host: mean body position at qpos0, rounded to 1/64 m).  Physics is
+  // translation invariant; fp32 rounding is not: a hand that sits 1 m from the world origin carries ~1e-7 m of absolute
+  // error in every point, i.e. ~2e-5 of a 5 mm tendon moment arm.  All positions inside the kernel are relative to this
+  // origin; qpos of free joints, task targets and every position OUTPUT stay in world coordinates.
+  float ox, oy, oz;
 };
 
 // per-env LDS tables (offsets in 32-bit words from the env's base)
@@ -92,6 +109,8 @@ struct KArgs {
   const float* ctrl;
   mm_task t;
   mm_derived o;
+  mm_rollout ro;         // rollout bookkeeping folded into the launch (mm_rollout_step); has_ro = 0: plain mm_env_step
+  int has_ro;
   int has_derived;
   int mode;              // 0: step(s) only, 1: forward only, 2: env step
   float* dbg;
@@ -633,13 +652,15 @@ struct Engine {
     for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; }
   }
 
+  __device__ __forceinline__ V3 origin() const { return v3(KD().ox, KD().oy, KD().oz); }
   __device__ __forceinline__ float com_of_body(int b, int k) const { return W[KL().com + 3 * AUXI(body_rootslot)[b] + k]; }
 
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
     ConstLayout& L = KL();
+    const V3 org = origin();
     if (g == 0) {
-      b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
+      b_xpos = -1.f * org; b_xipos = b_xpos;   // the world body (and everything attached to it) in the internal frame
       Q4 q = {1.f, 0.f, 0.f, 0.f};
       b_xquat = q;
       st3(W + L.xpos, b_xpos);
@@ -658,13 +679,14 @@ struct Engine {
     if (isb) {
       const int b = g;
       V3 pos = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(MF_(BODY_POS) + 3 * b);
+      if (b_parent == 0) pos = pos - org;
       Q4 quat = ldq(MF_(BODY_QUAT) + 4 * b);
       for (int i = 0; i < c_jn; i++) {
         const int j = c_ja + i;
         int type, qa; V3 jpos, jax; float q0;
         type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa];
         if (type == MM_JNT_FREE) {      // child of the world: its frame is the world frame
-          pos = ld3(W + L.qpos + qa);
+          pos = ld3(W + L.qpos + qa) - org;
           quat = qnorm(ldq(W + L.qpos + qa + 3));
           st3(W + L.xanchor + 3 * j, pos);
           M3 m = q2m(quat);
@@ -2041,8 +2063,20 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   E.status = a.s.status ? a.s.status[e] : 0;
   const __attribute__((address_space(4))) mm_task& t = KA().t;
   // ---- action -> ctrl (BaseV0.step: base_v0.py:82-108)
+  const bool has_ro = a.mode == 2 && a.has_ro && !obs_only;
   for (int u = g; u < d.nu; u += G) {
     float c = a.ctrl ? a.ctrl[(size_t)e * d.nu + u] : 0.f;
+    if (has_ro && !a.ctrl) {
+      // action ~ U[0,1) drawn here (benchmarks/mjx_benchmark.py:29), element-for-element what mm_uniform writes for the flat
+      // index of (global env, actuator)
+      const uint64_t i = (uint64_t)(a.s.env_index_base + e) * (uint64_t)d.nu + (uint64_t)u, i4 = i >> 2;
+      const uint64_t sd = KA().ro.action_seed, sm = KA().ro.action_stream;
+      uint32_t cc[4] = {(uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)sm, (uint32_t)(sm >> 32)};
+      philox4x32_10(cc, (uint32_t)sd, (uint32_t)(sd >> 32));
+      const int w = (int)(i & 3);
+      c = u01(w == 0 ? cc[0] : (w == 1 ? cc[1] : (w == 2 ? cc[2] : cc[3])));
+      if (KA().ro.action_out && !dup) KA().ro.action_out[(size_t)e * d.nu + u] = c;
+    }
     const bool mus = MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE;
     if (obs_only) c = 0.f;
     if (a.mode == 2 && !obs_only && t.normalize_act && mus) c = 1.f / (1.f + expf(-5.f * (c - 0.5f)));
@@ -2085,29 +2119,22 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   bool fwd = a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
   E.run(nsub, fwd, time);
 
-  // ---- store state (surplus groups never write)
-  if (dup) return;
-  for (int i = g; i < d.nq; i += G) a.s.qpos[(size_t)e * d.nq + i] = W[L.qpos + i];
-  if (g < d.nv) {
-    a.s.qvel[(size_t)e * d.nv + g] = E.d_qvel;
-    a.s.qacc_warmstart[(size_t)e * d.nv + g] = E.d_warm;
-  }
-  for (int i = g; i < d.na; i += G) a.s.act[(size_t)e * d.na + i] = W[L.act + i];
-  if (g == 0) { a.s.time[e] = time; if (a.s.status) a.s.status[e] = E.status; }
+  if (dup) return;   // surplus groups never write
 
   // ---- derived outputs of the final forward
   if (fwd && a.has_derived) {
     const mm_derived& o = a.o;
     const bool isb = g < d.nbody;
-    if (o.xpos && isb) st3(o.xpos + ((size_t)e * d.nbody + g) * 3, E.b_xpos);
+    const V3 org = E.origin();   // outputs are world coordinates
+    if (o.xpos && isb) st3(o.xpos + ((size_t)e * d.nbody + g) * 3, E.b_xpos + org);
     if (o.xquat && isb) { float* q = o.xquat + ((size_t)e * d.nbody + g) * 4; q[0] = E.b_xquat.w; q[1] = E.b_xquat.x; q[2] = E.b_xquat.y; q[3] = E.b_xquat.z; }
-    if (o.xipos && isb) st3(o.xipos + ((size_t)e * d.nbody + g) * 3, E.b_xipos);
+    if (o.xipos && isb) st3(o.xipos + ((size_t)e * d.nbody + g) * 3, E.b_xipos + org);
     if (o.cvel && isb) for (int k = 0; k < 6; k++) o.cvel[((size_t)e * d.nbody + g) * 6 + k] = E.b_cvel[k];
-    if (o.subtree_com && isb) st3(o.subtree_com + ((size_t)e * d.nbody + g) * 3, ld3(W + L.com + 3 * AUXI(body_rootslot)[g]));
+    if (o.subtree_com && isb) st3(o.subtree_com + ((size_t)e * d.nbody + g) * 3, ld3(W + L.com + 3 * AUXI(body_rootslot)[g]) + org);
     if (o.site_xpos)
-      for (int s = g; s < d.nsite; s += G) st3(o.site_xpos + ((size_t)e * d.nsite + s) * 3, E.site_pos(s));
+      for (int s = g; s < d.nsite; s += G) st3(o.site_xpos + ((size_t)e * d.nsite + s) * 3, E.site_pos(s) + org);
     if (o.geom_xpos)
-      for (int s = g; s < d.ngeom; s += G) st3(o.geom_xpos + ((size_t)e * d.ngeom + s) * 3, E.geom_pos(s));
+      for (int s = g; s < d.ngeom; s += G) st3(o.geom_xpos + ((size_t)e * d.ngeom + s) * 3, E.geom_pos(s) + org);
     if (o.actuator_length) for (int i = g; i < d.nu; i += G) o.actuator_length[(size_t)e * d.nu + i] = W[L.actlen + i];
     if (o.actuator_velocity) for (int i = g; i < d.nu; i += G) o.actuator_velocity[(size_t)e * d.nu + i] = W[L.actvel + i];
     if (o.actuator_force) for (int i = g; i < d.nu; i += G) o.actuator_force[(size_t)e * d.nu + i] = W[L.actfrc + i];
@@ -2119,7 +2146,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (a.dbg) {  // tests only: owner registers and tables in a flat record
     float* D = a.dbg + (size_t)e * a.D.total;
     if (g < d.nbody) {
-      st3(D + a.D.xpos + 3 * g, E.b_xpos); st3(D + a.D.xipos + 3 * g, E.b_xipos);
+      st3(D + a.D.xpos + 3 * g, E.b_xpos + E.origin()); st3(D + a.D.xipos + 3 * g, E.b_xipos + E.origin());
       D[a.D.xquat + 4 * g] = E.b_xquat.w; D[a.D.xquat + 4 * g + 1] = E.b_xquat.x;
       D[a.D.xquat + 4 * g + 2] = E.b_xquat.y; D[a.D.xquat + 4 * g + 3] = E.b_xquat.z;
       for (int k = 0; k < 6; k++) D[a.D.cvel + 6 * g + k] = E.b_cvel[k];
@@ -2146,6 +2173,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   }
 
   // ---- task stage: obs_dict / reward_dict (pose_v0.py:100-140), TimeLimit counter
+  // results of the task stage the rollout bookkeeping needs: dense reward / solved / done (valid in lane 0 of the group),
+  // and whether this env is re-armed inside this launch (group-uniform; POSE task with mm_rollout.autoreset)
+  float rw_dense = 0.f, rw_solved = 0.f;
+  bool rw_done = false, will_reset = false;
   if (a.mode == 2) {
     int sc = 0, sc0 = 0;
     if (t.step_count) { sc0 = t.step_count[e]; sc = obs_only ? sc0 : sc0 + 1; }
@@ -2156,34 +2187,41 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       float err2 = 0.f, act2 = 0.f;
       float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
       for (int i = g; i < d.nq; i += G) {
-        float q = W[L.qpos + i];
-        float pe = t.target_jnt_value[(size_t)e * d.nq + i] - q;
+        const float pe = t.target_jnt_value[(size_t)e * d.nq + i] - W[L.qpos + i];
         err2 += pe * pe;
-        if (ob) { ob[i] = q; ob[o_err + i] = pe; }
       }
-      if (ob && g < d.nv) ob[d.nq + g] = E.d_qvel * dt;
-      for (int i = g; i < d.na; i += G) {
-        float x = W[L.act + i];
-        act2 += x * x;
-        if (ob) ob[o_act + i] = x;
-      }
+      for (int i = g; i < d.na; i += G) { const float x = W[L.act + i]; act2 += x * x; }
       err2 = gsum<G>(err2); act2 = gsum<G>(act2);
+      // group-uniform (gsum is bitwise uniform): every lane knows whether the episode ends here
+      const float pose_dist = sqrtf(err2);
+      const bool done = pose_dist > t.far_th;
+      rw_done = done;
+      will_reset = has_ro && KA().ro.autoreset && (done || (t.max_episode_steps > 0 && sc >= t.max_episode_steps));
+      if (ob && !will_reset) {      // an env that resets in this launch gets the first observation of its new episode instead
+        for (int i = g; i < d.nq; i += G) {
+          const float q = W[L.qpos + i];
+          ob[i] = q; ob[o_err + i] = t.target_jnt_value[(size_t)e * d.nq + i] - q;
+        }
+        if (g < d.nv) ob[d.nq + g] = E.d_qvel * dt;
+        for (int i = g; i < d.na; i += G) ob[o_act + i] = W[L.act + i];
+      }
       if (g == 0) {
-        float pose_dist = sqrtf(err2), act_mag = sqrtf(act2);
+        float act_mag = sqrtf(act2);
         if (d.na != 0 && t.act_reg_mean) act_mag = act_mag / (float)d.na;
         float r_pose = -pose_dist;
         float r_bonus = (pose_dist < t.pose_thd ? 1.f : 0.f) + (pose_dist < 1.5f * t.pose_thd ? 1.f : 0.f);
         float r_pen = pose_dist > t.far_th ? -1.f : 0.f;
         float r_act = -act_mag;
-        bool done = pose_dist > t.far_th;
-        if (t.rwd) {
+        rw_dense = t.w_pose * r_pose + t.w_bonus * r_bonus + t.w_act_reg * r_act + t.w_penalty * r_pen;
+        rw_solved = pose_dist < t.pose_thd ? 1.f : 0.f;
+        if (t.rwd && !obs_only) {   // the reset observation leaves the terminal step's reward terms in place
           float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
           r[MM_RWD_POSE] = r_pose; r[MM_RWD_BONUS] = r_bonus; r[MM_RWD_PENALTY] = r_pen; r[MM_RWD_ACT_REG] = r_act;
-          r[MM_RWD_SPARSE] = -pose_dist; r[MM_RWD_SOLVED] = pose_dist < t.pose_thd ? 1.f : 0.f;
+          r[MM_RWD_SPARSE] = -pose_dist; r[MM_RWD_SOLVED] = rw_solved;
           r[MM_RWD_DONE] = done ? 1.f : 0.f;
-          r[MM_RWD_DENSE] = t.w_pose * r_pose + t.w_bonus * r_bonus + t.w_act_reg * r_act + t.w_penalty * r_pen;
+          r[MM_RWD_DENSE] = rw_dense;
         }
-        if (t.done) t.done[e] = done ? 1 : 0;
+        if (t.done && !obs_only) t.done[e] = done ? 1 : 0;
       }
     }
     if (t.task == MM_TASK_REACH) {
@@ -2199,9 +2237,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       const float vs = g < d.nv ? E.d_qvel * t.obs_dt : 0.f;
       const float vel2 = t.reach_stand ? gsum<G>(vs * vs) : 0.f;
       for (int i = g; i < t.ntip; i += G) {
-        V3 tip = E.site_pos(t.tip_sites[i]);
+        const V3 tip_i = E.site_pos(t.tip_sites[i]);
+        V3 tip = tip_i + E.origin();
         V3 tgt = ld3(t.target_pos + (size_t)e * n3 + 3 * i);
-        V3 er = tgt - tip;
+        V3 er = (tgt - E.origin()) - tip_i;
         err2 += dot(er, er);
         if (ob) { st3(ob + o_tip + 3 * i, tip); st3(ob + o_tip + n3 + 3 * i, er); }
       }
@@ -2220,6 +2259,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         float r_bonus = (reach_dist < 2.f * near_th ? 1.f : 0.f) + (reach_dist < near_th ? 1.f : 0.f);
         float r_pen = reach_dist > far_th ? -1.f : 0.f;
         bool done = reach_dist > far_th;
+        rw_done = done; rw_solved = reach_dist < near_th ? 1.f : 0.f;
+        rw_dense = t.w_pose * r_reach + t.w_bonus * r_bonus + t.w_act_reg * (-act_mag) + t.w_penalty * r_pen;
         if (t.rwd && !obs_only) {
           float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
           r[MM_RWD_POSE] = r_reach; r[MM_RWD_BONUS] = r_bonus; r[MM_RWD_PENALTY] = r_pen; r[MM_RWD_ACT_REG] = -act_mag;
@@ -2242,7 +2283,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       const float mtot = gsum<G>(ms);
       // com velocity with the reference's sign convention: mean of -cvel[:, 3:5]
       const float cvx = gsum<G>(ms * -E.b_cvel[3]) / mtot, cvy = gsum<G>(ms * -E.b_cvel[4]) / mtot;
-      const float height = gsum<G>(ms * E.b_xipos.z) / mtot;
+      const float height = gsum<G>(ms * E.b_xipos.z) / mtot + d.oz;
       const int bp = t.walk_body[0], bt = t.walk_body[1], bl = t.walk_body[2], br = t.walk_body[3];
       const V3 xp = v3(bc<G>(E.b_xpos.x, bp), bc<G>(E.b_xpos.y, bp), bc<G>(E.b_xpos.z, bp));
       const V3 xl = v3(bc<G>(E.b_xpos.x, bl), bc<G>(E.b_xpos.y, bl), bc<G>(E.b_xpos.z, bl));
@@ -2271,7 +2312,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         if (ob) {
           ob[o_cv] = cvx; ob[o_cv + 1] = cvy;
           ob[o_tq] = tq0; ob[o_tq + 1] = tq1; ob[o_tq + 2] = tq2; ob[o_tq + 3] = tq3;
-          ob[o_fh] = xl.z; ob[o_fh + 1] = xr.z;
+          ob[o_fh] = xl.z + d.oz; ob[o_fh + 1] = xr.z + d.oz;
           ob[o_h] = height;
           st3(ob + o_fr, xl - xp); st3(ob + o_fr + 3, xr - xp);
           ob[o_ph] = phase;
@@ -2293,6 +2334,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         const float nq_ = q[3] * q[3] + q[4] * q[4] + q[5] * q[5] + q[6] * q[6];   // quat_math.py:151-174
         const float r00 = nq_ > 1.1920929e-07f * 4.f ? 1.f - (2.f / nq_) * (q[5] * q[5] + q[6] * q[6]) : 1.f;
         const bool done = height < t.walk_min_height || fabsf(r00) > t.walk_max_rot;
+        rw_done = done; rw_solved = vel_reward >= 1.f ? 1.f : 0.f;
+        rw_dense = t.walk_w[0] * vel_reward + t.walk_w[1] * (done ? 1.f : 0.f) + t.walk_w[2] * cyclic_hip +
+                   t.walk_w[3] * ref_rot + t.walk_w[4] * joint_angle_rew;
         if (t.rwd && !obs_only) {   // the reset observation leaves the terminal step's reward terms in place
           float* r = t.rwd + (size_t)e * MM_RWDW_COUNT;
           r[MM_RWDW_VEL] = vel_reward; r[MM_RWDW_CYCLIC_HIP] = cyclic_hip; r[MM_RWDW_REF_ROT] = ref_rot;
@@ -2320,13 +2364,16 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       }
       act2 = gsum<G>(act2);
       if (g == 0) {
-        const V3 op = E.site_pos(t.tip_sites[0]);
-        const V3 er = ld3(t.target_pos + (size_t)e * 3) - op;
+        const V3 op_i = E.site_pos(t.tip_sites[0]);
+        const V3 op = op_i + E.origin();
+        const V3 er = (ld3(t.target_pos + (size_t)e * 3) - E.origin()) - op_i;
         if (ob) { st3(ob + nh + nhv, op); st3(ob + nh + nhv + 3, er); }
         const float goal_dist = sqrtf(dot(er, er)), act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
         const float goal_th = 0.010f;
         const bool drop = goal_dist > 0.300f;
         const float bonus = (goal_dist < 2.f * goal_th ? 1.f : 0.f) + (goal_dist < goal_th ? 1.f : 0.f);
+        rw_done = drop; rw_solved = goal_dist < goal_th ? 1.f : 0.f;
+        rw_dense = t.w_pose * -goal_dist + t.w_bonus * bonus + t.w_act_reg * -act_mag + t.w_penalty * (drop ? -1.f : 0.f);
         if (t.rwd && !obs_only) {
           float* r = t.rwd + (size_t)e * MM_RWD_COUNT;
           r[MM_RWD_POSE] = -goal_dist; r[MM_RWD_BONUS] = bonus; r[MM_RWD_PENALTY] = drop ? -1.f : 0.f; r[MM_RWD_ACT_REG] = -act_mag;
@@ -2364,6 +2411,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         const float bonus = (key_pos > 0.5f * pi_ ? 1.f : 0.f) + (key_pos > pi_ ? 1.f : 0.f);
         const float penalty = -(ifd > 0.5f * far_th ? 1.f : 0.f) - (thd > 0.5f * far_th ? 1.f : 0.f);
         const bool done = ifd > far_th || thd > far_th;
+        rw_done = done; rw_solved = key_pos > t.key_goal_th ? 1.f : 0.f;
+        rw_dense = t.key_w[0] * key_pos + t.key_w[1] * -ifd + t.key_w[2] * -thd + t.key_w[3] * -act_mag +
+                   t.key_w[4] * bonus + t.key_w[5] * penalty;
         if (t.rwd && !obs_only) {
           float* r = t.rwd + (size_t)e * MM_RWDK_COUNT;
           r[MM_RWDK_KEY_TURN] = key_pos; r[MM_RWDK_IF_APPROACH] = -ifd; r[MM_RWDK_TH_APPROACH] = -thd; r[MM_RWDK_ACT_REG] = -act_mag;
@@ -2396,12 +2446,13 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       act2 = gsum<G>(act2);
       if (g == 0) {
         const int bo = t.reor_obj_body;
-        V3 opos = ld3(W + L.xpos + 3 * bo);
+        const V3 opos_i = ld3(W + L.xpos + 3 * bo);
+        const V3 opos = opos_i + E.origin();
         const float* R = W + L.xmat + 9 * bo;
         const float sc_ = 2.f * t.reor_axis_half[e] / t.reor_pen_length;   // pen_v0.py: the same vector through the top / bottom sites
         V3 orot = v3(R[2] * sc_, R[5] * sc_, R[8] * sc_);
         V3 odes = ld3(t.reor_des_rot + (size_t)e * 3);
-        V3 epos = opos - E.site_pos(t.reor_eps_site), erot = orot - odes;
+        V3 epos = opos_i - E.site_pos(t.reor_eps_site), erot = orot - odes;
         if (ob) { st3(ob + o_pos, opos); st3(ob + o_rot, orot); st3(ob + o_des, odes); st3(ob + o_ep, epos); st3(ob + o_er, erot); }
         const float pos_align = sqrtf(dot(epos, epos));
         float nrm = sqrtf(dot(orot, orot)) * sqrtf(dot(odes, odes));
@@ -2410,6 +2461,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         const bool dropped = pos_align > 0.075f;
         const float act_mag = d.na != 0 ? sqrtf(act2) / (float)d.na : 0.f;
         const float bonus = ((rot_align > 0.9f && pos_align < 0.075f) ? 1.f : 0.f) + ((rot_align > 0.95f && pos_align < 0.075f) ? 5.f : 0.f);
+        rw_done = dropped; rw_solved = (rot_align > 0.95f && !dropped) ? 1.f : 0.f;
+        rw_dense = t.reor_w[0] * -pos_align + t.reor_w[1] * rot_align + t.reor_w[2] * -act_mag +
+                   t.reor_w[3] * (dropped ? -1.f : 0.f) + t.reor_w[4] * bonus;
         if (t.rwd && !obs_only) {
           float* r = t.rwd + (size_t)e * MM_RWDR_COUNT;
           r[MM_RWDR_POS_ALIGN] = -pos_align; r[MM_RWDR_ROT_ALIGN] = rot_align; r[MM_RWDR_ACT_REG] = -act_mag;
@@ -2422,9 +2476,55 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       }
     }
     if (g == 0 && !obs_only) {
-      if (t.step_count) t.step_count[e] = sc;
-      if (t.truncated) t.truncated[e] = (t.max_episode_steps > 0 && sc >= t.max_episode_steps) ? 1 : 0;
+      const bool trunc = t.max_episode_steps > 0 && sc >= t.max_episode_steps;
+      if (t.step_count) t.step_count[e] = will_reset ? 0 : sc;
+      if (t.truncated) t.truncated[e] = trunc ? 1 : 0;
+      if (has_ro) {   // rollout bookkeeping (mm_rollout): what mm_episode_stats does in its own launch
+        const __attribute__((address_space(4))) mm_rollout& ro = KA().ro;
+        if (ro.ep_stats) {
+          float* st = ro.ep_stats + (size_t)e * 3;
+          st[0] += rw_dense; st[1] += 1.f; st[2] = fmaxf(st[2], rw_solved);
+        }
+        if (ro.reset_mask) ro.reset_mask[e] = (rw_done || trunc) ? 1 : 0;
+      }
     }
+  }
+
+  // ---- store state
+  if (!will_reset) {
+    for (int i = g; i < d.nq; i += G) a.s.qpos[(size_t)e * d.nq + i] = W[L.qpos + i];
+    if (g < d.nv) {
+      a.s.qvel[(size_t)e * d.nv + g] = E.d_qvel;
+      a.s.qacc_warmstart[(size_t)e * d.nv + g] = E.d_warm;
+    }
+    for (int i = g; i < d.na; i += G) a.s.act[(size_t)e * d.na + i] = W[L.act + i];
+    if (g == 0) { a.s.time[e] = time; if (a.s.status) a.s.status[e] = E.status; }
+  } else {
+    // masked auto-reset of a POSE env folded into this launch: the draws, state and first observation k_reset produces for
+    // mm_pose_reset (pose_v0.py:174-257; Philox counter (i/2, 0, global env, episode): words 0/1 -> qpos, 2/3 -> target)
+    const __attribute__((address_space(4))) mm_rollout& ro = KA().ro;
+    const int ep = ro.episode[e];
+    const uint64_t sd = ro.reset_seed;
+    const int o_err = t.obs_layout == 1 ? d.nq + d.nv + d.na : d.nq + d.nv;
+    const int o_act = t.obs_layout == 1 ? d.nq + d.nv : 2 * d.nq + d.nv;
+    float* ob = t.obs ? t.obs + (size_t)e * t.obs_dim : nullptr;
+    for (int i = g; i < d.nq; i += G) {
+      uint32_t c[4] = {(uint32_t)(i >> 1), 0u, (uint32_t)(a.s.env_index_base + e), (uint32_t)ep};
+      philox4x32_10(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+      const float uq = u01((i & 1) ? c[1] : c[0]), ut = u01((i & 1) ? c[3] : c[2]);
+      const float q = ro.random_qpos ? ro.qlo[i] + (ro.qhi[i] - ro.qlo[i]) * uq : MF_(QPOS0)[i];
+      const float tg = ro.tlo[i] + (ro.thi[i] - ro.tlo[i]) * ut;
+      a.s.qpos[(size_t)e * d.nq + i] = q;
+      ro.target[(size_t)e * d.nq + i] = tg;
+      if (ob) { ob[i] = q; ob[o_err + i] = tg - q; }
+    }
+    if (g < d.nv) {
+      a.s.qvel[(size_t)e * d.nv + g] = 0.f;
+      a.s.qacc_warmstart[(size_t)e * d.nv + g] = 0.f;
+      if (ob) ob[d.nq + g] = 0.f;
+    }
+    for (int i = g; i < d.na; i += G) { a.s.act[(size_t)e * d.na + i] = 0.f; if (ob) ob[o_act + i] = 0.f; }
+    if (g == 0) { a.s.time[e] = 0.f; if (a.s.status) a.s.status[e] = 0; ro.episode[e] = ep + 1; }
   }
 }
 

@@ -93,7 +93,7 @@ class mm_state(C.Structure):
                 ("qacc_warmstart", C.c_void_p), ("time", C.c_void_p), ("status", C.c_void_p),
                 ("geom_size_env", C.c_void_p), ("geom_env_id", C.c_int), ("geom_type_env", C.c_void_p),
                 ("body_mass_env", C.c_void_p), ("body_mass_env_id", C.c_int),
-                ("body_pos_env", C.c_void_p), ("body_pos_env_id", C.c_int)]
+                ("body_pos_env", C.c_void_p), ("body_pos_env_id", C.c_int), ("env_index_base", C.c_int)]
 
 
 _DERIVED_FIELDS = ["xpos", "xquat", "xipos", "site_xpos", "geom_xpos", "cvel", "subtree_com", "actuator_length",
@@ -126,6 +126,13 @@ class mm_task(C.Structure):
                 ("env_mask", C.c_void_p), ("obs_only", C.c_int)]
 
 
+class mm_rollout(C.Structure):
+    _fields_ = [("action", C.c_void_p), ("action_seed", C.c_uint64), ("action_stream", C.c_uint64), ("action_out", C.c_void_p),
+                ("ep_stats", C.c_void_p), ("reset_mask", C.c_void_p), ("autoreset", C.c_int), ("random_qpos", C.c_int),
+                ("qlo", C.c_void_p), ("qhi", C.c_void_p), ("tlo", C.c_void_p), ("thi", C.c_void_p), ("target", C.c_void_p),
+                ("episode", C.c_void_p), ("reset_seed", C.c_uint64)]
+
+
 def lib():
     """Load libmyosim_hip.so; raises (never falls back) when it is absent."""
     global _lib
@@ -143,6 +150,10 @@ def lib():
         L.mm_forward.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.POINTER(mm_derived), C.c_void_p]
         L.mm_env_step.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.POINTER(mm_task),
                                   C.POINTER(mm_derived), C.c_void_p]
+        L.mm_rollout_step.argtypes = [C.c_void_p, C.POINTER(mm_state), C.POINTER(mm_task), C.POINTER(mm_rollout),
+                                      C.POINTER(mm_derived), C.c_void_p]
+        L.mm_model_launch_lanes.argtypes = [C.c_void_p, C.c_int]
+        L.mm_uniform_at.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p]
         L.mm_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mm_pose_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -151,7 +162,7 @@ def lib():
         L.mm_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p]
         L.mm_env_draw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_uint64, C.c_uint32, C.c_void_p]
+                                  C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
         L.mm_reach_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.mm_walk_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -188,8 +199,9 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """current torch stream of `device` (the model's / output tensor's device, not whatever device happens to be current)"""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class HipModel:
@@ -210,6 +222,10 @@ class HipModel:
 
     def info(self, which: int) -> int:
         return lib().mm_model_info(self.h, which)
+
+    def launch_lanes(self, nenv: int) -> int:
+        """lanes per env a launch over `nenv` envs uses (picked from the batch size unless pinned)"""
+        return lib().mm_model_launch_lanes(self.h, int(nenv))
 
     def set_option(self, name: str, value: int):
         _chk(lib().mm_model_set_option(self.h, name.encode(), int(value)), "mm_model_set_option")
@@ -242,7 +258,7 @@ class BatchState:
         self.status = torch.zeros(nenv, dtype=torch.int32, device=dev)
         self.geom_size_env = None
         self._c = mm_state(nenv, _ptr(self.qpos), _ptr(self.qvel), self.act.data_ptr(), _ptr(self.qacc_warmstart),
-                           _ptr(self.time), _ptr(self.status), None, -1, None, None, -1, None, -1)
+                           _ptr(self.time), _ptr(self.status), None, -1, None, None, -1, None, -1, 0)
         self.geom_type_env = None
         self.body_mass_env = None
         self.body_pos_env = None
@@ -270,6 +286,15 @@ class BatchState:
         assert types.shape == (self.nenv,) and types.dtype == torch.int32 and types.is_contiguous() and types.is_cuda
         self.geom_type_env = types
         self._c.geom_type_env = types.data_ptr()
+
+    @property
+    def env_index_base(self) -> int:
+        return int(self._c.env_index_base)
+
+    @env_index_base.setter
+    def env_index_base(self, v: int):
+        """global index of env 0 of this shard: every Philox stream (resets, draws, in-kernel actions) is keyed by base + e"""
+        self._c.env_index_base = int(v)
 
     @property
     def c(self):
@@ -304,12 +329,12 @@ class Derived:
 def step(model: HipModel, state: BatchState, ctrl: torch.Tensor, nsub: int = 1):
     """`nsub` raw mj_step substeps with ctrl [E,nu] applied unchanged."""
     assert ctrl.shape == (state.nenv, model.cm.nu) and ctrl.dtype == torch.float32
-    _chk(lib().mm_step(model.h, state.c, _ptr(ctrl.contiguous()), int(nsub), _stream()), "mm_step")
+    _chk(lib().mm_step(model.h, state.c, _ptr(ctrl.contiguous()), int(nsub), _stream(model.device)), "mm_step")
 
 
 def forward(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] = None, derived: Optional[Derived] = None):
     _chk(lib().mm_forward(model.h, state.c, _ptr(ctrl) if ctrl is not None else None,
-                          derived.c if derived is not None else None, _stream()), "mm_forward")
+                          derived.c if derived is not None else None, _stream(model.device)), "mm_forward")
 
 
 def env_step(model: HipModel, state: BatchState, action: Optional[torch.Tensor], task: mm_task,
@@ -319,7 +344,13 @@ def env_step(model: HipModel, state: BatchState, action: Optional[torch.Tensor],
     else:
         assert task.obs_only, "action may only be omitted for an obs_only pass"
     _chk(lib().mm_env_step(model.h, state.c, _ptr(action), C.byref(task), derived.c if derived is not None else None,
-                           _stream()), "mm_env_step")
+                           _stream(model.device)), "mm_env_step")
+
+
+def rollout_step(model: HipModel, state: BatchState, task: mm_task, ro: mm_rollout, derived: Optional[Derived] = None):
+    """mm_env_step with the rollout bookkeeping of `ro` folded into the same launch (mm_rollout_step)."""
+    _chk(lib().mm_rollout_step(model.h, state.c, C.byref(task), C.byref(ro), derived.c if derived is not None else None,
+                               _stream(model.device)), "mm_rollout_step")
 
 
 def reset_observation(model: HipModel, state: BatchState, task: mm_task, mask: Optional[torch.Tensor] = None):
@@ -335,14 +366,14 @@ def reset(model: HipModel, state: BatchState, mask: Optional[torch.Tensor] = Non
           qvel: Optional[torch.Tensor] = None):
     if mask is not None:
         assert mask.dtype == torch.uint8
-    _chk(lib().mm_reset(model.h, state.c, _ptr(mask), _ptr(qpos), _ptr(qvel), _stream()), "mm_reset")
+    _chk(lib().mm_reset(model.h, state.c, _ptr(mask), _ptr(qpos), _ptr(qvel), _stream(model.device)), "mm_reset")
 
 
 def pose_reset(model: HipModel, state: BatchState, mask, qlo, qhi, tlo, thi, target, episode, step_count, seed: int,
                random_qpos: bool, obs=None, obs_layout: int = 0):
     _chk(lib().mm_pose_reset(model.h, state.c, _ptr(mask), _ptr(qlo), _ptr(qhi), _ptr(tlo), _ptr(thi), _ptr(target),
                              _ptr(episode), _ptr(step_count), C.c_uint64(seed), int(random_qpos), _ptr(obs),
-                             0 if obs is None else int(obs.shape[1]), int(obs_layout), _stream()),
+                             0 if obs is None else int(obs.shape[1]), int(obs_layout), _stream(model.device)),
          "mm_pose_reset")
 
 
@@ -350,13 +381,13 @@ def reach_reset(model: HipModel, state: BatchState, mask, tlo, thi, target, tip0
                 seed: int, obs=None):
     _chk(lib().mm_reach_reset(model.h, state.c, _ptr(mask), _ptr(tlo), _ptr(thi), _ptr(target), _ptr(tip0), int(ntip),
                               _ptr(episode), _ptr(step_count), C.c_uint64(seed), _ptr(obs),
-                              0 if obs is None else int(obs.shape[1]), _stream()), "mm_reach_reset")
+                              0 if obs is None else int(obs.shape[1]), _stream(model.device)), "mm_reach_reset")
 
 
 def walk_reset(model: HipModel, state: BatchState, mask, key_a_qpos, key_a_qvel, key_b_qpos, key_b_qvel, random: bool,
                episode, step_count, seed: int):
     _chk(lib().mm_walk_reset(model.h, state.c, _ptr(mask), _ptr(key_a_qpos), _ptr(key_a_qvel), _ptr(key_b_qpos),
-                             _ptr(key_b_qvel), int(random), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()),
+                             _ptr(key_b_qvel), int(random), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream(model.device)),
          "mm_walk_reset")
 
 
@@ -365,7 +396,7 @@ def reorient_reset(model: HipModel, state: BatchState, mask, init_qpos, size_tab
     assert state.geom_size_env is not None, "call BatchState.set_geom_size_env first"
     _chk(lib().mm_reorient_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(size_table), int(size_table.shape[0]),
                                  _ptr(state.geom_size_env), _ptr(axis_half), _ptr(des_rot), C.c_float(tar_length),
-                                 _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()), "mm_reorient_reset")
+                                 _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream(model.device)), "mm_reorient_reset")
 
 
 def reorient_reset_typed(model: HipModel, state: BatchState, mask, init_qpos, size_tables, axis_half, des_rot,
@@ -375,14 +406,14 @@ def reorient_reset_typed(model: HipModel, state: BatchState, mask, init_qpos, si
     _chk(lib().mm_reorient_reset_typed(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(size_tables),
                                        int(size_tables.shape[1]), _ptr(state.geom_size_env), _ptr(state.geom_type_env),
                                        _ptr(axis_half), _ptr(des_rot), C.c_float(tar_length), _ptr(episode),
-                                       _ptr(step_count), C.c_uint64(seed), _stream()), "mm_reorient_reset_typed")
+                                       _ptr(step_count), C.c_uint64(seed), _stream(model.device)), "mm_reorient_reset_typed")
 
 
 def pen_reset(model: HipModel, state: BatchState, mask, init_qpos, axis_half: float, ranges, des_rot, tar_length: float,
               episode, step_count, seed: int):
     """ranges = (lo0, hi0, lo1, hi1) of desired_orien[0:2] (pen_v0.py:175-178); zeros for the Fixed task"""
     _chk(lib().mm_pen_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), C.c_float(axis_half), *[C.c_float(x) for x in ranges],
-                            _ptr(des_rot), C.c_float(tar_length), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream()),
+                            _ptr(des_rot), C.c_float(tar_length), _ptr(episode), _ptr(step_count), C.c_uint64(seed), _stream(model.device)),
          "mm_pen_reset")
 
 
@@ -393,17 +424,18 @@ def objhold_reset(model: HipModel, state: BatchState, mask, init_qpos, goal_cent
     lo, hi = size_range if size_range is not None else (0.0, 0.0)
     _chk(lib().mm_objhold_reset(model.h, state.c, _ptr(mask), _ptr(init_qpos), _ptr(goal_center), C.c_float(goal_half),
                                 C.c_float(lo), C.c_float(hi), _ptr(goal), _ptr(gs), _ptr(episode), _ptr(step_count),
-                                C.c_uint64(seed), _stream()), "mm_objhold_reset")
+                                C.c_uint64(seed), _stream(model.device)), "mm_objhold_reset")
 
 
-def env_draw(out: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, mask, episode, seed: int, stream_id: int, base=None):
+def env_draw(out: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, mask, episode, seed: int, stream_id: int, base=None,
+             env_index_base: int = 0):
     """out[e, k] = base[k] + lo[k] + (hi[k]-lo[k]) * U[0,1): per-episode draw of a per-env model delta (mm_env_draw); call before
     the task reset of the same episode."""
     assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
     n, k = out.shape[0], (out.shape[1] if out.dim() > 1 else 1)
     assert lo.numel() == k and hi.numel() == k and (base is None or base.numel() == k)
     _chk(lib().mm_env_draw(out.data_ptr(), n, k, _ptr(base), _ptr(lo), _ptr(hi), _ptr(mask), _ptr(episode), C.c_uint64(seed),
-                           C.c_uint32(stream_id), _stream()), "mm_env_draw")
+                           C.c_uint32(stream_id), int(env_index_base), _stream(out.device)), "mm_env_draw")
     return out
 
 
@@ -412,13 +444,15 @@ def episode_stats(stats: torch.Tensor, reset_mask: torch.Tensor, rwd: torch.Tens
     """stats[e] = (return, length, solved) accumulated with this step's reward row; reset_mask = done | truncated (one launch)."""
     assert stats.shape == (rwd.shape[0], 3) and stats.dtype == torch.float32 and reset_mask.dtype == torch.uint8
     _chk(lib().mm_episode_stats(_ptr(stats), _ptr(reset_mask), _ptr(rwd), int(rwd.shape[1]), int(dense_col), int(solved_col),
-                                _ptr(done), _ptr(truncated), int(rwd.shape[0]), _stream()), "mm_episode_stats")
+                                _ptr(done), _ptr(truncated), int(rwd.shape[0]), _stream(stats.device)), "mm_episode_stats")
 
 
-def uniform(out: torch.Tensor, seed: int, stream_id: int):
-    """out[...] = U[0,1) float32, Philox4x32-10, counter=(i/4, stream_id), key=seed."""
+def uniform(out: torch.Tensor, seed: int, stream_id: int, first_index: int = 0):
+    """out[...] = U[0,1) float32, Philox4x32-10: flat element i is word (first_index+i)%4 of counter ((first_index+i)/4,
+    stream_id), key=seed.  A shard of envs passes first_index = env_index_base * nu to draw its slice of the global matrix."""
     assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
-    _chk(lib().mm_uniform(out.data_ptr(), out.numel(), C.c_uint64(seed), C.c_uint64(stream_id), _stream()), "mm_uniform")
+    _chk(lib().mm_uniform_at(out.data_ptr(), out.numel(), C.c_uint64(seed), C.c_uint64(stream_id), int(first_index),
+                             _stream(out.device)), "mm_uniform")
     return out
 
 

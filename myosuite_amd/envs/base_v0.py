@@ -26,27 +26,21 @@ from .spaces import Box
 _MODEL_CACHE: Dict[tuple, object] = {}
 
 
+def _weaken(spec):
+    """sarcopenia (base_v0.py:60-67): actuator_gainprm[:, 2] *= 0.5 on EVERY actuator row (the peak force of a muscle; 0 on
+    motors / servos, whose gain lives in gainprm[0]); biasprm is left untouched"""
+    for a in spec.actuators:
+        g = list(a.gainprm)
+        if len(g) > 2:
+            g[2] = 0.5 * g[2]
+            a.gainprm = tuple(g)
+
+
 def _compiled_model(name: str, muscle_condition: str):
-    """Compiled model, with the sarcopenia edit applied before compilation
-    (base_v0.py:63-67: gainprm[:,2] *= 0.5; biasprm is left untouched)."""
+    """Compiled model of any synthetic model name, with the sarcopenia edit applied before compilation."""
     key = (name, muscle_condition == "sarcopenia")
     if key not in _MODEL_CACHE:
-        if muscle_condition != "sarcopenia":
-            _MODEL_CACHE[key] = synth.get_model(name)
-        else:
-            spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg,
-                    "hand_reorient": synth.make_hand_reorient, "hand_pen": synth.make_hand_pen,
-                    "hand_hold": synth.make_hand_hold}[name]()
-            for a in spec.actuators:
-                g = list(a.gainprm)
-                g[2] = 0.5 * g[2]
-                a.gainprm = tuple(g)
-            cm = spec.compile()
-            base = synth.get_model(name)
-            for k in ("key_qpos", "key_qvel"):     # keyframes are geometry only: identical for the weakened model
-                if hasattr(base, k):
-                    setattr(cm, k, getattr(base, k))
-            _MODEL_CACHE[key] = cm
+        _MODEL_CACHE[key] = synth.get_model(name) if muscle_condition != "sarcopenia" else synth.compile_spec(name, _weaken)
     return _MODEL_CACHE[key]
 
 
@@ -54,7 +48,7 @@ class BaseV0:
     MYO_CREDIT = "MyoSuite: A contact-rich simulation suite for musculoskeletal motor control"
 
     def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None,
-                 max_episode_steps: int = 0, lanes_per_env: int = 0, autoreset: bool = True):
+                 max_episode_steps: int = 0, lanes_per_env: int = 0, autoreset: bool = True, env_index_base: int = 0):
         self.env_id = env_id
         self.model_name = model
         self.num_envs = int(num_envs)
@@ -63,6 +57,7 @@ class BaseV0:
         self.input_seed = seed
         self._lanes = lanes_per_env
         self._device = device
+        self.env_index_base = int(env_index_base)   # global index of env 0 (env sharding over ranks): keys the Philox streams
         self.np_random = np.random.default_rng(seed)
         self.unwrapped = self
 
@@ -92,6 +87,7 @@ class BaseV0:
         n = self.num_envs
         dev = self.device
         self.state = E.BatchState(self.hm, n)
+        self.state.env_index_base = self.env_index_base
         self.step_count = torch.zeros(n, dtype=torch.int32, device=dev)
         self.episode = torch.zeros(n, dtype=torch.int32, device=dev)
         self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -224,16 +220,62 @@ class BaseV0:
         a = a.contiguous()
         E.env_step(self.hm, self.state, a, self._task)
         self._refresh_dicts()
-        reward = self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]
+        # fresh arrays, as the reference returns: the buffers behind rwd_dict / obs_dict are rewritten by the next step
+        reward = (self.rwd_dict["dense"] if self.rwd_mode == "dense" else self.rwd_dict["sparse"]).clone()
         terminated = self.done.bool()
         truncated = self.truncated.bool() & ~terminated
         info = self.get_env_infos()
         obs = self.obs
         if self.autoreset:
+            # info describes the step that just ended (its obs_dict views would otherwise show the post-reset observation of
+            # finished envs): snapshot before the masked reset rewrites self.obs
             info["final_obs"] = obs.clone()
+            info["obs_dict"] = collections.OrderedDict((k, v.clone()) for k, v in self.obs_dict.items())
             self.reset(mask=(self.done | self.truncated))
             obs = self.obs
         return obs, reward, terminated, truncated, info
+
+    # ------------------------------------------------------------------ rollout step (one launch)
+    def rollout_setup(self, ep_stats: Optional[torch.Tensor] = None, action_seed: int = 0, action_out: Optional[torch.Tensor] = None):
+        """Prepare `rollout_step`: per-env (return, length, solved) accumulators and, for the Pose family, the masked
+        auto-reset folded into the env-step launch (mm_rollout).  Tasks without a folded reset re-arm finished envs with
+        their reset call, driven by the reset mask the launch writes."""
+        n, dev = self.num_envs, self.device
+        self._ro_stats = ep_stats if ep_stats is not None else torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        self._ro_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self._ro_action_out = action_out
+        ro = E.mm_rollout()
+        ro.action_seed = int(action_seed)
+        ro.ep_stats = self._ro_stats.data_ptr(); ro.reset_mask = self._ro_mask.data_ptr()
+        ro.action_out = action_out.data_ptr() if action_out is not None else None
+        ro.autoreset = 0
+        self._rollout_fill_reset(ro)
+        self._ro = ro
+        return self._ro_stats
+
+    def _rollout_fill_reset(self, ro):
+        """tasks whose reset is folded into the launch fill mm_rollout's reset fields here (PoseEnvV0)"""
+
+    def rollout_step(self, action: Optional[torch.Tensor] = None, stream_id: int = 0, events=None):
+        """env.step + auto-reset + episode statistics for rollout harnesses, without the gym-level dict plumbing: ONE kernel
+        launch for the Pose family (action ~ U[0,1) drawn in the kernel when `action` is None, benchmarks/mjx_benchmark.py:29),
+        one more (the task's masked reset) for the others.  Returns (obs, reward_row_view, reset_mask): obs holds the first
+        observation of the new episode for re-armed envs; views are rewritten by the next call."""
+        ro = self._ro
+        if action is not None:
+            assert action.shape == (self.num_envs, self.cm.nu) and action.dtype == torch.float32 and action.is_contiguous()
+            ro.action = action.data_ptr()
+        else:
+            ro.action = None
+        ro.action_stream = int(stream_id)
+        if events is not None:      # (start, end) torch.cuda.Event pair around the fused env-step launch alone
+            events[0].record()
+        E.rollout_step(self.hm, self.state, self._task, ro)
+        if events is not None:
+            events[1].record()
+        if not ro.autoreset and self.autoreset:
+            self.reset(mask=self._ro_mask)
+        return self.obs, self.rwd, self._ro_mask
 
     def capture_step_graph(self, warmup: int = 2):
         """Capture ``step()`` (fused env-step launch + masked auto-reset + the few tensor ops between them) into a HIP graph.

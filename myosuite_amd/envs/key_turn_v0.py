@@ -25,8 +25,8 @@ class KeyTurnEnvV0(BaseV0):
                                     "bonus": 4.0, "penalty": 25.0}                                              # key_turn_v0.py:24-31
 
     def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=200,
-                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
-        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+                 lanes_per_env: int = 0, autoreset: bool = True, env_index_base: int = 0, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset, env_index_base)
         self._setup(**kwargs)
 
     def _setup(self, goal_th: float = 3.14, obs_keys=DEFAULT_OBS_KEYS, weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS,
@@ -89,9 +89,9 @@ class KeyTurnEnvV0(BaseV0):
         if mask is not None:
             mask = mask.to(torch.uint8).contiguous()
         self._fatigue_reset(mask)
-        E.env_draw(self.key_q0, self._klo, self._khi, mask, self.episode, self._seed_u64, 17)
+        E.env_draw(self.key_q0, self._klo, self._khi, mask, self.episode, self._seed_u64, 17, env_index_base=self.env_index_base)
         if self.randomize:
-            E.env_draw(self.body_pos, self._plo, self._phi, mask, self.episode, self._seed_u64, 18, base=self._pbase)
+            E.env_draw(self.body_pos, self._plo, self._phi, mask, self.episode, self._seed_u64, 18, base=self._pbase, env_index_base=self.env_index_base)
         q = self._init_q.expand(self.num_envs, -1).clone()
         q[:, -1] = self.key_q0[:, 0]
         E.reset(self.hm, self.state, mask, q.contiguous(), None)

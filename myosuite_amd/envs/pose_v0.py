@@ -22,10 +22,12 @@ class PoseEnvV0(BaseV0):
     FAR_TH = 4 * math.pi / 2                                               # pose_v0.py:118
     DEFAULT_OBS_KEYS = ["qpos", "qvel", "pose_err"]                        # pose_v0.py:17
     DEFAULT_RWD_KEYS_AND_WEIGHTS = {"pose": 1.0, "bonus": 4.0, "act_reg": 1.0, "penalty": 50}   # pose_v0.py:18-23
+    SWITCH_POSES = ((-0.145125, 0.92524251, 1.08978337, 1.39425813, -0.78286243, -0.77179383, -0.15042819, 0.64445902),
+                    (-0.12756566, 0.06741454, 1.51352705, 0.91777418, -0.63884237, 0.22452487, 0.42103326, 0.4139465))   # pose_v0.py:201-228
 
     def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=100,
-                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
-        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+                 lanes_per_env: int = 0, autoreset: bool = True, env_index_base: int = 0, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset, env_index_base)
         self._setup(**kwargs)
 
     def _setup(self, viz_site_targets: tuple = None, target_jnt_range: dict = None, target_jnt_value=None,
@@ -123,6 +125,21 @@ class PoseEnvV0(BaseV0):
         rwd["dense"] = sum(wt * rwd[k] for k, wt in self.rwd_keys_wt.items())
         return rwd
 
+    def _rollout_fill_reset(self, ro):
+        """the Pose family's reset (targets ~ U(target range), qpos ~ U(joint range) or qpos0) runs inside the env-step launch;
+        per-episode model deltas (carried weight) and the "none" / "switch" modes keep the separate reset call"""
+        if (self.weight_bodyname is None and self.reset_type in ("init", "random") and self.target_type in ("generate", "fixed")
+                and self.muscle_condition != "fatigue" and self.autoreset):
+            generate = self.target_type == "generate"
+            self._ro_tfix = None if generate else self.target_jnt_value[0].clone().contiguous()
+            ro.autoreset = 1
+            ro.random_qpos = int(self.reset_type == "random")
+            ro.qlo, ro.qhi = self._qlo.data_ptr(), self._qhi.data_ptr()
+            ro.tlo = self._tlo.data_ptr() if generate else self._ro_tfix.data_ptr()
+            ro.thi = self._thi.data_ptr() if generate else self._ro_tfix.data_ptr()
+            ro.target = self.target_jnt_value.data_ptr(); ro.episode = self.episode.data_ptr()
+            ro.reset_seed = self._seed_u64
+
     def get_obs(self):
         """Observation vector of the current state without stepping (mm_forward-free: Pose needs none)."""
         d = self.get_obs_dict()
@@ -135,21 +152,39 @@ class PoseEnvV0(BaseV0):
             self._seed_u64 = int(seed)
         if mask is not None:
             mask = mask.to(torch.uint8).contiguous()
-        self._fatigue_reset(mask)
         if self.reset_type in (None, "none"):
-            # no state reset; only targets (and counters) are refreshed
+            # no state reset; only targets (and counters) are refreshed.  The fatigue state is not reset either
+            # (pose_v0.py: "NOTE: fatigue is also not reset in this case": BaseV0.reset is skipped)
             keep = self.get_env_state()
+        else:
+            self._fatigue_reset(mask)
         if self.weight_bodyname is not None:     # weight ~ U(weight_range), Philox stream 16 of (seed, env, episode)
-            E.env_draw(self.body_mass, self._wlo, self._whi, mask, self.episode, self._seed_u64, 16)
+            E.env_draw(self.body_mass, self._wlo, self._whi, mask, self.episode, self._seed_u64, 16,
+                       env_index_base=self.env_index_base)
+        if self.target_type not in ("generate", "fixed", "switch"):
+            raise TypeError("Unknown Target type: {}".format(self.target_type))          # pose_v0.py:150-151
+        if getattr(self, "_ro", None) is not None:
+            self._ro.reset_seed = self._seed_u64
         generate = self.target_type == "generate"
         random_q = self.reset_type == "random" and reset_qpos is None
+        switch_prev = self.target_jnt_value.clone() if self.target_type == "switch" else None
         # targets ~ U(target range) and (optionally) qpos ~ U(joint range): Philox keyed by (seed, env, episode)
         E.pose_reset(self.hm, self.state, mask, self._qlo, self._qhi,
                      self._tlo if generate else self.target_jnt_value[0].contiguous(),
                      self._thi if generate else self.target_jnt_value[0].contiguous(),
                      self.target_jnt_value, self.episode, self.step_count, self._seed_u64, random_q,
                      obs=self.obs, obs_layout=0)
-        simple = reset_qpos is None and self.reset_type not in (None, "none")
+        if switch_prev is not None:
+            # pose_v0.py:197-243: alternate between the reference's two hard-coded 8-joint poses (per env, at its resets)
+            if self.cm.nq != 8:
+                raise NotImplementedError("target_type='switch' alternates between two hard-coded 8-joint poses in the "
+                                          "reference (pose_v0.py:201-239); this model has nq = %d" % self.cm.nq)
+            A = torch.tensor(self.SWITCH_POSES[0], dtype=torch.float32, device=self.device)
+            B = torch.tensor(self.SWITCH_POSES[1], dtype=torch.float32, device=self.device)
+            new_t = torch.where((switch_prev[:, :1] != A[0]), A[None, :], B[None, :])
+            sel = torch.ones(self.num_envs, 1, dtype=torch.bool, device=self.device) if mask is None else mask.bool()[:, None]
+            self.target_jnt_value.copy_(torch.where(sel, new_t, switch_prev))
+        simple = reset_qpos is None and self.reset_type not in (None, "none") and switch_prev is None
         if reset_qpos is not None:
             q = torch.as_tensor(reset_qpos, dtype=torch.float32, device=self.device).expand(self.num_envs, -1).contiguous()
             v = None if reset_qvel is None else torch.as_tensor(reset_qvel, dtype=torch.float32, device=self.device).expand(self.num_envs, -1).contiguous()

@@ -29,8 +29,8 @@ class ReorientEnvV0(BaseV0):
     DEFAULT_RWD_KEYS_AND_WEIGHTS = {"pos_align": 1.0, "rot_align": 1.0, "act_reg": 5.0, "drop": 5.0, "bonus": 10.0}   # :38-44
 
     def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=50,
-                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
-        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+                 lanes_per_env: int = 0, autoreset: bool = True, env_index_base: int = 0, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset, env_index_base)
         self._setup(**kwargs)
 
     def _setup(self, geometries: str = "100", obs_keys=DEFAULT_OBS_KEYS, weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS,

@@ -24,8 +24,8 @@ class StandEnvV0(BaseV0):
     DEFAULT_RWD_KEYS_AND_WEIGHTS = {"reach": 1.0, "bonus": 4.0, "penalty": 50, "act_reg": 1}      # walk_v0.py:19-24
 
     def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=150,
-                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
-        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+                 lanes_per_env: int = 0, autoreset: bool = True, env_index_base: int = 0, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset, env_index_base)
         self._setup(**kwargs)
 
     def _setup(self, target_reach_range: dict, joint_random_range: tuple = (0.0, 0.0), far_th=0.35, obs_keys=DEFAULT_OBS_KEYS,
@@ -82,7 +82,7 @@ class StandEnvV0(BaseV0):
 
     def _generate_qpos(self, mask, stream_id: int) -> torch.Tensor:
         """walk_v0.py:153-168 (Philox stream `stream_id` of (seed, env, episode))."""
-        E.env_draw(self._draw_q, self._jlo, self._jhi, mask, self.episode, self._seed_u64, stream_id)
+        E.env_draw(self._draw_q, self._jlo, self._jhi, mask, self.episode, self._seed_u64, stream_id, env_index_base=self.env_index_base)
         q = self._q0 + self._sel * self._draw_q
         return torch.where(self._sel > 0, torch.minimum(torch.maximum(q, self._clo), self._chi), q).contiguous()
 
@@ -100,7 +100,7 @@ class StandEnvV0(BaseV0):
         E.reset(self.hm, self.state, mask, q1, None)
         E.reset_observation(self.hm, self.state, self._task, mask)
         nq, nv, n3 = self.cm.nq, self.cm.nv, 3 * self.ntip
-        E.env_draw(self._draw_t, self._slo, self._shi, mask, self.episode, self._seed_u64, 20)
+        E.env_draw(self._draw_t, self._slo, self._shi, mask, self.episode, self._seed_u64, 20, env_index_base=self.env_index_base)
         tgt = self.obs[:, nq + nv:nq + nv + n3] + self._draw_t
         self.target_pos.copy_(tgt if m is None else torch.where(m[:, None], tgt, self.target_pos))
         # the episode starts from a second draw (walk_v0.py:181-184)

@@ -28,8 +28,8 @@ class WalkEnvV0(BaseV0):
                                     "joint_angle_rew": 5.0}                                                        # walk_v0.py:205-211
 
     def __init__(self, env_id: str, model: str, num_envs: int = 1, device=None, seed=None, max_episode_steps=1000,
-                 lanes_per_env: int = 0, autoreset: bool = True, **kwargs):
-        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset)
+                 lanes_per_env: int = 0, autoreset: bool = True, env_index_base: int = 0, **kwargs):
+        super().__init__(env_id, model, num_envs, device, seed, max_episode_steps, lanes_per_env, autoreset, env_index_base)
         self._setup(**kwargs)
 
     def _setup(self, obs_keys=DEFAULT_OBS_KEYS, weighted_reward_keys=DEFAULT_RWD_KEYS_AND_WEIGHTS, min_height=0.8,

@@ -69,7 +69,7 @@ class MjxPoseEnv:
     def _metrics(self):
         r, w = self._env.rwd, self._env.rwd_keys_wt
         return {"pose_reward": w["pose"] * r[:, 0], "act_reg_reward": w["act_reg"] * r[:, 3], "bonus_reward": w["bonus"] * r[:, 1],
-                "penalty_reward": r[:, 2], "solved_frac": r[:, 5] / self.max_episode_steps}
+                "penalty_reward": r[:, 2].clone(), "solved_frac": r[:, 5] / self.max_episode_steps}
 
     def reset(self, rng: int) -> State:
         env = self._env

@@ -255,9 +255,15 @@ HAND_MUSCLES = ["ECRL", "ECRB", "ECU", "FCR", "FCU", "PL", "PT", "PQ", "EIP", "E
                 "UI_UB2", "UI_UB3", "UI_UB4", "UI_UB5"]
 
 
-def make_hand() -> ModelSpec:
-    """myoHand: 23 DoF, 39 muscle-tendon units, 29 bones.  Frame: +x distal, +z dorsal, -y radial."""
-    s = ModelSpec("myohand")
+def make_hand(self_collision: bool = False) -> ModelSpec:
+    """myoHand: 23 DoF, 39 muscle-tendon units, 29 bones.  Frame: +x distal, +z dorsal, -y radial.
+
+    ``self_collision``: the real myoHand collides with itself even in the Pose task ("avoiding self collisions poses
+    additional challenges", docs/source/suite.rst:288; the MJX README blames HandReach's scaling on "greater contact
+    complexity", envs/myo/mjx/README.md:55).  The flag adds collision capsules along metacarpals / phalanges / carpal row and
+    20 explicit capsule-capsule pairs (neighbouring fingers segment by segment, thumb against index / middle, finger tips
+    against their own metacarpal), condim 3, at most 10 simultaneous contacts (njmax 63)."""
+    s = ModelSpec("myohand_contact" if self_collision else "myohand")
     WX = 0.25  # wrist centre
     s.add_body("ulna", "world", pos=(0, 0, 1.0), mass=0.6, ipos=(0.12, 0.01, 0),
                inertia=_cyl_inertia(0.6, 0.015, 0.25, "x"))
@@ -434,6 +440,19 @@ def make_hand() -> ModelSpec:
                              site(f"proxph{k}", (0.010, 0.007, -0.002))], 50.0)
     assert [a.name for a in s.actuators] == HAND_MUSCLES
     assert [j.name for j in s.joints] == HAND_JOINTS
+    if self_collision:
+        _add_hand_capsules(s)
+        s.nconmax = 10
+        pairs = []
+        for k in (2, 3, 4):                       # neighbouring fingers, segment against segment
+            for seg in ("proxph", "midph", "distph"):
+                pairs.append((f"col_{seg}{k}", f"col_{seg}{k + 1}"))
+        pairs += [("col_distal_thumb", "col_proxph2"), ("col_distal_thumb", "col_midph2"), ("col_distal_thumb", "col_distph2"),
+                  ("col_distal_thumb", "col_midph3"), ("col_distal_thumb", "col_distph3"), ("col_proximal_thumb", "col_proxph2"),
+                  ("col_distal_thumb", "col_mc2")]
+        pairs += [(f"col_distph{k}", f"col_mc{k}") for k in (2, 3, 4, 5)]     # a fully curled finger reaches its own metacarpal
+        for g1, g2 in pairs:
+            s.add_contact_pair(g1, g2, condim=3, friction=(1.0, 0.005, 0.0001))
     return s
 
 
@@ -936,20 +955,32 @@ def _ground_keyframes(cm):
 _CACHE = {}
 
 
+def builders() -> dict:
+    """name -> ModelSpec builder of every synthetic model (the one table get_model and the muscle-condition variants use)."""
+    return {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
+            "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen,
+            "hand_hold": make_hand_hold, "elbow_exo": make_elbow_exo, "finger": make_finger,
+            "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
+            "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
+            "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True)}
+
+
+def compile_spec(name: str, edit=None) -> CompiledModel:
+    """Build the named spec, optionally edit it (sarcopenia: base_v0.py:63-67), compile, attach keyframes."""
+    spec = builders()[name]()
+    if edit is not None:
+        edit(spec)
+    cm = spec.compile()
+    keys = getattr(spec, "keys", None)
+    if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob
+        cm.key_qpos = np.array([k[0] for k in keys]); cm.key_qvel = np.array([k[1] for k in keys])
+        if name == "leg":
+            _ground_keyframes(cm)
+    return cm
+
+
 def get_model(name: str) -> CompiledModel:
-    """Compiled synthetic model by short name: 'elbow' | 'hand' | 'leg'."""
+    """Compiled synthetic model by short name ('elbow' | 'hand' | 'leg' | ...: see builders())."""
     if name not in _CACHE:
-        spec = {"elbow": make_elbow, "hand": make_hand, "leg": make_leg, "contact_toy": make_contact_toy,
-                "hand_reorient": make_hand_reorient, "hand_pen": make_hand_pen,
-                "hand_hold": make_hand_hold, "elbow_exo": make_elbow_exo, "finger": make_finger,
-                "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
-                "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
-                "tendon_limit_toy": make_tendon_limit_toy}[name]()
-        cm = spec.compile()
-        keys = getattr(spec, "keys", None)
-        if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob
-            cm.key_qpos = np.array([k[0] for k in keys]); cm.key_qvel = np.array([k[1] for k in keys])
-            if name == "leg":
-                _ground_keyframes(cm)
-        _CACHE[name] = cm
+        _CACHE[name] = compile_spec(name)
     return _CACHE[name]

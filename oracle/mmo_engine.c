@@ -36,7 +36,10 @@
 #include "../include/myosim_model.h"
 
 #define MINVAL MM_MINVAL
-typedef double real;
+#ifndef MMO_REAL
+#define MMO_REAL double   /* -DMMO_REAL=float builds the fp32 rounding-error study variant (tests/experiments) */
+#endif
+typedef MMO_REAL real;
 
 /* ------------------------------------------------------------------ model */
 typedef struct {

@@ -262,3 +262,69 @@ def test_tendon_limit_rows_gpu_match_oracle(oracle_lib):
             q = rng.uniform(0.0, 2.27, (n, 1)); v = rng.standard_normal((n, 1)) * 2.0
     assert worst < 2e-4, worst
     assert max(rows) >= 2 and int(st.status.max()) == 0
+
+
+def test_self_colliding_hand_model_has_finger_contacts(oracle_lib):
+    """synth.make_hand(self_collision=True): capsules along the hand's segments and 20 explicit finger / thumb / palm pairs
+    (docs/source/suite.rst:288); co-contraction curls the fingers into each other and the oracle reports contacts."""
+    cm = synth.get_model("hand_contact"); base = synth.get_model("hand")
+    assert (cm.nq, cm.nv, cm.nu) == (base.nq, base.nv, base.nu) and cm.npair == 20 and cm.njmax <= 64
+    np.testing.assert_array_equal(cm.arrays["ACT_GAINPRM"], base.arrays["ACT_GAINPRM"])
+    om = O.OracleModel(cm)
+    rng = np.random.default_rng(0)
+    seen = 0
+    for trial in range(4):
+        d = O.OracleData(om); d.reset(); d.ctrl[:] = rng.random(cm.nu)
+        for _ in range(40):
+            d.step(10)
+            seen = max(seen, d.ncon)
+        assert d.warn == 0 and np.all(np.isfinite(d.qpos))
+    assert seen >= 2
+
+
+@pytest.mark.gpu
+def test_self_colliding_hand_gpu_matches_oracle(oracle_lib):
+    """The Pose task on the self-colliding hand (registry.make(..., model="hand_contact")): teacher-forced env-steps against
+    the oracle env while fingers are in contact, and a finite, overflow-free full-size batch."""
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    from oracle import env_oracle as EO
+    n, nsteps = 12, 10
+    env = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=2, autoreset=False, model="hand_contact")
+    cm = env.cm
+    assert cm.npair == 20 and env.hm.launch_lanes(n) == 64
+    env.reset(seed=2)
+    orc = []
+    for e in range(n):
+        o = EO.PoseEnvOracle(cm, pose_thd=env.pose_thd)
+        o.reset(env.state.qpos[e].cpu().numpy(), env.target_jnt_value[e].cpu().numpy())
+        orc.append(o)
+    a = torch.empty(n, cm.nu, device="cuda")
+    ncon = 0
+    for s in range(nsteps):
+        st = env.get_env_state()
+        for e in range(n):                       # teacher-forced per env-step (contact onsets are discontinuous)
+            d = orc[e].d
+            for k in ("qpos", "qvel", "act", "qacc_warmstart"):
+                v = getattr(d, k).astype(np.float32); getattr(d, k)[:] = v
+                st[k][e] = torch.from_numpy(v)
+        env.set_env_state(st)
+        E.uniform(a, 41, s)
+        act = (0.5 + 0.5 * a).contiguous()       # strong co-contraction: the fingers curl into each other
+        obs, r, term, trunc, info = env.step(act)
+        an = act.cpu().numpy()
+        for e in range(n):
+            ob, rr, done, rd = orc[e].step(an[e].astype(np.float64))
+            ncon = max(ncon, orc[e].d.ncon)
+            got = obs[e].cpu().numpy()
+            tol = np.full(got.shape, 2e-3); tol[cm.nq:cm.nq + cm.nv] = 1e-2
+            bad = np.abs(got - ob) / np.maximum(1.0, np.abs(ob)) > tol
+            assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], np.abs(got - ob)[bad][:5])
+            assert abs(float(r[e]) - rr) < 5e-3 * max(1.0, abs(rr))
+    assert ncon >= 1
+    big = registry.make("myoHandPoseRandom-v0", num_envs=4096, seed=3, model="hand_contact")
+    big.rollout_setup(action_seed=5)
+    for s in range(30):
+        obs, rwd, mask = big.rollout_step(None, stream_id=s)
+    assert bool(torch.isfinite(obs).all()) and int((big.state.status & 0xA).max()) == 0

@@ -1,0 +1,215 @@
+"""Oracle parity ON THE KERNELS THAT ARE BENCHMARKED: BASELINE.json's full per-GPU batches with the group width the launcher
+picks for them (hand 4096 envs -> 32 lanes per env, elbow 4096 -> 8, reorient 2048 / fati-leg-walk 1024 -> 64), 32 sampled envs
+each against the fp64 oracle (forward-pass stage dump + one teacher-forced env-step through the gym-level API), and the
+north-star accuracy gate: 1000 free-running physics steps, max over the WHOLE run < 1e-4 relative (robot/robot.py:856-861).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from myosuite_amd import engine as E
+from myosuite_amd.envs import registry
+from myosuite_amd.model import synth
+from oracle import env_oracle as EO
+from oracle import oracle as O
+
+from test_gpu_parity import STAGE_NAMES, STAGE_OMAP, _rel   # noqa: E402  (same directory)
+
+NSAMPLE = 32
+CONFIGS = [  # env id, envs per GPU (BASELINE.json configs 2-5), expected lanes per env, stage tolerance
+    ("myoElbowPose1D6MRandom-v0", 4096, 8, 2e-4),
+    ("myoHandPoseRandom-v0", 4096, 32, 2e-4),
+    ("myoHandReorient100-v0", 2048, 64, 5e-4),
+    ("myoFatiLegWalk-v0", 1024, 64, 5e-4),
+]
+
+
+def _env_oracle(env, e):
+    """env-level oracle of env `e` of the batched env, placed in the batched env's current state"""
+    cm = env.cm
+    if env.env_id.startswith(("myoElbowPose", "myoHandPose")):
+        o = EO.PoseEnvOracle(cm, pose_thd=env.pose_thd, frame_skip=env.frame_skip)
+        o.target_jnt_value = env.target_jnt_value[e].cpu().numpy().astype(np.float64)
+    elif "Reorient" in env.env_id:
+        o = EO.ReorientEnvOracle(cm, frame_skip=env.frame_skip)
+        o.d.set_geom_size(o.obj_g, env.geom_size[e].cpu().numpy().astype(np.float64), int(env.geom_type[e]))
+        o.axis_half = float(env.axis_half[e]); o.des_rot = env.des_rot[e].cpu().numpy().astype(np.float64)
+    else:
+        o = EO.WalkEnvOracle(cm, frame_skip=env.frame_skip, muscle_condition=env.muscle_condition)
+        if env.muscle_condition == "fatigue":
+            o.fatigue._MA = env.fat_MA[e].cpu().numpy().astype(np.float64)
+            o.fatigue._MR = env.fat_MR[e].cpu().numpy().astype(np.float64)
+            o.fatigue._MF = env.fat_MF[e].cpu().numpy().astype(np.float64)
+    st = env.state
+    o.d.qpos[:] = st.qpos[e].cpu().numpy(); o.d.qvel[:] = st.qvel[e].cpu().numpy()
+    if cm.na:
+        o.d.act[:] = st.act[e].cpu().numpy()
+    o.d.qacc_warmstart[:] = st.qacc_warmstart[e].cpu().numpy()
+    o.d.time = float(st.time[e])
+    o.steps = int(env.step_count[e])
+    return o
+
+
+@pytest.mark.parametrize("env_id,nenv,lanes,stage_tol", CONFIGS, ids=[f"{c[0]}@{c[1]}-G{c[2]}" for c in CONFIGS])
+def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stage_tol):
+    env = registry.make(env_id, num_envs=nenv, seed=17, autoreset=False)
+    cm, hm = env.cm, env.hm
+    assert hm.launch_lanes(nenv) == lanes, "the benchmarked launch does not use the width this test is named after"
+    env.reset(seed=17)
+    a = torch.empty(nenv, cm.nu, device="cuda")
+    for s in range(3):                       # off the reset state: velocities, activations, fatigue, contacts
+        E.uniform(a, 5, s)
+        env.step((0.2 + 0.6 * a).contiguous())
+    pick = np.linspace(0, nenv - 1, NSAMPLE).astype(int)
+
+    # ---- (i) every forward-pass stage of the sampled envs (mm_forward with the per-env debug record, full batch)
+    om = O.OracleModel(cm)
+    E.uniform(a, 5, 100)
+    dump = E.debug_dump(hm, env.state, a).cpu().numpy()
+    st = env.state
+    qpos, qvel = st.qpos.cpu().numpy(), st.qvel.cpu().numpy()
+    act = st.act.cpu().numpy() if cm.na else np.zeros((nenv, 0), np.float32)
+    ctrl = a.cpu().numpy()
+    worst = {}
+    for e in pick:
+        d = O.OracleData(om)
+        if "Reorient" in env_id:
+            d.set_geom_size(cm.names["geom"]["obj"], env.geom_size[e].cpu().numpy().astype(np.float64), int(env.geom_type[e]))
+        d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.act[:] = act[e]; d.ctrl[:] = ctrl[e]
+        d.qacc_warmstart[:] = st.qacc_warmstart[e].cpu().numpy()
+        d.forward()
+        for n in STAGE_NAMES:
+            ref = getattr(d, STAGE_OMAP.get(n, n)).ravel()
+            got = dump[e, hm.layout(n):hm.layout(n) + ref.size]
+            # qacc of a contact model: compare in units of the unconstrained acceleration scale
+            r = _rel(got, ref) if n != "qacc" else float(np.abs(got - ref).max() / max(1.0, np.abs(d.qacc_smooth).max()))
+            worst[n] = max(worst.get(n, 0.0), r)
+        M = dump[e, hm.layout("M"):hm.layout("M") + cm.nv * cm.nv].reshape(cm.nv, cm.nv)
+        worst["M"] = max(worst.get("M", 0.0), _rel(M, d.full_M()))
+    print("stage errors", env_id, {k: f"{v:.1e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v >= (2e-5 if k == "M" else stage_tol)}
+    assert not bad, bad
+
+    # ---- (ii) one teacher-forced env-step through the gym-level API (ctrl map / fatigue, frame_skip substeps, final
+    # forward, obs, reward, done) for the same envs
+    oracles = {int(e): _env_oracle(env, int(e)) for e in pick}
+    E.uniform(a, 5, 200)
+    act_in = (0.1 + 0.8 * a).contiguous()
+    obs, rwd, term, trunc, info = env.step(act_in)
+    an = act_in.cpu().numpy()
+    for e, o in oracles.items():
+        ob, r, done, rd = o.step(an[e].astype(np.float64))
+        got = obs[e].cpu().numpy()
+        scale = np.maximum(1.0, np.abs(ob))
+        if env_id.startswith(("myoElbowPose", "myoHandPose")):
+            tol = np.full(got.shape, 5e-4 if cm.nq > 1 else 5e-5)
+        elif "Reorient" in env_id:
+            tol = np.full(200, 2e-3); tol[26:32] = 2e-2; tol[44 + 39:44 + 78] = 2e-2; tol[44 + 78:44 + 117] = 0.5
+        else:
+            tol = np.full(403, 2e-3); tol[33:69] = 1e-2; tol[83 + 80:83 + 160] = 2e-2; tol[83 + 160:83 + 240] = 1e-2
+        badi = np.abs(got - ob) / scale > tol
+        assert not badi.any(), (e, np.nonzero(badi)[0][:5], (np.abs(got - ob) / scale)[badi][:5])
+        assert abs(float(rwd[e]) - r) < 5e-3 * max(1.0, abs(r)), (e, float(rwd[e]), r)
+        assert bool(term[e]) == done
+    assert int((env.state.status & 0xA).max()) == 0
+
+
+@pytest.mark.parametrize("name,lanes,nsub", [("elbow", 8, 10), ("hand", 32, 10), ("hand", 64, 10)],
+                         ids=["elbow-G8", "hand-G32", "hand-G64"])
+def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
+    """BASELINE.json: "state divergence vs CPU mj_step < 1e-4 rel over 1000 steps".  100 env-steps x 10 substeps, random
+    actions through the muscle ctrl map, free running from the Pose task's random reset; the error is
+    max|qpos_gpu - qpos_oracle| / max(1, max|qpos|) and the bound holds for the MAXIMUM over the whole run, on the group
+    widths the 4096-env benchmark launches."""
+    nenv = 16
+    cm = synth.get_model(name); om = O.OracleModel(cm)
+    hm = E.HipModel(cm, lanes_per_env=lanes)
+    assert hm.launch_lanes(nenv) == lanes
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    q0 = np.stack([(lo + (hi - lo) * EO.pose_reset_draws(cm.nq, e, 0, 0)[0]).astype(np.float32) for e in range(nenv)])
+    st = E.BatchState(hm, nenv); st.qpos.copy_(torch.from_numpy(q0))
+    ds = []
+    for e in range(nenv):
+        d = O.OracleData(om); d.qpos[:] = q0[e]; ds.append(d)
+    a = torch.empty(nenv, cm.nu, device="cuda")
+    rel = []
+    for s in range(100):
+        E.uniform(a, 0, s)
+        ctrl = (1.0 / (1.0 + torch.exp(-5.0 * (a - 0.5)))).contiguous()
+        E.step(hm, st, ctrl, nsub)
+        c = ctrl.cpu().numpy()
+        for e, d in enumerate(ds):
+            d.ctrl[:] = c[e]; d.step(nsub)
+        oq = np.stack([d.qpos for d in ds]); gq = st.qpos.cpu().numpy()
+        rel.append(float(np.abs(gq - oq).max() / max(1.0, np.abs(oq).max())))
+    print(f"1000-step divergence {name} G={lanes}: at 100/300/1000 steps {rel[9]:.2e} {rel[29]:.2e} {rel[99]:.2e}, max over run {max(rel):.2e}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"parity_1000_{name}_G{lanes}.json"), "w") as f:
+        import json
+        json.dump({"rel_err_per_env_step": rel, "max_over_run": max(rel), "nenv": nenv, "lanes": lanes}, f)
+    assert max(rel) < 1e-4, (max(rel), int(np.argmax(rel)))
+    assert int(st.status.max()) == 0
+
+
+@pytest.mark.parametrize("env_id,n", [("myoElbowPose1D6MRandom-v0", 256), ("myoHandPoseRandom-v0", 96), ("myoHandPoseFixed-v0", 64)])
+def test_rollout_step_one_launch_matches_stepwise_path(env_id, n):
+    """mm_rollout_step (action draw + env-step + episode stats + masked auto-reset in ONE launch) against the separate calls
+    it replaces (mm_uniform, mm_env_step, mm_episode_stats, mm_pose_reset): bit-identical state, observations, targets,
+    counters and statistics across episode boundaries."""
+    kw = dict(num_envs=n, seed=11, max_episode_steps=7)
+    fused = registry.make(env_id, **kw)
+    ref = registry.make(env_id, **kw)
+    stats_f = fused.rollout_setup(action_seed=23)
+    assert fused._ro.autoreset == 1
+    stats_r = torch.zeros(n, 3, device="cuda"); need = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    a = torch.empty(n, ref.cm.nu, device="cuda")
+    dense_col = ref.rwd.shape[1] - 1
+    crossed = 0
+    for s in range(20):
+        obs_f, rwd_f, mask_f = fused.rollout_step(None, stream_id=s)
+        E.uniform(a, 23, s)
+        E.env_step(ref.hm, ref.state, a, ref._task)
+        E.episode_stats(stats_r, need, ref.rwd, dense_col, dense_col - 2, ref.done, ref.truncated)
+        ref.reset(mask=need)
+        crossed += int(need.sum())
+        assert torch.equal(mask_f, need), s
+        assert torch.equal(obs_f, ref.obs), s
+        assert torch.equal(rwd_f, ref.rwd), s
+        for k in ("qpos", "qvel", "act", "qacc_warmstart", "time"):
+            assert torch.equal(getattr(fused.state, k), getattr(ref.state, k)), (k, s)
+        assert torch.equal(fused.target_jnt_value, ref.target_jnt_value) and torch.equal(fused.episode, ref.episode)
+        assert torch.equal(fused.step_count, ref.step_count)
+        assert torch.equal(stats_f, stats_r)
+    assert crossed >= 2 * n          # horizon 7: every env was re-armed at least twice
+
+
+def test_rollout_step_other_tasks_and_sharded_streams():
+    """Tasks without a folded reset: the launch writes the reset mask and the task's reset re-arms; env_index_base shifts every
+    Philox stream so that a shard reproduces its slice of the unsharded rollout."""
+    n = 64
+    full = registry.make("myoHandReachRandom-v0", num_envs=n, seed=4, max_episode_steps=5)
+    half = registry.make("myoHandReachRandom-v0", num_envs=n // 2, seed=4, max_episode_steps=5, env_index_base=n // 2)
+    assert torch.equal(full.target_pos[n // 2:], half.target_pos)
+    sf = full.rollout_setup(action_seed=9); sh = half.rollout_setup(action_seed=9)
+    assert full._ro.autoreset == 0
+    for s in range(12):
+        of, rf, mf = full.rollout_step(None, stream_id=s)
+        oh, rh, mh = half.rollout_step(None, stream_id=s)
+        assert torch.equal(of[n // 2:], oh) and torch.equal(rf[n // 2:], rh) and torch.equal(mf[n // 2:], mh), s
+    assert torch.equal(sf[n // 2:], sh) and float(sf[:, 1].min()) == 12.0
+    assert int(full.episode.min()) >= 3
+    # the same for the Pose family's folded reset
+    full = registry.make("myoElbowPose1D6MRandom-v0", num_envs=n, seed=4, max_episode_steps=5)
+    half = registry.make("myoElbowPose1D6MRandom-v0", num_envs=n // 2, seed=4, max_episode_steps=5, env_index_base=n // 2)
+    full.rollout_setup(action_seed=9); half.rollout_setup(action_seed=9)
+    for s in range(12):
+        of, rf, mf = full.rollout_step(None, stream_id=s)
+        oh, rh, mh = half.rollout_step(None, stream_id=s)
+        assert torch.equal(of[n // 2:], oh) and torch.equal(full.target_jnt_value[n // 2:], half.target_jnt_value), s
+    u = torch.empty(n // 2, full.cm.nu, device="cuda"); v = torch.empty(n, full.cm.nu, device="cuda")
+    E.uniform(v, 3, 1); E.uniform(u, 3, 1, first_index=(n // 2) * full.cm.nu)
+    assert torch.equal(v[n // 2:], u)

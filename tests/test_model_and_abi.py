@@ -77,8 +77,32 @@ def test_ctypes_structs_match_header_field_order():
                 out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", decl)[-1])
         return out
 
-    for cls, end in ((E.mm_state, "} mm_state;"), (E.mm_derived, "} mm_derived;"), (E.mm_task, "} mm_task;")):
+    for cls, end in ((E.mm_state, "} mm_state;"), (E.mm_derived, "} mm_derived;"), (E.mm_task, "} mm_task;"),
+                     (E.mm_rollout, "} mm_rollout;")):
         assert [f[0] for f in cls._fields_] == c_fields(end), cls.__name__
+
+
+def test_sarcopenia_model_compiles_for_every_registered_sarc_id():
+    """registry registers a myoSarc* variant for every myo* id (myobase/__init__.py:25-31): each must have a model whose
+    muscle peak forces are halved and nothing else changed (base_v0.py:63-67)."""
+    from myosuite_amd.envs import registry, base_v0
+    seen = set()
+    for env_id, sp in registry.registry_specs().items():
+        if sp["kwargs"].get("muscle_condition") != "sarcopenia":
+            continue
+        name = sp["kwargs"]["model"]
+        if name in seen:
+            continue
+        seen.add(name)
+        weak = base_v0._compiled_model(name, "sarcopenia"); base = base_v0._compiled_model(name, "")
+        gw = weak.arrays["ACT_GAINPRM"].reshape(-1, 9); gb = base.arrays["ACT_GAINPRM"].reshape(-1, 9)
+        np.testing.assert_allclose(gw[:, 2], 0.5 * gb[:, 2], err_msg=env_id)
+        np.testing.assert_array_equal(np.delete(gw, 2, axis=1), np.delete(gb, 2, axis=1))
+        assert float(np.abs(gb[:, 2]).max()) > 0
+        np.testing.assert_array_equal(weak.arrays["ACT_BIASPRM"], base.arrays["ACT_BIASPRM"])
+        for k in ("key_qpos", "key_qvel"):
+            assert hasattr(weak, k) == hasattr(base, k)
+    assert {"finger", "elbow_exo", "hand_keyturn", "torso", "hand", "leg", "elbow"} <= seen, seen
 
 
 def test_no_cpu_fallback_without_gpu():

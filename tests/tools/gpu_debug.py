@@ -3,7 +3,7 @@ against the fp64 oracle on random states, then compare multi-step rollouts.  Run
     python tools/gpu_debug.py [elbow|hand] [lanes]
 """
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 

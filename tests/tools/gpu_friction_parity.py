@@ -1,6 +1,6 @@
 """Debug: teacher-forced friction_toy steps, report the worst qacc mismatches (GPU forward vs oracle forward)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from myosuite_amd import engine as E
 from myosuite_amd.model import synth

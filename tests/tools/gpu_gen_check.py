@@ -1,6 +1,6 @@
 """GEN (contact/equality) path check on the GPU: forward + rollouts of contact_toy and leg vs the fp64 oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from myosuite_amd import engine as E
 from myosuite_amd.model import synth

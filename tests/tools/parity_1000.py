@@ -1,7 +1,7 @@
 """Free-running divergence vs the fp64 oracle over 100 env-steps = 1000 physics steps (north_star accuracy metric).
 python tools/parity_1000.py [nenv]"""
 import sys, os, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from myosuite_amd.model import synth
 from myosuite_amd import engine as E

@@ -3,7 +3,7 @@
 over 100 env-steps (free-running comparison is not meaningful across contact onsets).
 Writes gpurun_out/soak_contact_parity.json."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from myosuite_amd import engine as E
 from myosuite_amd.envs import registry
