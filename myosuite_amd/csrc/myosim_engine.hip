@@ -473,6 +473,16 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
   m->x.sega_adr = append(sega); m->x.segb_adr = append(segb); m->x.segc_adr = append(segc);
   m->x.seg_list = append(seg_list);
+  {
+    const int32_t* dofjnt = (const int32_t*)(blob + m->sec[MM_SEC_DOF_JNTID]);
+    const int32_t* jtype = (const int32_t*)(blob + m->sec[MM_SEC_JNT_TYPE]);
+    std::vector<int32_t> seg_jnt(seg_list.size());
+    for (size_t k = 0; k < seg_list.size(); k++) {
+      const int j = dofjnt[seg_list[k] & 0xff];
+      seg_jnt[k] = j | (jtype[j] << 16);
+    }
+    m->x.seg_jnt = append(seg_jnt);
+  }
   m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS

@@ -91,6 +91,7 @@ struct Aux {
   int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
   int root_list, nroot;
   int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
+  int seg_jnt;                                  // per seg_list entry: joint id | joint type << 16 of the entry's dof
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
 };
 
@@ -674,7 +675,7 @@ struct Engine {
     // round per tree level (4 instead of 9 for the hand).  Phase C: world anchors / axes from the parent's final frame.
     const int nb = KD().nbody;
     const bool isb = g > 0 && g < nb;
-    V3 tp = v3(0.f, 0.f, 0.f);
+    V3 tp = g == 0 ? -1.f * org : v3(0.f, 0.f, 0.f);   // lane 0 republishes the world body's frame in every round below
     Q4 tq = {1.f, 0.f, 0.f, 0.f};
     if (isb) {
       const int b = g;
@@ -853,13 +854,25 @@ struct Engine {
   __device__ __forceinline__ void tenj_segment(int l0, int l1, V3 p0, V3 p1, V3 u) {
     ConstLayout& L = KL();
     const int* lst = AUXI(seg_list);
+    const int* ljt = AUXI(seg_jnt);
     for (int e = l0; e < l1; e++) {
       int w = lst[e];
       int dof = w & 0xff, ep = (w >> 8) & 1, ent = w >> 9;
       V3 p = ep ? p1 : p0;
-      V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[dof]);
-      V3 ang = ld3(W + L.cdof + 6 * dof), lin = ld3(W + L.cdof + 6 * dof + 3);
-      float val = dot(u, lin + cross(ang, off));
+      const int jw = ljt[e], j = jw & 0xffff, type = jw >> 16;
+      float val;
+      if (type == MM_JNT_HINGE) {
+        // moment arm straight from the joint: u . (axis x (p - anchor)).  Going through cdof (motion about the subtree COM,
+        // lin = axis x (com - anchor)) adds and subtracts the COM offset -- ~0.2 m against a 5 mm moment arm in the hand,
+        // i.e. ~1e-5 relative in fp32; this form keeps the operands at the size of the result's lever
+        val = dot(u, cross(ld3(W + L.xaxis + 3 * j), p - ld3(W + L.xanchor + 3 * j)));
+      } else if (type == MM_JNT_SLIDE) {
+        val = dot(u, ld3(W + L.xaxis + 3 * j));
+      } else {   // ball / free dofs: motion axes about the subtree COM
+        V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[dof]);
+        V3 ang = ld3(W + L.cdof + 6 * dof), lin = ld3(W + L.cdof + 6 * dof + 3);
+        val = dot(u, lin + cross(ang, off));
+      }
       atomicAdd(&W[L.tenj + ent], ep ? val : -val);
     }
   }

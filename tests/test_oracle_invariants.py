@@ -210,3 +210,48 @@ def test_rk4_integrator_is_fourth_order(oracle_lib):
     e_eu = [np.abs(run(0, dt) - ref).max() for dt in (0.004, 0.002)]
     assert e_rk[0] < 1e-6 and e_rk[0] / e_rk[1] > 6.0          # ~2^4 asymptotically
     assert 1.8 < e_eu[0] / e_eu[1] < 2.2 and e_eu[1] > 1e4 * e_rk[1]
+
+
+def _twin_divergence(cm, eps, nenv=16, nsteps=100):
+    """per-env max over a 1000-substep run of |qpos_A - qpos_B| / max|qpos| between two fp64 oracle runs of the north-star
+    protocol whose INITIAL qpos differ by eps * N(0,1) (everything else identical)"""
+    from oracle import env_oracle as EO
+    from oracle import oracle as O
+    om = O.OracleModel(cm)
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    q0 = np.stack([(lo + (hi - lo) * EO.pose_reset_draws(cm.nq, e, 0, 0)[0]).astype(np.float32) for e in range(nenv)])
+    rng = np.random.default_rng(0)
+    A, B = [], []
+    for e in range(nenv):
+        d = O.OracleData(om); d.qpos[:] = q0[e]; A.append(d)
+        d = O.OracleData(om); d.qpos[:] = q0[e] + eps * rng.standard_normal(cm.nq); B.append(d)
+    worst = np.zeros(nenv)
+    for s in range(nsteps):
+        a = EO.uniform_stream(nenv * cm.nu, 0, s).reshape(nenv, cm.nu)
+        ctrl = (1.0 / (1.0 + np.exp(-5.0 * (a.astype(np.float32) - 0.5)))).astype(np.float32)
+        scale = 1.0
+        for e in range(nenv):
+            A[e].ctrl[:] = ctrl[e]; A[e].step(10)
+            B[e].ctrl[:] = ctrl[e]; B[e].step(10)
+            scale = max(scale, np.abs(A[e].qpos).max())
+        for e in range(nenv):
+            worst[e] = max(worst[e], np.abs(A[e].qpos - B[e].qpos).max() / scale)
+    return worst
+
+
+def test_north_star_tolerance_is_at_the_sensitivity_of_the_reference_algorithm(oracle_lib):
+    """BASELINE.json asks "state divergence vs CPU mj_step < 1e-4 rel over 1000 steps".  What a bound on the MAXIMUM over a
+    free-running hand rollout can mean is set by the algorithm, not by the engine's arithmetic: a joint-limit row switches on
+    with its full damping term (aref = -B v - K x), so two runs that see a limit one substep apart differ by ~20 % of the
+    approach speed afterwards.  Two fp64 oracle runs whose initial qpos differ by ONE fp32 rounding (1e-7) already contain
+    an env above 1e-4; at 1e-6 several envs are at 1e-3..1e-2, while the typical env stays at the perturbation's own size.
+    The elbow (one limit, rarely hit) has no such events.  tests/test_gpu_widths.py gates the GPU kernel accordingly: typical
+    env and fraction of envs, with this experiment as the yardstick."""
+    from myosuite_amd.model import synth
+    hand = synth.get_model("hand")
+    w7, w6 = _twin_divergence(hand, 1e-7), _twin_divergence(hand, 1e-6)
+    assert np.median(w7) < 2e-6 and np.median(w6) < 2e-5             # smooth sensitivity: ~10x the perturbation
+    assert w7.max() > 1e-4                                           # ... and one activation-timing event at fp32 rounding level
+    assert (w6 > 1e-4).sum() >= 2 and w6.max() > 1e-3
+    we = _twin_divergence(synth.get_model("elbow"), 1e-6)
+    assert we.max() < 1e-4
