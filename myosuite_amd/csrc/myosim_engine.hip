@@ -472,17 +472,21 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->x.dofj_adr = append(dj_adr); m->x.dofj_entry = append(dj_entry); m->x.dofj_tendon = append(dj_tendon);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
   m->x.sega_adr = append(sega); m->x.segb_adr = append(segb); m->x.segc_adr = append(segc);
-  m->x.seg_list = append(seg_list);
   {
+    // hinge / slide dofs (the only kinds a tendon of these models crosses, but ball / free are handled): the word carries the
+    // JOINT id and its type instead of the dof, so that the kernel reads anchor / axis without a second table
     const int32_t* dofjnt = (const int32_t*)(blob + m->sec[MM_SEC_DOF_JNTID]);
     const int32_t* jtype = (const int32_t*)(blob + m->sec[MM_SEC_JNT_TYPE]);
-    std::vector<int32_t> seg_jnt(seg_list.size());
     for (size_t k = 0; k < seg_list.size(); k++) {
-      const int j = dofjnt[seg_list[k] & 0xff];
-      seg_jnt[k] = j | (jtype[j] << 16);
+      const int w = seg_list[k], dof = w & 0xff, ep = (w >> 8) & 1, ent = w >> 9;
+      const int j = dofjnt[dof], ty = jtype[j];
+      const bool direct = (ty == MM_JNT_HINGE || ty == MM_JNT_SLIDE) && j < 256;
+      if (ent >= (1 << 20)) seg_ok = false;
+      seg_list[k] = (direct ? j : dof) | (ep << 8) | ((direct ? (ty == MM_JNT_HINGE ? 1 : 2) : 0) << 9) | (ent << 11);
     }
-    m->x.seg_jnt = append(seg_jnt);
+    if (!seg_ok) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian has more than 2^20 entries"); }
   }
+  m->x.seg_list = append(seg_list);
   m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS

@@ -91,7 +91,6 @@ struct Aux {
   int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
   int root_list, nroot;
   int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
-  int seg_jnt;                                  // per seg_list entry: joint id | joint type << 16 of the entry's dof
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
 };
 
@@ -124,7 +123,7 @@ enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_A
 // section offsets come from the blob header in global memory through the scalar cache (s_load at use) instead of ~100
 // kernel-argument words that live in (spilled) SGPRs for the whole kernel
 typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
-#define SECOFF_(S) ((int)(reinterpret_cast<ConstWords>(reinterpret_cast<uintptr_t>(a.blob))[MM_HEADER_WORDS + 2 * (MM_SEC_##S)]))
+#define SECOFF_G_(S) ((int)(reinterpret_cast<ConstWords>(reinterpret_cast<uintptr_t>(a.blob))[MM_HEADER_WORDS + 2 * (MM_SEC_##S)]))
 typedef const __attribute__((address_space(4))) ConstBlock ConstBlockC;
 typedef const __attribute__((address_space(4))) Dims ConstDims;
 typedef const __attribute__((address_space(4))) Layout ConstLayout;
@@ -134,9 +133,35 @@ typedef const __attribute__((address_space(4))) Aux ConstAux;
 typedef const __attribute__((address_space(4))) KArgs ConstKArgs;
 #define KA() (*(ConstKArgs*)(__builtin_amdgcn_kernarg_segment_ptr()))
 #define KCB_() (*reinterpret_cast<ConstBlockC*>(reinterpret_cast<uintptr_t>(a.blob + a.cofs)))
+// MM_CONST_IN_REGS = 1 (experiment, not the default): the ConstBlock and the section-offset table are read ONCE at kernel entry
+// into a by-value struct instead of through the scalar cache at every use (285 s_load per forward pass of the hand kernel,
+// SQ_INSTS_SMEM, each followed by an s_waitcnt lgkmcnt(0) that also drains the wave's LDS queue).  Measured on MI355X (A/B in
+// one session, tools/gpu_ab.sh): the ~150 extra long-lived wave-uniform values push SGPR spills from 324 to 478 lanes, the
+// two extra spill VGPRs tip the 241-VGPR hand kernel into 79 VGPR spills / 296 B scratch, and it LOSES: hand 4.63 -> 4.34 M,
+// reorient 2.08 -> 1.73 M env-steps/s, elbow unchanged (its time is dependent-latency, not scalar loads).  With only the
+// ConstBlock by value (MM_SEC_IN_REGS = 0): 38 VGPR spills, hand 4.56 M.  The scalar-cache path stays.
+#ifndef MM_CONST_IN_REGS
+#define MM_CONST_IN_REGS 0
+#endif
+struct KConst { Dims d; Layout L; Aux x; int sec[MM_NSEC]; };
+#ifndef MM_SEC_IN_REGS
+#define MM_SEC_IN_REGS 1
+#endif
+#if MM_CONST_IN_REGS
+#if MM_SEC_IN_REGS
+#define SECOFF_(S) (kc.sec[MM_SEC_##S])
+#else
+#define SECOFF_(S) SECOFF_G_(S)
+#endif
+#define KD() (kc.d)
+#define KL() (kc.L)
+#define KX() (kc.x)
+#else
+#define SECOFF_(S) SECOFF_G_(S)
 #define KD() (KCB_().d)
 #define KL() (KCB_().L)
 #define KX() (KCB_().x)
+#endif
 #define MI_(S) (reinterpret_cast<const int*>(mb + SECOFF_(S)))
 #define MF_(S) (reinterpret_cast<const float*>(mb + SECOFF_(S)))
 #define AUXI(f) (reinterpret_cast<const int*>(mb + KX().f))
@@ -592,6 +617,7 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 template <int G, int NVP, bool GEN, bool RK4>
 struct Engine {
   const KArgs& a;
+  const KConst& kc;    // model constants of the launch (see MM_CONST_IN_REGS)
   const uint32_t* mb;  // model words (LDS-resident copy or global)
   unsigned long long pf[NPROF];
   float* W;     // LDS tables of this env
@@ -626,8 +652,8 @@ struct Engine {
   int env_gtype;            // this env's entry of mm_state.geom_type_env (or -1)
   int env;                  // env index (per-env model deltas on a body: mm_state.body_mass_env / body_pos_env)
 
-  __device__ __forceinline__ Engine(const KArgs& a_, const uint32_t* mb_, float* W_, int g_)
-      : a(a_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
+  __device__ __forceinline__ Engine(const KArgs& a_, const KConst& kc_, const uint32_t* mb_, float* W_, int g_)
+      : a(a_), kc(kc_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
 #pragma unroll
     for (int i = 0; i < NPROF; i++) pf[i] = 0;
     d_warm = 0.f; d_qvel = 0.f;
@@ -658,7 +684,7 @@ struct Engine {
 
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const V3 org = origin();
     if (g == 0) {
       b_xpos = -1.f * org; b_xipos = b_xpos;   // the world body (and everything attached to it) in the internal frame
@@ -788,7 +814,7 @@ struct Engine {
 
   // subtree COM of each tree root, body inertias about it (registers), dof motion axes (LDS + registers)
   __device__ __forceinline__ void com_pos() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const int nb = KD().nbody;
     const bool isb = g > 0 && g < nb;
     float ms = isb ? MF_(BODY_MASS)[g] : 0.f;
@@ -851,26 +877,24 @@ struct Engine {
 
   // ---------------------------------------------------------------- A2 tendons
   // add the contributions of one straight segment (point p0 -> p1, unit direction u) to the sparse J row
+  // seg_list word: [7:0] joint id (hinge / slide) or dof (ball / free), [8] endpoint, [10:9] 1 hinge / 2 slide / 0 via cdof, [31:11] J entry
   __device__ __forceinline__ void tenj_segment(int l0, int l1, V3 p0, V3 p1, V3 u) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const int* lst = AUXI(seg_list);
-    const int* ljt = AUXI(seg_jnt);
     for (int e = l0; e < l1; e++) {
-      int w = lst[e];
-      int dof = w & 0xff, ep = (w >> 8) & 1, ent = w >> 9;
-      V3 p = ep ? p1 : p0;
-      const int jw = ljt[e], j = jw & 0xffff, type = jw >> 16;
+      const int w = lst[e];
+      const int id = w & 0xff, ep = (w >> 8) & 1, kind = (w >> 9) & 3, ent = w >> 11;
+      const V3 p = ep ? p1 : p0;
       float val;
-      if (type == MM_JNT_HINGE) {
+      if (kind == 1) {
         // moment arm straight from the joint: u . (axis x (p - anchor)).  Going through cdof (motion about the subtree COM,
-        // lin = axis x (com - anchor)) adds and subtracts the COM offset -- ~0.2 m against a 5 mm moment arm in the hand,
-        // i.e. ~1e-5 relative in fp32; this form keeps the operands at the size of the result's lever
-        val = dot(u, cross(ld3(W + L.xaxis + 3 * j), p - ld3(W + L.xanchor + 3 * j)));
-      } else if (type == MM_JNT_SLIDE) {
-        val = dot(u, ld3(W + L.xaxis + 3 * j));
+        // lin = axis x (com - anchor)) adds and subtracts the COM offset -- ~0.2 m against a 5 mm moment arm in the hand
+        val = dot(u, cross(ld3(W + L.xaxis + 3 * id), p - ld3(W + L.xanchor + 3 * id)));
+      } else if (kind == 2) {
+        val = dot(u, ld3(W + L.xaxis + 3 * id));
       } else {   // ball / free dofs: motion axes about the subtree COM
-        V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[dof]);
-        V3 ang = ld3(W + L.cdof + 6 * dof), lin = ld3(W + L.cdof + 6 * dof + 3);
+        V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[id]);
+        V3 ang = ld3(W + L.cdof + 6 * id), lin = ld3(W + L.cdof + 6 * id + 3);
         val = dot(u, lin + cross(ang, off));
       }
       atomicAdd(&W[L.tenj + ent], ep ? val : -val);
@@ -883,7 +907,7 @@ struct Engine {
   // of G lanes then executes one kind of item, instead of every lane walking its own tendon with divergent item kinds.
   // Lengths and Jacobian entries are accumulated with LDS float atomics (one wave: deterministic lane order).
   __device__ __forceinline__ void tendon() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const int *sa = AUXI(sega_adr), *sb = AUXI(segb_adr), *sc = AUXI(segc_adr);
     const int* items = AUXI(item_tab);
     for (int e = g; e < KD().ntenJ; e += G) W[L.tenj + e] = 0.f;
@@ -966,7 +990,7 @@ struct Engine {
   // time (mm_model_create rejects ranges narrower than 2*margin).
   __device__ __forceinline__ void make_constraint() {
     if constexpr (GEN) { make_constraint_gen(); return; }
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const int j = g;
     r_active = false; r_D = 0.f; r_aref = 0.f; r_dof = 0; r_sign = 1.f;
     if (j < KD().njnt) {
@@ -998,7 +1022,7 @@ struct Engine {
 
   // ----------------------------------------------------- A5 velocity stage + bias forces
   __device__ __forceinline__ void velocity_bias() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const int nb = KD().nbody;
     for (int t = g; t < KD().ntendon; t += G) {
       float s = 0.f;
@@ -1137,7 +1161,7 @@ struct Engine {
 
   // ---------------------------------------------------------------- A4 CRB -> dense M rows
   __device__ __forceinline__ void crb() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const int nb = KD().nbody, nv = KD().nv;
     if (g < nb)
 #pragma unroll
@@ -1195,7 +1219,7 @@ struct Engine {
   }
   template <bool DIAG>
   __device__ __forceinline__ void factor_core(float (&A)[NVP], float dadd = 0.f) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     if constexpr (G < 64 && NVP >= 8) {
       // Left-looking form for groups narrower than the wave.  A cross-lane broadcast costs ~5 issue slots there (two
       // v_readlane + v_mov + v_cndmask + hazard nops), and the right-looking update needs NVP^2/2 of them.  Here row j of L
@@ -1281,7 +1305,7 @@ struct Engine {
 
   // ------------------------------------------- A5/A6 passive + actuation -> qfrc_smooth
   __device__ __forceinline__ void passive_actuation() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     for (int t = g; t < KD().ntendon; t += G) {
       float k = MF_(TENDON_STIFFNESS)[t], bd = MF_(TENDON_DAMPING)[t], f = 0.f;
       if (k != 0.f || bd != 0.f) {
@@ -1463,7 +1487,7 @@ struct Engine {
   }
   // Jacobian entries of one contact: rows r0.. get  +-(edge . (J_b2 - J_b1))  over the two kinematic chains
   __device__ __forceinline__ void contact_rows(int r0, int nrow, int b1, int b2, V3 pos, V3 n, V3 t1, V3 t2, float mu) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     for (int side = 0; side < 2; side++) {
       int b = side ? b2 : b1;
       const float sg = side ? 1.f : -1.f;
@@ -1504,7 +1528,7 @@ struct Engine {
   }
 
   __device__ __forceinline__ void make_constraint_gen() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     float* RT = W + L.rowtab;
     {
       float4* Jz = reinterpret_cast<float4*>(W + L.efcJ);
@@ -1884,7 +1908,7 @@ struct Engine {
   }
 
   __device__ __forceinline__ bool bad_state(bool check_acc) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     int bad = 0;
     for (int i = g; i < KD().nq; i += G) bad |= !(fabsf(W[L.qpos + i]) < 1e10f);
     if (g < KD().nv) {
@@ -1894,7 +1918,7 @@ struct Engine {
     return gor<G>(bad) != 0;
   }
   __device__ __forceinline__ void reset_data() {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     for (int i = g; i < KD().nq; i += G) W[L.qpos + i] = MF_(QPOS0)[i];
     d_qvel = 0.f; d_warm = 0.f;
     if (g < KD().nv) W[L.qvel + g] = 0.f;
@@ -1904,7 +1928,7 @@ struct Engine {
 
   // A9 semi-implicit Euler with implicit joint damping
   __device__ __forceinline__ void euler(float& time) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const float h = KD().timestep;
     d_warm = d_qacc;
     float qa_ = d_qacc;
@@ -1931,7 +1955,7 @@ struct Engine {
 
   // qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos); vel = LDS vector at word offset `voff`
   __device__ __forceinline__ void integrate_pos(int voff, float hh) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     for (int j = g; j < KD().njnt; j += G) {
       int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j], da = MI_(JNT_DOFADR)[j];
       if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[L.qpos + qa] += hh * W[voff + da]; continue; }
@@ -1955,7 +1979,7 @@ struct Engine {
   // One stage of classical RK4 (mj_RungeKutta, N = 4; oracle: mmo_rk4).  Called after the forward pass of stage `i`
   // (i = 0 is mj_step's own forward).  Stages 0..2 move the state to X0 + h a_i F_i; stage 3 applies the weighted update.
   __device__ __forceinline__ void rk4_stage(int i, float& time, float t0) {
-    ConstLayout& L = KL();
+    const auto& L = KL();
     const float h = KD().timestep;
     const float A_ = i == 2 ? 1.f : 0.5f;
     const float B_ = (i == 0 || i == 3) ? (1.f / 6.f) : (1.f / 3.f);
@@ -2048,6 +2072,21 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     mb = lm;
     wsbase = lds + ((a.blob_words + 3) & ~3);
   }
+  KConst kc;
+#if MM_CONST_IN_REGS
+  {
+    ConstWords hdr = reinterpret_cast<ConstWords>(reinterpret_cast<uintptr_t>(a.blob));
+    ConstWords cbw = reinterpret_cast<ConstWords>(reinterpret_cast<uintptr_t>(a.blob + a.cofs));
+    static_assert(sizeof(ConstBlock) == sizeof(Dims) + sizeof(Layout) + sizeof(Aux) && sizeof(ConstBlock) % 4 == 0, "ConstBlock is three packed word structs");
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&kc);   // KConst starts with {Dims, Layout, Aux} = the ConstBlock
+#pragma unroll
+    for (int w_ = 0; w_ < (int)(sizeof(ConstBlock) / 4); w_++) dst[w_] = cbw[w_];
+#if MM_SEC_IN_REGS
+#pragma unroll
+    for (int s_ = 0; s_ < MM_NSEC; s_++) kc.sec[s_] = (int)hdr[MM_HEADER_WORDS + 2 * s_];
+#endif
+  }
+#endif
   int e = (blockIdx.x * wpb + wave) * EPW + lane / G;
   const int nenv = a.s.nenv;
   if ((blockIdx.x * wpb + wave) * EPW >= nenv) return;  // whole wave idle
@@ -2057,9 +2096,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   const bool obs_only = a.mode == 2 && KA().t.obs_only;
   if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * KL().total;
-  ConstLayout& L = KL();
-  ConstDims& d = KD();
-  Engine<G, NVP, GEN, RK4> E(a, mb, W, g);
+  const auto& L = KL();
+  const auto& d = KD();
+  Engine<G, NVP, GEN, RK4> E(a, kc, mb, W, g);
   if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
   if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
   E.env = e;
