@@ -37,10 +37,24 @@ def _weaken(spec):
 
 
 def _compiled_model(name: str, muscle_condition: str):
-    """Compiled model of any synthetic model name, with the sarcopenia edit applied before compilation."""
+    """Compiled model for ``model=``: the short name of a synthetic model (synth.builders()) or -- the reference's
+    ``model_path`` (envs/env_base.py:72,96-106) -- the path of an MJCF file, imported by model/mjcf.py (includes into the
+    ``simhive/myo_sim`` submodule resolve through $MYOSUITE_MYO_SIM_ROOT).  The sarcopenia edit is applied before compilation."""
     key = (name, muscle_condition == "sarcopenia")
     if key not in _MODEL_CACHE:
-        _MODEL_CACHE[key] = synth.get_model(name) if muscle_condition != "sarcopenia" else synth.compile_spec(name, _weaken)
+        edit = _weaken if muscle_condition == "sarcopenia" else None
+        if isinstance(name, str) and name.lower().endswith(".xml"):
+            from ..model import mjcf
+            spec = mjcf.load(name)
+            if edit is not None:
+                edit(spec)
+            cm = spec.compile()
+            keys = getattr(spec, "keys", None)
+            if keys:
+                cm.key_qpos = np.array([k[0] for k in keys]); cm.key_qvel = np.array([k[1] for k in keys])
+            _MODEL_CACHE[key] = cm
+        else:
+            _MODEL_CACHE[key] = synth.get_model(name) if edit is None else synth.compile_spec(name, edit)
     return _MODEL_CACHE[key]
 
 

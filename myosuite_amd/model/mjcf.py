@@ -201,37 +201,47 @@ def _principal(I: np.ndarray):
 
 
 # ----------------------------------------------------------------------------- loader
-def _expand_includes(node: ET.Element, base: str, missing: str):
+def _expand_includes(node: ET.Element, base: str, missing: str, include_map=None):
     i = 0
     while i < len(node):
         ch = node[i]
         if ch.tag == "include":
-            path = os.path.join(base, ch.attrib["file"])
+            fn = ch.attrib["file"]
+            for old, new in (include_map or {}).items():     # e.g. the empty simhive/myo_sim submodule -> a local model tree
+                if old in fn:
+                    fn = os.path.join(new, fn[fn.index(old) + len(old):].lstrip("/"))
+                    break
+            path = fn if os.path.isabs(fn) else os.path.join(base, fn)
             node.remove(ch)
             if not os.path.exists(path):
                 if missing == "skip":
                     continue
                 raise MjcfError(f"<include> file not found: {path}")
             sub = ET.parse(path).getroot()
-            _expand_includes(sub, os.path.dirname(path), missing)
+            _expand_includes(sub, os.path.dirname(path), missing, include_map)
             kids = list(sub) if sub.tag in ("mujoco", "mujocoinclude") else [sub]
             for k, el in enumerate(kids):
                 node.insert(i + k, el)
             i += len(kids)
         else:
-            _expand_includes(ch, base, missing)
+            _expand_includes(ch, base, missing, include_map)
             i += 1
 
 
-def load(source: str, missing_include: str = "error") -> ModelSpec:
-    """MJCF file path (or XML string) -> ModelSpec."""
+def load(source: str, missing_include: str = "error", include_map: Optional[Dict[str, str]] = None) -> ModelSpec:
+    """MJCF file path (or XML string) -> ModelSpec.  ``include_map`` {substring of an <include file=...>: replacement directory}
+    resolves includes that point into a tree living elsewhere -- the reference's task XMLs include
+    ``../../../../simhive/myo_sim/...`` (an empty git submodule in the reference checkout): pass
+    ``{"simhive/myo_sim": "/path/to/myo_sim"}`` (or set MYOSUITE_MYO_SIM_ROOT) to load them against a real or stand-in tree."""
+    if include_map is None and os.environ.get("MYOSUITE_MYO_SIM_ROOT"):
+        include_map = {"simhive/myo_sim": os.environ["MYOSUITE_MYO_SIM_ROOT"]}
     if os.path.exists(source):
         root = ET.parse(source).getroot(); base = os.path.dirname(os.path.abspath(source))
     else:
         root = ET.fromstring(source); base = os.getcwd()
     if root.tag != "mujoco":
         raise MjcfError("root element must be <mujoco>")
-    _expand_includes(root, base, missing_include)
+    _expand_includes(root, base, missing_include, include_map)
     ctx = _Ctx()
     opt = dict(timestep=0.002, gravity=(0.0, 0.0, -9.81), integrator=0, iterations=100, tolerance=1e-8, ls_iterations=50,
                ls_tolerance=0.01, eulerdamp=True)
@@ -710,3 +720,33 @@ def dump(spec: ModelSpec) -> str:
             ET.SubElement(kf, "key", qpos=_f(q), qvel=_f(v))
     ET.indent(root)
     return ET.tostring(root, encoding="unicode")
+
+
+def dump_tree(spec: ModelSpec, root_dir: str, family: str = "hand", assets: str = "myohand_assets.xml", body: str = "myohand_body.xml",
+              drop_world_sites=()) -> Dict[str, str]:
+    """Write ``spec`` as the include tree the reference's task XMLs expect from the ``myo_sim`` submodule
+    (envs/myo/assets/hand/myohand_pose.xml:10-15): ``<root>/<family>/assets/<assets>`` (compiler / option / size / tendon /
+    actuator / equality / contact), ``<root>/<family>/assets/<body>`` (the body tree, included inside <worldbody>) and an empty
+    ``<root>/scene/myosuite_scene.xml``.  ``drop_world_sites``: world-attached sites the task XML authors itself (the *_target
+    sites).  A stand-in for the (absent) real tree; returns the written paths."""
+    root = ET.fromstring(dump(spec))
+    wb = root.find("worldbody")
+    body_inc = ET.Element("mujocoinclude")
+    for ch in list(wb):
+        if ch.tag == "site" and ch.attrib.get("name") in set(drop_world_sites):
+            continue
+        body_inc.append(ch)
+    assets_inc = ET.Element("mujocoinclude")
+    for ch in list(root):
+        if ch.tag not in ("worldbody", "keyframe"):
+            assets_inc.append(ch)
+    out = {}
+    for rel, el in ((os.path.join(family, "assets", assets), assets_inc), (os.path.join(family, "assets", body), body_inc),
+                    (os.path.join("scene", "myosuite_scene.xml"), ET.Element("mujocoinclude"))):
+        path = os.path.join(root_dir, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        ET.indent(el)
+        with open(path, "w") as f:
+            f.write(ET.tostring(el, encoding="unicode"))
+        out[rel] = path
+    return out

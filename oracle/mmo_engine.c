@@ -1414,7 +1414,7 @@ static const field_t kFields[] = {
     FLD(cvel), FLD(cdof_dot), FLD(qfrc_passive), FLD(qfrc_bias), FLD(act_dot), FLD(actuator_force),
     FLD(qfrc_actuator), FLD(qfrc_smooth), FLD(qacc_smooth), FLD(efc_J), FLD(efc_pos), FLD(efc_margin),
     FLD(efc_R), FLD(efc_D), FLD(efc_vel), FLD(efc_aref), FLD(efc_force), FLD(qfrc_constraint), FLD(qacc),
-    FLD(cfrc), FLD(cacc), FLD(con_dist), FLD(con_pos), FLD(con_frame), FLD(efc_diagApprox)};
+    FLD(cfrc), FLD(cacc), FLD(con_dist), FLD(con_pos), FLD(con_frame), FLD(efc_diagApprox), FLD(efc_floss)};
 
 real* mmo_field(mmo_data* d, const char* name) {
   for (unsigned i = 0; i < sizeof(kFields) / sizeof(kFields[0]); i++)

@@ -102,6 +102,7 @@ _SHAPES = {
     "cfrc": lambda m: (m.nbody, 6), "cacc": lambda m: (m.nbody, 6),
     "con_dist": lambda m: (max(m.nconmax, 1),), "con_pos": lambda m: (max(m.nconmax, 1), 3),
     "con_frame": lambda m: (max(m.nconmax, 1), 9), "efc_diagApprox": lambda m: (max(m.njmax, 1),),
+    "efc_floss": lambda m: (max(m.njmax, 1),),
 }
 
 
@@ -136,6 +137,12 @@ class OracleData:
     @time.setter
     def time(self, t):
         lib().mmo_set_time(self.ptr, float(t))
+
+    @property
+    def efc_type(self):
+        """constraint kind of every active row (MM_CON_*: 0 equality, 1 joint limit, 2 tendon limit, 3 contact, 4 dof friction)"""
+        n = self.nefc
+        return np.ctypeslib.as_array(lib().mmo_efc_type(self.ptr), shape=(max(n, 1),))[:n].copy()
 
     @property
     def nefc(self):

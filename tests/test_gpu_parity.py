@@ -595,3 +595,29 @@ def test_ragged_and_single_env_batches(env_id, lanes):
         for n, env in outs.items():
             o, r, *_ = env.step(a[:n].contiguous())
             assert torch.equal(o, ob[:n]) and torch.equal(r, rb[:n]), (n, s)
+
+
+def _mujoco_fixtures():
+    import glob
+    return sorted(glob.glob(os.path.join(G, "mujoco_*.npz")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", _mujoco_fixtures() or [None])
+def test_hip_matches_libmujoco_fixture(path):
+    """HIP engine vs libmujoco's own trajectory (tests/golden/mujoco_<model>.npz, written by
+    tests/tools/validate_against_mujoco.py --write-fixture where mujoco is installed); skipped while none is committed."""
+    if path is None:
+        pytest.skip("no tests/golden/mujoco_*.npz committed")
+    g = np.load(path)
+    cm = synth.get_model(str(g["model"]))
+    assert cm.hash() == str(g["model_hash"])
+    hm = E.HipModel(cm); st = E.BatchState(hm, 1)
+    st.qpos.copy_(torch.from_numpy(g["q0"].astype(np.float32))[None]); st.qvel.copy_(torch.from_numpy(g["v0"].astype(np.float32))[None])
+    st.act.copy_(torch.from_numpy(g["a0"].astype(np.float32))[None])
+    worst = 0.0
+    for s in range(g["ctrl"].shape[0]):
+        E.step(hm, st, torch.from_numpy(g["ctrl"][s].astype(np.float32))[None].cuda().contiguous(), 1)
+        ref = g["t_qpos"][s]
+        worst = max(worst, float(np.abs(st.qpos[0].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())))
+    assert worst < 1e-4, worst

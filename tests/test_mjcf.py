@@ -160,3 +160,122 @@ def test_position_and_velocity_servos_import(oracle_lib):
     np.testing.assert_allclose(d.act, [0.2 + 0.002 * 12.0, 0.1 - 0.002 * 0.5], rtol=1e-6)
     spec2 = mjcf.load(mjcf.dump(mjcf.load(xml)))
     assert np.array_equal(spec2.compile().blob, cm.blob)
+
+
+# ------------------------------------------------------------------ task XML against a stand-in myo_sim tree
+# Our own restatement of the STRUCTURE of the reference's hand-pose task file (envs/myo/assets/hand/myohand_pose.xml:10-49): the
+# model proper comes from three includes into the simhive/myo_sim submodule, the task adds five world-attached *_target sites
+# and five visual tip -> target tendons.
+TASK_XML = """
+<mujoco model="hand pose task on a stand-in myo_sim tree">
+  <include file="../../../../simhive/myo_sim/hand/assets/myohand_assets.xml"/>
+  <include file="../../../../simhive/myo_sim/scene/myosuite_scene.xml"/>
+  <worldbody>
+    <include file="../../../../simhive/myo_sim/hand/assets/myohand_body.xml"/>
+    <site name="THtip_target" pos="0 0 0.002"/>
+    <site name="IFtip_target" pos="0 0 0.002"/>
+    <site name="MFtip_target" pos="0 0 0.002"/>
+    <site name="RFtip_target" pos="0 0 0.002"/>
+    <site name="LFtip_target" pos="0 0 0.002"/>
+  </worldbody>
+  <tendon>
+    <spatial name="THtip_err"><site site="THtip"/><site site="THtip_target"/></spatial>
+    <spatial name="IFtip_err"><site site="IFtip"/><site site="IFtip_target"/></spatial>
+    <spatial name="MFtip_err"><site site="MFtip"/><site site="MFtip_target"/></spatial>
+    <spatial name="RFtip_err"><site site="RFtip"/><site site="RFtip_target"/></spatial>
+    <spatial name="LFtip_err"><site site="LFtip"/><site site="LFtip_target"/></spatial>
+  </tendon>
+</mujoco>
+"""
+TARGET_SITES = ("THtip_target", "IFtip_target", "MFtip_target", "RFtip_target", "LFtip_target")
+
+
+def standin_hand_task(tmp_path):
+    """(task xml path, include_map): synth.make_hand() written as the myo_sim include tree + the task file four levels below a
+    fake package root, exactly where the reference keeps envs/myo/assets/hand/*.xml relative to simhive/"""
+    root = tmp_path / "pkg"
+    mjcf.dump_tree(synth.make_hand(), str(root / "simhive" / "myo_sim"), drop_world_sites=TARGET_SITES)
+    task_dir = root / "envs" / "myo" / "assets" / "hand"
+    task_dir.mkdir(parents=True)
+    (task_dir / "myohand_pose.xml").write_text(TASK_XML)
+    return str(task_dir / "myohand_pose.xml"), {"simhive/myo_sim": str(root / "simhive" / "myo_sim")}
+
+
+def test_task_xml_resolves_against_a_standin_myo_sim_tree(oracle_lib, tmp_path):
+    path, imap = standin_hand_task(tmp_path)
+    # the relative includes resolve on their own (the tree sits where the task file expects it) and through the include map
+    cm = mjcf.load(path).compile()
+    cm_map = mjcf.load(path, include_map=imap).compile()
+    assert np.array_equal(cm.blob, cm_map.blob)
+    base = synth.get_model("hand")
+    assert (cm.nq, cm.nv, cm.nu, cm.nbody) == (base.nq, base.nv, base.nu, base.nbody) and cm.ntendon == base.ntendon + 5
+    assert list(cm.names["joint"]) == list(base.names["joint"]) and list(cm.names["actuator"]) == list(base.names["actuator"])
+    for s in TARGET_SITES:
+        assert s in cm.names["site"]
+    # same physics as the synthetic hand: the five extra tendons carry no stiffness and no actuator
+    d0, d1 = O.OracleData(O.OracleModel(base)), O.OracleData(O.OracleModel(cm))
+    rng = np.random.default_rng(0)
+    lo, hi = base.jnt_range[:, 0].astype(float), base.jnt_range[:, 1].astype(float)
+    q = lo + (hi - lo) * rng.random(base.nq); v = rng.standard_normal(base.nv); ctrl = rng.random(base.nu)
+    for d in (d0, d1):
+        d.qpos[:] = q; d.qvel[:] = v; d.ctrl[:] = ctrl
+        d.step(30)
+    assert np.abs(d0.qpos - d1.qpos).max() < 1e-12
+    np.testing.assert_allclose(d1.ten_length[:base.ntendon], d0.ten_length, atol=1e-14)
+    # the reference's own task file resolves against the same tree (where the reference checkout exists)
+    ref = "/root/reference/myosuite/envs/myo/assets/hand/myohand_pose.xml"
+    if os.path.exists(ref):
+        s_ref = mjcf.load(ref, include_map=imap)
+        cm_ref = s_ref.compile()
+        assert np.array_equal(cm_ref.blob, cm.blob)                      # same model: the task file adds exactly what ours adds
+        assert len(s_ref.keys) == 1 and len(s_ref.keys[0][0]) == 23      # its keyframe (xml:24-26)
+    # a missing tree still fails loudly
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.load(path, include_map={"simhive/myo_sim": str(tmp_path / "nowhere")})
+
+
+@pytest.mark.gpu
+def test_mjcf_imported_models_step_on_the_hip_path(oracle_lib, tmp_path, monkeypatch):
+    """SURVEY 8f row 2 on the GPU: (1) the hand-pose task file over the stand-in myo_sim tree through
+    registry.make(..., model=<xml path>) -- the reference's model_path -- and (2) the dumped leg model through the same door,
+    each stepped by the fused HIP kernel and checked against the oracle env built from the same imported model."""
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.envs import registry
+    from oracle import env_oracle as EO
+    path, imap = standin_hand_task(tmp_path)
+    monkeypatch.setenv("MYOSUITE_MYO_SIM_ROOT", imap["simhive/myo_sim"])
+    n = 8
+    env = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=6, autoreset=False, model=path)
+    cm = env.cm
+    assert cm.ntendon == 44 and cm.name.startswith("hand pose task")
+    obs0, _ = env.reset(seed=6)
+    orc = []
+    for e in range(n):
+        o = EO.PoseEnvOracle(cm, pose_thd=env.pose_thd)
+        ob = o.reset(env.state.qpos[e].cpu().numpy(), env.target_jnt_value[e].cpu().numpy())
+        np.testing.assert_allclose(obs0[e].cpu().numpy(), ob, rtol=1e-6, atol=1e-6)
+        orc.append(o)
+    rng = np.random.default_rng(2)
+    for s in range(8):
+        a = rng.uniform(-1, 1, (n, cm.nu)).astype(np.float32)
+        obs, rwd, term, trunc, info = env.step(torch.from_numpy(a))
+        for e, o in enumerate(orc):
+            ob, r, done, rd = o.step(a[e])
+            np.testing.assert_allclose(obs[e].cpu().numpy(), ob, rtol=0, atol=5e-4)
+            assert abs(float(rwd[e]) - r) < 2e-3 * max(1.0, abs(r)) and bool(term[e]) == done
+    # (2) contacts + equalities + free joint through the importer: the leg, dumped and re-imported
+    leg_xml = tmp_path / "myolegs.xml"
+    leg_xml.write_text(mjcf.dump(synth.make_leg()))
+    cm_leg = mjcf.load(str(leg_xml)).compile()
+    ref_leg = synth.get_model("leg")
+    hm = E.HipModel(cm_leg); om = O.OracleModel(cm_leg)
+    st = E.BatchState(hm, 4)
+    q0 = np.tile(ref_leg.key_qpos[2].astype(np.float32), (4, 1))
+    st.qpos.copy_(torch.from_numpy(q0))
+    ctrl = torch.from_numpy(rng.random((4, cm_leg.nu)).astype(np.float32)).cuda()
+    E.step(hm, st, ctrl, 20)
+    for e in range(4):
+        d = O.OracleData(om); d.qpos[:] = q0[e]; d.ctrl[:] = ctrl[e].cpu().numpy(); d.step(20)
+        assert np.abs(st.qpos[e].cpu().numpy() - d.qpos).max() < 2e-4, e
+    assert int(st.status.max()) == 0

@@ -1,7 +1,7 @@
 """Pin the engine against libmujoco where it is available (NOT runnable in the authoring container or on
 the GPU boxes of this project: `mujoco` is not installed and there is no network).
 
-    python tools/validate_against_mujoco.py [--model hand|elbow|leg|contact_toy|hand_reorient|hand_keyturn|friction_toy|tendon_limit_toy|finger|torso|... | --xml path.xml] [--steps 200] [--gpu]
+    python tests/tools/validate_against_mujoco.py [--write-fixture] [--model hand|elbow|leg|contact_toy|hand_reorient|hand_keyturn|friction_toy|tendon_limit_toy|finger|torso|... | --xml path.xml] [--steps 200] [--gpu]
 
 1. writes the model as MJCF (`myosuite_amd.model.mjcf.dump`) or takes an MJCF file (e.g. the real myo_sim models) and imports it
    with `mjcf.load`;
@@ -11,6 +11,11 @@ the GPU boxes of this project: `mujoco` is not installed and there is no network
    mj_forward (xpos, ten_length, actuator_force, qfrc_bias, qacc_smooth, efc count, qacc) and the state divergence over `--steps`
    mj_step calls: mujoco (fp64) vs oracle (fp64) vs, with --gpu, the HIP engine (fp32).
 The report is what would turn "PARITY UNPINNED"  into pinned parity.
+4. --write-fixture stores what libmujoco computed -- compile-time constants, every per-stage field of one mj_forward, a
+   `--steps`-step (qpos, qvel, act) trajectory and the ctrl stream -- as tests/golden/mujoco_<model>.npz.  Committed, that file
+   makes tests/test_golden.py::test_oracle_matches_libmujoco_fixture (CPU) and
+   tests/test_gpu_parity.py::test_hip_matches_libmujoco_fixture (GPU) run against libmujoco's numbers on hosts WITHOUT mujoco:
+   one run by anyone who has `pip install mujoco` flips the engine rows of the scope table from "unpinned" to pinned.
 """
 import argparse
 import json
@@ -22,12 +27,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 
 
+# mjData fields of one mj_forward stored in the fixture (same names in the oracle's OracleData)
+FORWARD_FIELDS = ["xpos", "xquat", "xipos", "site_xpos", "subtree_com", "cdof", "cvel", "ten_length", "ten_velocity", "actuator_length",
+                  "actuator_velocity", "actuator_force", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qacc_smooth",
+                  "qfrc_constraint", "qacc"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="hand")
     ap.add_argument("--xml", default=None)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--write-fixture", action="store_true")
     args = ap.parse_args()
     try:
         import mujoco
@@ -67,6 +79,16 @@ def main():
     mjd.qpos[:] = q0; mjd.qvel[:] = v0; mjd.act[:] = a0; mjd.ctrl[:] = ctrl[0]
     d.qpos[:] = q0; d.qvel[:] = v0; d.act[:] = a0; d.ctrl[:] = ctrl[0]
     mujoco.mj_forward(mjm, mjd); d.forward()
+    fix = None
+    if args.write_fixture:
+        fix = dict(model=np.array(args.model if not args.xml else os.path.basename(args.xml)), model_hash=np.array(cm.hash()),
+                   mujoco_version=np.array(mujoco.__version__), q0=q0, v0=v0, a0=a0, ctrl=ctrl,
+                   c_dof_invweight0=np.array(mjm.dof_invweight0), c_body_invweight0=np.array(mjm.body_invweight0),
+                   c_tendon_invweight0=np.array(mjm.tendon_invweight0), c_actuator_acc0=np.array(mjm.actuator_acc0),
+                   c_actuator_lengthrange=np.array(mjm.actuator_lengthrange), c_meaninertia=np.array(mjm.stat.meaninertia))
+        for f in FORWARD_FIELDS:
+            fix["f_" + f] = np.array(getattr(mjd, f)).copy()
+        fix["f_nefc"] = np.array(int(mjd.nefc))
     fw = {}
     for ours, theirs in (("xpos", "xpos"), ("ten_length", "ten_length"), ("actuator_force", "actuator_force"),
                          ("qfrc_bias", "qfrc_bias"), ("qacc_smooth", "qacc_smooth"), ("qacc", "qacc")):
@@ -83,9 +105,11 @@ def main():
         st.act.copy_(torch.from_numpy(a0.astype(np.float32))[None])
         hip = (hm, st, E, torch)
     div = {"oracle_vs_mujoco": [], "hip_vs_mujoco": []}
+    traj = {"qpos": [], "qvel": [], "act": []}
     for s in range(args.steps):
         mjd.ctrl[:] = ctrl[s]; d.ctrl[:] = ctrl[s]
         mujoco.mj_step(mjm, mjd); d.step()
+        traj["qpos"].append(np.array(mjd.qpos)); traj["qvel"].append(np.array(mjd.qvel)); traj["act"].append(np.array(mjd.act))
         div["oracle_vs_mujoco"].append(float(np.abs(d.qpos - mjd.qpos).max()))
         if hip:
             hm, st, E, torch = hip
@@ -93,6 +117,12 @@ def main():
             div["hip_vs_mujoco"].append(float(np.abs(st.qpos[0].cpu().numpy() - mjd.qpos).max()))
     rep["qpos_divergence"] = {k: {"after_10": v[9] if len(v) > 9 else None, "final": v[-1], "max": max(v)} for k, v in div.items() if v}
     print(json.dumps(rep, indent=1))
+    if fix is not None:
+        for k, v in traj.items():
+            fix["t_" + k] = np.array(v)
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden", f"mujoco_{str(fix['model']).replace('.xml', '')}.npz")
+        np.savez_compressed(out, **fix)
+        print("wrote", out)
     return 0
 
 
