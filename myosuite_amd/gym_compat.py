@@ -1,0 +1,232 @@
+"""gym / gymnasium / Stable-Baselines3 boundary: the doors the reference's agents come through.
+
+    import myosuite_amd.gym_compat as mg
+    mg.register_all()                                  # what `import myosuite` does (myosuite/__init__.py:25-67)
+    env = gym.make("myoHandPoseRandom-v0")             # single env, numpy in / out, TimeLimit from the registry horizon
+    venv = gym.make_vec("myoHandPoseRandom-v0", num_envs=4096, vectorization_mode="vector_entry_point")   # gymnasium >= 0.29
+    venv = mg.make_vec_env("myoHandPoseRandom-v0", n_envs=4096)   # stable_baselines3.common.env_util.make_vec_env's signature
+                                                                   # (agents/sb3_job_script.py:49): ONE batched env, not n copies
+
+Everything behind these doors is the batched engine: a `SingleEnv` is a 1-env batch, a `MyoVecEnv` is an n-env batch whose
+step is one fused kernel launch.  `gymnasium` / `stable_baselines3` are optional: when importable, ids are registered with
+gymnasium, spaces are gymnasium spaces and the classes derive from gymnasium.Env / SB3's VecEnv (so VecNormalize & co. accept
+them); when absent (this image), the same classes work on the numpy shim in envs/spaces.py.
+"""
+from __future__ import annotations
+
+import importlib
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .envs import registry
+from .envs import spaces as shim
+
+
+def _gym():
+    for name in ("gymnasium", "gym"):
+        try:
+            return importlib.import_module(name)
+        except ImportError:
+            continue
+    return None
+
+
+def _box(low, high, seed=None):
+    g = _gym()
+    if g is not None and hasattr(g, "spaces"):
+        return g.spaces.Box(low=np.asarray(low, np.float32), high=np.asarray(high, np.float32), dtype=np.float32)
+    return shim.Box(low, high, dtype=np.float32, seed=seed)
+
+
+_EnvBase = object
+_g = _gym()
+if _g is not None and hasattr(_g, "Env"):
+    _EnvBase = _g.Env
+try:
+    from stable_baselines3.common.vec_env import VecEnv as _VecBase      # noqa: F401
+    _HAVE_SB3 = True
+except ImportError:
+    _VecBase = object
+    _HAVE_SB3 = False
+
+
+class SingleEnv(_EnvBase):
+    """`gym.make(id)`: one environment with the reference's single-env signatures (envs/env_base.py:395-407, 640-654):
+    reset(seed=...) -> (obs, {}), step(a) -> (obs, reward, terminated, truncated=False, info); numpy float32 observations.
+    Episode truncation is gym.make's TimeLimit wrapper's job (max_episode_steps of the registry)."""
+    metadata: Dict[str, Any] = {"render_modes": []}
+
+    def __init__(self, env_id: str, device=None, seed=None, **kwargs):
+        kwargs.pop("max_episode_steps", None)
+        self._env = registry.make(env_id, num_envs=1, device=device, seed=seed, autoreset=False, max_episode_steps=0, **kwargs)
+        b = self._env
+        self.observation_space = _box(b.observation_space.low, b.observation_space.high)
+        self.action_space = _box(b.action_space.low, b.action_space.high, seed=seed)
+        self.spec = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def __getattr__(self, name):         # mj-model-free attributes the reference's tests touch: obs_dict, rwd_dict, dt, ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._env, name)
+
+    def reset(self, *, seed=None, options=None, **kwargs):
+        obs, info = self._env.reset(seed=seed, **kwargs)
+        return obs[0].cpu().numpy(), info
+
+    def step(self, a):
+        obs, rwd, term, trunc, info = self._env.step(np.asarray(a, np.float32)[None])
+        flat = {"time": float(info["time"][0]), "rwd_dense": float(info["rwd_dense"][0]), "rwd_sparse": float(info["rwd_sparse"][0]),
+                "solved": bool(info["solved"][0]), "done": bool(info["done"][0]), "obs_dict": info["obs_dict"],
+                "rwd_dict": info["rwd_dict"], "visual_dict": {}, "proprio_dict": {}, "state": info.get("state")}   # env_base.py:604-615
+        return obs[0].cpu().numpy(), float(rwd[0]), bool(term[0]), False, flat
+
+    def render(self):
+        return None
+
+    def close(self):
+        self._env.close()
+
+
+class MyoVecEnv(_VecBase):
+    """n environments as ONE batched env behind Stable-Baselines3's VecEnv protocol (numpy in / out, auto-reset with
+    ``terminal_observation`` / ``TimeLimit.truncated`` in the per-env info dicts, step_async / step_wait, get_attr / set_attr /
+    env_method / env_is_wrapped / seed).  Also offers gymnasium.vector.VectorEnv's 5-tuple through `step5`."""
+
+    def __init__(self, env_id: str, n_envs: int, seed=None, device=None, **env_kwargs):
+        self.env = registry.make(env_id, num_envs=n_envs, device=device, seed=seed, autoreset=True, **env_kwargs)
+        b = self.env
+        self.num_envs = int(n_envs)
+        self.observation_space = _box(b.observation_space.low, b.observation_space.high)
+        self.action_space = _box(b.action_space.low, b.action_space.high, seed=seed)
+        if _HAVE_SB3:
+            _VecBase.__init__(self, self.num_envs, self.observation_space, self.action_space)
+        self.single_observation_space, self.single_action_space = self.observation_space, self.action_space
+        self._actions = None
+        self.render_mode = None
+
+    # ---- SB3 VecEnv
+    def reset(self):
+        obs, _ = self.env.reset()
+        return obs.cpu().numpy()
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, np.float32).reshape(self.num_envs, -1)
+
+    def step_wait(self):
+        obs, rwd, term, trunc, info = self.env.step(self._actions)
+        done = (term | trunc).cpu().numpy()
+        tr = trunc.cpu().numpy()
+        final = info["final_obs"].cpu().numpy() if done.any() else None
+        solved = info["solved"].cpu().numpy()
+        infos: List[Dict[str, Any]] = [{"solved": bool(solved[i])} for i in range(self.num_envs)]
+        for i in np.nonzero(done)[0]:
+            infos[i]["terminal_observation"] = final[i]
+            infos[i]["TimeLimit.truncated"] = bool(tr[i])
+        return obs.cpu().numpy(), rwd.cpu().numpy().astype(np.float32), done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.env.close()
+
+    def seed(self, seed: Optional[int] = None):
+        self.env.seed(seed)
+        return [seed] * self.num_envs
+
+    def _idx(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        return [indices] if isinstance(indices, int) else list(indices)
+
+    def get_attr(self, attr_name: str, indices=None):
+        v = getattr(self.env, attr_name)
+        return [v for _ in self._idx(indices)]
+
+    def set_attr(self, attr_name: str, value, indices=None):
+        setattr(self.env, attr_name, value)
+
+    def env_method(self, method_name: str, *method_args, indices=None, **method_kwargs):
+        r = getattr(self.env, method_name)(*method_args, **method_kwargs)
+        return [r for _ in self._idx(indices)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._idx(indices)]
+
+    def get_images(self) -> Sequence[Optional[np.ndarray]]:
+        return [None] * self.num_envs
+
+    def render(self, mode: Optional[str] = None):
+        return None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ---- gymnasium.vector.VectorEnv flavour
+    def reset5(self, *, seed=None, options=None):
+        obs, info = self.env.reset(seed=seed)
+        return obs.cpu().numpy(), info
+
+    def step5(self, actions):
+        obs, rwd, term, trunc, info = self.env.step(np.asarray(actions, np.float32).reshape(self.num_envs, -1))
+        return obs.cpu().numpy(), rwd.cpu().numpy(), term.cpu().numpy(), trunc.cpu().numpy(), info
+
+
+def make_vec_env(env_id: str, n_envs: int = 1, seed: Optional[int] = None, start_index: int = 0, monitor_dir=None,
+                 wrapper_class=None, env_kwargs: Optional[dict] = None, vec_env_cls=None, vec_env_kwargs=None,
+                 monitor_kwargs=None, wrapper_kwargs=None) -> MyoVecEnv:
+    """Drop-in for ``stable_baselines3.common.env_util.make_vec_env`` (agents/sb3_job_script.py:49,52): same signature, but the
+    n environments are one batched env on the GPU (the per-env Monitor / wrapper_class / vec_env_cls arguments have nothing to
+    wrap and must be left at their defaults)."""
+    if wrapper_class is not None or vec_env_cls is not None or monitor_dir is not None:
+        raise ValueError("myosuite_amd.gym_compat.make_vec_env builds ONE batched env: per-env wrappers / monitors / vec_env_cls do not apply")
+    return MyoVecEnv(env_id, n_envs, seed=seed, **(env_kwargs or {}))
+
+
+def _vector_entry_point(env_id: str):
+    def make(num_envs: int = 1, **kwargs):
+        kwargs.pop("max_episode_steps", None)
+        return MyoVecEnv(env_id, num_envs, **kwargs)
+    return make
+
+
+def _single_entry_point(env_id: str):
+    def make(**kwargs):
+        return SingleEnv(env_id, **kwargs)
+    return make
+
+
+_REGISTERED: List[str] = []
+
+
+def register_all(force: bool = False) -> List[str]:
+    """Register every id of envs/registry.py with gymnasium (or gym) when it is importable -- the side effect `import myosuite`
+    has in the reference (myosuite/__init__.py:25-67; envs/env_variants.py for the Sarc / Fati / Reaf variants).  Returns the
+    ids registered; an empty list (and no error) when neither package is installed."""
+    g = _gym()
+    if g is None or not hasattr(g, "register"):
+        return []
+    existing = set()
+    try:
+        existing = set(g.envs.registry.keys()) if hasattr(g.envs.registry, "keys") else set(g.envs.registry.env_specs.keys())
+    except Exception:
+        pass
+    out = []
+    for env_id, sp in registry.registry_specs().items():
+        if env_id in existing and not force:
+            continue
+        kw = dict(id=env_id, entry_point=_single_entry_point(env_id), max_episode_steps=sp["max_episode_steps"])
+        try:
+            g.register(vector_entry_point=_vector_entry_point(env_id), **kw)     # gymnasium >= 0.29
+        except TypeError:
+            g.register(**kw)
+        out.append(env_id)
+    _REGISTERED.extend(out)
+    return out
