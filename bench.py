@@ -27,9 +27,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes... per the microarch guide), dense, no MFMA
 
-# BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288) reported next to the headline line
+# BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288, and the MuJoCo-default leg on the
+# implicitfast integrator) reported next to the headline line
 EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
-                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"})]
+                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"})]
 
 
 def algorithmic_bytes(env) -> int:

@@ -70,7 +70,7 @@ enum { MM_BIAS_NONE = 0, MM_BIAS_AFFINE = 1, MM_BIAS_MUSCLE = 2 };   /* affine: 
 /* equality types */
 enum { MM_EQ_JOINT = 2 };
 /* mjtIntegrator values carried in MM_OI_INTEGRATOR */
-enum { MM_INT_EULER = 0, MM_INT_RK4 = 1 };
+enum { MM_INT_EULER = 0, MM_INT_RK4 = 1, MM_INT_IMPLICITFAST = 3 };   /* mjtIntegrator values (2 = the full `implicit`, not implemented) */
 /* constraint row types (oracle + engine internal) */
 enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
        MM_CON_CONTACT = 3, MM_CON_FRICTION_DOF = 4 };

@@ -193,6 +193,8 @@ extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mm_version(void) { return "myosim-hip 0.2 (gfx950, lane=item engine)"; }
 
 static const int kNvpChoices[] = {4, 24, 32, 36, 40};
+// integrator -> kernel variant (template argument INTEG)
+static int integ_kernel(int integrator) { return integrator == MM_INT_RK4 ? 1 : (integrator == MM_INT_IMPLICITFAST ? 2 : 0); }
 
 // is (lanes_per_env, padded nv, general-rows, integrator) a compiled instantiation?  (myosim_inst_list.hpp)
 static bool have_kernel(int G, int nvp, int gen, int rk4 = 0) {
@@ -223,6 +225,8 @@ static void build_layout(mm_model* m) {
   L.efcJ = L.rowtab = 0;
   L.rk_qpos0 = L.rk_act0 = L.rk_adot = 0;
   if (d.integrator == MM_INT_RK4) { L.rk_qpos0 = take(d.nq); L.rk_act0 = take(d.na); L.rk_adot = take(d.na); }
+  L.tenw = L.dofw = 0;
+  if (d.integrator == MM_INT_IMPLICITFAST) { L.tenw = take(d.ntendon); L.dofw = take(d.nv); }
   if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(d.efc_rows * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
@@ -268,7 +272,9 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.timestep = of[MM_OF_TIMESTEP]; d.gx = of[MM_OF_GRAV_X]; d.gy = of[MM_OF_GRAV_Y]; d.gz = of[MM_OF_GRAV_Z];
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
   d.integrator = oi[MM_OI_INTEGRATOR];
-  if (d.integrator != MM_INT_EULER && d.integrator != MM_INT_RK4) { delete m; return fail(MM_EUNSUPPORTED, "integrator must be Euler (0) or RK4 (1)"); }
+  if (d.integrator != MM_INT_EULER && d.integrator != MM_INT_RK4 && d.integrator != MM_INT_IMPLICITFAST) {
+    delete m; return fail(MM_EUNSUPPORTED, "integrator must be Euler (0), RK4 (1) or implicitfast (3)");
+  }
   d.ntlim = 0;
   {
     const int32_t* tlim = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_LIMITED]);
@@ -488,13 +494,23 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   }
   m->x.seg_list = append(seg_list);
   m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
+  {
+    const int32_t* dpar = (const int32_t*)(blob + m->sec[MM_SEC_DOF_PARENTID]);
+    std::vector<int32_t> rel(2 * (size_t)d.nv, 0);
+    for (int i = 0; i < d.nv && d.nv <= 64; i++)
+      for (int k = i; k >= 0; k = dpar[k]) {   // k is an ancestor-or-self of i: the pair is on one chain, both ways
+        rel[2 * i + (k >> 5)] |= (int32_t)(1u << (k & 31));
+        rel[2 * k + (i >> 5)] |= (int32_t)(1u << (i & 31));
+      }
+    m->x.dof_rel = append(rel);
+  }
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS
   dev.resize(dev.size() + (sizeof(ConstBlock) + 3) / 4, 0u);
 
   // default group width: the smallest that can own every body / dof / constraint row and has a compiled kernel
   m->lanes = 0;
-  const int rk4 = d.integrator == MM_INT_RK4 ? 1 : 0;
+  const int rk4 = integ_kernel(d.integrator);
   for (int c : {4, 8, 16, 32, 64}) if (check_lanes(m, c) && have_kernel(c, m->nvp, d.gen, rk4)) { m->lanes = c; break; }
   if (!m->lanes) {
     // a model whose rows need a wider group than its dofs do (torso: 18 dofs, 33 rows): take the next larger dense tile
@@ -540,7 +556,7 @@ extern "C" void mm_model_destroy(mm_model* m) {
 extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
   if (!m) return MM_EARG;
   if (lanes == 0) return MM_OK;
-  if (!check_lanes(m, lanes) || !have_kernel(lanes, m->nvp, m->d.gen, m->d.integrator == MM_INT_RK4))
+  if (!check_lanes(m, lanes) || !have_kernel(lanes, m->nvp, m->d.gen, integ_kernel(m->d.integrator)))
     return fail(MM_EARG, "lanes_per_env must be 4/8/16/32/64, >= nbody, nv, njnt, padded nv (and constraint rows), with a compiled kernel");
   m->lanes = lanes;
   m->lanes_auto = 0;
@@ -587,7 +603,7 @@ extern "C" void mm_debug_set_dump(float* dev_ptr) { g_dbg = dev_ptr; }
 static unsigned long long* g_prof = nullptr;
 extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_ptr; }
 
-template <int G, int NVP, bool GEN, bool RK4>
+template <int G, int NVP, bool GEN, int RK4>
 static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st, int lm) {
   // the dynamic-LDS limit is a per-device attribute of the function: one flag per (device, LM variant) of this instantiation
   static std::atomic<unsigned> attr_done[2] = {{0u}, {0u}};   // bit d = set on device d (devices >= 32: set on every launch)
@@ -674,9 +690,9 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   hipStream_t st = (hipStream_t)stream;
   a.blob_words = m->blob_words;
   a.prof = g_prof;
-  const int rk4 = m->d.integrator == MM_INT_RK4 ? 1 : 0;
+  const int rk4 = integ_kernel(m->d.integrator);
 #define X(G_, N_, GN_, RK_) \
-  if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_t<G_, N_, GN_ != 0, RK_ != 0>(m, a, grid, block, lds, st, lm);
+  if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_t<G_, N_, GN_ != 0, RK_>(m, a, grid, block, lds, st, lm);
   MM_KERNEL_LIST(X)
 #undef X
   return fail(MM_EUNSUPPORTED, "no compiled kernel for this (lanes_per_env, nv) combination");

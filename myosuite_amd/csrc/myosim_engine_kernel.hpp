@@ -55,7 +55,7 @@ struct Dims {
   int gen;   // model has equality / friction-loss / contact rows: general (dense-J) constraint path
   int nfric; // dofs with frictionloss > 0 (one friction-loss row each, behind the equalities)
   int ntlim; // limited tendons (at most one limit row each, behind the joint-limit rows)
-  int integrator;   // MM_INT_EULER | MM_INT_RK4
+  int integrator;   // MM_INT_EULER | MM_INT_RK4 | MM_INT_IMPLICITFAST
   int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // Origin of the kernel's internal world frame (host: mean body position at qpos0, rounded to 1/64 m).  Physics is
@@ -75,6 +75,7 @@ struct Layout {
   int vec;  // nv: joint-transmission actuator forces
   int xvec; // NVP (16-byte aligned): operand vector of M x products routed through LDS
   int rk_qpos0, rk_act0, rk_adot;   // RK4: state at the start of the step, weighted act_dot sum (RK4 models only)
+  int tenw, dofw;   // implicitfast: velocity-derivative weights per tendon (b_t - sum_a s_a gear_a^2) and per dof (damping - joint actuators)
   int efcJ, rowtab;   // general constraint rows: J [G][NVP+4] (16-byte aligned rows), row table [G][3] (GEN models only)
   int total;
 };
@@ -92,6 +93,7 @@ struct Aux {
   int root_list, nroot;
   int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
+  int dof_rel;           // per dof: 64-bit mask (2 words) of the dofs on its kinematic chain (ancestors, descendants, itself)
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)
@@ -614,8 +616,11 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 
 // =========================================================================== engine
 // All member functions are collective over the G lanes of one env group.  NVP = padded nv (compile time).
-template <int G, int NVP, bool GEN, bool RK4>
+// INTEG: 0 semi-implicit Euler (eulerdamp), 1 RK4, 2 implicitfast (compile-time variants: each one's state machine would cost
+// the others registers)
+template <int G, int NVP, bool GEN, int INTEG>
 struct Engine {
+  static constexpr bool RK4 = INTEG == 1, IMPL = INTEG == 2;
   const KArgs& a;
   const KConst& kc;    // model constants of the launch (see MM_CONST_IN_REGS)
   const uint32_t* mb;  // model words (LDS-resident copy or global)
@@ -1306,6 +1311,10 @@ struct Engine {
   // ------------------------------------------- A5/A6 passive + actuation -> qfrc_smooth
   __device__ __forceinline__ void passive_actuation() {
     const auto& L = KL();
+    if constexpr (IMPL) {   // implicitfast: start the velocity-derivative weights from the passive dampers (mjd_passive_vel)
+      for (int t = g; t < KD().ntendon; t += G) W[L.tenw + t] = MF_(TENDON_DAMPING)[t];
+      if (g < KD().nv) W[L.dofw + g] = MF_(DOF_DAMPING)[g];
+    }
     for (int t = g; t < KD().ntendon; t += G) {
       float k = MF_(TENDON_STIFFNESS)[t], bd = MF_(TENDON_DAMPING)[t], f = 0.f;
       if (k != 0.f || bd != 0.f) {
@@ -1344,10 +1353,35 @@ struct Engine {
       else if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_AFFINE)   // position / velocity servos
         bias = MF_(ACT_BIASPRM)[9 * u] + MF_(ACT_BIASPRM)[9 * u + 1] * len + MF_(ACT_BIASPRM)[9 * u + 2] * vel;
       float f = gain * input + bias;
-      if (MI_(ACT_FORCELIMITED)[u]) f = clampf(f, MF_(ACT_FORCERANGE)[2 * u], MF_(ACT_FORCERANGE)[2 * u + 1]);
+      bool clamped = false;
+      if (MI_(ACT_FORCELIMITED)[u]) {
+        const float flo = MF_(ACT_FORCERANGE)[2 * u], fhi = MF_(ACT_FORCERANGE)[2 * u + 1];
+        f = clampf(f, flo, fhi);
+        clamped = f <= flo || f >= fhi;
+      }
       W[L.actfrc + u] = f; W[L.actlen + u] = len; W[L.actvel + u] = vel;
       if (ten) atomicAdd(&W[L.tenfrc + id], gear * f);
       else atomicAdd(&W[L.vec + MI_(JNT_DOFADR)[id]], gear * f);
+      if constexpr (IMPL) {
+        // s = d force / d velocity (mjd_actuator_vel: bias_vel + gain_vel * input; none while the force sits on its range)
+        float s = 0.f;
+        if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_AFFINE) s = MF_(ACT_BIASPRM)[9 * u + 2];
+        if (MI_(ACT_GAINTYPE)[u] == MM_GAIN_MUSCLE) {
+          const float* prm = MF_(ACT_GAINPRM) + 9 * u;
+          const float force = muscle_f0(prm, acc0);
+          const float L0 = (lr1 - lr0) / fmaxf(MINVALF, prm[1] - prm[0]);
+          const float Ln = prm[0] + (len - lr0) / fmaxf(MINVALF, L0);
+          const float vs = fmaxf(MINVALF, L0 * prm[6]), V = vel / vs;
+          const float fvmax = prm[8], y = fvmax - 1.f;
+          const float dFV = V <= -1.f ? 0.f : (V <= 0.f ? 2.f * (V + 1.f) : (V <= y ? 2.f * (y - V) / fmaxf(MINVALF, y) : 0.f));
+          s += -force * muscle_fl(Ln, prm[4], prm[5]) * dFV / vs * input;
+        }
+        if (clamped) s = 0.f;
+        if (s != 0.f) {
+          if (ten) atomicAdd(&W[L.tenw + id], -s * gear * gear);
+          else atomicAdd(&W[L.dofw + MI_(JNT_DOFADR)[id]], -s * gear * gear);
+        }
+      }
     }
     GSYNC();
     // J' f: every tendon lane scatters its (<= 8) Jacobian entries into the per-dof accumulator with LDS float
@@ -1953,6 +1987,69 @@ struct Engine {
     GSYNC();
   }
 
+  // mjINT_IMPLICITFAST (oracle: mmo_implicitfast): (M + h W) qacc* = qfrc_smooth + qfrc_constraint with
+  // W = diag(dofw) + sum_t tenw_t J_t'J_t restricted to dof pairs on one kinematic chain (the pattern of M), then mj_advance.
+  // Lane i builds row i of W in its own row of the dense LDS tile (the factor of M in there is dead once Newton is done).
+  __device__ __forceinline__ void implicit_step(float& time) {
+    const auto& L = KL();
+    const float h = KD().timestep;
+    const int nv = KD().nv;
+    d_warm = d_qacc;
+    float* T = W + L.u1;
+    const int row = g < NVP ? g : 0;
+    if (g < NVP)
+#pragma unroll
+      for (int k4 = 0; k4 < NVP / 4; k4++) *reinterpret_cast<float4*>(T + row * NVP + 4 * k4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    GSYNC();
+    if (g < nv) {
+      const int* dja = AUXI(dofj_adr); const int* dje = AUXI(dofj_entry); const int* djt = AUXI(dofj_tendon);
+      const unsigned rlo = (unsigned)AUXI(dof_rel)[2 * g], rhi = (unsigned)AUXI(dof_rel)[2 * g + 1];
+      for (int q = dja[g]; q < dja[g + 1]; q++) {
+        const int t = djt[q];
+        const float wt = W[L.tenw + t] * W[L.tenj + dje[q]];
+        if (wt == 0.f) continue;
+        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) {
+          const int k = MI_(TENJ_DOF)[e];
+          const bool rel = k < 32 ? (rlo >> k) & 1u : (rhi >> (k - 32)) & 1u;
+          if (rel) T[g * NVP + k] += wt * W[L.tenj + e];     // own row: no other lane touches it
+        }
+      }
+    }
+    GSYNC();
+    float A[NVP];
+#pragma unroll
+    for (int k4 = 0; k4 < NVP / 4; k4++) {
+      const float4 r = *reinterpret_cast<const float4*>(T + row * NVP + 4 * k4);
+      A[4 * k4] = Mrow[4 * k4] + h * r.x; A[4 * k4 + 1] = Mrow[4 * k4 + 1] + h * r.y;
+      A[4 * k4 + 2] = Mrow[4 * k4 + 2] + h * r.z; A[4 * k4 + 3] = Mrow[4 * k4 + 3] + h * r.w;
+    }
+    if (g >= NVP) {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) A[k] = 0.f;
+    }
+    const float dw = g < nv ? h * W[L.dofw + g] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NVP; k++) A[k] += (k == g) ? dw : 0.f;
+    GSYNC();
+    factor_core<false>(A);
+    const float qa_ = solve(g < nv ? d_smooth + d_qfrccon : 0.f);
+    for (int u = g; u < KD().nu; u += G) {
+      int aa = MI_(ACT_ACTADR)[u];
+      if (aa < 0) continue;
+      float x = W[L.act + aa] + h * W[L.actdot + aa];
+      if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
+      W[L.act + aa] = x;
+    }
+    if (g < nv) {
+      d_qvel += h * qa_;
+      W[L.qvel + g] = d_qvel;
+    }
+    GSYNC();
+    integrate_pos(L.qvel, h);
+    time += h;
+    GSYNC();
+  }
+
   // qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos); vel = LDS vector at word offset `voff`
   __device__ __forceinline__ void integrate_pos(int voff, float hh) {
     const auto& L = KL();
@@ -2026,7 +2123,8 @@ struct Engine {
         forward();
         if (stepping) {
           if (!redo && bad_state(true)) { reset_data(); time = 0.f; status |= 1; redo = true; continue; }
-          PFT(PF_EULER, euler(time));
+          if constexpr (IMPL) { PFT(PF_EULER, implicit_step(time)); }
+          else { PFT(PF_EULER, euler(time)); }
           redo = false;
         }
         s++;
@@ -2054,7 +2152,7 @@ struct Engine {
 };
 
 // =========================================================================== kernels
-template <int G, int NVP, bool LM, bool GEN, bool RK4>
+template <int G, int NVP, bool LM, bool GEN, int INTEG>
 __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   extern __shared__ float lds[];
   constexpr int EPW = 64 / G;  // envs per wave
@@ -2098,7 +2196,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * KL().total;
   const auto& L = KL();
   const auto& d = KD();
-  Engine<G, NVP, GEN, RK4> E(a, kc, mb, W, g);
+  Engine<G, NVP, GEN, INTEG> E(a, kc, mb, W, g);
   if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
   if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
   E.env = e;

@@ -1,5 +1,5 @@
-// myosim_inst_list.hpp -- the ONE list of compiled k_engine<G, NVP, LM, GEN, RK4> instantiations (both LM variants each).
-// X(lanes_per_env, padded_nv, general_rows, rk4).  Used for: explicit instantiation (myosim_inst_*.hip, one group per
+// myosim_inst_list.hpp -- the ONE list of compiled k_engine<G, NVP, LM, GEN, INTEG> instantiations (both LM variants each).
+// X(lanes_per_env, padded_nv, general_rows, integrator kernel: 0 Euler, 1 RK4, 2 implicitfast).  Used for: explicit instantiation (myosim_inst_*.hip, one group per
 // translation unit so they build in parallel), extern declarations + have_kernel() + the launch table (myosim_engine.hip).
 #pragma once
 #define MM_KERNELS_A(X) X(4, 4, 0, 0) X(8, 4, 0, 0) X(16, 4, 0, 0) X(32, 4, 0, 0) X(64, 4, 0, 0)
@@ -11,10 +11,11 @@
 #define MM_KERNELS_G(X) X(64, 32, 1, 1) X(64, 40, 1, 1)
 #define MM_KERNELS_H(X) X(64, 36, 1, 0)   /* leg models: 34 dofs (the 40-wide tile wastes 20 % of the dense linear algebra) */
 #define MM_KERNELS_I(X) X(64, 24, 1, 0)   /* row-rich models with <= 24 dofs (key turn, torso) */
-#define MM_KERNEL_LIST(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X) MM_KERNELS_H(X) MM_KERNELS_I(X)
+#define MM_KERNELS_J(X) X(4, 4, 0, 2) X(32, 24, 0, 2) X(64, 36, 1, 2)   /* implicitfast: elbow, hand, leg at their default widths */
+#define MM_KERNEL_LIST(X) MM_KERNELS_J(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X) MM_KERNELS_H(X) MM_KERNELS_I(X)
 #define MM_INSTANTIATE(G_, N_, GN_, RK_)                                        \
-  template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_ != 0>(KArgs);   \
-  template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_ != 0>(KArgs);
+  template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_>(KArgs);   \
+  template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_>(KArgs);
 #define MM_DECLARE(G_, N_, GN_, RK_)                                                   \
-  extern template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_ != 0>(KArgs);   \
-  extern template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_ != 0>(KArgs);
+  extern template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_>(KArgs);   \
+  extern template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_>(KArgs);

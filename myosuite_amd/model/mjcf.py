@@ -9,7 +9,7 @@ generated from contype / conaffinity (with ``<exclude>``), keyframes -- into a `
 as MJCF (radians, explicit inertials, explicit contact pairs).  Elements that do not affect the physics path (asset, visual,
 camera, light, sensor, rgba, material, group ...) are ignored; physics features the engine does not implement raise
 ``MjcfError`` (never silently dropped): mesh / hfield collision geoms, ball joints with limits, weld / connect equalities,
-elliptic cones, tendon limits, implicit integrators, non-muscle stateful actuators.
+elliptic cones, the full `implicit` integrator (`implicitfast` is implemented).
 
 Written from MuJoCo's public XML reference; it does not use or need the ``mujoco`` package.  The real ``myo_sim`` MJCF is an
 empty submodule in the reference checkout, so the tests exercise the importer on MJCF written by ``dump`` (round trip of the
@@ -264,9 +264,9 @@ def load(source: str, missing_include: str = "error", include_map: Optional[Dict
         if "gravity" in a:
             opt["gravity"] = tuple(_floats(a["gravity"], 3))
         if "integrator" in a:
-            if a["integrator"] not in ("Euler", "RK4"):
-                raise MjcfError(f"integrator {a['integrator']!r} is not implemented (Euler, RK4)")
-            opt["integrator"] = 0 if a["integrator"] == "Euler" else 1
+            if a["integrator"] not in ("Euler", "RK4", "implicitfast"):
+                raise MjcfError(f"integrator {a['integrator']!r} is not implemented (Euler, RK4, implicitfast)")
+            opt["integrator"] = {"Euler": 0, "RK4": 1, "implicitfast": 3}[a["integrator"]]
         if a.get("cone", "pyramidal") != "pyramidal":
             raise MjcfError("only pyramidal friction cones are implemented")
         if a.get("solver", "Newton") != "Newton":
@@ -614,7 +614,7 @@ def dump(spec: ModelSpec) -> str:
     root = ET.Element("mujoco", model=spec.name)
     ET.SubElement(root, "compiler", angle="radian", autolimits="true", inertiafromgeom="false")
     o = ET.SubElement(root, "option", timestep=repr(float(spec.timestep)), gravity=_f(spec.gravity),
-                      integrator="RK4" if spec.integrator == 1 else "Euler", iterations=str(spec.iterations),
+                      integrator={0: "Euler", 1: "RK4", 3: "implicitfast"}[spec.integrator], iterations=str(spec.iterations),
                       tolerance=repr(float(spec.tolerance)), ls_iterations=str(spec.ls_iterations),
                       ls_tolerance=repr(float(spec.ls_tolerance)), cone="pyramidal", solver="Newton")
     if not spec.eulerdamp:

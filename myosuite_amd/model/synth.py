@@ -507,14 +507,18 @@ def _reframe_z(s: ModelSpec, angle: float):
         g["pos"] = R @ g["pos"]; g["quat"] = _qmul(r, g["quat"])
 
 
-def make_leg() -> ModelSpec:
-    """myoLeg: free-floating pelvis + torso, 2 x 14 leg joints (34 DoF, nq 35), 80 muscles, 14 knee joint-equalities,
+def make_leg(implicit: bool = False) -> ModelSpec:
+    """``implicit``: the MuJoCo-default version of the model -- force-velocity range vmax = 1.5 L0/s on every muscle, no
+    reflected-inertia padding on the foot joints, integrator implicitfast (what explicit Euler cannot step at this timestep:
+    see DESIGN.md).  The default (explicit Euler) version softens both.
+
+    myoLeg: free-floating pelvis + torso, 2 x 14 leg joints (34 DoF, nq 35), 80 muscles, 14 knee joint-equalities,
     8 foot-ground contact pairs.  Authored below with x right / y forward / z up, then re-framed to MyoLeg's body frames
     (x forward, y left, z up).  The keyframes carry the root quaternion (0.7071, 0, 0, -0.7071), i.e. the model faces
     world -y: that is what makes the reference's reward / termination arithmetic consistent (walk_v0.py:438-446 negates
     cvel and rewards y-velocity 1.2; walk_v0.py:461-472 terminates when |R[0,0]| of the root exceeds max_rot).
     Joint / muscle names and dimensions: SURVEY.md 8d (walk_v0.py:236-241,438-451; docs/source/suite.rst)."""
-    s = ModelSpec("myolegs", timestep=0.001)  # x frame_skip 10 (BaseV0 default) = 0.01 s per env step: hip_period 100 -> 1 s stride
+    s = ModelSpec("myolegs_implicitfast" if implicit else "myolegs", timestep=0.001, integrator=3 if implicit else 0)  # x frame_skip 10 (BaseV0 default) = 0.01 s per env step: hip_period 100 -> 1 s stride
     s.add_geom("floor", "world", "plane", (0, 0, 0))
     PZ = 0.982
     s.add_body("pelvis", "world", pos=(0, 0, PZ), mass=11.8, ipos=(0, -0.04, 0.0), inertia=(0.10, 0.09, 0.06))
@@ -543,12 +547,12 @@ def make_leg() -> ModelSpec:
         s.add_joint(_jname("knee_angle_rotation3", side), B["tibia"], "hinge", axis=(0, 0, sx), damping=0.1, armature=0.002)
         s.add_body(B["talus"], B["tibia"], pos=(0, 0, -0.43), mass=0.1, inertia=(0.001, 0.001, 0.001))
         s.add_joint(_jname("ankle_angle", side), B["talus"], "hinge", axis=(1, 0, 0), range=(-0.70, 0.52),
-                    damping=0.5, armature=0.03)
+                    damping=0.5, armature=0.003 if implicit else 0.03)
         s.add_body(B["calcn"], B["talus"], pos=X((-0.005, -0.049, -0.042)), mass=1.25, ipos=(0, 0.09, 0.012),
                    inertia=(0.004, 0.0014, 0.0041))
         ax = np.array([sx * 0.12, 0.787, 0.605]); ax /= np.linalg.norm(ax)      # oblique subtalar axis (inversion +)
         s.add_joint(_jname("subtalar_angle", side), B["calcn"], "hinge", axis=tuple(-ax if sx > 0 else ax),
-                    range=(-0.35, 0.35), damping=0.3, armature=0.015)
+                    range=(-0.35, 0.35), damping=0.3, armature=0.002 if implicit else 0.015)
         s.add_body(B["toes"], B["calcn"], pos=(0, 0.179, -0.002), mass=0.22, ipos=(0, 0.03, -0.005),
                    inertia=(0.0001, 0.0002, 0.0002))
         s.add_joint(_jname("mtp_angle", side), B["toes"], "hinge", axis=(1, 0, 0), range=(-0.52, 0.52),
@@ -588,7 +592,7 @@ def make_leg() -> ModelSpec:
             s.add_tendon(tn, path)
             # vmax 10 L0/s (physiological): with MuJoCo's default 1.5 the force-velocity slope of the big ankle /
             # knee muscles is too stiff for explicit Euler at this timestep (synthetic models)
-            s.add_muscle(f"{name}_{side}", tn, force=force, range=(0.60, 1.35), vmax=10.0)
+            s.add_muscle(f"{name}_{side}", tn, force=force, range=(0.60, 1.35), vmax=1.5 if implicit else 10.0)
 
         P, F, T, Cn, TO = "pelvis", "femur", "tibia", "calcn", "toes"
         muscle("addbrev", [site(P, (0.020, 0.010, -0.090)), site(F, (0.005, -0.005, -0.13))], 600.0)
@@ -962,7 +966,8 @@ def builders() -> dict:
             "hand_hold": make_hand_hold, "elbow_exo": make_elbow_exo, "finger": make_finger,
             "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
             "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
-            "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True)}
+            "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True),
+            "leg_implicit": lambda: make_leg(implicit=True)}
 
 
 def compile_spec(name: str, edit=None) -> CompiledModel:
@@ -974,7 +979,7 @@ def compile_spec(name: str, edit=None) -> CompiledModel:
     keys = getattr(spec, "keys", None)
     if keys:   # keyframes (mjModel.key_qpos / key_qvel); host-side only, not part of the blob
         cm.key_qpos = np.array([k[0] for k in keys]); cm.key_qvel = np.array([k[1] for k in keys])
-        if name == "leg":
+        if name in ("leg", "leg_implicit"):
             _ground_keyframes(cm)
     return cm
 

@@ -1283,21 +1283,11 @@ static int bad_state(const mmo_model* m, const mmo_data* d, int check_acc) {
   return 0;
 }
 
-/* A9: semi-implicit Euler with implicit joint damping */
-static void mmo_euler(const mmo_model* m, mmo_data* d) {
+void mmo_full_m(const mmo_model* m, const mmo_data* d, real* out);
+/* mj_advance: activations, qvel += h qacc, qpos on the manifold, time */
+static void mmo_advance(const mmo_model* m, mmo_data* d, const real* qacc) {
   int nv = m->nv;
   real h = m->timestep;
-  real* qacc = d->tmp_nv;
-  int damped = 0;
-  for (int i = 0; i < nv; i++) if (MF(m, DOF_DAMPING)[i] > 0) damped = 1;
-  if (damped && m->eulerdamp) {
-    memcpy(d->qH, d->qM, sizeof(real) * m->nM);
-    for (int i = 0; i < nv; i++) d->qH[MI(m, DOF_MADR)[i]] += h * MF(m, DOF_DAMPING)[i];
-    mmo_factor(m, d->qH, d->qHDiagInv);
-    for (int i = 0; i < nv; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
-    mmo_solve_ld(m, d->qH, d->qHDiagInv, qacc);
-  } else memcpy(qacc, d->qacc, sizeof(real) * nv);
-  /* activations */
   for (int a = 0; a < m->nu; a++) {
     int aa = MI(m, ACT_ACTADR)[a];
     if (aa < 0) continue;
@@ -1326,6 +1316,109 @@ static void mmo_euler(const mmo_model* m, mmo_data* d) {
     }
   }
   d->time += h;
+}
+
+/* A9: semi-implicit Euler with implicit joint damping */
+static void mmo_euler(const mmo_model* m, mmo_data* d) {
+  int nv = m->nv;
+  real h = m->timestep;
+  real* qacc = d->tmp_nv;
+  int damped = 0;
+  for (int i = 0; i < nv; i++) if (MF(m, DOF_DAMPING)[i] > 0) damped = 1;
+  if (damped && m->eulerdamp) {
+    memcpy(d->qH, d->qM, sizeof(real) * m->nM);
+    for (int i = 0; i < nv; i++) d->qH[MI(m, DOF_MADR)[i]] += h * MF(m, DOF_DAMPING)[i];
+    mmo_factor(m, d->qH, d->qHDiagInv);
+    for (int i = 0; i < nv; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+    mmo_solve_ld(m, d->qH, d->qHDiagInv, qacc);
+  } else memcpy(qacc, d->qacc, sizeof(real) * nv);
+  mmo_advance(m, d, qacc);
+}
+
+/* d(actuator force)/d(actuator velocity): mjd_actuator_vel of MuJoCo's derivatives.c (bias_vel + gain_vel * input; a force
+   sitting on its forcerange has no derivative).  Muscle: gain = -F0 FL(L) FV(V), V = vel / (L0 vmax) */
+static real actuator_dforce_dvel(const mmo_model* m, const mmo_data* d, int a) {
+  real bias_vel = 0, gain_vel = 0;
+  if (MI(m, ACT_BIASTYPE)[a] == MM_BIAS_AFFINE) bias_vel = MF(m, ACT_BIASPRM)[9 * a + 2];
+  if (MI(m, ACT_GAINTYPE)[a] == MM_GAIN_MUSCLE) {
+    const real* prm = MF(m, ACT_GAINPRM) + 9 * a; const real* lr = MF(m, ACT_LENGTHRANGE) + 2 * a;
+    real force = muscle_f0(prm, MF(m, ACT_ACC0)[a]);
+    real L0 = (lr[1] - lr[0]) / fmax(MINVAL, prm[1] - prm[0]);
+    real L = prm[0] + (d->actuator_length[a] - lr[0]) / fmax(MINVAL, L0);
+    real vs = fmax(MINVAL, L0 * prm[6]), V = d->actuator_velocity[a] / vs;
+    real FL = muscle_fl(L, prm[4], prm[5]);
+    real fvmax = prm[8], y = fvmax - 1, dFV;
+    if (V <= -1) dFV = 0;
+    else if (V <= 0) dFV = 2 * (V + 1);
+    else if (V <= y) dFV = 2 * (y - V) / fmax(MINVAL, y);
+    else dFV = 0;
+    gain_vel = -force * FL * dFV / vs;
+  }
+  if (MI(m, ACT_FORCELIMITED)[a]) {
+    real f = d->actuator_force[a];
+    if (f <= MF(m, ACT_FORCERANGE)[2 * a] || f >= MF(m, ACT_FORCERANGE)[2 * a + 1]) return 0;
+  }
+  int aa = MI(m, ACT_ACTADR)[a];
+  real input = aa >= 0 ? d->act[aa] : d->ctrl[a];
+  if (aa < 0 && MI(m, ACT_CTRLLIMITED)[a]) {
+    real lo = MF(m, ACT_CTRLRANGE)[2 * a], hi = MF(m, ACT_CTRLRANGE)[2 * a + 1];
+    input = input < lo ? lo : (input > hi ? hi : input);
+  }
+  return bias_vel + gain_vel * input;
+}
+
+/* mjINT_IMPLICITFAST (MuJoCo "Computation / Numerical integration": implicit-in-velocity Euler with the velocity derivative of
+   the smooth forces, Coriolis / centripetal terms dropped and the matrix kept symmetric):
+     (M - h D) qacc* = qfrc_smooth + qfrc_constraint,   D = d(qfrc_passive + qfrc_actuator)/d(qvel)
+                                                          = -diag(damping) - sum_t b_t J_t'J_t + sum_a s_a moment_a' moment_a
+   with s_a = d force_a / d velocity_a (mjd_passive_vel / mjd_actuator_vel).  D is kept in the sparsity pattern of M (dof pairs
+   on one kinematic chain -- mjData.qDeriv's pattern): a tendon whose two ends sit on different branches contributes its
+   on-chain blocks only.  Dense Cholesky here (the oracle favours clarity). */
+static void mmo_implicitfast(const mmo_model* m, mmo_data* d) {
+  int nv = m->nv;
+  real h = m->timestep;
+  real* MM = ralloc(nv * nv);
+  real* Dm = ralloc(nv * nv);
+  mmo_full_m(m, d, MM);
+  for (int i = 0; i < nv; i++) Dm[i * nv + i] -= MF(m, DOF_DAMPING)[i];
+  for (int t = 0; t < m->ntendon; t++) {
+    real b = MF(m, TENDON_DAMPING)[t];
+    if (b == 0) continue;
+    for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) Dm[i * nv + j] -= b * d->ten_J[t * nv + i] * d->ten_J[t * nv + j];
+  }
+  for (int a = 0; a < m->nu; a++) {
+    real s = actuator_dforce_dvel(m, d, a);
+    if (s == 0) continue;
+    const real* mom = d->actuator_moment + (size_t)a * nv;
+    for (int i = 0; i < nv; i++) if (mom[i] != 0) for (int j = 0; j < nv; j++) Dm[i * nv + j] += s * mom[i] * mom[j];
+  }
+  /* keep the pattern of M: (i, j) with j an ancestor-or-self of i (and its mirror) */
+  for (int i = 0; i < nv; i++) {
+    for (int j = 0; j < nv; j++) {
+      int rel = 0;
+      for (int k = i; k >= 0; k = MI(m, DOF_PARENTID)[k]) if (k == j) rel = 1;
+      for (int k = j; k >= 0; k = MI(m, DOF_PARENTID)[k]) if (k == i) rel = 1;
+      if (rel) MM[i * nv + j] -= h * Dm[i * nv + j];
+    }
+  }
+  /* dense Cholesky MM = L L', solve */
+  real* qacc = d->tmp_nv;
+  for (int i = 0; i < nv; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+  for (int j = 0; j < nv; j++) {
+    real s = MM[j * nv + j];
+    for (int k = 0; k < j; k++) s -= MM[j * nv + k] * MM[j * nv + k];
+    real l = sqrt(fmax(s, MINVAL));
+    MM[j * nv + j] = l;
+    for (int i = j + 1; i < nv; i++) {
+      real v = MM[i * nv + j];
+      for (int k = 0; k < j; k++) v -= MM[i * nv + k] * MM[j * nv + k];
+      MM[i * nv + j] = v / l;
+    }
+  }
+  for (int i = 0; i < nv; i++) { real v = qacc[i]; for (int k = 0; k < i; k++) v -= MM[i * nv + k] * qacc[k]; qacc[i] = v / MM[i * nv + i]; }
+  for (int i = nv - 1; i >= 0; i--) { real v = qacc[i]; for (int k = i + 1; k < nv; k++) v -= MM[k * nv + i] * qacc[k]; qacc[i] = v / MM[i * nv + i]; }
+  free(MM); free(Dm);
+  mmo_advance(m, d, qacc);
 }
 
 /* qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos) */
@@ -1399,7 +1492,9 @@ void mmo_step(const mmo_model* m, mmo_data* d) {
     memcpy(c, d->ctrl, sizeof(real) * nu); mmo_reset(m, d); memcpy(d->ctrl, c, sizeof(real) * nu); d->warn_bad |= 1;
     mmo_forward(m, d); }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * m->nv);
-  if (m->integrator == MM_INT_RK4) mmo_rk4(m, d); else mmo_euler(m, d);
+  if (m->integrator == MM_INT_RK4) mmo_rk4(m, d);
+  else if (m->integrator == MM_INT_IMPLICITFAST) mmo_implicitfast(m, d);
+  else mmo_euler(m, d);
 }
 
 /* ---------------------------------------------------------- accessors */

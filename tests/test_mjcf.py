@@ -106,7 +106,8 @@ def test_include_and_unsupported_features_fail_loudly(tmp_path):
     with pytest.raises(mjcf.MjcfError):
         mjcf.load('<mujoco><worldbody><include file="/nonexistent/x.xml"/></worldbody></mujoco>')
     assert mjcf.load('<mujoco><worldbody><include file="/nonexistent/x.xml"/></worldbody></mujoco>', missing_include="skip").bodies
-    for bad in ('<mujoco><option integrator="implicitfast"/></mujoco>', '<mujoco><option cone="elliptic"/></mujoco>',
+    assert mjcf.load('<mujoco><option integrator="implicitfast"/></mujoco>').integrator == 3
+    for bad in ('<mujoco><option integrator="implicit"/></mujoco>', '<mujoco><option cone="elliptic"/></mujoco>',
                 '<mujoco><worldbody><body><geom type="mesh" mesh="m"/></body></worldbody></mujoco>',
                 '<mujoco><worldbody><body name="a"><joint name="j"/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/></body></worldbody>'
                 '<equality><weld body1="a"/></equality></mujoco>'):
