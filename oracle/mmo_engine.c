@@ -36,10 +36,12 @@
 #include "../include/myosim_model.h"
 
 #define MINVAL MM_MINVAL
+#ifndef MMO_REAL_EXTERNAL   /* tests/tools/count_flops.py compiles this file as C++ with `real` = an operation-counting class */
 #ifndef MMO_REAL
-#define MMO_REAL double   /* -DMMO_REAL=float builds the fp32 rounding-error study variant (tests/experiments) */
+#define MMO_REAL double   /* -DMMO_REAL=float builds the fp32 rounding-error study variant */
 #endif
 typedef MMO_REAL real;
+#endif
 
 /* ------------------------------------------------------------------ model */
 typedef struct {
@@ -1522,7 +1524,7 @@ void mmo_set_body_mass(mmo_data* d, int body, double mass) { d->bmass_id = body;
 void mmo_set_body_pos(mmo_data* d, int body, double x, double y, double z) { d->bpos_id = body; d->bpos_val[0] = x; d->bpos_val[1] = y; d->bpos_val[2] = z; }
 /* test hook: capsule-axis segment vs convex primitive in the primitive's frame -> signed distance, t, outward normal */
 double mmo_test_seg_shape(int type, const double* size, const double* a, const double* u, double h, double* t, double* grad);
-double mmo_time(const mmo_data* d) { return d->time; }
+double mmo_time(const mmo_data* d) { return (double)d->time; }
 void mmo_set_time(mmo_data* d, double t) { d->time = t; }
 int mmo_nefc(const mmo_data* d) { return d->nefc; }
 int mmo_ncon(const mmo_data* d) { return d->ncon; }
@@ -1541,6 +1543,8 @@ void mmo_full_m(const mmo_model* m, const mmo_data* d, real* out) {
   }
 }
 
+#ifndef MMO_REAL_EXTERNAL
 double mmo_test_seg_shape(int type, const double* size, const double* a, const double* u, double h, double* t, double* grad) {
   return seg_shape(type, size, a, u, h, t, grad);
 }
+#endif

@@ -1,0 +1,78 @@
+"""Algorithmic floating-point operations of ONE env-step (frame_skip x mj_step + the final mj_forward + nothing else) of the
+reference algorithm, counted -- not estimated -- by running the fp64 oracle compiled with an operation-counting scalar type
+(tests/tools/flopcount/): every +, -, *, /, sqrt and transcendental on a `real` bumps a counter.
+
+    python tests/tools/count_flops.py          ->  profiles/flops_per_env_step.json   (read by bench.py: roofline.flops)
+
+flops = add + mul + div + sqrt + transcendental (a multiply-add is two).  The oracle factors M with MuJoCo's tree-sparse L'DL and
+walks sparse Jacobians, so this is the work of the ALGORITHM; the kernel's dense register Cholesky executes more.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build():
+    out = os.path.join(tempfile.gettempdir(), "libmmo_flopcount.so")
+    src = os.path.join(HERE, "flopcount", "flop_oracle.cpp")
+    subprocess.check_call(["g++", "-O1", "-fPIC", "-shared", "-std=c++17", "-fpermissive", "-w", "-DMMO_REAL_EXTERNAL", "-o", out, src])
+    return out
+
+
+def main():
+    from oracle import oracle as O
+    O._LIB_PATH = build(); O._lib = None
+    from oracle import env_oracle as EO
+    from myosuite_amd.envs import registry
+    from myosuite_amd.model import synth
+    L = O.lib()
+    L.mmo_flops_get.argtypes = [C.c_void_p]
+    res = {}
+    for env_id, model, warm in (("myoElbowPose1D6MRandom-v0", None, 5), ("myoHandPoseRandom-v0", None, 5), ("myoHandReorient100-v0", None, 3),
+                                ("myoFatiLegWalk-v0", None, 5), ("myoLegWalk-v0", None, 5)):
+        sp = registry.spec(env_id)
+        cm = synth.get_model(model or sp["kwargs"]["model"])
+        fs = sp["kwargs"].get("frame_skip", 10)
+        om = O.OracleModel(cm)
+        tot = np.zeros(6, np.uint64); n = 0
+        for e in range(6):
+            d = O.OracleData(om)
+            if hasattr(cm, "key_qpos"):
+                d.qpos[:] = cm.key_qpos[2]; d.qvel[:] = cm.key_qvel[2]
+            elif "Object" in cm.names["body"]:
+                q = cm.qpos0.astype(np.float64).copy(); q[:-6] = 0; q[0] = -1.5; d.qpos[:] = q
+                gt, size, _, _ = EO.reorient_reset_draws(synth.reorient_tables("100"), e, 0, 0, 0.07)
+                d.set_geom_size(cm.names["geom"]["obj"], size, gt)
+            else:
+                lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+                d.qpos[:] = lo + (hi - lo) * EO.pose_reset_draws(cm.nq, e, 0, 0)[0]
+            for s in range(warm + 8):
+                a = EO.uniform_stream(cm.nu, e, s).astype(np.float64)
+                d.ctrl[:] = 1.0 / (1.0 + np.exp(-5.0 * (a - 0.5)))
+                if s >= warm:
+                    L.mmo_flops_reset()
+                d.step(fs); d.forward()
+                if s >= warm:
+                    c = (C.c_uint64 * 6)(); L.mmo_flops_get(c)
+                    tot += np.array(list(c), np.uint64); n += 1
+        add, mul, div, sq, tr, cmp_ = (tot / n).tolist()
+        res[env_id] = {"flops": add + mul + div + sq + tr, "add": add, "mul": mul, "div": div, "sqrt": sq, "transcendental": tr,
+                       "compare_minmax": cmp_, "frame_skip": fs,
+                       "source": "tests/tools/count_flops.py: fp64 oracle compiled with an operation-counting scalar, mean of 48 env-steps "
+                                 "(frame_skip substeps + final forward), random actions"}
+        print(env_id, json.dumps(res[env_id]))
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "profiles", "flops_per_env_step.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
