@@ -615,6 +615,9 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 }
 
 // =========================================================================== engine
+#define PIN_S(x) asm volatile("" : "+s"(x))   /* keep a wave-uniform value in an SGPR: opaque to rematerialisation (an s_load + s_waitcnt at every use) */
+#define AI_(o) (reinterpret_cast<const int*>(mb + (o)))
+#define AF_(o) (reinterpret_cast<const float*>(mb + (o)))
 // All member functions are collective over the G lanes of one env group.  NVP = padded nv (compile time).
 // INTEG: 0 semi-implicit Euler (eulerdamp), 1 RK4, 2 implicitfast (compile-time variants: each one's state machine would cost
 // the others registers)
@@ -689,76 +692,78 @@ struct Engine {
 
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
+    // offsets read once and pinned in SGPRs for this stage (see PIN_S)
+    int o_xpos = KL().xpos; PIN_S(o_xpos); int o_u1 = KL().u1; PIN_S(o_u1); int o_xmat = KL().xmat; PIN_S(o_xmat); int o_xanchor = KL().xanchor; PIN_S(o_xanchor); int o_xaxis = KL().xaxis; PIN_S(o_xaxis); int o_qpos = KL().qpos; PIN_S(o_qpos); int s_JNT_TYPE = SECOFF_(JNT_TYPE); PIN_S(s_JNT_TYPE); int s_JNT_QPOSADR = SECOFF_(JNT_QPOSADR); PIN_S(s_JNT_QPOSADR); int s_JNT_POS = SECOFF_(JNT_POS); PIN_S(s_JNT_POS); int s_JNT_AXIS = SECOFF_(JNT_AXIS); PIN_S(s_JNT_AXIS); int s_QPOS0 = SECOFF_(QPOS0); PIN_S(s_QPOS0); int s_BODY_POS = SECOFF_(BODY_POS); PIN_S(s_BODY_POS); int s_BODY_QUAT = SECOFF_(BODY_QUAT); PIN_S(s_BODY_QUAT); int s_BODY_IPOS = SECOFF_(BODY_IPOS); PIN_S(s_BODY_IPOS); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_);
     const auto& L = KL();
     const V3 org = origin();
     if (g == 0) {
       b_xpos = -1.f * org; b_xipos = b_xpos;   // the world body (and everything attached to it) in the internal frame
       Q4 q = {1.f, 0.f, 0.f, 0.f};
       b_xquat = q;
-      st3(W + L.xpos, b_xpos);
-      W[L.u1] = 1.f; W[L.u1 + 1] = 0.f; W[L.u1 + 2] = 0.f; W[L.u1 + 3] = 0.f;
-      for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+      st3(W + o_xpos, b_xpos);
+      W[o_u1] = 1.f; W[o_u1 + 1] = 0.f; W[o_u1 + 2] = 0.f; W[o_u1 + 3] = 0.f;
+      for (int k = 0; k < 9; k++) W[o_xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
     }
     GSYNC();
     // Phase A (all bodies at once): transform of every body in its PARENT's frame, its joints applied; joint anchors / axes
     // are left in LDS in that frame.  Phase B: pointer jumping -- every body composes its transform with the one of the
     // ancestor it currently points at and then points at that ancestor's target: ceil(log2(depth)) rounds instead of one
     // round per tree level (4 instead of 9 for the hand).  Phase C: world anchors / axes from the parent's final frame.
-    const int nb = KD().nbody;
+    const int nb = d_nbody_;
     const bool isb = g > 0 && g < nb;
     V3 tp = g == 0 ? -1.f * org : v3(0.f, 0.f, 0.f);   // lane 0 republishes the world body's frame in every round below
     Q4 tq = {1.f, 0.f, 0.f, 0.f};
     if (isb) {
       const int b = g;
-      V3 pos = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(MF_(BODY_POS) + 3 * b);
+      V3 pos = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(AF_(s_BODY_POS) + 3 * b);
       if (b_parent == 0) pos = pos - org;
-      Q4 quat = ldq(MF_(BODY_QUAT) + 4 * b);
+      Q4 quat = ldq(AF_(s_BODY_QUAT) + 4 * b);
       for (int i = 0; i < c_jn; i++) {
         const int j = c_ja + i;
         int type, qa; V3 jpos, jax; float q0;
-        type = MI_(JNT_TYPE)[j]; qa = MI_(JNT_QPOSADR)[j]; jpos = ld3(MF_(JNT_POS) + 3 * j); jax = ld3(MF_(JNT_AXIS) + 3 * j); q0 = MF_(QPOS0)[qa];
+        type = AI_(s_JNT_TYPE)[j]; qa = AI_(s_JNT_QPOSADR)[j]; jpos = ld3(AF_(s_JNT_POS) + 3 * j); jax = ld3(AF_(s_JNT_AXIS) + 3 * j); q0 = AF_(s_QPOS0)[qa];
         if (type == MM_JNT_FREE) {      // child of the world: its frame is the world frame
-          pos = ld3(W + L.qpos + qa) - org;
-          quat = qnorm(ldq(W + L.qpos + qa + 3));
-          st3(W + L.xanchor + 3 * j, pos);
+          pos = ld3(W + o_qpos + qa) - org;
+          quat = qnorm(ldq(W + o_qpos + qa + 3));
+          st3(W + o_xanchor + 3 * j, pos);
           M3 m = q2m(quat);
-          st3(W + L.xaxis + 3 * j, v3(m.m[2], m.m[5], m.m[8]));
+          st3(W + o_xaxis + 3 * j, v3(m.m[2], m.m[5], m.m[8]));
           continue;
         }
         M3 m = q2m(quat);
         V3 anchor = pos + mv(m, jpos), axis = mv(m, jax);
-        st3(W + L.xanchor + 3 * j, anchor);
-        st3(W + L.xaxis + 3 * j, axis);
+        st3(W + o_xanchor + 3 * j, anchor);
+        st3(W + o_xaxis + 3 * j, axis);
         if (type == MM_JNT_SLIDE) {
-          pos = pos + (W[L.qpos + qa] - q0) * axis;
+          pos = pos + (W[o_qpos + qa] - q0) * axis;
         } else if (type == MM_JNT_HINGE) {
-          float ang = W[L.qpos + qa] - q0;
+          float ang = W[o_qpos + qa] - q0;
           float sn, cs;
           sincos_small(0.5f * ang, &sn, &cs);
           Q4 ql = {cs, jax.x * sn, jax.y * sn, jax.z * sn};
           quat = qmul(quat, ql);
           pos = anchor - mv(q2m(quat), jpos);
         } else {  // ball
-          quat = qmul(quat, qnorm(ldq(W + L.qpos + qa)));
+          quat = qmul(quat, qnorm(ldq(W + o_qpos + qa)));
           pos = anchor - mv(q2m(quat), jpos);
         }
       }
       tp = pos; tq = qnorm(quat);
     }
     int up = isb ? b_parent : 0;
-    int* UP = reinterpret_cast<int*>(W + L.xmat);     // scratch: xmat is written last
+    int* UP = reinterpret_cast<int*>(W + o_xmat);     // scratch: xmat is written last
     int nround = 0;
-    for (int s_ = 1; s_ < KD().nlevel; s_ <<= 1) nround++;
+    for (int s_ = 1; s_ < d_nlevel_; s_ <<= 1) nround++;
     for (int r = 0; r < nround; r++) {
       if (g < nb) {
-        st3(W + L.xpos + 3 * g, tp);
-        W[L.u1 + 4 * g] = tq.w; W[L.u1 + 4 * g + 1] = tq.x; W[L.u1 + 4 * g + 2] = tq.y; W[L.u1 + 4 * g + 3] = tq.z;
+        st3(W + o_xpos + 3 * g, tp);
+        W[o_u1 + 4 * g] = tq.w; W[o_u1 + 4 * g + 1] = tq.x; W[o_u1 + 4 * g + 2] = tq.y; W[o_u1 + 4 * g + 3] = tq.z;
         UP[g] = up;
       }
       GSYNC();
       if (up > 0) {
-        const V3 pp = ld3(W + L.xpos + 3 * up);
-        const Q4 pq = ldq(W + L.u1 + 4 * up);
+        const V3 pp = ld3(W + o_xpos + 3 * up);
+        const Q4 pq = ldq(W + o_u1 + 4 * up);
         const int uu = UP[up];
         tp = pp + mv(q2m(pq), tp);
         tq = qmul(pq, tq);
@@ -769,32 +774,32 @@ struct Engine {
     // final frames
     if (isb) {
       tq = qnorm(tq);
-      st3(W + L.xpos + 3 * g, tp);
-      W[L.u1 + 4 * g] = tq.w; W[L.u1 + 4 * g + 1] = tq.x; W[L.u1 + 4 * g + 2] = tq.y; W[L.u1 + 4 * g + 3] = tq.z;
+      st3(W + o_xpos + 3 * g, tp);
+      W[o_u1 + 4 * g] = tq.w; W[o_u1 + 4 * g + 1] = tq.x; W[o_u1 + 4 * g + 2] = tq.y; W[o_u1 + 4 * g + 3] = tq.z;
       b_xpos = tp; b_xquat = tq;
     }
     GSYNC();
     if (isb) {
       const M3 m = q2m(tq);
-      b_xipos = tp + mv(m, ld3(MF_(BODY_IPOS) + 3 * g));
+      b_xipos = tp + mv(m, ld3(AF_(s_BODY_IPOS) + 3 * g));
       // joint anchors / axes: parent frame -> world (a free joint's parent is the world: nothing to do)
       const int p = b_parent;
       if (p > 0) {
-        const V3 pp = ld3(W + L.xpos + 3 * p);
-        const M3 pm = q2m(ldq(W + L.u1 + 4 * p));
+        const V3 pp = ld3(W + o_xpos + 3 * p);
+        const M3 pm = q2m(ldq(W + o_u1 + 4 * p));
         for (int i = 0; i < c_jn; i++) {
           const int j = c_ja + i;
-          st3(W + L.xanchor + 3 * j, pp + mv(pm, ld3(W + L.xanchor + 3 * j)));
-          st3(W + L.xaxis + 3 * j, mv(pm, ld3(W + L.xaxis + 3 * j)));
+          st3(W + o_xanchor + 3 * j, pp + mv(pm, ld3(W + o_xanchor + 3 * j)));
+          st3(W + o_xaxis + 3 * j, mv(pm, ld3(W + o_xaxis + 3 * j)));
         }
       }
     }
     GSYNC();   // UP scratch (xmat region) is dead for everybody: write the rotation matrices
     if (g == 0)
-      for (int k = 0; k < 9; k++) W[L.xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+      for (int k = 0; k < 9; k++) W[o_xmat + k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
     if (isb) {
       const M3 m = q2m(tq);
-      for (int k = 0; k < 9; k++) W[L.xmat + 9 * g + k] = m.m[k];
+      for (int k = 0; k < 9; k++) W[o_xmat + 9 * g + k] = m.m[k];
     }
     GSYNC();
   }
@@ -883,79 +888,109 @@ struct Engine {
   // ---------------------------------------------------------------- A2 tendons
   // add the contributions of one straight segment (point p0 -> p1, unit direction u) to the sparse J row
   // seg_list word: [7:0] joint id (hinge / slide) or dof (ball / free), [8] endpoint, [10:9] 1 hinge / 2 slide / 0 via cdof, [31:11] J entry
-  __device__ __forceinline__ void tenj_segment(int l0, int l1, V3 p0, V3 p1, V3 u) {
-    const auto& L = KL();
-    const int* lst = AUXI(seg_list);
-    for (int e = l0; e < l1; e++) {
-      const int w = lst[e];
-      const int id = w & 0xff, ep = (w >> 8) & 1, kind = (w >> 9) & 3, ent = w >> 11;
-      const V3 p = ep ? p1 : p0;
-      float val;
-      if (kind == 1) {
-        // moment arm straight from the joint: u . (axis x (p - anchor)).  Going through cdof (motion about the subtree COM,
-        // lin = axis x (com - anchor)) adds and subtracts the COM offset -- ~0.2 m against a 5 mm moment arm in the hand
-        val = dot(u, cross(ld3(W + L.xaxis + 3 * id), p - ld3(W + L.xanchor + 3 * id)));
-      } else if (kind == 2) {
-        val = dot(u, ld3(W + L.xaxis + 3 * id));
-      } else {   // ball / free dofs: motion axes about the subtree COM
-        V3 off = p - ld3(W + L.com + 3 * AUXI(dof_rootslot)[id]);
-        V3 ang = ld3(W + L.cdof + 6 * id), lin = ld3(W + L.cdof + 6 * id + 3);
-        val = dot(u, lin + cross(ang, off));
-      }
-      atomicAdd(&W[L.tenj + ent], ep ? val : -val);
-    }
-  }
-
   // Path items are flattened over ALL tendons on the host (Aux.item_tab, 8 words each:
   // {tendon, kind, k0, site0, site1, geom, sidesite, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site,
   // 2 = site-cylinder-site, 3 = fixed-tendon joint term) and sorted so that the expensive wrap items come first: a sweep
   // of G lanes then executes one kind of item, instead of every lane walking its own tendon with divergent item kinds.
   // Lengths and Jacobian entries are accumulated with LDS float atomics (one wave: deterministic lane order).
+  // Word offsets the item sweep needs (LDS table bases, model sections, engine tables), read ONCE and pinned in SGPRs for the
+  // duration of the stage: left to itself the compiler rematerialises each of them with an s_load + s_waitcnt lgkmcnt(0)
+  // inside the item / segment loops (the wait also drains the LDS queue), which made the Jacobian scatter 55 % of this stage.
+  struct TendonOff {
+    int xpos, xmat, tenlen, tenj, xaxis, xanchor, com, cdof, qpos;
+    int site_body, site_pos, geom_body, geom_pos, geom_quat, geom_size, seg_list, rootslot;
+  };
+  __device__ __forceinline__ V3 site_pos_o(const TendonOff& o, int s_) const {
+    const int b = reinterpret_cast<const int*>(mb + o.site_body)[s_];
+    return ld3(W + o.xpos + 3 * b) + mv(ldm(W + o.xmat + 9 * b), ld3(reinterpret_cast<const float*>(mb + o.site_pos) + 3 * s_));
+  }
+  __device__ __forceinline__ void tenj_segment_o(const TendonOff& o, int l0, int l1, V3 p0, V3 p1, V3 u) {
+    const int* lst = reinterpret_cast<const int*>(mb + o.seg_list);
+    for (int e = l0; e < l1; e++) {
+      const int w = lst[e];
+      const int id = w & 0xff, ep = (w >> 8) & 1, kind = (w >> 9) & 3, ent = w >> 11;
+      const V3 p = ep ? p1 : p0;
+      float val;
+      if (kind != 0) {
+        // hinge: moment arm straight from the joint, u . (axis x (p - anchor)); slide: u . axis.  (Going through cdof -- motion
+        // about the subtree COM -- adds and subtracts the COM offset: ~0.2 m against a 5 mm moment arm in the hand.)
+        const V3 ax = ld3(W + o.xaxis + 3 * id), an = ld3(W + o.xanchor + 3 * id);
+        const V3 c = cross(ax, p - an);
+        val = kind == 1 ? dot(u, c) : dot(u, ax);
+      } else {   // ball / free dofs: motion axes about the subtree COM
+        V3 off = p - ld3(W + o.com + 3 * reinterpret_cast<const int*>(mb + o.rootslot)[id]);
+        V3 ang = ld3(W + o.cdof + 6 * id), lin = ld3(W + o.cdof + 6 * id + 3);
+        val = dot(u, lin + cross(ang, off));
+      }
+      atomicAdd(&W[o.tenj + ent], ep ? val : -val);
+    }
+  }
+
   __device__ __forceinline__ void tendon() {
     const auto& L = KL();
-    const int *sa = AUXI(sega_adr), *sb = AUXI(segb_adr), *sc = AUXI(segc_adr);
-    const int* items = AUXI(item_tab);
-    for (int e = g; e < KD().ntenJ; e += G) W[L.tenj + e] = 0.f;
-    for (int t = g; t < KD().ntendon; t += G) W[L.tenlen + t] = 0.f;
+    TendonOff o;
+    o.xpos = L.xpos; o.xmat = L.xmat; o.tenlen = L.tenlen; o.tenj = L.tenj; o.xaxis = L.xaxis; o.xanchor = L.xanchor;
+    o.com = L.com; o.cdof = L.cdof; o.qpos = L.qpos;
+    o.site_body = SECOFF_(SITE_BODYID); o.site_pos = SECOFF_(SITE_POS); o.geom_body = SECOFF_(GEOM_BODYID);
+    o.geom_pos = SECOFF_(GEOM_POS); o.geom_quat = SECOFF_(GEOM_QUAT); o.geom_size = SECOFF_(GEOM_SIZE);
+    o.seg_list = KX().seg_list; o.rootslot = KX().dof_rootslot;
+    int o_sa = KX().sega_adr, o_sb = KX().segb_adr, o_sc = KX().segc_adr, o_items = KX().item_tab, nitem = KX().nitem;
+    PIN_S(o.xpos); PIN_S(o.xmat); PIN_S(o.tenlen); PIN_S(o.tenj); PIN_S(o.xaxis); PIN_S(o.xanchor); PIN_S(o.site_body);
+    PIN_S(o.site_pos); PIN_S(o.seg_list); PIN_S(o_sa); PIN_S(o_sb); PIN_S(o_sc); PIN_S(o_items); PIN_S(nitem);
+    const int *sa = reinterpret_cast<const int*>(mb + o_sa), *sb = reinterpret_cast<const int*>(mb + o_sb),
+              *sc = reinterpret_cast<const int*>(mb + o_sc);
+    const int* items = reinterpret_cast<const int*>(mb + o_items);
+    for (int e = g; e < KD().ntenJ; e += G) W[o.tenj + e] = 0.f;
+    for (int t = g; t < KD().ntendon; t += G) W[o.tenlen + t] = 0.f;
     GSYNC();
-    for (int it = g; it < KX().nitem; it += G) {
+    for (int it = g; it < nitem; it += G) {
       const int* I = items + 8 * it;
       const int t = I[0], kind = I[1], k0 = I[2];
       const float inv_div = __int_as_float(I[7]);
       if (kind == 3) {   // fixed tendon: coef * q_joint
         const int jn = I[3];
         const float coef = __int_as_float(I[4]);
-        atomicAdd(&W[L.tenlen + t], coef * W[L.qpos + MI_(JNT_QPOSADR)[jn]]);
+        atomicAdd(&W[o.tenlen + t], coef * W[o.qpos + MI_(JNT_QPOSADR)[jn]]);
         const int dof = MI_(JNT_DOFADR)[jn];
         for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++)
-          if (MI_(TENJ_DOF)[e] == dof) { atomicAdd(&W[L.tenj + e], coef); break; }
+          if (MI_(TENJ_DOF)[e] == dof) { atomicAdd(&W[o.tenj + e], coef); break; }
         continue;
       }
-      V3 p0 = site_pos(I[3]), p1 = site_pos(I[4]);
+      // dof-list ranges of the item's segments, requested together with the sites
+      const int sa0 = sa[k0], sa1 = sa[k0 + 1], sb0 = sb[k0], sb1 = sb[k0 + 1], sc0 = sc[k0], sc1 = sc[k0 + 1];
+      V3 p0 = site_pos_o(o, I[3]), p1 = site_pos_o(o, I[4]);
       float wlen = -1.f;
       V3 w0, w1;
       if (kind != 0) {
         const int gi = I[5], sideid = I[6];
         V3 side = v3(0.f, 0.f, 0.f);
-        if (sideid >= 0) side = site_pos(sideid);
-        wlen = wrap_geom(w0, w1, p0, p1, geom_pos(gi), geom_mat(gi), MF_(GEOM_SIZE)[3 * gi], kind == 2, sideid >= 0, side);
+        if (sideid >= 0) side = site_pos_o(o, sideid);
+        const int gb = reinterpret_cast<const int*>(mb + o.geom_body)[gi];
+        const M3 A = ldm(W + o.xmat + 9 * gb), B = q2m(ldq(reinterpret_cast<const float*>(mb + o.geom_quat) + 4 * gi));
+        const V3 gp = ld3(W + o.xpos + 3 * gb) + mv(A, ld3(reinterpret_cast<const float*>(mb + o.geom_pos) + 3 * gi));
+        M3 R;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) R.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+        wlen = wrap_geom(w0, w1, p0, p1, gp, R, reinterpret_cast<const float*>(mb + o.geom_size)[3 * gi], kind == 2, sideid >= 0, side);
       }
       if (wlen < 0.f) {
         V3 dif = p1 - p0;
         float n = sqrtf(dot(dif, dif));
-        atomicAdd(&W[L.tenlen + t], n * inv_div);
-        if (sa[k0 + 1] > sa[k0]) {
+        atomicAdd(&W[o.tenlen + t], n * inv_div);
+        if (sa1 > sa0) {
           V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
-          tenj_segment(sa[k0], sa[k0 + 1], p0, p1, u);
+          tenj_segment_o(o, sa0, sa1, p0, p1, u);
         }
       } else {
         V3 d0 = w0 - p0, d1 = p1 - w1;
         float n0 = sqrtf(dot(d0, d0)), n1 = sqrtf(dot(d1, d1));
-        atomicAdd(&W[L.tenlen + t], (n0 + wlen + n1) * inv_div);
-        if (sb[k0 + 1] > sb[k0])
-          tenj_segment(sb[k0], sb[k0 + 1], p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
-        if (sc[k0 + 1] > sc[k0])
-          tenj_segment(sc[k0], sc[k0 + 1], w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
+        atomicAdd(&W[o.tenlen + t], (n0 + wlen + n1) * inv_div);
+        if (sb1 > sb0)
+          tenj_segment_o(o, sb0, sb1, p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
+        if (sc1 > sc0)
+          tenj_segment_o(o, sc0, sc1, w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
       }
     }
     GSYNC();
@@ -1027,12 +1062,19 @@ struct Engine {
 
   // ----------------------------------------------------- A5 velocity stage + bias forces
   __device__ __forceinline__ void velocity_bias() {
+    // offsets read once and pinned in SGPRs for this stage (see PIN_S)
+    int o_cdof = KL().cdof; PIN_S(o_cdof); int o_u1 = KL().u1; PIN_S(o_u1); int o_qvel = KL().qvel; PIN_S(o_qvel); int s_JNT_TYPE = SECOFF_(JNT_TYPE); PIN_S(s_JNT_TYPE); int s_JNT_DOFADR = SECOFF_(JNT_DOFADR); PIN_S(s_JNT_DOFADR); int s_DOF_BODYID = SECOFF_(DOF_BODYID); PIN_S(s_DOF_BODYID); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_); int d_nv_ = KD().nv; PIN_S(d_nv_);
     const auto& L = KL();
-    const int nb = KD().nbody;
-    for (int t = g; t < KD().ntendon; t += G) {
-      float s = 0.f;
-      for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) s += W[L.tenj + e] * W[L.qvel + MI_(TENJ_DOF)[e]];
-      W[L.tenvel + t] = s;
+    const int nb = d_nbody_;
+    {
+      int s_ja = SECOFF_(TENJ_ADR), s_jd = SECOFF_(TENJ_DOF), o_tj = L.tenj, o_qv = o_qvel, o_tv = L.tenvel;
+      PIN_S(s_ja); PIN_S(s_jd); PIN_S(o_tj); PIN_S(o_qv); PIN_S(o_tv);
+      for (int t = g; t < KD().ntendon; t += G) {
+        float s = 0.f;
+        const int e0 = reinterpret_cast<const int*>(mb + s_ja)[t], e1 = reinterpret_cast<const int*>(mb + s_ja)[t + 1];
+        for (int e = e0; e < e1; e++) s += W[o_tj + e] * W[o_qv + reinterpret_cast<const int*>(mb + s_jd)[e]];
+        W[o_tv + t] = s;
+      }
     }
     // Forward pass by pointer jumping (see kinematics): cvel of a body is the SUM of cdof * qvel over the dofs of its
     // ancestors and itself (everything is expressed about the subtree COM: no frame change along the chain), so it is a
@@ -1044,17 +1086,17 @@ struct Engine {
     for (int k = 0; k < 6; k++) { cv[k] = 0.f; ca[k] = 0.f; }
     const bool isb = g > 0 && g < nb;
     int nround = 0;
-    for (int s_ = 1; s_ < KD().nlevel; s_ <<= 1) nround++;
-    int* UP = reinterpret_cast<int*>(W + L.u1 + 12 * nb);   // pointer scratch behind the (cvel, cacc) slots: u1 holds >= 13 nbody words
+    for (int s_ = 1; s_ < d_nlevel_; s_ <<= 1) nround++;
+    int* UP = reinterpret_cast<int*>(W + o_u1 + 12 * nb);   // pointer scratch behind the (cvel, cacc) slots: u1 holds >= 13 nbody words
     if (isb) {      // own dofs: local velocity contribution
       for (int i = 0; i < c_jn; i++) {
         int type, da;
-        type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i];
+        type = AI_(s_JNT_TYPE)[c_ja + i]; da = AI_(s_JNT_DOFADR)[c_ja + i];
         const int nd = type == MM_JNT_FREE ? 6 : (type == MM_JNT_BALL ? 3 : 1);
         for (int d3 = 0; d3 < nd; d3++) {
-          const float qv = W[L.qvel + da + d3];
+          const float qv = W[o_qvel + da + d3];
 #pragma unroll
-          for (int k = 0; k < 6; k++) cv[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
+          for (int k = 0; k < 6; k++) cv[k] += W[o_cdof + 6 * (da + d3) + k] * qv;
         }
       }
     }
@@ -1066,13 +1108,13 @@ struct Engine {
       for (int r = 0; r < nround; r++) {
         if (g < nb) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) W[L.u1 + 12 * g + k] = cv[k];
+          for (int k = 0; k < 6; k++) W[o_u1 + 12 * g + k] = cv[k];
           UP[g] = up;
         }
         GSYNC();
         if (up > 0) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) cv[k] += W[L.u1 + 12 * up + k];
+          for (int k = 0; k < 6; k++) cv[k] += W[o_u1 + 12 * up + k];
           up = UP[up];
         }
         GSYNC();
@@ -1085,12 +1127,12 @@ struct Engine {
       for (int k = 0; k < 6; k++) run[k] = cv[k] - own[k];
       for (int i = 0; i < c_jn; i++) {
         int type, da;
-        type = MI_(JNT_TYPE)[c_ja + i]; da = MI_(JNT_DOFADR)[c_ja + i];
+        type = AI_(s_JNT_TYPE)[c_ja + i]; da = AI_(s_JNT_DOFADR)[c_ja + i];
         if (type == MM_JNT_FREE) {     // translational dofs: cdof_dot = 0, they only move the running velocity
           for (int d3 = 0; d3 < 3; d3++) {
-            const float qv = W[L.qvel + da + d3];
+            const float qv = W[o_qvel + da + d3];
 #pragma unroll
-            for (int k = 0; k < 6; k++) run[k] += W[L.cdof + 6 * (da + d3) + k] * qv;
+            for (int k = 0; k < 6; k++) run[k] += W[o_cdof + 6 * (da + d3) + k] * qv;
           }
           da += 3;
           type = MM_JNT_BALL;
@@ -1102,9 +1144,9 @@ struct Engine {
         for (int d3 = 0; d3 < nd; d3++) {
           float cd[6], cdd[6];
 #pragma unroll
-          for (int k = 0; k < 6; k++) cd[k] = W[L.cdof + 6 * (da + d3) + k];
+          for (int k = 0; k < 6; k++) cd[k] = W[o_cdof + 6 * (da + d3) + k];
           cross_motion(cdd, base, cd);
-          const float qv = W[L.qvel + da + d3];
+          const float qv = W[o_qvel + da + d3];
 #pragma unroll
           for (int k = 0; k < 6; k++) { run[k] += cd[k] * qv; ca[k] += cdd[k] * qv; }
         }
@@ -1115,13 +1157,13 @@ struct Engine {
       for (int r = 0; r < nround; r++) {
         if (g < nb) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) W[L.u1 + 12 * g + 6 + k] = ca[k];
+          for (int k = 0; k < 6; k++) W[o_u1 + 12 * g + 6 + k] = ca[k];
           UP[g] = up;
         }
         GSYNC();
         if (up > 0) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) ca[k] += W[L.u1 + 12 * up + 6 + k];
+          for (int k = 0; k < 6; k++) ca[k] += W[o_u1 + 12 * up + 6 + k];
           up = UP[up];
         }
         GSYNC();
@@ -1142,68 +1184,70 @@ struct Engine {
     GSYNC();
     if (g < nb)
 #pragma unroll
-      for (int k = 0; k < 6; k++) W[L.u1 + 6 * g + k] = 0.f;
+      for (int k = 0; k < 6; k++) W[o_u1 + 6 * g + k] = 0.f;
     GSYNC();
-    for (int lv = KD().nlevel; lv >= 1; lv--) {
+    for (int lv = d_nlevel_; lv >= 1; lv--) {
       if (b_depth == lv) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-          float tot = cf[k] + W[L.u1 + 6 * g + k];
-          W[L.u1 + 6 * g + k] = tot;
-          if (b_parent > 0) atomicAdd(&W[L.u1 + 6 * b_parent + k], tot);
+          float tot = cf[k] + W[o_u1 + 6 * g + k];
+          W[o_u1 + 6 * g + k] = tot;
+          if (b_parent > 0) atomicAdd(&W[o_u1 + 6 * b_parent + k], tot);
         }
       }
       GSYNC();
     }
     d_bias = 0.f;
-    if (g < KD().nv) {
-      int b = MI_(DOF_BODYID)[g];
+    if (g < d_nv_) {
+      int b = AI_(s_DOF_BODYID)[g];
 #pragma unroll
-      for (int k = 0; k < 6; k++) d_bias += d_cdof[k] * W[L.u1 + 6 * b + k];
+      for (int k = 0; k < 6; k++) d_bias += d_cdof[k] * W[o_u1 + 6 * b + k];
     }
     GSYNC();
   }
 
   // ---------------------------------------------------------------- A4 CRB -> dense M rows
   __device__ __forceinline__ void crb() {
+    // offsets read once and pinned in SGPRs for this stage (see PIN_S)
+    int o_cdof = KL().cdof; PIN_S(o_cdof); int o_u1 = KL().u1; PIN_S(o_u1); int o_crb = KL().crb; PIN_S(o_crb); int s_DOF_PARENTID = SECOFF_(DOF_PARENTID); PIN_S(s_DOF_PARENTID); int s_DOF_BODYID = SECOFF_(DOF_BODYID); PIN_S(s_DOF_BODYID); int s_DOF_ARMATURE = SECOFF_(DOF_ARMATURE); PIN_S(s_DOF_ARMATURE); int d_nv_ = KD().nv; PIN_S(d_nv_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_);
     const auto& L = KL();
-    const int nb = KD().nbody, nv = KD().nv;
+    const int nb = d_nbody_, nv = d_nv_;
     if (g < nb)
 #pragma unroll
-      for (int k = 0; k < 10; k++) W[L.crb + 10 * g + k] = b_cinert[k];
+      for (int k = 0; k < 10; k++) W[o_crb + 10 * g + k] = b_cinert[k];
     // zero the dense tile (u1 region; cfrc is dead now) and put 1 on the padded diagonal
-    for (int e = g; e < NVP * NVP; e += G) W[L.u1 + e] = 0.f;
+    for (int e = g; e < NVP * NVP; e += G) W[o_u1 + e] = 0.f;
     GSYNC();
     for (int lv = KD().nlevel; lv >= 2; lv--) {
       if (b_depth == lv && b_parent > 0)
 #pragma unroll
-        for (int k = 0; k < 10; k++) atomicAdd(&W[L.crb + 10 * b_parent + k], W[L.crb + 10 * g + k]);
+        for (int k = 0; k < 10; k++) atomicAdd(&W[o_crb + 10 * b_parent + k], W[o_crb + 10 * g + k]);
       GSYNC();
     }
     if (g < nv) {
       float I[10], buf[6];
-      int b = MI_(DOF_BODYID)[g];
+      int b = AI_(s_DOF_BODYID)[g];
 #pragma unroll
-      for (int k = 0; k < 10; k++) I[k] = W[L.crb + 10 * b + k];
+      for (int k = 0; k < 10; k++) I[k] = W[o_crb + 10 * b + k];
       inert_mul(buf, I, d_cdof);
-      const int* dpar = MI_(DOF_PARENTID);
+      const int* dpar = AI_(s_DOF_PARENTID);
       int j = g;
       while (j >= 0) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) s += W[L.cdof + 6 * j + k] * buf[k];
-        if (j == g) s += MF_(DOF_ARMATURE)[g];
-        W[L.u1 + g * NVP + j] = s;
-        W[L.u1 + j * NVP + g] = s;
+        for (int k = 0; k < 6; k++) s += W[o_cdof + 6 * j + k] * buf[k];
+        if (j == g) s += AF_(s_DOF_ARMATURE)[g];
+        W[o_u1 + g * NVP + j] = s;
+        W[o_u1 + j * NVP + g] = s;
         j = dpar[j];
       }
     } else if (g < NVP) {
-      W[L.u1 + g * NVP + g] = 1.f;
+      W[o_u1 + g * NVP + g] = 1.f;
     }
     GSYNC();
     if (g < NVP) {
 #pragma unroll
-      for (int k = 0; k < NVP; k++) Mrow[k] = W[L.u1 + g * NVP + k];
+      for (int k = 0; k < NVP; k++) Mrow[k] = W[o_u1 + g * NVP + k];
     } else {
 #pragma unroll
       for (int k = 0; k < NVP; k++) Mrow[k] = 0.f;
@@ -1327,35 +1371,42 @@ struct Engine {
     }
     if (g < KD().nv) W[L.vec + g] = 0.f;
     GSYNC();
+    // section offsets of the actuator tables, pinned for the loop (see PIN_S)
+    int s_cl = SECOFF_(ACT_CTRLLIMITED), s_cr = SECOFF_(ACT_CTRLRANGE), s_aa = SECOFF_(ACT_ACTADR), s_id = SECOFF_(ACT_TRNID),
+        s_gr = SECOFF_(ACT_GEAR), s_tt = SECOFF_(ACT_TRNTYPE), s_dt = SECOFF_(ACT_DYNTYPE), s_dp = SECOFF_(ACT_DYNPRM),
+        s_lr = SECOFF_(ACT_LENGTHRANGE), s_a0 = SECOFF_(ACT_ACC0), s_gt = SECOFF_(ACT_GAINTYPE), s_gp = SECOFF_(ACT_GAINPRM),
+        s_bt = SECOFF_(ACT_BIASTYPE), s_bp = SECOFF_(ACT_BIASPRM), s_fl = SECOFF_(ACT_FORCELIMITED), s_fr = SECOFF_(ACT_FORCERANGE);
+    PIN_S(s_cl); PIN_S(s_cr); PIN_S(s_aa); PIN_S(s_id); PIN_S(s_gr); PIN_S(s_tt); PIN_S(s_dt); PIN_S(s_dp); PIN_S(s_lr); PIN_S(s_a0);
+    PIN_S(s_gt); PIN_S(s_gp); PIN_S(s_bt); PIN_S(s_bp); PIN_S(s_fl); PIN_S(s_fr);
     for (int u = g; u < KD().nu; u += G) {
       float ctrl = W[L.ctrl + u];
-      if (MI_(ACT_CTRLLIMITED)[u]) ctrl = clampf(ctrl, MF_(ACT_CTRLRANGE)[2 * u], MF_(ACT_CTRLRANGE)[2 * u + 1]);
-      int aa = MI_(ACT_ACTADR)[u], id = MI_(ACT_TRNID)[u];
-      float gear = MF_(ACT_GEAR)[u], len, vel, input = ctrl;
-      bool ten = MI_(ACT_TRNTYPE)[u] == MM_TRN_TENDON;
+      if (AI_(s_cl)[u]) ctrl = clampf(ctrl, AF_(s_cr)[2 * u], AF_(s_cr)[2 * u + 1]);
+      int aa = AI_(s_aa)[u], id = AI_(s_id)[u];
+      float gear = AF_(s_gr)[u], len, vel, input = ctrl;
+      bool ten = AI_(s_tt)[u] == MM_TRN_TENDON;
       if (ten) { len = gear * W[L.tenlen + id]; vel = gear * W[L.tenvel + id]; }
       else { len = gear * W[L.qpos + MI_(JNT_QPOSADR)[id]]; vel = gear * W[L.qvel + MI_(JNT_DOFADR)[id]]; }
-      if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) {
+      if (AI_(s_dt)[u] == MM_DYN_MUSCLE) {
         float act = W[L.act + aa];
-        W[L.actdot + aa] = muscle_dynamics(ctrl, act, MF_(ACT_DYNPRM) + 3 * u);
+        W[L.actdot + aa] = muscle_dynamics(ctrl, act, AF_(s_dp) + 3 * u);
         input = act;
-      } else if (MI_(ACT_DYNTYPE)[u] == MM_DYN_INTEGRATOR) {
+      } else if (AI_(s_dt)[u] == MM_DYN_INTEGRATOR) {
         W[L.actdot + aa] = ctrl; input = W[L.act + aa];
-      } else if (MI_(ACT_DYNTYPE)[u] == MM_DYN_FILTER) {
+      } else if (AI_(s_dt)[u] == MM_DYN_FILTER) {
         const float act = W[L.act + aa];
-        W[L.actdot + aa] = (ctrl - act) / fmaxf(MINVALF, MF_(ACT_DYNPRM)[3 * u]); input = act;
+        W[L.actdot + aa] = (ctrl - act) / fmaxf(MINVALF, AF_(s_dp)[3 * u]); input = act;
       }
-      float lr0 = MF_(ACT_LENGTHRANGE)[2 * u], lr1 = MF_(ACT_LENGTHRANGE)[2 * u + 1], acc0 = MF_(ACT_ACC0)[u];
+      float lr0 = AF_(s_lr)[2 * u], lr1 = AF_(s_lr)[2 * u + 1], acc0 = AF_(s_a0)[u];
       float gain, bias = 0.f;
-      if (MI_(ACT_GAINTYPE)[u] == MM_GAIN_MUSCLE) gain = muscle_gain(len, vel, lr0, lr1, acc0, MF_(ACT_GAINPRM) + 9 * u);
-      else gain = MF_(ACT_GAINPRM)[9 * u];
-      if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_MUSCLE) bias = muscle_bias(len, lr0, lr1, acc0, MF_(ACT_BIASPRM) + 9 * u);
-      else if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_AFFINE)   // position / velocity servos
-        bias = MF_(ACT_BIASPRM)[9 * u] + MF_(ACT_BIASPRM)[9 * u + 1] * len + MF_(ACT_BIASPRM)[9 * u + 2] * vel;
+      if (AI_(s_gt)[u] == MM_GAIN_MUSCLE) gain = muscle_gain(len, vel, lr0, lr1, acc0, AF_(s_gp) + 9 * u);
+      else gain = AF_(s_gp)[9 * u];
+      if (AI_(s_bt)[u] == MM_BIAS_MUSCLE) bias = muscle_bias(len, lr0, lr1, acc0, AF_(s_bp) + 9 * u);
+      else if (AI_(s_bt)[u] == MM_BIAS_AFFINE)   // position / velocity servos
+        bias = AF_(s_bp)[9 * u] + AF_(s_bp)[9 * u + 1] * len + AF_(s_bp)[9 * u + 2] * vel;
       float f = gain * input + bias;
       bool clamped = false;
-      if (MI_(ACT_FORCELIMITED)[u]) {
-        const float flo = MF_(ACT_FORCERANGE)[2 * u], fhi = MF_(ACT_FORCERANGE)[2 * u + 1];
+      if (AI_(s_fl)[u]) {
+        const float flo = AF_(s_fr)[2 * u], fhi = AF_(s_fr)[2 * u + 1];
         f = clampf(f, flo, fhi);
         clamped = f <= flo || f >= fhi;
       }
@@ -1365,9 +1416,9 @@ struct Engine {
       if constexpr (IMPL) {
         // s = d force / d velocity (mjd_actuator_vel: bias_vel + gain_vel * input; none while the force sits on its range)
         float s = 0.f;
-        if (MI_(ACT_BIASTYPE)[u] == MM_BIAS_AFFINE) s = MF_(ACT_BIASPRM)[9 * u + 2];
-        if (MI_(ACT_GAINTYPE)[u] == MM_GAIN_MUSCLE) {
-          const float* prm = MF_(ACT_GAINPRM) + 9 * u;
+        if (AI_(s_bt)[u] == MM_BIAS_AFFINE) s = AF_(s_bp)[9 * u + 2];
+        if (AI_(s_gt)[u] == MM_GAIN_MUSCLE) {
+          const float* prm = AF_(s_gp) + 9 * u;
           const float force = muscle_f0(prm, acc0);
           const float L0 = (lr1 - lr0) / fmaxf(MINVALF, prm[1] - prm[0]);
           const float Ln = prm[0] + (len - lr0) / fmaxf(MINVALF, L0);
@@ -1386,10 +1437,15 @@ struct Engine {
     GSYNC();
     // J' f: every tendon lane scatters its (<= 8) Jacobian entries into the per-dof accumulator with LDS float
     // atomics (one wave => deterministic lane order); shorter critical path than gathering ~25 entries per wrist dof
-    for (int t = g; t < KD().ntendon; t += G) {
-      float f = W[L.tenfrc + t];
-      if (f != 0.f)
-        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) atomicAdd(&W[L.vec + MI_(TENJ_DOF)[e]], W[L.tenj + e] * f);
+    {
+      int s_ja = SECOFF_(TENJ_ADR), s_jd = SECOFF_(TENJ_DOF), o_tj = L.tenj, o_vec = L.vec, o_tf = L.tenfrc;
+      PIN_S(s_ja); PIN_S(s_jd); PIN_S(o_tj); PIN_S(o_vec); PIN_S(o_tf);
+      for (int t = g; t < KD().ntendon; t += G) {
+        float f = W[o_tf + t];
+        const int e0 = AI_(s_ja)[t], e1 = AI_(s_ja)[t + 1];
+        if (f != 0.f)
+          for (int e = e0; e < e1; e++) atomicAdd(&W[o_vec + AI_(s_jd)[e]], W[o_tj + e] * f);
+      }
     }
     GSYNC();
     d_smooth = 0.f;
@@ -1521,21 +1577,23 @@ struct Engine {
   }
   // Jacobian entries of one contact: rows r0.. get  +-(edge . (J_b2 - J_b1))  over the two kinematic chains
   __device__ __forceinline__ void contact_rows(int r0, int nrow, int b1, int b2, V3 pos, V3 n, V3 t1, V3 t2, float mu) {
+    // offsets read once and pinned in SGPRs for this stage (see PIN_S)
+    int o_cdof = KL().cdof; PIN_S(o_cdof); int o_com = KL().com; PIN_S(o_com); int s_BODY_DOFADR = SECOFF_(BODY_DOFADR); PIN_S(s_BODY_DOFADR); int s_BODY_DOFNUM = SECOFF_(BODY_DOFNUM); PIN_S(s_BODY_DOFNUM); int s_BODY_PARENT = SECOFF_(BODY_PARENT); PIN_S(s_BODY_PARENT); int x_dof_rootslot = KX().dof_rootslot; PIN_S(x_dof_rootslot);
     const auto& L = KL();
     for (int side = 0; side < 2; side++) {
       int b = side ? b2 : b1;
       const float sg = side ? 1.f : -1.f;
       while (b > 0) {
-        const int da = MI_(BODY_DOFADR)[b], dn = MI_(BODY_DOFNUM)[b];
+        const int da = AI_(s_BODY_DOFADR)[b], dn = AI_(s_BODY_DOFNUM)[b];
         for (int i = da; i < da + dn; i++) {
-          V3 ang = ld3(W + L.cdof + 6 * i), lin = ld3(W + L.cdof + 6 * i + 3);
-          V3 off = pos - ld3(W + L.com + 3 * AUXI(dof_rootslot)[i]);
+          V3 ang = ld3(W + o_cdof + 6 * i), lin = ld3(W + o_cdof + 6 * i + 3);
+          V3 off = pos - ld3(W + o_com + 3 * AI_(x_dof_rootslot)[i]);
           V3 v = lin + cross(ang, off);
           float vn = sg * dot(n, v), v1 = sg * mu * dot(t1, v), v2 = sg * mu * dot(t2, v);
           if (nrow == 1) Jrow(r0)[i] += vn;
           else { Jrow(r0)[i] += vn + v1; Jrow(r0 + 1)[i] += vn - v1; Jrow(r0 + 2)[i] += vn + v2; Jrow(r0 + 3)[i] += vn - v2; }
         }
-        b = MI_(BODY_PARENT)[b];
+        b = AI_(s_BODY_PARENT)[b];
       }
     }
   }
@@ -2052,12 +2110,14 @@ struct Engine {
 
   // qpos <- qpos (+) hh * vel on the configuration manifold (mj_integratePos); vel = LDS vector at word offset `voff`
   __device__ __forceinline__ void integrate_pos(int voff, float hh) {
+    // offsets read once and pinned in SGPRs for this stage (see PIN_S)
+    int o_qpos = KL().qpos; PIN_S(o_qpos); int s_JNT_TYPE = SECOFF_(JNT_TYPE); PIN_S(s_JNT_TYPE); int s_JNT_QPOSADR = SECOFF_(JNT_QPOSADR); PIN_S(s_JNT_QPOSADR); int s_JNT_DOFADR = SECOFF_(JNT_DOFADR); PIN_S(s_JNT_DOFADR); int d_njnt_ = KD().njnt; PIN_S(d_njnt_);
     const auto& L = KL();
-    for (int j = g; j < KD().njnt; j += G) {
-      int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j], da = MI_(JNT_DOFADR)[j];
-      if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[L.qpos + qa] += hh * W[voff + da]; continue; }
+    for (int j = g; j < d_njnt_; j += G) {
+      int type = AI_(s_JNT_TYPE)[j], qa = AI_(s_JNT_QPOSADR)[j], da = AI_(s_JNT_DOFADR)[j];
+      if (type == MM_JNT_HINGE || type == MM_JNT_SLIDE) { W[o_qpos + qa] += hh * W[voff + da]; continue; }
       if (type == MM_JNT_FREE) {
-        for (int k = 0; k < 3; k++) W[L.qpos + qa + k] += hh * W[voff + da + k];
+        for (int k = 0; k < 3; k++) W[o_qpos + qa + k] += hh * W[voff + da + k];
         qa += 3; da += 3;
       }
       V3 w = ld3(W + voff + da);
@@ -2067,8 +2127,8 @@ struct Engine {
         sincos_small(0.5f * ang, &sn, &cs);
         float is = sn / nw;
         Q4 dq = {cs, w.x * is, w.y * is, w.z * is};
-        Q4 qn = qnorm(qmul(ldq(W + L.qpos + qa), dq));
-        W[L.qpos + qa] = qn.w; W[L.qpos + qa + 1] = qn.x; W[L.qpos + qa + 2] = qn.y; W[L.qpos + qa + 3] = qn.z;
+        Q4 qn = qnorm(qmul(ldq(W + o_qpos + qa), dq));
+        W[o_qpos + qa] = qn.w; W[o_qpos + qa + 1] = qn.x; W[o_qpos + qa + 2] = qn.y; W[o_qpos + qa + 3] = qn.z;
       }
     }
   }
