@@ -37,10 +37,11 @@ def shard_envs(total_envs: int, rank: int, world: int) -> Tuple[int, int]:
     return start, count
 
 
-def gather_episode_stats(stats: torch.Tensor) -> torch.Tensor:
+def gather_episode_stats(stats: torch.Tensor, always_collective: bool = False) -> torch.Tensor:
     """All-gather [E_local, 3] (episode_return, episode_length, solved) -> [world*E_local, 3] on every rank.
-    Shards must be equal-sized (weak scaling: fixed envs per GPU)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    Shards must be equal-sized (weak scaling: fixed envs per GPU).  `always_collective` issues the RCCL / gloo call even in a
+    one-rank group (the single-GPU smoke test of the collective path)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return stats
     world = dist.get_world_size()
     out = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype, device=stats.device)

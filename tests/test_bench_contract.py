@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_lines_follow_the_contract():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01?_*_bench_under_rocprof.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_under_rocprof.json")))
     assert files, "no committed bench lines"
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for f in files:
@@ -17,10 +17,22 @@ def test_committed_bench_lines_follow_the_contract():
             assert k in d, (f, k)
         assert d["metric"].startswith("env-steps/sec") and base["metric"].startswith("env-steps/sec")
         assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-        assert "workload" in d["config"] and "model" not in d["config"]
+        assert "workload" in d["config"] and "model" not in d["config"] and d["n_gpus"] == 1
         r = d["roofline"]
         assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
         assert d["value"] > 0 and abs(d["ms_per_step"] - 1e3 * d["config"]["envs_per_gpu"] * d["n_gpus"] / d["value"]) < 1e-6 * d["ms_per_step"] + 1e-9
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_the_request(tmp_path):
+    """`--gpus N` never prints a line for another N: under a launcher with a different WORLD_SIZE it exits with an error, and
+    without a launcher it re-executes itself under torch.distributed.run (respawn_under_launcher) instead of running one rank."""
+    import subprocess, sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (out.stderr + out.stdout) and "n_gpus" not in out.stdout
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "respawn_under_launcher" in src and "torch.distributed.run" in src and 'if args.gpus > 1 and "WORLD_SIZE" not in os.environ' in src
 
 
 def test_bench_defaults_are_the_baseline_workload():
