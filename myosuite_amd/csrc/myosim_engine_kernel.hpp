@@ -35,6 +35,9 @@
 #include "../../include/myosim.h"
 
 #define MINVALF 1e-15f
+#ifndef MM_MFMA_HBUILD
+#define MM_MFMA_HBUILD 1   /* Newton Hessian update J'DJ of one-env-per-wave kernels on the matrix cores (0: the row-broadcast loop) */
+#endif
 
 // ---- Philox4x32-10 (counter based; the oracle side reproduces it in numpy: oracle/env_oracle.py) -----------
 __device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -1907,11 +1910,79 @@ struct Engine {
       }
       if (__ballot(!done) == 0ull) break;
       set_prev = set_now; sat_prev = sat_now;
-      // H = M + J_A' D J_A : lane i accumulates row i, the J row is an LDS broadcast
+      // H = M + J_A' D J_A
       float A[NVP];
+#if MM_MFMA_HBUILD
+      if constexpr (G == 64) {
+        // One env per wave: the rank-nefc update J' D J is a (NVP x K)(K x NVP) product -- the one GEMM-shaped piece of the step
+        // -- and goes through the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, same peak rate as the vector
+        // pipe, but 64 multiply-adds per lane-instruction instead of 1) on 16 x 16 output tiles, upper triangle only.  Operands
+        // come straight from the row-major efc_J table in LDS (A[i][k] = J[k][i], B[k][j] = D_k J[k][j]: the same load serves
+        // both), the tiles go back through the dense LDS tile into the row-per-lane layout the Cholesky wants.  Replaces a loop
+        // over the active rows (broadcast D_r, nine 128-bit row loads, NVP FMAs per row: ~550 cycles x ~30 rows per iteration).
+        constexpr int NT = (NVP + 15) / 16;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v acc[NT * (NT + 1) / 2];
 #pragma unroll
-      for (int k = 0; k < NVP; k++) A[k] = Mrow[k];
+        for (int q = 0; q < NT * (NT + 1) / 2; q++) acc[q] = f4v{0.f, 0.f, 0.f, 0.f};
+        float* Dv = W + KL().rowtab;              // row table of make_constraint: dead since the owner stage
+        Dv[g] = on ? r_D : 0.f;
+        GSYNC();
+        const int lr = g & 15, lk = g >> 4;
+        const float* Jb = W + KL().efcJ;
+        const int erows = KD().efc_rows;
+        const int K4 = (nrows_wave + 3) >> 2;
+        for (int kb = 0; kb < K4; kb++) {
+          const int row = 4 * kb + lk;
+          const bool rok = row < erows;
+          const float dsc = rok ? Dv[row] : 0.f;
+          float av[NT];
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            const int col = 16 * t + lr;
+            av[t] = (rok && col < NVP) ? Jb[row * RS + col] : 0.f;
+          }
+          int q = 0;
+#pragma unroll
+          for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+            for (int tj = ti; tj < NT; tj++, q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], av[tj] * dsc, acc[q], 0, 0, 0);
+        }
+        float* T = W + KL().u1;                   // the dense tile: the previous factor in there is dead
+        {
+          int q = 0;
+#pragma unroll
+          for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+            for (int tj = ti; tj < NT; tj++, q++)
+#pragma unroll
+              for (int v = 0; v < 4; v++) {
+                const int i = 16 * ti + 4 * lk + v, j = 16 * tj + lr;
+                if (i < NVP && j < NVP) {
+                  T[i * NVP + j] = acc[q][v];
+                  if (ti != tj) T[j * NVP + i] = acc[q][v];
+                }
+              }
+        }
+        GSYNC();
+        const int row = g < NVP ? g : 0;
+#pragma unroll
+        for (int k4 = 0; k4 < NVP / 4; k4++) {
+          const float4 r = *reinterpret_cast<const float4*>(T + row * NVP + 4 * k4);
+          A[4 * k4] = Mrow[4 * k4] + r.x; A[4 * k4 + 1] = Mrow[4 * k4 + 1] + r.y;
+          A[4 * k4 + 2] = Mrow[4 * k4 + 2] + r.z; A[4 * k4 + 3] = Mrow[4 * k4 + 3] + r.w;
+        }
+        if (g >= NVP) {
+#pragma unroll
+          for (int k = 0; k < NVP; k++) A[k] = 0.f;
+        }
+        GSYNC();                                  // the factor below rewrites the tile
+      } else
+#endif
       {
+        // narrower groups (several envs per wave): lane i accumulates row i, the J row is an LDS broadcast
+#pragma unroll
+        for (int k = 0; k < NVP; k++) A[k] = Mrow[k];
         const float dr = on ? r_D : 0.f;
         const int col = g < NVP ? g : 0;
         for (int r = 0; r < nrows_wave; r++) {
@@ -2059,17 +2130,52 @@ struct Engine {
 #pragma unroll
       for (int k4 = 0; k4 < NVP / 4; k4++) *reinterpret_cast<float4*>(T + row * NVP + 4 * k4) = make_float4(0.f, 0.f, 0.f, 0.f);
     GSYNC();
-    if (g < nv) {
-      const int* dja = AUXI(dofj_adr); const int* dje = AUXI(dofj_entry); const int* djt = AUXI(dofj_tendon);
-      const unsigned rlo = (unsigned)AUXI(dof_rel)[2 * g], rhi = (unsigned)AUXI(dof_rel)[2 * g + 1];
-      for (int q = dja[g]; q < dja[g + 1]; q++) {
-        const int t = djt[q];
-        const float wt = W[L.tenw + t] * W[L.tenj + dje[q]];
+    {
+      // one lane per tendon: its (<= 8 x 8) on-chain entry pairs go into the tile with LDS float atomics (a lane per dof walking
+      // every tendon that crosses it -- ~20 for a hip dof -- serialises ~160 dependent read-modify-writes)
+      int s_ja = SECOFF_(TENJ_ADR), s_jd = SECOFF_(TENJ_DOF), o_tj = L.tenj, o_tw = L.tenw, x_rel = KX().dof_rel;
+      PIN_S(s_ja); PIN_S(s_jd); PIN_S(o_tj); PIN_S(o_tw); PIN_S(x_rel);
+      for (int t = g; t < KD().ntendon; t += G) {
+        const float wt = W[o_tw + t];
         if (wt == 0.f) continue;
-        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++) {
-          const int k = MI_(TENJ_DOF)[e];
-          const bool rel = k < 32 ? (rlo >> k) & 1u : (rhi >> (k - 32)) & 1u;
-          if (rel) T[g * NVP + k] += wt * W[L.tenj + e];     // own row: no other lane touches it
+        const int e0 = AI_(s_ja)[t], e1 = AI_(s_ja)[t + 1];
+        for (int c0 = e0; c0 < e1; c0 += 8) {          // entries in chunks of eight held in registers: the pair loop below is
+          int dd[8]; float jj[8]; unsigned rl[8], rh[8];   // then pure arithmetic + atomics, no load in its dependency chain
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const bool ok = c0 + k < e1;
+            dd[k] = ok ? AI_(s_jd)[c0 + k] : -1;
+            jj[k] = ok ? W[o_tj + c0 + k] : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const int d1 = dd[k] < 0 ? 0 : dd[k];
+            rl[k] = (unsigned)AI_(x_rel)[2 * d1]; rh[k] = (unsigned)AI_(x_rel)[2 * d1 + 1];
+          }
+          for (int c1 = e0; c1 < e1; c1 += 8) {
+            int d2[8]; float j2[8];
+            if (c1 == c0) {
+#pragma unroll
+              for (int k = 0; k < 8; k++) { d2[k] = dd[k]; j2[k] = jj[k]; }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 8; k++) {
+                const bool ok = c1 + k < e1;
+                d2[k] = ok ? AI_(s_jd)[c1 + k] : -1; j2[k] = ok ? W[o_tj + c1 + k] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < 8; a_++) {
+              if (dd[a_] < 0) continue;
+              const float w1 = wt * jj[a_];
+#pragma unroll
+              for (int b_ = 0; b_ < 8; b_++) {
+                if (d2[b_] < 0) continue;
+                const bool rel = d2[b_] < 32 ? (rl[a_] >> d2[b_]) & 1u : (rh[a_] >> (d2[b_] - 32)) & 1u;
+                if (rel) atomicAdd(&T[dd[a_] * NVP + d2[b_]], w1 * j2[b_]);
+              }
+            }
+          }
         }
       }
     }
