@@ -503,6 +503,12 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
         rel[2 * k + (i >> 5)] |= (int32_t)(1u << (i & 31));
       }
     m->x.dof_rel = append(rel);
+    std::vector<int32_t> bm(2 * (size_t)d.nbody, 0);
+    for (int b = 1; b < d.nbody && d.nv <= 64; b++) {
+      if (bpar[b] > 0) { bm[2 * b] = bm[2 * bpar[b]]; bm[2 * b + 1] = bm[2 * bpar[b] + 1]; }     // parent < child: already final
+      for (int i = bdofadr[b]; i >= 0 && i < bdofadr[b] + bdofnum[b]; i++) bm[2 * b + (i >> 5)] |= (int32_t)(1u << (i & 31));
+    }
+    m->x.body_dofmask = append(bm);
   }
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS

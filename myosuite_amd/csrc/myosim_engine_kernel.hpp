@@ -97,6 +97,7 @@ struct Aux {
   int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
   int dof_rel;           // per dof: 64-bit mask (2 words) of the dofs on its kinematic chain (ancestors, descendants, itself)
+  int body_dofmask;      // per body: 64-bit mask (2 words) of the dofs between the body and the root of its tree (its chain)
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)
@@ -1567,38 +1568,23 @@ struct Engine {
   // limits (compacted), contact pyramid edges (compacted).  Restates mmo_make_constraint / mmo_collision.inc.
   static constexpr int RS = NVP + 4;
   __device__ __forceinline__ float* Jrow(int r) const { return W + KL().efcJ + (r < KD().efc_rows ? r : 0) * RS; }
+  // exclusive prefix count of a 0/1 flag over the lanes of the group: ballot + population count of the lower lanes (three
+  // instructions; a shuffle scan is log2(G) dependent trips through the LDS crossbar, ~800 cycles for G = 64)
+  __device__ __forceinline__ int gscan_flag(bool f) const {
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63;
+    unsigned long long below = m & ((1ull << lane) - 1ull);
+    if constexpr (G < 64) below &= ((1ull << G) - 1ull) << (lane - g);      // this group's lanes only
+    return __popcll(below);
+  }
+  // exclusive prefix sum of small non-negative counts (<= 15): one flag scan per bit
   __device__ __forceinline__ int gscan_excl(int v) const {
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < G; d <<= 1) { int t = __shfl_up(incl, d, G); if (g >= d) incl += t; }
-    return incl - v;
+    return gscan_flag(v & 1) + 2 * gscan_flag(v & 2) + 4 * gscan_flag(v & 4) + 8 * gscan_flag(v & 8);
   }
   __device__ __forceinline__ int gsum_i(int v) const { return (int)(gsum<G>((float)v) + 0.5f); }   // counts <= 64: exact
   __device__ __forceinline__ V3 geom_zaxis(int gi) const {
     M3 R = geom_mat(gi);
     return v3(R.m[2], R.m[5], R.m[8]);
-  }
-  // Jacobian entries of one contact: rows r0.. get  +-(edge . (J_b2 - J_b1))  over the two kinematic chains
-  __device__ __forceinline__ void contact_rows(int r0, int nrow, int b1, int b2, V3 pos, V3 n, V3 t1, V3 t2, float mu) {
-    // offsets read once and pinned in SGPRs for this stage (see PIN_S)
-    int o_cdof = KL().cdof; PIN_S(o_cdof); int o_com = KL().com; PIN_S(o_com); int s_BODY_DOFADR = SECOFF_(BODY_DOFADR); PIN_S(s_BODY_DOFADR); int s_BODY_DOFNUM = SECOFF_(BODY_DOFNUM); PIN_S(s_BODY_DOFNUM); int s_BODY_PARENT = SECOFF_(BODY_PARENT); PIN_S(s_BODY_PARENT); int x_dof_rootslot = KX().dof_rootslot; PIN_S(x_dof_rootslot);
-    const auto& L = KL();
-    for (int side = 0; side < 2; side++) {
-      int b = side ? b2 : b1;
-      const float sg = side ? 1.f : -1.f;
-      while (b > 0) {
-        const int da = AI_(s_BODY_DOFADR)[b], dn = AI_(s_BODY_DOFNUM)[b];
-        for (int i = da; i < da + dn; i++) {
-          V3 ang = ld3(W + o_cdof + 6 * i), lin = ld3(W + o_cdof + 6 * i + 3);
-          V3 off = pos - ld3(W + o_com + 3 * AI_(x_dof_rootslot)[i]);
-          V3 v = lin + cross(ang, off);
-          float vn = sg * dot(n, v), v1 = sg * mu * dot(t1, v), v2 = sg * mu * dot(t2, v);
-          if (nrow == 1) Jrow(r0)[i] += vn;
-          else { Jrow(r0)[i] += vn + v1; Jrow(r0 + 1)[i] += vn - v1; Jrow(r0 + 2)[i] += vn + v2; Jrow(r0 + 3)[i] += vn - v2; }
-        }
-        b = AI_(s_BODY_PARENT)[b];
-      }
-    }
   }
   // sphere-sphere building block (mmo_collision.inc: sphere_sphere); returns false when dist >= margin
   __device__ __forceinline__ bool sph_sph(V3 c1, float r1, V3 c2, float r2, float margin, float& dist, V3& pos, V3& n) const {
@@ -1653,7 +1639,7 @@ struct Engine {
     int nfr = 0;
     if (KD().nfric) {
       const int fr = (g < KD().nv && MF_(DOF_FRICTIONLOSS)[g] > 0.f) ? 1 : 0;
-      const int frank = gscan_excl(fr);
+      const int frank = gscan_flag(fr != 0);
       nfr = gsum_i(fr);
       if (fr) {
         const int r = neq + frank;
@@ -1678,7 +1664,7 @@ struct Engine {
         lim = ldist < lmargin ? 1 : 0;
       }
     }
-    const int lrank = gscan_excl(lim), nlim = gsum_i(lim);
+    const int lrank = gscan_flag(lim != 0), nlim = gsum_i(lim);
     int over = 0;
     if (lim) {
       const int r = neq + nfr + lrank;
@@ -1702,7 +1688,7 @@ struct Engine {
           if (!(dlo < tmargin) && dhi < tmargin) { tdist = dhi; tsign = -1.f; }
           tl = tdist < tmargin ? 1 : 0;
         }
-        const int trank = gscan_excl(tl), tcnt = gsum_i(tl);
+        const int trank = gscan_flag(tl != 0), tcnt = gsum_i(tl);
         if (tl) {
           const int r = neq + nfr + nlim + ntl + trank;
           if (r < KD().efc_rows) {
@@ -1788,16 +1774,15 @@ struct Engine {
     for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
     int base = neq + nfr + nlim + ntl + gscan_excl(myrows);
     const int ncrows = gsum_i(myrows);
+    // Row table entries by the pair's lane; the Jacobian rows by ALL lanes of the group, one dof each: lane i holds its dof's
+    // motion axis in registers and knows from a per-body chain mask (Aux.body_dofmask) whether dof i moves geom1's or geom2's
+    // body, so a contact costs a handful of broadcasts + 4 stores per lane instead of one lane walking two kinematic chains
+    // with two dependent LDS round trips per dof (11 k cycles per forward pass for the leg's foot contacts).
+    int cbase[2] = {-1, -1};
     for (int c = 0; c < 2; c++) {
       if (!(c < nc && cdist[c] < incl)) continue;
       if (base + rowsper > KD().efc_rows) { over = 1; continue; }
-      // contact frame (mmo_collision.inc: make_frame)
-      V3 n = cn[c];
-      V3 y = (n.y < 0.5f && n.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
-      y = y - dot(n, y) * n;
-      y = (1.f / fmaxf(sqrtf(dot(y, y)), MINVALF)) * y;
-      V3 z = cross(n, y);
-      contact_rows(base, rowsper, b1, b2, cpos[c], n, y, z, mu);
+      cbase[c] = base;
       const float tran = MF_(BODY_INVWEIGHT0)[2 * b1] + MF_(BODY_INVWEIGHT0)[2 * b2];
       for (int k = 0; k < rowsper; k++) {
         RT[3 * (base + k)] = __int_as_float(MM_CON_CONTACT | (g << 3));
@@ -1805,6 +1790,37 @@ struct Engine {
         RT[3 * (base + k) + 2] = rowsper == 1 ? tran : tran + mu * mu * tran;
       }
       base += rowsper;
+    }
+    {
+      const int np_ = KD().npair, nv_ = KD().nv;
+      V3 off_c = v3(0.f, 0.f, 0.f);     // subtree COM of this lane's dof (cdof is expressed about it)
+      if (g < nv_) off_c = ld3(W + L.com + 3 * AUXI(dof_rootslot)[g]);
+      const int* bmask = AUXI(body_dofmask);
+      for (int p = 0; p < np_; p++) {
+        for (int c = 0; c < 2; c++) {
+          const int rb = (int)bc<G>((float)cbase[c], p);                  // row base of contact c of pair p in THIS group (-1: none)
+          if (__ballot(rb >= 0) == 0ull) continue;
+          const int pb1 = (int)bc<G>((float)b1, p), pb2 = (int)bc<G>((float)b2, p), prow = (int)bc<G>((float)rowsper, p);
+          const V3 pn = v3(bc<G>(cn[c].x, p), bc<G>(cn[c].y, p), bc<G>(cn[c].z, p));
+          const V3 pp = v3(bc<G>(cpos[c].x, p), bc<G>(cpos[c].y, p), bc<G>(cpos[c].z, p));
+          const float pmu = bc<G>(mu, p);
+          if (rb < 0 || g >= nv_) continue;
+          const bool in1 = g < 32 ? (bmask[2 * pb1] >> g) & 1 : (bmask[2 * pb1 + 1] >> (g - 32)) & 1;
+          const bool in2 = g < 32 ? (bmask[2 * pb2] >> g) & 1 : (bmask[2 * pb2 + 1] >> (g - 32)) & 1;
+          if (in1 == in2) continue;                                       // on neither chain, or on both (the two terms cancel)
+          // contact frame (mmo_collision.inc: make_frame)
+          V3 y = (pn.y < 0.5f && pn.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
+          y = y - dot(pn, y) * pn;
+          y = (1.f / fmaxf(sqrtf(dot(y, y)), MINVALF)) * y;
+          const V3 z = cross(pn, y);
+          const V3 ang = v3(d_cdof[0], d_cdof[1], d_cdof[2]), lin = v3(d_cdof[3], d_cdof[4], d_cdof[5]);
+          const V3 v = lin + cross(ang, pp - off_c);
+          const float sg = in2 ? 1.f : -1.f;
+          const float vn = sg * dot(pn, v), v1 = sg * pmu * dot(y, v), v2 = sg * pmu * dot(z, v);
+          if (prow == 1) Jrow(rb)[g] = vn;
+          else { Jrow(rb)[g] = vn + v1; Jrow(rb + 1)[g] = vn - v1; Jrow(rb + 2)[g] = vn + v2; Jrow(rb + 3)[g] = vn - v2; }
+        }
+      }
     }
     if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
     nefc = neq + nfr + nlim + ntl + ncrows;
@@ -1822,8 +1838,16 @@ struct Engine {
       const int desc = __float_as_int(RT[3 * g]), kind = desc & 7, id = desc >> 3;
       const float x = RT[3 * g + 1], dA = RT[3 * g + 2];
       float vel = 0.f;
-      const float* J = Jrow(g);
-      for (int k = 0; k < KD().nv; k++) vel += J[k] * W[L.qvel + k];
+      {   // J_row . qvel with 128-bit loads (rows and the qvel table are 16-byte aligned; columns >= nv of a row are zero)
+        const float4* J4 = reinterpret_cast<const float4*>(Jrow(g));
+        const int nv_ = KD().nv;
+        for (int k4 = 0; 4 * k4 < nv_; k4++) {
+          const float4 j4 = J4[k4];
+          const float* qv = W + L.qvel + 4 * k4;
+          vel += j4.x * qv[0] + (4 * k4 + 1 < nv_ ? j4.y * qv[1] : 0.f) + (4 * k4 + 2 < nv_ ? j4.z * qv[2] : 0.f) +
+                 (4 * k4 + 3 < nv_ ? j4.w * qv[3] : 0.f);
+        }
+      }
       const float *si, *sr;
       if (kind == MM_CON_EQUALITY) { si = MF_(EQ_SOLIMP) + 5 * id; sr = MF_(EQ_SOLREF) + 2 * id; }
       else if (kind == MM_CON_LIMIT_JOINT) { si = MF_(JNT_SOLIMP) + 5 * id; sr = MF_(JNT_SOLREF) + 2 * id; }
