@@ -300,6 +300,10 @@ int  mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask,
  * same episode (which increments episode[e]).  base may be NULL (= 0). */
 int  mm_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi, const uint8_t* mask,
                  const int32_t* episode, uint64_t seed, uint32_t stream_id, int env_index_base, void* stream);
+/* 3CC-r fatigue state of the masked envs back to rest (CumulativeFatigue.reset, fatigue.py:82-99): MF = fatigue_reset_vec
+ * (NULL = 0), MR = 1 - MF, MA = 0; arrays are [nenv][na] (the buffers of mm_task.fat_*). */
+int  mm_fatigue_reset(float* MA, float* MR, float* MF, const uint8_t* mask, const float* fatigue_reset_vec, int nenv, int na,
+                      void* stream);
 /* Rollout bookkeeping in one launch (what a gym vector wrapper's RecordEpisodeStatistics + autoreset mask do with a handful
  * of elementwise ops): stats[e] = {return += rwd[e][dense_col], length += 1, solved = max(solved, rwd[e][solved_col])},
  * reset_mask[e] = done[e] | truncated[e].  stats is [nenv][3] float32, rwd has row stride rwd_cols. */

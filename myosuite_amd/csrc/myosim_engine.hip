@@ -851,6 +851,24 @@ extern "C" int mm_episode_stats(float* stats, uint8_t* reset_mask, const float* 
   return MM_OK;
 }
 
+// 3CC-r fatigue state of the masked envs back to rest (fatigue.py:82-99): MF = vec (or 0), MR = 1 - MF, MA = 0
+__global__ void k_fatigue_reset(float* MA, float* MR, float* MF, const uint8_t* mask, const float* vec, int nenv, int na) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nenv * na) return;
+  const int e = i / na, k = i - e * na;
+  if (mask && !mask[e]) return;
+  const float f = vec ? vec[k] : 0.f;
+  MA[i] = 0.f; MR[i] = 1.f - f; MF[i] = f;
+}
+
+extern "C" int mm_fatigue_reset(float* MA, float* MR, float* MF, const uint8_t* mask, const float* vec, int nenv, int na,
+                                void* stream) {
+  if (!MA || !MR || !MF || nenv <= 0 || na <= 0) return fail(MM_EARG, "mm_fatigue_reset: bad argument");
+  hipLaunchKernelGGL(k_fatigue_reset, dim3((nenv * na + 255) / 256), dim3(256), 0, (hipStream_t)stream, MA, MR, MF, mask, vec, nenv, na);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
 __global__ void k_env_draw(float* out, int nenv, int ncomp, const float* base, const float* lo, const float* hi,
                            const uint8_t* mask, const int32_t* episode, uint64_t seed, uint32_t stream_id, int env_index_base) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -2350,6 +2350,15 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   const int wpb = blockDim.x >> 6;
   const int g = lane % G;
   unsigned long long t_start = a.prof ? clock64() : 0;
+  // reset-observation pass (mm_task.obs_only with an env mask): a block none of whose envs is flagged leaves before the model
+  // is staged -- every wave scans the block's whole env range, so the decision is block-uniform and nobody is left waiting at
+  // the barrier (the pass is launched after every step of the non-Pose tasks and usually has nothing to do)
+  if (a.mode == 2 && KA().t.obs_only && KA().t.env_mask) {
+    const int epb = (blockDim.x >> 6) * EPW, e0 = blockIdx.x * epb;
+    bool any = false;
+    for (int i = lane; i < epb; i += 64) any |= (e0 + i < a.s.nenv) && KA().t.env_mask[e0 + i] != 0;
+    if (__ballot(any) == 0ull) return;
+  }
   // ---- stage the model tables into LDS once per block (all waves participate)
   const uint32_t* mb = a.blob;
   float* wsbase = lds;

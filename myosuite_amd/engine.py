@@ -161,6 +161,7 @@ def lib():
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
         L.mm_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p]
+        L.mm_fatigue_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mm_env_draw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
         L.mm_reach_reset.argtypes = [C.c_void_p, C.POINTER(mm_state), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -437,6 +438,13 @@ def env_draw(out: torch.Tensor, lo: torch.Tensor, hi: torch.Tensor, mask, episod
     _chk(lib().mm_env_draw(out.data_ptr(), n, k, _ptr(base), _ptr(lo), _ptr(hi), _ptr(mask), _ptr(episode), C.c_uint64(seed),
                            C.c_uint32(stream_id), int(env_index_base), _stream(out.device)), "mm_env_draw")
     return out
+
+
+def fatigue_reset(MA: torch.Tensor, MR: torch.Tensor, MF: torch.Tensor, mask, vec=None):
+    """3CC-r state of the masked envs back to rest in one launch (fatigue.py:82-99): MF = vec or 0, MR = 1 - MF, MA = 0"""
+    assert MA.shape == MR.shape == MF.shape and MA.is_contiguous() and MR.is_contiguous() and MF.is_contiguous()
+    _chk(lib().mm_fatigue_reset(_ptr(MA), _ptr(MR), _ptr(MF), _ptr(mask), _ptr(vec), int(MA.shape[0]), int(MA.shape[1]),
+                                _stream(MA.device)), "mm_fatigue_reset")
 
 
 def episode_stats(stats: torch.Tensor, reset_mask: torch.Tensor, rwd: torch.Tensor, dense_col: int, solved_col: int,

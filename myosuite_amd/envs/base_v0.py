@@ -166,11 +166,12 @@ class BaseV0:
             nf = torch.from_numpy(self._fat_rng.random((n, na)).astype(np.float32)).to(self.device)
             ap = torch.from_numpy(self._fat_rng.random((n, na)).astype(np.float32)).to(self.device)
             MA, MR, MF = nf * ap, nf * (1 - ap), 1 - nf
-        elif self.fatigue_reset_vec is not None:
-            v = torch.as_tensor(np.asarray(self.fatigue_reset_vec, np.float32), device=self.device).expand(n, na)
-            MA, MR, MF = torch.zeros_like(v), 1 - v, v.clone()
         else:
-            MA = torch.zeros(n, na, device=self.device); MR = torch.ones_like(MA); MF = torch.zeros_like(MA)
+            # deterministic reset (to rest, or to fatigue_reset_vec): one launch, no temporaries
+            if self.fatigue_reset_vec is not None and getattr(self, "_fat_vec", None) is None:
+                self._fat_vec = torch.as_tensor(np.asarray(self.fatigue_reset_vec, np.float32), device=self.device).expand(na).contiguous()
+            E.fatigue_reset(self.fat_MA, self.fat_MR, self.fat_MF, mask, getattr(self, "_fat_vec", None))
+            return
         if mask is None:
             self.fat_MA.copy_(MA); self.fat_MR.copy_(MR); self.fat_MF.copy_(MF)
         else:
