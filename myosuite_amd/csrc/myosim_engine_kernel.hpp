@@ -1946,9 +1946,6 @@ struct Engine {
         // over the active rows (broadcast D_r, nine 128-bit row loads, NVP FMAs per row: ~550 cycles x ~30 rows per iteration).
         constexpr int NT = (NVP + 15) / 16;
         typedef float f4v __attribute__((ext_vector_type(4)));
-        f4v acc[NT * (NT + 1) / 2];
-#pragma unroll
-        for (int q = 0; q < NT * (NT + 1) / 2; q++) acc[q] = f4v{0.f, 0.f, 0.f, 0.f};
         float* Dv = W + KL().rowtab;              // row table of make_constraint: dead since the owner stage
         Dv[g] = on ? r_D : 0.f;
         GSYNC();
@@ -1956,37 +1953,37 @@ struct Engine {
         const float* Jb = W + KL().efcJ;
         const int erows = KD().efc_rows;
         const int K4 = (nrows_wave + 3) >> 2;
-        for (int kb = 0; kb < K4; kb++) {
-          const int row = 4 * kb + lk;
-          const bool rok = row < erows;
-          const float dsc = rok ? Dv[row] : 0.f;
-          float av[NT];
-#pragma unroll
-          for (int t = 0; t < NT; t++) {
-            const int col = 16 * t + lr;
-            av[t] = (rok && col < NVP) ? Jb[row * RS + col] : 0.f;
-          }
-          int q = 0;
-#pragma unroll
-          for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-            for (int tj = ti; tj < NT; tj++, q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], av[tj] * dsc, acc[q], 0, 0, 0);
-        }
         float* T = W + KL().u1;                   // the dense tile: the previous factor in there is dead
-        {
-          int q = 0;
+        // one tile ROW (ti) at a time: NT - ti accumulator tiles live instead of NT (NT + 1) / 2 (12 instead of 24 VGPRs for the
+        // 36-dof leg, whose kernel sits at the 256-VGPR limit); the K sweep is repeated per tile row, its operand loads are cheap
 #pragma unroll
-          for (int ti = 0; ti < NT; ti++)
+        for (int ti = 0; ti < NT; ti++) {
+          f4v acc[NT];
 #pragma unroll
-            for (int tj = ti; tj < NT; tj++, q++)
+          for (int q = 0; q < NT; q++) acc[q] = f4v{0.f, 0.f, 0.f, 0.f};
+          for (int kb = 0; kb < K4; kb++) {
+            const int row = 4 * kb + lk;
+            const bool rok = row < erows;
+            const float dsc = rok ? Dv[row] : 0.f;
+            float av[NT];
 #pragma unroll
-              for (int v = 0; v < 4; v++) {
-                const int i = 16 * ti + 4 * lk + v, j = 16 * tj + lr;
-                if (i < NVP && j < NVP) {
-                  T[i * NVP + j] = acc[q][v];
-                  if (ti != tj) T[j * NVP + i] = acc[q][v];
-                }
+            for (int t = ti; t < NT; t++) {
+              const int col = 16 * t + lr;
+              av[t] = (rok && col < NVP) ? Jb[row * RS + col] : 0.f;
+            }
+#pragma unroll
+            for (int tj = ti; tj < NT; tj++) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], av[tj] * dsc, acc[tj], 0, 0, 0);
+          }
+#pragma unroll
+          for (int tj = ti; tj < NT; tj++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              const int i = 16 * ti + 4 * lk + v, j = 16 * tj + lr;
+              if (i < NVP && j < NVP) {
+                T[i * NVP + j] = acc[tj][v];
+                if (ti != tj) T[j * NVP + i] = acc[tj][v];
               }
+            }
         }
         GSYNC();
         const int row = g < NVP ? g : 0;
