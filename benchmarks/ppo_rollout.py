@@ -55,7 +55,10 @@ def main():
     rank, world, local = D.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    env = registry.make(args.env, num_envs=args.num_envs, seed=1000 * rank, device=dev)
+    # rank r owns the global envs [r n, (r+1) n): Philox streams are keyed by the global env index (mm_state.env_index_base)
+    env = registry.make(args.env, num_envs=args.num_envs, seed=0, device=dev, env_index_base=rank * args.num_envs)
+    env.rollout_setup()                              # env.step + auto-reset + episode stats as one launch (mm_rollout_step)
+    dense_col = env.rwd.shape[1] - 1
     n, T = args.num_envs, args.unroll
     obs_dim, act_dim = env.obs_dim, env.cm.nu
     torch.manual_seed(0)
@@ -78,8 +81,9 @@ def main():
                 d = net.dist(obs)
                 a = d.sample()
                 buf["obs"][t] = obs; buf["act"][t] = a; buf["logp"][t] = d.log_prob(a).sum(-1); buf["val"][t] = net.v(obs).squeeze(-1)
-                o, r, term, trunc, info = env.step(torch.sigmoid(a))       # policy output -> [0,1] excitations
-                buf["rew"][t] = r; buf["done"][t] = (term | trunc).float()
+                o, rw, ended = env.rollout_step(torch.sigmoid(a).contiguous())       # policy output -> [0,1] excitations
+                r = rw[:, dense_col]
+                buf["rew"][t] = r; buf["done"][t] = ended.float()
                 ret_sum += r
                 obs = o.clone()
             buf["val"][T] = net.v(obs).squeeze(-1)

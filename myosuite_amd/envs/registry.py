@@ -241,12 +241,17 @@ register_env_with_variants(
     id="myoHandKeyTurnRandom-v0", entry_point=_keyturn, max_episode_steps=200,
     kwargs={"model": "hand_keyturn", "normalize_act": True, "key_init_range": (-np.pi / 2, np.pi / 2), "goal_th": 2 * np.pi})
 
-# MyoTorso posing (myobase/__init__.py:638-670).  myoTorsoExoPoseFixed-v0 (:671-701) needs the exosuit model
-# (myotorso_exosuit.xml, absent) and is not registered.
+# MyoTorso posing (myobase/__init__.py:638-701); myoTorsoExoPoseFixed-v0 runs on the torso with a synthetic back exosuit
+# (two elastic cables with tension actuators: synth.make_torso(exosuit=True); the reference's myotorso_exosuit.xml is absent).
 from ..model.synth import TORSO_JOINTS as _TJ
 register_env_with_variants(
     id="myoTorsoPoseFixed-v0", entry_point=_torso, max_episode_steps=200,
     kwargs={"model": "torso", "normalize_act": True, "frame_skip": 5,
+            "target_jnt_range": {j: ((-0.1, 0.1) if j == "lat_bending" else (0.0, 0.0)) for j in _TJ}})
+
+register_env_with_variants(
+    id="myoTorsoExoPoseFixed-v0", entry_point=_torso, max_episode_steps=200,
+    kwargs={"model": "torso_exo", "normalize_act": True, "frame_skip": 5,
             "target_jnt_range": {j: ((-0.1, 0.1) if j == "lat_bending" else (0.0, 0.0)) for j in _TJ}})
 
 # SAR reorient (myobase/__init__.py:703-749): frame_skip 5, horizon 50.

@@ -162,7 +162,7 @@ TORSO_GROUPS = [("rect_abd", 1), ("IL", 12), ("QL", 18), ("MF", 25), ("LT", 19),
                 ("LD", 7)]                                                                    # fascicles per side: 105
 
 
-def make_torso() -> ModelSpec:
+def make_torso(exosuit: bool = False) -> ModelSpec:
     """myoTorso: "210 actuators and 18 joints" (docs/source/suite.rst:207), generated from OpenSim's *constrained* lumbar spine
     model: the pelvis is fixed, the three L5/S1 rotations (flex_extension, lat_bending, axial_rotation) drive the L4-L5 ...
     L1-L2 rotations and the abdomen's Abs_t1/Abs_t2/Abs_r3 through joint equalities (here: linear couplings).  210 muscle
@@ -239,6 +239,18 @@ def make_torso() -> ModelSpec:
                 s.add_muscle(name, name + "_tendon", force=fmax * (0.7 + 0.6 * (f % 3) / 2.0))
                 nm += 1
     assert nm == 210
+    if exosuit:
+        # back exosuit (simhive/myo_sim/torso/myotorso_exosuit.xml, absent from the reference checkout): two elastic cables
+        # from the back of the pelvis to the thorax that stretch in flexion (spring beyond their slack length, damped), each
+        # with a cable-tension actuator (a tendon-transmission <general>, no activation state) behind the 210 muscles
+        for side, sg in (("r", -1.0), ("l", 1.0)):
+            s.add_site(f"exo_o_{side}", "pelvis", (-0.11, sg * 0.06, 0.02))
+            s.add_site(f"exo_v_{side}", "lumbar3", (-0.075, sg * 0.055, 0.0))
+            s.add_site(f"exo_i_{side}", "lumbar1", (-0.09, sg * 0.06, 0.26))
+            s.add_tendon(f"exo_cable_{side}", [("site", f"exo_o_{side}"), ("site", f"exo_v_{side}"), ("site", f"exo_i_{side}")],
+                         stiffness=4000.0, damping=20.0, springlength=(0.0, 0.355))
+            s.add_general(f"Exo_{side}", tendon=f"exo_cable_{side}", gainprm=(-150.0,), ctrlrange=(0.0, 1.0))
+        s.name = "myotorso_exosuit"
     return s
 
 
@@ -967,7 +979,7 @@ def builders() -> dict:
             "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
             "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
             "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True),
-            "leg_implicit": lambda: make_leg(implicit=True)}
+            "leg_implicit": lambda: make_leg(implicit=True), "torso_exo": lambda: make_torso(exosuit=True)}
 
 
 def compile_spec(name: str, edit=None) -> CompiledModel:

@@ -410,7 +410,7 @@ def test_mjx_style_reach_api(models):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env_id", ["myoFingerPoseRandom-v0", "motorFingerPoseRandom-v0", "myoElbowPose1D6MExoRandom-v0",
-                                    "myoElbowPose1D6MExoFixed-v0", "myoTorsoPoseFixed-v0", "myoHandPoseFixed-v0"])
+                                    "myoElbowPose1D6MExoFixed-v0", "myoTorsoPoseFixed-v0", "myoTorsoExoPoseFixed-v0", "myoHandPoseFixed-v0"])
 def test_more_pose_family_envs_match_env_oracle(oracle_lib, env_id):
     """The rest of the myobase Pose family (finger / motor finger / exo elbow with per-episode carried weight / torso with
     joint equalities and 210 muscles / fixed-target hand): reset draws, ctrl map (incl. the [-1,1] -> ctrlrange map of the
