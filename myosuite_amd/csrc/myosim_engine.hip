@@ -178,6 +178,8 @@ struct mm_model {
   size_t lds_per_env = 0;
   int device = 0;
   float origin[3] = {0.f, 0.f, 0.f};   // internal world-frame origin (see Dims::ox)
+  std::vector<int32_t> desc_all, seg_tab;   // Aux::dof_desc / dof_seg, built with the dims
+  int nseg = 0;                             // segments of the dof tree (SP kernels)
 };
 
 static int upload_consts(mm_model* m);
@@ -214,7 +216,10 @@ static void build_layout(mm_model* m) {
   L.xpos = take(3 * d.nbody); L.xmat = take(9 * d.nbody);
   L.com = take(3 * m->x.nroot); L.cdof = take(6 * d.nv);
   o = (o + 3) & ~3;
-  L.u1 = take(std::max(13 * d.nbody, m->nvp * m->nvp));   // 12 words (cvel, cacc) + 1 pointer-jumping word per body | dense tile
+  // 12 words (cvel, cacc) + 1 pointer-jumping word per body | dense tile | SP kernels: published rows [nvp][12], x [nvp], update
+  // matrices [nseg][36]
+  m->d.seg_u = 13 * m->nvp;
+  L.u1 = take(std::max(std::max(13 * d.nbody, m->nvp * m->nvp), m->d.seg_u + 36 * m->nseg));
   L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
   L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
@@ -292,6 +297,82 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     for (int i = 0; i < d.nv; i++) if (fl[i] > 0.f) d.nfric++;
   }
   d.gen = (d.neq > 0 || d.npair > 0 || d.nfric > 0 || d.ntlim > 0) ? 1 : 0;
+  {
+    // dof-tree depth.  The limit-rows-only kernels keep M tree-sparse with at most 8 entries per row (dof + 7 ancestors);
+    // a deeper tree takes the general-row kernels, whose factorisations are dense.
+    const int32_t* dpar = (const int32_t*)(blob + m->sec[MM_SEC_DOF_PARENTID]);
+    int maxd = 0;
+    for (int i = 0; i < d.nv; i++) {
+      int dep = 0;
+      for (int j = dpar[i]; j >= 0; j = dpar[j]) dep++;
+      if (dep > maxd) maxd = dep;
+    }
+    d.dof_nlevel = maxd + 1;
+    // Tables of the tree-sparse factorisation (Engine::sp_factor_solve / sp_mul_m): depth of every dof, its descendants, and the
+    // SEGMENTS of the dof tree (maximal unbranched chains; a dof starts a segment when its parent has another child too).
+    std::vector<int> dep(d.nv, 0), nchild(d.nv, 0);
+    for (int i = 0; i < d.nv; i++) { dep[i] = dpar[i] < 0 ? 0 : dep[dpar[i]] + 1; if (dpar[i] >= 0) nchild[dpar[i]]++; }
+    bool fits = d.dof_nlevel <= 8 && d.nv < 255;
+    const size_t nvs = (size_t)(d.nv > 0 ? d.nv : 1);
+    m->desc_all.assign(nvs * 8, -1);
+    m->seg_tab.assign(nvs * 6, -1);
+    d.seg_nlevel = 0; d.seg_lvinfo[0] = d.seg_lvinfo[1] = 0; d.seg_lvtb[0] = d.seg_lvtb[1] = 0; d.seg_zero = 0; d.desc_words = 0; m->nseg = 0;
+    if (fits) {
+      std::vector<int> ndesc(d.nv, 0);
+      for (int k = 0; k < d.nv && fits; k++)
+        for (int i = dpar[k]; i >= 0; i = dpar[i]) {
+          const int c = ndesc[i]++;
+          if (c >= 32) { fits = false; break; }
+          uint32_t* w = (uint32_t*)&m->desc_all[(size_t)i * 8 + (c >> 2)];
+          *w = (*w & ~(255u << (8 * (c & 3)))) | ((uint32_t)k << (8 * (c & 3)));
+          d.desc_words = std::max(d.desc_words, (c >> 2) + 1);
+        }
+    }
+    if (fits) {
+      struct Seg { int top, bottom, parent, level, nch; int ch[8]; };
+      std::vector<Seg> segs;
+      std::vector<int> seg_of(d.nv, -1);
+      for (int k = 0; k < d.nv && fits; k++) {
+        if (dpar[k] >= 0 && nchild[dpar[k]] == 1) { seg_of[k] = seg_of[dpar[k]]; segs[seg_of[k]].bottom = k; continue; }
+        Seg sg{}; sg.top = sg.bottom = k; sg.parent = dpar[k] >= 0 ? seg_of[dpar[k]] : -1;
+        sg.level = sg.parent >= 0 ? segs[sg.parent].level + 1 : 0;
+        if (sg.parent >= 0) {
+          Seg& ps = segs[sg.parent];
+          if (ps.nch >= 8) { fits = false; break; }
+          ps.ch[ps.nch++] = (int)segs.size();
+        }
+        seg_of[k] = (int)segs.size();
+        segs.push_back(sg);
+      }
+      if (segs.size() > 255) fits = false;
+      if (fits) {
+        int mch[8] = {0}, lt[8], lb[8];
+        for (int l = 0; l < 8; l++) lt[l] = lb[l] = -1;
+        for (size_t si = 0; si < segs.size(); si++) {
+          const Seg& sg = segs[si];
+          const int t = dep[sg.top], b = dep[sg.bottom];
+          d.seg_nlevel = std::max(d.seg_nlevel, sg.level + 1);
+          mch[sg.level] = std::max(mch[sg.level], sg.nch);
+          if (lt[sg.level] < 0) { lt[sg.level] = t; lb[sg.level] = b; }
+          else if (lt[sg.level] != t || lb[sg.level] != b) fits = false;   // the kernel's segment code is scalar in (t, b) per level
+          uint32_t path[2] = {0, 0}, ch[2] = {0xffffffffu, 0xffffffffu};
+          for (int k = sg.bottom; k >= 0; k = dpar[k]) path[dep[k] >> 2] |= (uint32_t)k << (8 * (dep[k] & 3));
+          for (int c = 0; c < sg.nch; c++) ch[c >> 2] = (ch[c >> 2] & ~(255u << (8 * (c & 3)))) | ((uint32_t)sg.ch[c] << (8 * (c & 3)));
+          int32_t* e = &m->seg_tab[(size_t)sg.top * 6];
+          e[0] = t | (b << 4) | (sg.level << 8) | ((int)si << 16);
+          e[1] = (int32_t)path[0]; e[2] = (int32_t)path[1]; e[3] = (int32_t)ch[0]; e[4] = (int32_t)ch[1]; e[5] = 0;
+        }
+        d.seg_lvtb[0] = d.seg_lvtb[1] = 0;
+        for (int l = 0; l < 8; l++) {
+          d.seg_lvinfo[l >> 2] |= mch[l] << (8 * (l & 3));
+          if (lt[l] >= 0) d.seg_lvtb[l >> 2] |= (lt[l] | (lb[l] << 4)) << (8 * (l & 3));
+        }
+        m->nseg = (int)segs.size() + 1;   // + the all-zero slot
+        d.seg_zero = (int)segs.size();
+      }
+    }
+    if (!d.gen && d.nv > 4 && !fits && d.integrator != MM_INT_IMPLICITFAST) d.gen = 1;
+  }
   {
     const int32_t* et = (const int32_t*)(blob + m->sec[MM_SEC_EQ_TYPE]);
     for (int e = 0; e < d.neq; e++)
@@ -509,6 +590,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
       for (int i = bdofadr[b]; i >= 0 && i < bdofadr[b] + bdofnum[b]; i++) bm[2 * b + (i >> 5)] |= (int32_t)(1u << (i & 31));
     }
     m->x.body_dofmask = append(bm);
+    m->x.dof_desc = append(m->desc_all); m->x.dof_seg = append(m->seg_tab);
   }
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS

@@ -58,6 +58,14 @@ struct Dims {
   int gen;   // model has equality / friction-loss / contact rows: general (dense-J) constraint path
   int nfric; // dofs with frictionloss > 0 (one friction-loss row each, behind the equalities)
   int ntlim; // limited tendons (at most one limit row each, behind the joint-limit rows)
+  int dof_nlevel;   // levels of the dof tree (1 + maximum number of ancestor dofs)
+  // SP kernels: the dof tree cut into segments (maximal unbranched chains); one lane eliminates a whole segment
+  int seg_nlevel;       // levels of the segment tree
+  int seg_lvinfo[2];    // one byte per segment level: [3:0] most child segments of a segment there
+  int seg_lvtb[2];      // one byte per segment level: [3:0] top depth, [7:4] bottom depth of the segments there (all alike)
+  int seg_zero;         // index of the all-zero update-matrix slot (absent children)
+  int seg_u;            // word offset (in the u1 LDS region) of the update matrices, 36 words per segment
+  int desc_words;       // words of the per-dof descendant list (4 ids each) a product M x has to walk
   int integrator;   // MM_INT_EULER | MM_INT_RK4 | MM_INT_IMPLICITFAST
   int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
@@ -98,6 +106,8 @@ struct Aux {
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
   int dof_rel;           // per dof: 64-bit mask (2 words) of the dofs on its kinematic chain (ancestors, descendants, itself)
   int body_dofmask;      // per body: 64-bit mask (2 words) of the dofs between the body and the root of its tree (its chain)
+  int dof_desc;          // per dof: ids of all its descendants, one byte each, 0xff-padded to 8 words
+  int dof_seg;           // per dof, 6 words: segment owned by the dof's lane (the segment's top dof) or -1; path and child bytes
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)
@@ -618,6 +628,9 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
   return dctrl / fmaxf(MINVALF, tau);
 }
 
+#ifndef MM_SPARSE_LDL
+#define MM_SPARSE_LDL 1   /* 0: dense register Cholesky in every kernel (A/B switch) */
+#endif
 // =========================================================================== engine
 #define PIN_S(x) asm volatile("" : "+s"(x))   /* keep a wave-uniform value in an SGPR: opaque to rematerialisation (an s_load + s_waitcnt at every use) */
 #define AI_(o) (reinterpret_cast<const int*>(mb + (o)))
@@ -650,7 +663,22 @@ struct Engine {
   float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
   float Mrow[NVP];   // row g of M (dense, symmetric)
   float Lrow[NVP];   // row g of the current Cholesky factor  (L[g][k], k <= g)
-  float d_dinv;      // 1 / L[g][g]
+  float d_dinv;      // 1 / L[g][g]   (SP: 1 / D[g])
+  // Tree-sparse storage (SP kernels: limit rows only, so every matrix that gets factorised -- M, M + h B, M + diag(D_active) --
+  // has M's pattern: non-zero only between a dof and its ancestors).  Lane g keeps its row indexed by the ABSOLUTE depth of the
+  // ancestor: Ms[e] = M[g][ancestor of g at depth e] for e < d_depth (0 beyond), Md = M[g][g].  (A descendant's row and its
+  // ancestor's row then agree on the index of every common ancestor, so an ancestor reads a descendant's row with aligned
+  // 128-bit loads.)
+  static constexpr int SD = 8;     // maximum depth of the dof tree of an SP model (host routes deeper ones to the GEN kernels)
+  static constexpr int TS = 12;    // row stride of the published rows: [row 0..7, 1/D, rhs, -, -]
+  static constexpr bool SP = MM_SPARSE_LDL && !GEN && NVP >= 8 && INTEG != 2;
+  float Ms[SD], Md;
+  unsigned anc_lo, anc_hi;   // ancestor dof ids by absolute depth, one byte each: depth 0..3 | 4..6
+  int d_depth;               // depth of dof g in the dof tree (0 = no parent dof); -1 on lanes without a dof
+  // segment owned by this lane (lane of the segment's top dof): depth range [sg_t, sg_b], level in the segment tree (-1: none),
+  // index (slot of its update matrix), dof ids on the path root .. bottom by depth, child segment indices (0xff = none)
+  int sg_t, sg_b, sg_lv, sg_id;
+  unsigned sg_path_lo, sg_path_hi, sg_ch_lo, sg_ch_hi;
   // ---- joint-limit row owned by this lane (lower side: lanes < G/2, upper side: lanes >= G/2)
   bool r_active;
   float r_D, r_aref, r_sign, r_jar;
@@ -689,6 +717,43 @@ struct Engine {
     d_bias = d_smooth = d_qaccsm = d_qacc = d_qfrccon = 0.f; d_dinv = 1.f;
 #pragma unroll
     for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < SD; k++) Ms[k] = 0.f;
+    Md = 1.f;
+    anc_lo = anc_hi = 0u; d_depth = -1;
+    sg_t = sg_b = 0; sg_lv = -1; sg_id = 0; sg_path_lo = sg_path_hi = 0u; sg_ch_lo = sg_ch_hi = 0xffffffffu;
+    if constexpr (SP) {
+      if (g < KD().nv) {
+        const int* dpar = MI_(DOF_PARENTID);
+        // (fixed trip counts: a data-dependent loop over the model table here runs into a backend error, "illegal VGPR to
+        // SGPR copy", in the LDS-model variants)
+        int dep = 0, j = dpar[g];
+#pragma unroll
+        for (int k = 0; k < SD - 1; k++)
+          if (j >= 0) { dep++; j = dpar[j]; }
+        d_depth = dep;
+        j = dpar[g];
+#pragma unroll
+        for (int k = 0; k < SD - 1; k++)
+          if (j >= 0) {
+            const int e = dep - 1 - k;
+            if (e < 4) anc_lo |= (unsigned)j << (8 * e); else anc_hi |= (unsigned)j << (8 * (e - 4));
+            j = dpar[j];
+          }
+        const int* sg = AUXI(dof_seg) + 6 * g;
+        const int w = sg[0];
+        if (w >= 0) {
+          sg_t = w & 15; sg_b = (w >> 4) & 15; sg_lv = (w >> 8) & 15; sg_id = (w >> 16) & 255;
+          sg_path_lo = (unsigned)sg[1]; sg_path_hi = (unsigned)sg[2]; sg_ch_lo = (unsigned)sg[3]; sg_ch_hi = (unsigned)sg[4];
+        }
+      }
+    }
+  }
+  // dof id of this lane's ancestor at absolute depth E_ (valid for E_ < d_depth)
+  template <int E_>
+  __device__ __forceinline__ int anc() const {
+    static_assert(E_ >= 0 && E_ < SD - 1, "ancestor depth");
+    return (int)(E_ < 4 ? (anc_lo >> (8 * E_)) & 255u : (anc_hi >> (8 * (E_ - 4))) & 255u);
   }
 
   __device__ __forceinline__ V3 origin() const { return v3(KD().ox, KD().oy, KD().oz); }
@@ -1220,13 +1285,31 @@ struct Engine {
 #pragma unroll
       for (int k = 0; k < 10; k++) W[o_crb + 10 * g + k] = b_cinert[k];
     // zero the dense tile (u1 region; cfrc is dead now) and put 1 on the padded diagonal
-    for (int e = g; e < NVP * NVP; e += G) W[o_u1 + e] = 0.f;
+    if constexpr (!SP)
+      for (int e = g; e < NVP * NVP; e += G) W[o_u1 + e] = 0.f;
     GSYNC();
     for (int lv = KD().nlevel; lv >= 2; lv--) {
       if (b_depth == lv && b_parent > 0)
 #pragma unroll
         for (int k = 0; k < 10; k++) atomicAdd(&W[o_crb + 10 * b_parent + k], W[o_crb + 10 * g + k]);
       GSYNC();
+    }
+    if constexpr (SP) {
+      // M[g][anc_d] = cdof_anc . (Ic_body(g) cdof_g): the ancestors' motion axes are independent LDS gathers
+      if (g < nv) {
+        float I[10], buf[6];
+        int b = AI_(s_DOF_BODYID)[g];
+#pragma unroll
+        for (int k = 0; k < 10; k++) I[k] = W[o_crb + 10 * b + k];
+        inert_mul(buf, I, d_cdof);
+        float diag = AF_(s_DOF_ARMATURE)[g];
+#pragma unroll
+        for (int k = 0; k < 6; k++) diag += d_cdof[k] * buf[k];
+        Md = diag;
+        sp_crb_entry<0>(buf, o_cdof);
+      }
+      GSYNC();
+      return;
     }
     if (g < nv) {
       float I[10], buf[6];
@@ -1257,6 +1340,245 @@ struct Engine {
       for (int k = 0; k < NVP; k++) Mrow[k] = 0.f;
     }
     GSYNC();
+  }
+
+  template <int E_>
+  __device__ __forceinline__ void sp_crb_entry(const float (&buf)[6], int o_cdof) {
+    if constexpr (E_ < SD) {
+      float s = 0.f;
+      if constexpr (E_ < SD - 1) {
+        if (E_ < d_depth) {
+          const int j = anc<E_>();
+#pragma unroll
+          for (int k = 0; k < 6; k++) s += W[o_cdof + 6 * j + k] * buf[k];
+        }
+      }
+      Ms[E_] = s;
+      sp_crb_entry<E_ + 1>(buf, o_cdof);
+    }
+  }
+
+  // ---- tree-sparse L'DL (MuJoCo's mj_factorI / mj_solveLD order: leaves first, no fill-in) fused with its one solve.
+  // Every factorisation in an SP kernel is followed by exactly one solve, so the elimination carries the right-hand side.
+  // The dof tree is cut into SEGMENTS, maximal unbranched chains (hand: the wrist chain and five finger chains).  One lane --
+  // the lane of the segment's top dof -- eliminates the whole segment in registers: it assembles the frontal matrix over the
+  // depths 0 .. bottom (rows of its own dofs, published by their lanes, plus the update matrices of its child segments),
+  // runs the dense L'DL pivots of its own depths with compile-time indices, keeps L for the back substitution and publishes
+  // the update matrix over its ancestors for the parent segment.  Sequential steps = levels of the SEGMENT tree (2 for the
+  // hand), ~350 instructions per factor + solve against ~1200 with one lane per dof and one step per tree level, and ~1400 for
+  // the dense form (24 pivots with a broadcast and an LDS round trip each, 48 substitution steps).  No LDS float atomics:
+  // gfx950 executes a ds_add_f32 at ~3 cycles per ACTIVE LANE, CU-wide (tools/micro/lds_atomic_bench.hip: 192 cycles for 64
+  // lanes against 8 for a ds_write_b32).
+  static constexpr int tri(int d) { return d * (d + 1) / 2; }
+  template <int D_>
+  __device__ __forceinline__ int sg_path() const {
+    return (int)(D_ < 4 ? (sg_path_lo >> (8 * D_)) & 255u : (sg_path_hi >> (8 * (D_ - 4))) & 255u);
+  }
+  __device__ __forceinline__ static unsigned byte_of(unsigned w0, unsigned w1, int c) {
+    return ((c < 4 ? w0 >> (8 * c) : w1 >> (8 * (c - 4))) & 255u);
+  }
+  // (t, b): depth range of the segments of the level at hand -- the same for every segment of one level of an SP model (the
+  // host routes other trees to the general-row kernels), so these are scalar branches around straight-line code
+  template <int D_>
+  __device__ __forceinline__ void sg_load_rows(const float* T, float (&F)[36], float (&r)[SD], int t, int b) const {
+    if constexpr (D_ < SD) {
+      if (D_ >= t && D_ <= b) {
+        const float* P = T + sg_path<D_>() * TS;
+        const float4 p0 = *reinterpret_cast<const float4*>(P);
+        const float v0[4] = {p0.x, p0.y, p0.z, p0.w};
+#pragma unroll
+        for (int e = 0; e <= (D_ < 3 ? D_ : 3); e++) F[tri(D_) + e] = v0[e];
+        if constexpr (D_ >= 4) {
+          const float4 p1 = *reinterpret_cast<const float4*>(P + 4);
+          const float v1[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+          for (int e = 4; e <= D_; e++) F[tri(D_) + e] = v1[e - 4];
+        }
+        r[D_] = P[8];
+      }
+      sg_load_rows<D_ + 1>(T, F, r, t, b);
+    }
+  }
+  template <int D_>
+  __device__ __forceinline__ void sg_pivots(float (&F)[36], float (&r)[SD], float (&iv)[SD], int t, int b) const {
+    if constexpr (D_ >= 0) {
+      if (D_ >= t && D_ <= b) {
+        const float inv = 1.f / fmaxf(F[tri(D_) + D_], MINVALF);
+        iv[D_] = inv;
+#pragma unroll
+        for (int e = D_ - 1; e >= 0; e--) {       // descending: F[D][e2], e2 <= e, is still unscaled when row e needs it
+          const float tt = F[tri(D_) + e] * inv;  // L[D][e]
+#pragma unroll
+          for (int e2 = 0; e2 <= e; e2++) F[tri(e) + e2] -= tt * F[tri(D_) + e2];
+          r[e] -= tt * r[D_];
+          F[tri(D_) + e] = tt;
+        }
+      }
+      sg_pivots<D_ - 1>(F, r, iv, t, b);
+    }
+  }
+  template <int D_>
+  __device__ __forceinline__ void sg_back(float* X, const float (&F)[36], const float (&r)[SD], const float (&iv)[SD], float (&x)[SD], int t, int b) const {
+    if constexpr (D_ < SD) {
+      if (D_ < t) x[D_] = X[sg_path<D_>()];
+      else if (D_ <= b) {
+        float v = r[D_] * iv[D_];
+#pragma unroll
+        for (int e = 0; e < D_; e++) v -= F[tri(D_) + e] * x[e];
+        x[D_] = v;
+        X[sg_path<D_>()] = v;
+      }
+      sg_back<D_ + 1>(X, F, r, iv, x, t, b);
+    }
+  }
+  // add the update matrices of the child segments (nq quads of the triangle + the rhs); slots of absent children read zeros.
+  // SHALLOW (parents no deeper than depth 2, the hand's wrist): two quads + rhs in flight per child; otherwise one quad at a
+  // time -- the 36-word front and a whole child matrix in flight do not fit the register file next to the engine's state.
+  template <bool SHALLOW>
+  __device__ __forceinline__ void sg_children(const float* U, int mch, int nq, int zslot, float (&F)[36], float (&r)[SD]) const {
+    for (int c = 0; c < mch; c++) {
+      const unsigned id = byte_of(sg_ch_lo, sg_ch_hi, c);
+      const float* Uc = U + (id == 255u ? zslot : (int)id) * 36;
+      if constexpr (SHALLOW) {
+        const float4 u0 = *reinterpret_cast<const float4*>(Uc), u1 = *reinterpret_cast<const float4*>(Uc + 4);
+        const float4 r0 = *reinterpret_cast<const float4*>(Uc + 28);
+        F[0] += u0.x; F[1] += u0.y; F[2] += u0.z; F[3] += u0.w; F[4] += u1.x; F[5] += u1.y;
+        r[0] += r0.x; r[1] += r0.y; r[2] += r0.z;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+          if (q < nq) {
+            const float4 u = *reinterpret_cast<const float4*>(Uc + 4 * q);
+            F[4 * q] += u.x; F[4 * q + 1] += u.y; F[4 * q + 2] += u.z; F[4 * q + 3] += u.w;
+          }
+        const float4 r0 = *reinterpret_cast<const float4*>(Uc + 28), r1 = *reinterpret_cast<const float4*>(Uc + 32);
+        r[0] += r0.x; r[1] += r0.y; r[2] += r0.z; r[3] += r0.w; r[4] += r1.x; r[5] += r1.y; r[6] += r1.z; r[7] += r1.w;
+      }
+    }
+  }
+  template <int NQ>
+  __device__ __forceinline__ void sg_publish(float* Us, const float (&F)[36], const float (&r)[SD]) const {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) *reinterpret_cast<float4*>(Us + 4 * q) = make_float4(F[4 * q], F[4 * q + 1], F[4 * q + 2], F[4 * q + 3]);
+    *reinterpret_cast<float4*>(Us + 28) = make_float4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<float4*>(Us + 32) = make_float4(r[4], r[5], r[6], r[7]);
+  }
+  // x = (A + diag(dadd))^-1 rhs for the matrix whose sparse rows are (Ms, Md)
+  __device__ __forceinline__ float sp_factor_solve(float dadd, float rhs) {
+    float* T = W + KL().u1;            // published rows [NVP][TS]: row by absolute depth (diagonal at the dof's depth), rhs at [8]
+    float* X = T + NVP * TS;           // solution by dof
+    float* U = T + KD().seg_u;         // update matrices [segment][36]: lower triangle over depths (28 words), rhs (8 words)
+    const int nsl = KD().seg_nlevel, zslot = KD().seg_zero;
+    const unsigned info_lo = (unsigned)KD().seg_lvinfo[0], info_hi = (unsigned)KD().seg_lvinfo[1];
+    const unsigned tb_lo = (unsigned)KD().seg_lvtb[0], tb_hi = (unsigned)KD().seg_lvtb[1];
+    const int di = d_depth;
+    if (di >= 0) {
+      float P[SD];
+#pragma unroll
+      for (int e = 0; e < SD; e++) P[e] = e == di ? Md + dadd : Ms[e];
+      float* Pg = T + g * TS;
+      *reinterpret_cast<float4*>(Pg) = make_float4(P[0], P[1], P[2], P[3]);
+      *reinterpret_cast<float4*>(Pg + 4) = make_float4(P[4], P[5], P[6], P[7]);
+      Pg[8] = rhs;
+    }
+    if (g < 9) *reinterpret_cast<float4*>(U + zslot * 36 + 4 * g) = make_float4(0.f, 0.f, 0.f, 0.f);
+    GSYNC();
+    float F[36], r[SD], iv[SD];
+#pragma unroll
+    for (int k = 0; k < 36; k++) F[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < SD; k++) { r[k] = 0.f; iv[k] = 1.f; }
+    for (int sl = nsl - 1; sl >= 0; sl--) {
+      const unsigned tb = byte_of(tb_lo, tb_hi, sl);
+      const int t = (int)(tb & 15u), b = (int)(tb >> 4);
+      if (sg_lv == sl) {
+        sg_load_rows<0>(T, F, r, t, b);
+        // child segments: their update matrices cover the depths 0 .. b, a linear prefix of the triangle
+        const int mch = (int)(byte_of(info_lo, info_hi, sl) & 15u);
+        if (mch > 0) {
+          if (b <= 2) sg_children<true>(U, mch, 2, zslot, F, r);
+          else sg_children<false>(U, mch, (tri(b + 1) + 3) >> 2, zslot, F, r);
+        }
+        sg_pivots<SD - 1>(F, r, iv, t, b);
+        if (sl > 0) {   // update matrix over the ancestors: depths 0 .. t - 1
+          float* Us = U + sg_id * 36;
+          if (t <= 3) sg_publish<2>(Us, F, r);
+          else sg_publish<7>(Us, F, r);
+        }
+      }
+      if (sl > 0) GSYNC();
+    }
+    float x[SD];
+#pragma unroll
+    for (int k = 0; k < SD; k++) x[k] = 0.f;
+    for (int sl = 0; sl < nsl; sl++) {
+      const unsigned tb = byte_of(tb_lo, tb_hi, sl);
+      if (sg_lv == sl) sg_back<0>(X, F, r, iv, x, (int)(tb & 15u), (int)(tb >> 4));
+      GSYNC();
+    }
+    const float out = di >= 0 ? X[g] : 0.f;
+    GSYNC();
+    return out;
+  }
+  // y = M x: the diagonal and ancestor entries are this lane's row; the descendant entries M[k][g] x_k are published by the
+  // descendants (their row times their x) and summed through the dof's descendant list
+  __device__ __forceinline__ float sp_mul_m(float x) const {
+    float* Q = W + KL().u1;            // [NVP][SD]
+    float* X = Q + NVP * TS;
+    const int di = d_depth;
+    if (di >= 0) {
+      *reinterpret_cast<float4*>(Q + g * SD) = make_float4(Ms[0] * x, Ms[1] * x, Ms[2] * x, Ms[3] * x);
+      *reinterpret_cast<float4*>(Q + g * SD + 4) = make_float4(Ms[4] * x, Ms[5] * x, Ms[6] * x, Ms[7] * x);
+      X[g] = x;
+    }
+    const int nw = KD().desc_words;
+    unsigned dw[8];
+    {
+      const int* dt = AUXI(dof_desc) + 8 * (di >= 0 ? g : 0);
+#pragma unroll
+      for (int q = 0; q < 8; q++) dw[q] = (q < nw && di >= 0) ? (unsigned)dt[q] : 0xffffffffu;
+    }
+    GSYNC();
+    float y = 0.f;
+    if (di >= 0) {
+      // Ms is zero beyond the lane's depth and the unused ancestor bytes point at dof 0: no predicates
+      y = Md * x + Ms[0] * X[anc<0>()] + Ms[1] * X[anc<1>()] + Ms[2] * X[anc<2>()] + Ms[3] * X[anc<3>()]
+          + Ms[4] * X[anc<4>()] + Ms[5] * X[anc<5>()] + Ms[6] * X[anc<6>()];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (q < nw) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const unsigned k = (dw[q] >> (8 * c)) & 255u;
+            v[c] = Q[(k != 255u ? (int)k : g) * SD + di];
+            if (k == 255u) v[c] = 0.f;
+          }
+          y += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    GSYNC();
+    return y;
+  }
+  template <int E_>
+  __device__ __forceinline__ void sp_dense_entry(float* T) const {
+    if constexpr (E_ < SD - 1) {
+      if (E_ < d_depth) { const int ja = anc<E_>(); T[g * NVP + ja] = Ms[E_]; T[ja * NVP + g] = Ms[E_]; }
+      sp_dense_entry<E_ + 1>(T);
+    }
+  }
+  // tests only: M as a dense symmetric NVP x NVP tile in the u1 region
+  __device__ __forceinline__ void sp_dense_tile() const {
+    float* T = W + KL().u1;
+    for (int e = g; e < NVP * NVP; e += G) T[e] = 0.f;
+    GSYNC();
+    if (d_depth >= 0) { T[g * NVP + g] = Md; sp_dense_entry<0>(T); }
+    GSYNC();
+  }
+  // (A + diag(dadd))^-1 rhs: the one entry point of every factor + solve pair
+  __device__ __forceinline__ float factor_solve(float dadd, float rhs) {
+    if constexpr (SP) return sp_factor_solve(dadd, rhs);
+    else { factor(dadd); return solve(rhs); }
   }
 
   // dense Cholesky H = L L' with lane i holding row i; `dadd` is added to this lane's diagonal element.
@@ -1340,6 +1662,7 @@ struct Engine {
   // y_i = sum_j M[i][j] x_j
   __device__ __forceinline__ float mul_m(float x) const {
     float y = 0.f;
+    if constexpr (SP) return sp_mul_m(x);
     if constexpr (G < 64 && NVP >= 8) {
       // x through LDS (one write, NVP/4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts
       float* X = W + KL().xvec;
@@ -1483,6 +1806,9 @@ struct Engine {
     d_qfrccon = 0.f;
     if (nefc == 0) { d_qacc = d_qaccsm; return; }
     const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
+#ifdef MM_PROF_NEWTON
+    unsigned long long tp0 = clock64();
+#endif
     // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_of(d_warm, Ma_ws);
@@ -1496,7 +1822,13 @@ struct Engine {
     // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull;
+#ifdef MM_PROF_NEWTON
+    pf[PF_KIN] += clock64() - tp0;
+#endif
     for (int iter = 0; iter < KD().iterations; iter++) {
+#ifdef MM_PROF_NEWTON
+      unsigned long long tg0 = clock64();
+#endif
       const bool on = r_active && r_jar < 0.f;
       const unsigned long long set_now = __ballot(on);
       float f = on ? -r_D * r_jar : 0.f;
@@ -1512,19 +1844,35 @@ struct Engine {
       }
       set_prev = set_now;
       float dadd = rows_to_dof(on ? r_D : 0.f);
-      factor(dadd);
-      float search = -solve(grad);
+#ifdef MM_PROF_NEWTON
+      unsigned long long tq0 = clock64();
+      pf[PF_TENDON] += tq0 - tg0;
+#endif
+      float search = -factor_solve(dadd, grad);
+#ifdef MM_PROF_NEWTON
+      pf[PF_FACTOR] += clock64() - tq0;
+#endif
       if (g >= nv) search = 0.f;
       float sn = sqrtf(gsum<G>(search * search));
       if (sn < MINVALF) break;
-      float Mv = mul_m(search);
+      // (M + diag(dadd)) search = -grad, so M search needs no product: the residual of the solve is of the order of the
+      // rounding of an explicit product
+      float Mv;
+      if constexpr (SP) Mv = g < nv ? -grad - dadd * search : 0.f;
+      else Mv = mul_m(search);
       float jv = r_sign * sh<G>(search, r_dof);
       float dm = Ma - d_smooth;
       float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
       const float gtol = KD().tolerance * KD().ls_tolerance * sn / scale;
       // exact line search on the convex piecewise-quadratic phi(alpha): safeguarded Newton on phi'(alpha) = 0
       float alpha = 1.f, lo = 0.f, hi = -1.f;
+#ifdef MM_PROF_NEWTON
+      unsigned long long tq1 = clock64();
+#endif
       for (int it = 0; it < KD().ls_iterations; it++) {
+#ifdef MM_PROF_NEWTON
+        pf[PF_COM] += 1000;
+#endif
         float x = r_jar + alpha * jv;
         float d1 = 0.f, d2 = 0.f;
         if (r_active && x < 0.f) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
@@ -1538,6 +1886,9 @@ struct Engine {
         if (next == alpha) break;
         alpha = next;
       }
+#ifdef MM_PROF_NEWTON
+      pf[PF_IO] += clock64() - tq1;
+#endif
       if (!(alpha > 0.f)) break;
       d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
       alpha_prev = alpha;
@@ -2085,9 +2436,10 @@ struct Engine {
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
-    PFT(PF_FACTOR, factor(0.f));
+    if constexpr (!SP) PFT(PF_FACTOR, factor(0.f));
     PFT(PF_ACT, passive_actuation());
-    PFT(PF_SOLVE0, d_qaccsm = solve(d_smooth));
+    if constexpr (SP) PFT(PF_SOLVE0, d_qaccsm = sp_factor_solve(0.f, d_smooth));
+    else PFT(PF_SOLVE0, d_qaccsm = solve(d_smooth));
     PFT(PF_NEWTON, solve_constraints());
   }
 
@@ -2117,8 +2469,7 @@ struct Engine {
     d_warm = d_qacc;
     float qa_ = d_qacc;
     if (KD().any_damping && KD().eulerdamp) {
-      factor(g < KD().nv ? h * MF_(DOF_DAMPING)[g] : 0.f);
-      qa_ = solve(g < KD().nv ? d_smooth + d_qfrccon : 0.f);
+      qa_ = factor_solve(g < KD().nv ? h * MF_(DOF_DAMPING)[g] : 0.f, g < KD().nv ? d_smooth + d_qfrccon : 0.f);
     }
     for (int u = g; u < KD().nu; u += G) {
       int aa = MI_(ACT_ACTADR)[u];
@@ -2491,6 +2842,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   }
   if (a.dbg) {  // tests only: owner registers and tables in a flat record
     float* D = a.dbg + (size_t)e * a.D.total;
+    if constexpr (Engine<G, NVP, GEN, INTEG>::SP) {
+      E.sp_dense_tile();
+      if (g < d.nv) for (int k = 0; k < d.nv; k++) D[a.D.M + g * d.nv + k] = W[L.u1 + g * NVP + k];
+    }
     if (g < d.nbody) {
       st3(D + a.D.xpos + 3 * g, E.b_xpos + E.origin()); st3(D + a.D.xipos + 3 * g, E.b_xipos + E.origin());
       D[a.D.xquat + 4 * g] = E.b_xquat.w; D[a.D.xquat + 4 * g + 1] = E.b_xquat.x;
@@ -2499,8 +2854,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     }
     if (g < d.nv) {
       for (int k = 0; k < 6; k++) D[a.D.cdof + 6 * g + k] = E.d_cdof[k];
+      if constexpr (!Engine<G, NVP, GEN, INTEG>::SP) {
 #pragma unroll
-      for (int k = 0; k < NVP; k++) if (k < d.nv) D[a.D.M + g * d.nv + k] = E.Mrow[k];
+        for (int k = 0; k < NVP; k++) if (k < d.nv) D[a.D.M + g * d.nv + k] = E.Mrow[k];
+      }
       D[a.D.bias + g] = E.d_bias; D[a.D.smooth + g] = E.d_smooth; D[a.D.qaccsm + g] = E.d_qaccsm;
       D[a.D.qacc + g] = E.d_qacc; D[a.D.qfrccon + g] = E.d_qfrccon;
     }

@@ -43,7 +43,11 @@ class EngineError(RuntimeError):
 # unchanged.  Infinities and NaNs stay honoured (far_th = inf, the bad-state check).  Group reductions do not depend on the
 # flags: gsum() hides its operand from the optimiser and its stages are separate instructions.
 EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
-                             "-fno-hip-fp32-correctly-rounded-divide-sqrt -ffast-math -fhonor-infinities -fhonor-nans").split()
+                             "-fno-hip-fp32-correctly-rounded-divide-sqrt -ffast-math -fhonor-infinities -fhonor-nans "
+                             "-fno-slp-vectorize").split()
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 operations into v_pk_fma_f32 / v_pk_add_f32, whose operands must sit
+# in aligned register pairs; in these kernels (every lane holds a few hundred live scalars) that costs more v_mov shuffles and
+# spills than the packed instructions save: hand 5.05 -> 5.53 M env-steps/s, the other kernels +1..3 %.
 
 
 # Machine-scheduler strategy per kernel group (measured on MI355X, env-steps/s, default scheduler -> chosen):
