@@ -180,6 +180,7 @@ struct mm_model {
   float origin[3] = {0.f, 0.f, 0.f};   // internal world-frame origin (see Dims::ox)
   std::vector<int32_t> desc_all, seg_tab;   // Aux::dof_desc / dof_seg, built with the dims
   int nseg = 0;                             // segments of the dof tree (SP kernels)
+  int nwrapitem = 0;                        // tendon path items that wrap a geom (tangent points kept in LDS)
 };
 
 static int upload_consts(mm_model* m);
@@ -223,6 +224,7 @@ static void build_layout(mm_model* m) {
   L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
   L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
+  L.wrapw = take(7 * m->nwrapitem);
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
   o = (o + 3) & ~3;
@@ -427,61 +429,34 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
         if (tj_dof[e] == i) { dj_entry.push_back(e); dj_tendon.push_back(t); }
   }
   dj_adr[d.nv] = (int)dj_entry.size();
-  // per path element: dof lists of the straight segments that can start there
   const int32_t* wt = (const int32_t*)(blob + m->sec[MM_SEC_WRAP_TYPE]);
   const int32_t* wo = (const int32_t*)(blob + m->sec[MM_SEC_WRAP_OBJID]);
   const int32_t* tadr = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_ADR]);
   const int32_t* tnum = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_NUM]);
   const int32_t* sbody = (const int32_t*)(blob + m->sec[MM_SEC_SITE_BODYID]);
   const int32_t* gbody = (const int32_t*)(blob + m->sec[MM_SEC_GEOM_BODYID]);
-  std::vector<int32_t> seg_list;
-  std::vector<int32_t> sega(d.nwrap + 1, 0), segb(d.nwrap + 1, 0), segc(d.nwrap + 1, 0);
   auto elem_body = [&](int k) -> int {
     if (wt[k] == MM_WRAP_SITE) return sbody[wo[k]];
     if (wt[k] == MM_WRAP_SPHERE || wt[k] == MM_WRAP_CYLINDER) return gbody[wo[k]];
     return -1;
   };
   bool seg_ok = true;
-  auto emit = [&](int t, int b0, int b1) {
+  struct Cross { int ent, ep; };   // J entry a straight segment contributes to, and the end that moves with the dof
+  auto crossings = [&](int t, int b0, int b1) {
     // dofs in chain(b0) XOR chain(b1): endpoint 0 for the b0 side (sign -), endpoint 1 for the b1 side (+)
+    std::vector<Cross> out;
     while (b0 != b1) {
       int b, ep;
       if (b0 > b1) { b = b0; ep = 0; b0 = bpar[b0]; } else { b = b1; ep = 1; b1 = bpar[b1]; }
       for (int i = bdofadr[b]; i >= 0 && i < bdofadr[b] + bdofnum[b]; i++) {
         int ent = -1;
         for (int e = tj_adr[t]; e < tj_adr[t + 1]; e++) if (tj_dof[e] == i) ent = e;
-        if (ent < 0 || ent >= (1 << 22)) { seg_ok = false; continue; }
-        seg_list.push_back(i | (ep << 8) | (ent << 9));
+        if (ent < 0) { seg_ok = false; continue; }
+        out.push_back(Cross{ent, ep});
       }
     }
+    return out;
   };
-  {
-    std::vector<int> tendon_of(d.nwrap, -1);
-    for (int t = 0; t < d.ntendon; t++) for (int k = tadr[t]; k < tadr[t] + tnum[t]; k++) tendon_of[k] = t;
-    // three passes so that each list family is contiguous with its own adr array
-    for (int pass = 0; pass < 3; pass++) {
-      std::vector<int32_t>& adr = pass == 0 ? sega : (pass == 1 ? segb : segc);
-      for (int k = 0; k < d.nwrap; k++) {
-        adr[k] = (int)seg_list.size();
-        int t = tendon_of[k];
-        if (t < 0 || wt[k] != MM_WRAP_SITE) continue;
-        int last = tadr[t] + tnum[t] - 1;
-        if (k + 1 > last) continue;
-        bool next_site = wt[k + 1] == MM_WRAP_SITE;
-        bool next_geom = wt[k + 1] == MM_WRAP_SPHERE || wt[k + 1] == MM_WRAP_CYLINDER;
-        if (pass == 0) {
-          if (next_site) emit(t, elem_body(k), elem_body(k + 1));
-          else if (next_geom && k + 2 <= last) emit(t, elem_body(k), elem_body(k + 2));
-        } else if (pass == 1) {
-          if (next_geom) emit(t, elem_body(k), elem_body(k + 1));
-        } else {
-          if (next_geom && k + 2 <= last) emit(t, elem_body(k + 1), elem_body(k + 2));
-        }
-      }
-      adr[d.nwrap] = (int)seg_list.size();
-    }
-  }
-  if (!seg_ok) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian pattern in the blob does not cover a path segment"); }
   // flattened path items (see Engine::tendon): wraps first, then straight segments, then fixed-tendon joint terms
   std::vector<int32_t> item_tab;
   {
@@ -517,6 +492,80 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     std::stable_sort(wraps.begin(), wraps.end(), [](const Item& x, const Item& y) { return x.w[1] > y.w[1]; });
     for (auto* v : {&wraps, &straights, &joints})
       for (const Item& it : *v) for (int k = 0; k < 8; k++) item_tab.push_back(it.w[k]);
+    m->nwrapitem = (int)wraps.size();
+  }
+  // Tendon Jacobian by ENTRY (see Engine::tendon): every sparse-J entry (tendon, dof) gets the list of path segments that cross
+  // its dof, one 8-word row per segment: S a site-site segment; a wrap item contributes its unwrapped segment A (site - site)
+  // or, when the tendon touches the geom, B (site - tangent point) and / or C (tangent point - site): rows A_OR_B, A_OR_C (the
+  // usual case: the dof lies between one site's body and the geom's body), B_ONLY, C_ONLY, A_ONLY; J a fixed-tendon coefficient;
+  // NONE pads an entry nothing crosses.  Row: [entry | joint word << 16, site0 | site1 << 16, body0 | body1 << 8 | mode << 16 |
+  // ep_unwrapped << 20 | ep_wrapped << 21, wrap slot, bits(1/divisor or coef), 0, 0, 0]; joint word = joint id | 1 (hinge) or
+  // 2 (slide) << 8 -- the kernel reads anchor / axis straight from the joint -- or dof id for ball / free dofs (via cdof).
+  // jent[i] = first row | rows << 24 of the i-th entry in processing order.
+  std::vector<int32_t> jent, jrow;
+  {
+    enum { R_S = 0, R_AB = 1, R_AC = 2, R_B = 3, R_C = 4, R_A = 5, R_J = 6, R_NONE = 7 };
+    struct Rec { int32_t sites, bm, wi, f2; };
+    std::vector<std::vector<Rec>> per_ent((size_t)d.ntenJ);
+    const int nit = (int)item_tab.size() / 8;
+    for (int ii = 0; ii < nit && seg_ok; ii++) {
+      const int32_t* I = &item_tab[8 * (size_t)ii];
+      const int t = I[0], kind = I[1], k0 = I[2];
+      if (kind == 3) {
+        const int32_t* jdof = (const int32_t*)(blob + m->sec[MM_SEC_JNT_DOFADR]);
+        const int dof = jdof[I[3]];
+        int ent = -1;
+        for (int e = tj_adr[t]; e < tj_adr[t + 1]; e++) if (tj_dof[e] == dof) ent = e;
+        if (ent < 0) { seg_ok = false; break; }
+        per_ent[ent].push_back(Rec{0, R_J << 16, 0, I[4]});
+        continue;
+      }
+      if (I[3] >= 65536 || I[4] >= 65536 || sbody[I[3]] >= 256 || sbody[I[4]] >= 256) { seg_ok = false; break; }
+      const int32_t sites = I[3] | (I[4] << 16), bodies = sbody[I[3]] | (sbody[I[4]] << 8);
+      if (kind == 0) {
+        for (const Cross& c : crossings(t, elem_body(k0), elem_body(k0 + 1)))
+          per_ent[c.ent].push_back(Rec{sites, bodies | (R_S << 16) | (c.ep << 20), 0, I[7]});
+        continue;
+      }
+      const int b0 = elem_body(k0), b1 = elem_body(k0 + 1), b2 = elem_body(k0 + 2);
+      std::vector<Cross> ca = crossings(t, b0, b2), cb = crossings(t, b0, b1), cc = crossings(t, b1, b2);
+      auto take = [](std::vector<Cross>& v, int ent, int& ep) {
+        for (size_t k = 0; k < v.size(); k++) if (v[k].ent == ent) { ep = v[k].ep; v.erase(v.begin() + k); return true; }
+        return false;
+      };
+      for (const Cross& a_ : ca) {
+        int epw = 0;
+        if (take(cb, a_.ent, epw)) per_ent[a_.ent].push_back(Rec{sites, bodies | (R_AB << 16) | (a_.ep << 20) | (epw << 21), ii, I[7]});
+        else if (take(cc, a_.ent, epw)) per_ent[a_.ent].push_back(Rec{sites, bodies | (R_AC << 16) | (a_.ep << 20) | (epw << 21), ii, I[7]});
+        else per_ent[a_.ent].push_back(Rec{sites, bodies | (R_A << 16) | (a_.ep << 20), ii, I[7]});
+      }
+      for (const Cross& b_ : cb) per_ent[b_.ent].push_back(Rec{sites, bodies | (R_B << 16) | (b_.ep << 21), ii, I[7]});
+      for (const Cross& c_ : cc) per_ent[c_.ent].push_back(Rec{sites, bodies | (R_C << 16) | (c_.ep << 21), ii, I[7]});
+    }
+    if (!seg_ok) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian pattern in the blob does not cover a path segment"); }
+    // entries with the most rows first, then by the flavour of their first row: a sweep of lanes runs alike
+    std::vector<int> order((size_t)d.ntenJ);
+    for (int e = 0; e < d.ntenJ; e++) { order[e] = e; if (per_ent[e].empty()) per_ent[e].push_back(Rec{0, R_NONE << 16, 0, 0}); }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      if (per_ent[x].size() != per_ent[y].size()) return per_ent[x].size() > per_ent[y].size();
+      return ((per_ent[x][0].bm >> 16) & 15) > ((per_ent[y][0].bm >> 16) & 15);
+    });
+    const int32_t* dofjnt = (const int32_t*)(blob + m->sec[MM_SEC_DOF_JNTID]);
+    const int32_t* jtype = (const int32_t*)(blob + m->sec[MM_SEC_JNT_TYPE]);
+    for (int e : order) {
+      const int dof = tj_dof[e], j = dofjnt[dof], ty = jtype[j];
+      const bool direct = (ty == MM_JNT_HINGE || ty == MM_JNT_SLIDE) && j < 256;
+      if ((!direct && dof >= 256) || e >= 65536 || per_ent[e].size() > 127 || jrow.size() / 8 >= (1u << 24)) {
+        delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian beyond the engine's table limits");
+      }
+      const int32_t jw = (direct ? j : dof) | ((direct ? (ty == MM_JNT_HINGE ? 1 : 2) : 0) << 8);
+      jent.push_back((int32_t)(jrow.size() / 8) | ((int32_t)per_ent[e].size() << 24));
+      for (const Rec& r : per_ent[e]) {
+        const int32_t row[8] = {e | (jw << 16), r.sites, r.bm, r.wi, r.f2, 0, 0, 0};
+        for (int k = 0; k < 8; k++) jrow.push_back(row[k]);
+      }
+    }
+    while (jrow.size() % 4) jrow.push_back(0);
   }
 
   std::vector<uint32_t> dev(m->h_blob);
@@ -558,22 +607,9 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->x.body_depth = append(depth); m->x.body_rootslot = append(rootslot); m->x.dof_rootslot = append(dofslot);
   m->x.dofj_adr = append(dj_adr); m->x.dofj_entry = append(dj_entry); m->x.dofj_tendon = append(dj_tendon);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
-  m->x.sega_adr = append(sega); m->x.segb_adr = append(segb); m->x.segc_adr = append(segc);
-  {
-    // hinge / slide dofs (the only kinds a tendon of these models crosses, but ball / free are handled): the word carries the
-    // JOINT id and its type instead of the dof, so that the kernel reads anchor / axis without a second table
-    const int32_t* dofjnt = (const int32_t*)(blob + m->sec[MM_SEC_DOF_JNTID]);
-    const int32_t* jtype = (const int32_t*)(blob + m->sec[MM_SEC_JNT_TYPE]);
-    for (size_t k = 0; k < seg_list.size(); k++) {
-      const int w = seg_list[k], dof = w & 0xff, ep = (w >> 8) & 1, ent = w >> 9;
-      const int j = dofjnt[dof], ty = jtype[j];
-      const bool direct = (ty == MM_JNT_HINGE || ty == MM_JNT_SLIDE) && j < 256;
-      if (ent >= (1 << 20)) seg_ok = false;
-      seg_list[k] = (direct ? j : dof) | (ep << 8) | ((direct ? (ty == MM_JNT_HINGE ? 1 : 2) : 0) << 9) | (ent << 11);
-    }
-    if (!seg_ok) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian has more than 2^20 entries"); }
-  }
-  m->x.seg_list = append(seg_list);
+  m->x.jent = append(jent);
+  while (dev.size() % 4) dev.push_back(0u);   // 16-byte rows
+  m->x.jrec = append(jrow);
   m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
   {
     const int32_t* dpar = (const int32_t*)(blob + m->sec[MM_SEC_DOF_PARENTID]);
@@ -763,6 +799,7 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   if (want > 8) want = 8;
   int lm = m->lds_model ? 1 : 0;
   if (m->lds_model == 1 && fit_waves(blob_bytes) < want && fit_waves(0) > fit_waves(blob_bytes)) lm = 0;
+  if (m->lds_model == 1 && blob_bytes + (size_t)epw * m->lds_per_env > kLds) lm = 0;   // not even one wave fits next to the model copy
   const size_t model_bytes = lm ? blob_bytes : 0;
   int wpb = m->waves_per_block;
   if (wpb <= 0) {

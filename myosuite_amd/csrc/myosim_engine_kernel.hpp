@@ -83,6 +83,7 @@ struct Layout {
   int u1;   // union: xquat[4nb] during FK | (cvel,cacc)[12nb] then cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
+  int wrapw;   // per wrapping path item: the two tangent points and a wrapped flag (7 words)
   int vec;  // nv: joint-transmission actuator forces
   int xvec; // NVP (16-byte aligned): operand vector of M x products routed through LDS
   int rk_qpos0, rk_act0, rk_adot;   // RK4: state at the start of the step, weighted act_dot sum (RK4 models only)
@@ -102,7 +103,7 @@ struct Aux {
   int body_depth, body_rootslot, dof_rootslot;
   int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
   int root_list, nroot;
-  int sega_adr, segb_adr, segc_adr, seg_list;   // per path element: dof lists of the straight segments
+  int jent, jrec;        // tendon Jacobian by entry: [ntenJ][4] {entry, joint word, first record, records}, records [..][4] (host: mm_model_create)
   int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
   int dof_rel;           // per dof: 64-bit mask (2 words) of the dofs on its kinematic chain (ancestors, descendants, itself)
   int body_dofmask;      // per body: 64-bit mask (2 words) of the dofs between the body and the root of its tree (its chain)
@@ -955,78 +956,50 @@ struct Engine {
   }
 
   // ---------------------------------------------------------------- A2 tendons
-  // add the contributions of one straight segment (point p0 -> p1, unit direction u) to the sparse J row
-  // seg_list word: [7:0] joint id (hinge / slide) or dof (ball / free), [8] endpoint, [10:9] 1 hinge / 2 slide / 0 via cdof, [31:11] J entry
-  // Path items are flattened over ALL tendons on the host (Aux.item_tab, 8 words each:
-  // {tendon, kind, k0, site0, site1, geom, sidesite, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site,
-  // 2 = site-cylinder-site, 3 = fixed-tendon joint term) and sorted so that the expensive wrap items come first: a sweep
-  // of G lanes then executes one kind of item, instead of every lane walking its own tendon with divergent item kinds.
-  // Lengths and Jacobian entries are accumulated with LDS float atomics (one wave: deterministic lane order).
-  // Word offsets the item sweep needs (LDS table bases, model sections, engine tables), read ONCE and pinned in SGPRs for the
+  // Two sweeps.  (1) Path items, flattened over ALL tendons on the host (Aux.item_tab, 8 words each: {tendon, kind, k0, site0,
+  // site1, geom, sidesite, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site, 2 = site-cylinder-site, 3 = fixed-tendon
+  // joint term) and sorted so that the expensive wrap items come first (a sweep of G lanes then executes one kind of item
+  // instead of every lane walking its own tendon): lengths, and for wrap items the two tangent points + a wrapped flag into LDS.
+  // (2) Jacobian entries, one lane per sparse-J entry (Aux.jent / jrec): the lane recomputes the end points of the segment(s)
+  // that cross its dof and stores the entry.  The Jacobian used to be scattered from sweep (1) with LDS float atomics, a
+  // data-dependent loop over each segment's dofs that ran to the longest list of the wave with two dependent LDS round trips
+  // per turn: half of the stage.
+  // Word offsets the sweeps need (LDS table bases, model sections, engine tables), read ONCE and pinned in SGPRs for the
   // duration of the stage: left to itself the compiler rematerialises each of them with an s_load + s_waitcnt lgkmcnt(0)
-  // inside the item / segment loops (the wait also drains the LDS queue), which made the Jacobian scatter 55 % of this stage.
+  // inside the loops (the wait also drains the LDS queue).
   struct TendonOff {
-    int xpos, xmat, tenlen, tenj, xaxis, xanchor, com, cdof, qpos;
-    int site_body, site_pos, geom_body, geom_pos, geom_quat, geom_size, seg_list, rootslot;
+    int xpos, xmat, tenlen, tenj, xaxis, xanchor, com, cdof, qpos, wrapw;
+    int site_body, site_pos, geom_body, geom_pos, geom_quat, geom_size, rootslot;
   };
   __device__ __forceinline__ V3 site_pos_o(const TendonOff& o, int s_) const {
     const int b = reinterpret_cast<const int*>(mb + o.site_body)[s_];
     return ld3(W + o.xpos + 3 * b) + mv(ldm(W + o.xmat + 9 * b), ld3(reinterpret_cast<const float*>(mb + o.site_pos) + 3 * s_));
-  }
-  __device__ __forceinline__ void tenj_segment_o(const TendonOff& o, int l0, int l1, V3 p0, V3 p1, V3 u) {
-    const int* lst = reinterpret_cast<const int*>(mb + o.seg_list);
-    for (int e = l0; e < l1; e++) {
-      const int w = lst[e];
-      const int id = w & 0xff, ep = (w >> 8) & 1, kind = (w >> 9) & 3, ent = w >> 11;
-      const V3 p = ep ? p1 : p0;
-      float val;
-      if (kind != 0) {
-        // hinge: moment arm straight from the joint, u . (axis x (p - anchor)); slide: u . axis.  (Going through cdof -- motion
-        // about the subtree COM -- adds and subtracts the COM offset: ~0.2 m against a 5 mm moment arm in the hand.)
-        const V3 ax = ld3(W + o.xaxis + 3 * id), an = ld3(W + o.xanchor + 3 * id);
-        const V3 c = cross(ax, p - an);
-        val = kind == 1 ? dot(u, c) : dot(u, ax);
-      } else {   // ball / free dofs: motion axes about the subtree COM
-        V3 off = p - ld3(W + o.com + 3 * reinterpret_cast<const int*>(mb + o.rootslot)[id]);
-        V3 ang = ld3(W + o.cdof + 6 * id), lin = ld3(W + o.cdof + 6 * id + 3);
-        val = dot(u, lin + cross(ang, off));
-      }
-      atomicAdd(&W[o.tenj + ent], ep ? val : -val);
-    }
   }
 
   __device__ __forceinline__ void tendon() {
     const auto& L = KL();
     TendonOff o;
     o.xpos = L.xpos; o.xmat = L.xmat; o.tenlen = L.tenlen; o.tenj = L.tenj; o.xaxis = L.xaxis; o.xanchor = L.xanchor;
-    o.com = L.com; o.cdof = L.cdof; o.qpos = L.qpos;
+    o.com = L.com; o.cdof = L.cdof; o.qpos = L.qpos; o.wrapw = L.wrapw;
     o.site_body = SECOFF_(SITE_BODYID); o.site_pos = SECOFF_(SITE_POS); o.geom_body = SECOFF_(GEOM_BODYID);
     o.geom_pos = SECOFF_(GEOM_POS); o.geom_quat = SECOFF_(GEOM_QUAT); o.geom_size = SECOFF_(GEOM_SIZE);
-    o.seg_list = KX().seg_list; o.rootslot = KX().dof_rootslot;
-    int o_sa = KX().sega_adr, o_sb = KX().segb_adr, o_sc = KX().segc_adr, o_items = KX().item_tab, nitem = KX().nitem;
+    o.rootslot = KX().dof_rootslot;
+    int o_items = KX().item_tab, nitem = KX().nitem, o_jent = KX().jent, o_jrec = KX().jrec, d_ntenJ = KD().ntenJ;
     PIN_S(o.xpos); PIN_S(o.xmat); PIN_S(o.tenlen); PIN_S(o.tenj); PIN_S(o.xaxis); PIN_S(o.xanchor); PIN_S(o.site_body);
-    PIN_S(o.site_pos); PIN_S(o.seg_list); PIN_S(o_sa); PIN_S(o_sb); PIN_S(o_sc); PIN_S(o_items); PIN_S(nitem);
-    const int *sa = reinterpret_cast<const int*>(mb + o_sa), *sb = reinterpret_cast<const int*>(mb + o_sb),
-              *sc = reinterpret_cast<const int*>(mb + o_sc);
+    PIN_S(o.site_pos); PIN_S(o.wrapw); PIN_S(o_items); PIN_S(nitem); PIN_S(o_jent); PIN_S(o_jrec); PIN_S(d_ntenJ);
     const int* items = reinterpret_cast<const int*>(mb + o_items);
-    for (int e = g; e < KD().ntenJ; e += G) W[o.tenj + e] = 0.f;
     for (int t = g; t < KD().ntendon; t += G) W[o.tenlen + t] = 0.f;
     GSYNC();
     for (int it = g; it < nitem; it += G) {
       const int* I = items + 8 * it;
-      const int t = I[0], kind = I[1], k0 = I[2];
+      const int t = I[0], kind = I[1];
       const float inv_div = __int_as_float(I[7]);
       if (kind == 3) {   // fixed tendon: coef * q_joint
         const int jn = I[3];
         const float coef = __int_as_float(I[4]);
         atomicAdd(&W[o.tenlen + t], coef * W[o.qpos + MI_(JNT_QPOSADR)[jn]]);
-        const int dof = MI_(JNT_DOFADR)[jn];
-        for (int e = MI_(TENJ_ADR)[t]; e < MI_(TENJ_ADR)[t + 1]; e++)
-          if (MI_(TENJ_DOF)[e] == dof) { atomicAdd(&W[o.tenj + e], coef); break; }
         continue;
       }
-      // dof-list ranges of the item's segments, requested together with the sites
-      const int sa0 = sa[k0], sa1 = sa[k0 + 1], sb0 = sb[k0], sb1 = sb[k0 + 1], sc0 = sc[k0], sc1 = sc[k0 + 1];
       V3 p0 = site_pos_o(o, I[3]), p1 = site_pos_o(o, I[4]);
       float wlen = -1.f;
       V3 w0, w1;
@@ -1043,24 +1016,63 @@ struct Engine {
 #pragma unroll
           for (int j = 0; j < 3; j++) R.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
         wlen = wrap_geom(w0, w1, p0, p1, gp, R, reinterpret_cast<const float*>(mb + o.geom_size)[3 * gi], kind == 2, sideid >= 0, side);
+        float* ws = W + o.wrapw + 7 * it;
+        if (wlen >= 0.f) { st3(ws, w0); st3(ws + 3, w1); }
+        ws[6] = wlen < 0.f ? 0.f : 1.f;
       }
       if (wlen < 0.f) {
         V3 dif = p1 - p0;
-        float n = sqrtf(dot(dif, dif));
-        atomicAdd(&W[o.tenlen + t], n * inv_div);
-        if (sa1 > sa0) {
-          V3 u = n < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n) * dif;
-          tenj_segment_o(o, sa0, sa1, p0, p1, u);
-        }
+        atomicAdd(&W[o.tenlen + t], sqrtf(dot(dif, dif)) * inv_div);
       } else {
         V3 d0 = w0 - p0, d1 = p1 - w1;
         float n0 = sqrtf(dot(d0, d0)), n1 = sqrtf(dot(d1, d1));
         atomicAdd(&W[o.tenlen + t], (n0 + wlen + n1) * inv_div);
-        if (sb1 > sb0)
-          tenj_segment_o(o, sb0, sb1, p0, w0, n0 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n0) * d0);
-        if (sc1 > sc0)
-          tenj_segment_o(o, sc0, sc1, w1, p1, n1 < MINVALF ? v3(inv_div, 0.f, 0.f) : (inv_div / n1) * d1);
       }
+    }
+    GSYNC();
+    const int* jent = reinterpret_cast<const int*>(mb + o_jent);
+    const int4* jrow = reinterpret_cast<const int4*>(mb + o_jrec);
+    int jn = g < d_ntenJ ? jent[g] : 0;
+    for (int i = g; i < d_ntenJ; i += G) {
+      const int r0 = jn & 0xffffff, nr = (jn >> 24) & 127;
+      if (i + G < d_ntenJ) jn = jent[i + G];   // next sweep's row index: off this sweep's dependency chain
+      float acc = 0.f;
+      int e = 0;
+      for (int r = r0; r < r0 + nr; r++) {
+        // one row, then every load it addresses at once (both sites, both tangent points, the joint): two round trips per row
+        const int4 ra = jrow[2 * r];
+        const float f2 = __int_as_float(reinterpret_cast<const int*>(jrow + 2 * r + 1)[0]);
+        e = ra.x & 0xffff;
+        const int jw = ra.x >> 16, id = jw & 0xff, jk = (jw >> 8) & 3;
+        const int mode = (ra.z >> 16) & 15;
+        const int s0 = ra.y & 0xffff, s1 = (ra.y >> 16) & 0xffff, b0 = ra.z & 0xff, b1 = (ra.z >> 8) & 0xff;
+        const float* ws = W + o.wrapw + 7 * ra.w;
+        const float wflag = ws[6];
+        const V3 t0 = ld3(ws), t1 = ld3(ws + 3);
+        const V3 q0 = ld3(W + o.xpos + 3 * b0) + mv(ldm(W + o.xmat + 9 * b0), ld3(reinterpret_cast<const float*>(mb + o.site_pos) + 3 * s0));
+        const V3 q1 = ld3(W + o.xpos + 3 * b1) + mv(ldm(W + o.xmat + 9 * b1), ld3(reinterpret_cast<const float*>(mb + o.site_pos) + 3 * s1));
+        // hinge: moment arm straight from the joint, u . (axis x (p - anchor)); slide: u . axis.  (Going through cdof -- motion
+        // about the subtree COM -- adds and subtracts the COM offset: ~0.2 m against a 5 mm moment arm in the hand.)
+        V3 ax, an, lin = v3(0.f, 0.f, 0.f);
+        if (jk != 0) { ax = ld3(W + o.xaxis + 3 * id); an = ld3(W + o.xanchor + 3 * id); }
+        else {   // ball / free dofs: motion axes about the subtree COM
+          ax = ld3(W + o.cdof + 6 * id); lin = ld3(W + o.cdof + 6 * id + 3);
+          an = ld3(W + o.com + 3 * reinterpret_cast<const int*>(mb + o.rootslot)[id]);
+        }
+        if (mode >= 6) { acc += mode == 6 ? f2 : 0.f; continue; }   // fixed tendon: the coefficient / nothing crosses the dof
+        const bool wrapped = mode != 0 && wflag != 0.f;
+        if (mode == 5 ? wrapped : (mode >= 3 && !wrapped)) continue;     // A only / B only, C only
+        const bool tb = wrapped && (mode == 1 || mode == 3), tc = wrapped && (mode == 2 || mode == 4);
+        const int ep = (ra.z >> (wrapped ? 21 : 20)) & 1;
+        const V3 p0 = tc ? t1 : q0, p1 = tb ? t0 : q1;
+        const V3 dif = p1 - p0;
+        const float n = sqrtf(dot(dif, dif));
+        const V3 u = n < MINVALF ? v3(f2, 0.f, 0.f) : (f2 / n) * dif;
+        const V3 p = ep ? p1 : p0;
+        const float val = jk == 2 ? dot(u, ax) : dot(u, lin + cross(ax, p - an));
+        acc += ep ? val : -val;
+      }
+      W[o.tenj + e] = acc;
     }
     GSYNC();
   }

@@ -15,7 +15,7 @@ def comp(src):
     if only and not any(o in base for o in only.split(",")):
         return os.path.join(E.CSRC, "_build", base + ".o")
     sched = E.SCHED_STRATEGY.get(os.path.basename(src), E.SCHED_STRATEGY["default"])
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + E.EXTRA_FLAGS + flags + \
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + E.EXTRA_FLAGS + E.FILE_FLAGS.get(os.path.basename(src), []) + flags + \
           (["-mllvm", f"-amdgpu-sched-strategy={sched}"] if "inst" in base else []) + ["-c", "-o", obj, src]
     subprocess.check_call(cmd)
     return obj

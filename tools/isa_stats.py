@@ -22,7 +22,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def device_object(src, out):
     base = os.path.basename(src)
     sched = E.SCHED_STRATEGY.get(base, E.SCHED_STRATEGY["default"])
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output"] + E.EXTRA_FLAGS + \
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output"] + E.EXTRA_FLAGS + E.FILE_FLAGS.get(base, []) + \
           ["-mllvm", f"-amdgpu-sched-strategy={sched}", "-c", "-o", out, src]
     subprocess.check_call(cmd)
 
