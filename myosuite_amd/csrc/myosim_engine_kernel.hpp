@@ -629,6 +629,10 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
   return dctrl / fmaxf(MINVALF, tau);
 }
 
+#ifndef MM_STAGE_PROF
+#define MM_STAGE_PROF 0   /* 1: in-kernel stage timers (mm_debug_set_prof); a tools build (tools/build_variant.py prof -DMM_STAGE_PROF=1): \
+                             the 26 SGPRs of the timer array and the clock reads cost the product kernels 1-2 % */
+#endif
 #ifndef MM_SPARSE_LDL
 #define MM_SPARSE_LDL 1   /* 0: dense register Cholesky in every kernel (A/B switch) */
 #endif
@@ -645,7 +649,7 @@ struct Engine {
   const KArgs& a;
   const KConst& kc;    // model constants of the launch (see MM_CONST_IN_REGS)
   const uint32_t* mb;  // model words (LDS-resident copy or global)
-  unsigned long long pf[NPROF];
+  unsigned long long pf[MM_STAGE_PROF ? NPROF : 1];
   float* W;     // LDS tables of this env
   const int g;  // lane within group == owned body / dof index
   int status;   // sticky status bits (group-uniform)
@@ -696,7 +700,7 @@ struct Engine {
   __device__ __forceinline__ Engine(const KArgs& a_, const KConst& kc_, const uint32_t* mb_, float* W_, int g_)
       : a(a_), kc(kc_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
 #pragma unroll
-    for (int i = 0; i < NPROF; i++) pf[i] = 0;
+    for (int i = 0; i < (MM_STAGE_PROF ? NPROF : 1); i++) pf[i] = 0;
     d_warm = 0.f; d_qvel = 0.f;
     b_depth = (g < KD().nbody) ? AUXI(body_depth)[g] : -1;
     b_parent = (g > 0 && g < KD().nbody) ? MI_(BODY_PARENT)[g] : 0;
@@ -1818,9 +1822,6 @@ struct Engine {
     d_qfrccon = 0.f;
     if (nefc == 0) { d_qacc = d_qaccsm; return; }
     const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
-#ifdef MM_PROF_NEWTON
-    unsigned long long tp0 = clock64();
-#endif
     // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_of(d_warm, Ma_ws);
@@ -1834,13 +1835,7 @@ struct Engine {
     // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull;
-#ifdef MM_PROF_NEWTON
-    pf[PF_KIN] += clock64() - tp0;
-#endif
     for (int iter = 0; iter < KD().iterations; iter++) {
-#ifdef MM_PROF_NEWTON
-      unsigned long long tg0 = clock64();
-#endif
       const bool on = r_active && r_jar < 0.f;
       const unsigned long long set_now = __ballot(on);
       float f = on ? -r_D * r_jar : 0.f;
@@ -1856,14 +1851,7 @@ struct Engine {
       }
       set_prev = set_now;
       float dadd = rows_to_dof(on ? r_D : 0.f);
-#ifdef MM_PROF_NEWTON
-      unsigned long long tq0 = clock64();
-      pf[PF_TENDON] += tq0 - tg0;
-#endif
       float search = -factor_solve(dadd, grad);
-#ifdef MM_PROF_NEWTON
-      pf[PF_FACTOR] += clock64() - tq0;
-#endif
       if (g >= nv) search = 0.f;
       float sn = sqrtf(gsum<G>(search * search));
       if (sn < MINVALF) break;
@@ -1878,13 +1866,7 @@ struct Engine {
       const float gtol = KD().tolerance * KD().ls_tolerance * sn / scale;
       // exact line search on the convex piecewise-quadratic phi(alpha): safeguarded Newton on phi'(alpha) = 0
       float alpha = 1.f, lo = 0.f, hi = -1.f;
-#ifdef MM_PROF_NEWTON
-      unsigned long long tq1 = clock64();
-#endif
       for (int it = 0; it < KD().ls_iterations; it++) {
-#ifdef MM_PROF_NEWTON
-        pf[PF_COM] += 1000;
-#endif
         float x = r_jar + alpha * jv;
         float d1 = 0.f, d2 = 0.f;
         if (r_active && x < 0.f) { d1 = r_D * x * jv; d2 = r_D * jv * jv; }
@@ -1898,9 +1880,6 @@ struct Engine {
         if (next == alpha) break;
         alpha = next;
       }
-#ifdef MM_PROF_NEWTON
-      pf[PF_IO] += clock64() - tq1;
-#endif
       if (!(alpha > 0.f)) break;
       d_qacc += alpha * search; Ma += alpha * Mv; r_jar += alpha * jv;
       alpha_prev = alpha;
@@ -2063,7 +2042,7 @@ struct Engine {
       }
     }
     // ---- contacts: lane p handles explicit pair p (up to two contacts for plane-capsule)
-    const unsigned long long tc0_ = a.prof ? clock64() : 0;
+    const unsigned long long tc0_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
     int nc = 0, rowsper = 0, b1 = 0, b2 = 0;
     float cdist[2] = {0.f, 0.f}, mu = 0.f, incl = 0.f;
     V3 cpos[2], cn[2];
@@ -2132,7 +2111,7 @@ struct Engine {
         }
       }
     }
-    if (a.prof) pf[PF_IO] += clock64() - tc0_;   // narrow phase only (reported as 'io' = collide)
+    if (MM_STAGE_PROF && a.prof) pf[MM_STAGE_PROF ? PF_IO : 0] += clock64() - tc0_;   // narrow phase only (reported as 'io' = collide)
     int myrows = 0;
     for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
     int base = neq + nfr + nlim + ntl + gscan_excl(myrows);
@@ -2437,9 +2416,9 @@ struct Engine {
   // ------------------------------------------------------------------ pipeline
 #define PFT(stage, call)                                   \
   do {                                                     \
-    unsigned long long t0_ = a.prof ? clock64() : 0;       \
+    unsigned long long t0_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;       \
     call;                                                  \
-    if (a.prof) pf[stage] += clock64() - t0_;              \
+    if (MM_STAGE_PROF && a.prof) pf[MM_STAGE_PROF ? stage : 0] += clock64() - t0_;              \
   } while (0)
   __device__ __forceinline__ void forward() {
     PFT(PF_KIN, kinematics());
@@ -2709,7 +2688,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wpb = blockDim.x >> 6;
   const int g = lane % G;
-  unsigned long long t_start = a.prof ? clock64() : 0;
+  unsigned long long t_start = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
   // reset-observation pass (mm_task.obs_only with an env mask): a block none of whose envs is flagged leaves before the model
   // is staged -- every wave scans the block's whole env range, so the decision is block-uniform and nobody is left waiting at
   // the barrier (the pass is launched after every step of the non-Pose tasks and usually has nothing to do)
@@ -2881,10 +2860,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     if (g == 0) D[a.D.scal] = (float)E.niter;
     if (g < 15) { D[a.D.scal + 1 + g] = E.r_jar; D[a.D.scal + 16 + g] = E.r_floss; }   // rows of small test models
   }
-  if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
-    E.pf[PF_TOTAL] = clock64() - t_start;
+  if (MM_STAGE_PROF && a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
+    E.pf[MM_STAGE_PROF ? PF_TOTAL : 0] = clock64() - t_start;
 #pragma unroll
-    for (int i = 0; i < NPROF; i++) a.prof[i] = E.pf[i];
+    for (int i = 0; i < (MM_STAGE_PROF ? NPROF : 1); i++) a.prof[i] = E.pf[i];
   }
 
   // ---- task stage: obs_dict / reward_dict (pose_v0.py:100-140), TimeLimit counter
