@@ -920,6 +920,39 @@ def make_tendon_limit_toy() -> ModelSpec:
     return s
 
 
+def make_tree_toy(kind: str = "star") -> ModelSpec:
+    """Limit-rows-only test models of different dof-tree shapes (hinges with ranges, damping, armature, one motor per joint; no
+    contacts, tendons or equalities), for the three routes of the engine's factorisation: ``star`` -- a 2-dof stem carrying three
+    equal 2-dof branches (regular segment tree: the tree-sparse L'DL kernels), ``chain`` -- a 10-link pendulum (deeper than the
+    sparse kernels' eight levels: general-row kernels, dense Cholesky), ``comb`` -- branches of unequal length (segment levels
+    that are not alike: general-row kernels).  Not reference assets."""
+    s = ModelSpec(f"tree_toy_{kind}", timestep=0.002)
+    n = [0]
+
+    def link(parent, axis, length, pos):
+        i = n[0]; n[0] += 1
+        s.add_body(f"b{i}", parent, pos=pos, mass=0.3 + 0.05 * (i % 3), ipos=(0, 0, -0.5 * length),
+                   inertia=(0.3 * length * length / 12 + 1e-4, 0.3 * length * length / 12 + 1e-4, 2e-4))
+        s.add_joint(f"j{i}", f"b{i}", "hinge", axis=axis, range=(-0.9 + 0.1 * (i % 4), 0.8), damping=0.05 + 0.01 * i, armature=0.002)
+        s.add_motor(f"m{i}", f"j{i}", gear=1.0 + 0.2 * (i % 5), ctrlrange=(-1.0, 1.0))
+        return f"b{i}"
+
+    ax = ((1, 0, 0), (0, 1, 0), (0.6, 0.8, 0))
+    if kind == "chain":
+        p = "world"
+        for i in range(10):
+            p = link(p, ax[i % 3], 0.12, (0, 0, 1.5) if i == 0 else (0, 0, -0.12))
+        return s
+    p = link("world", ax[0], 0.2, (0, 0, 1.0))
+    p = link(p, ax[1], 0.2, (0, 0, -0.2))
+    lengths = (2, 2, 2) if kind == "star" else (1, 2, 3)
+    for k, m in enumerate(lengths):
+        q = p
+        for i in range(m):
+            q = link(q, ax[(k + i) % 3], 0.15, (0.08 * (k - 1), 0, -0.2) if i == 0 else (0, 0, -0.15))
+    return s
+
+
 def make_friction_toy() -> ModelSpec:
     """Two-link arm with dry joint friction (``frictionloss``), limits, damping and torque motors, plus a slider coupled to the
     elbow by a joint equality.  Test model for the friction-loss constraint rows (Huber cost); not a reference asset."""
@@ -979,7 +1012,9 @@ def builders() -> dict:
             "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
             "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
             "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True),
-            "leg_implicit": lambda: make_leg(implicit=True), "torso_exo": lambda: make_torso(exosuit=True)}
+            "leg_implicit": lambda: make_leg(implicit=True), "torso_exo": lambda: make_torso(exosuit=True),
+            "tree_star": lambda: make_tree_toy("star"), "tree_chain": lambda: make_tree_toy("chain"),
+            "tree_comb": lambda: make_tree_toy("comb")}
 
 
 def compile_spec(name: str, edit=None) -> CompiledModel:

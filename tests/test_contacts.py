@@ -328,3 +328,46 @@ def test_self_colliding_hand_gpu_matches_oracle(oracle_lib):
     for s in range(30):
         obs, rwd, mask = big.rollout_step(None, stream_id=s)
     assert bool(torch.isfinite(obs).all()) and int((big.state.status & 0xA).max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,family", [("star", 1), ("chain", 2), ("comb", 2)])
+def test_dof_tree_shapes_route_and_match_oracle(oracle_lib, kind, family):
+    """tree_toy models (limit rows only; dof trees of different shapes): the regular tree takes the tree-sparse L'DL kernels
+    (one lane per segment of the dof tree), the 10-deep chain and the irregular tree the general-row kernels with the dense
+    Cholesky -- and all three agree with the oracle, stage by stage (M, qacc_smooth, qacc) and over a free run with joint
+    limits coming and going."""
+    import torch
+    from myosuite_amd import engine as E
+    cm = synth.get_model(f"tree_{kind}")
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    assert hm.info(E.INFO_KERNEL_FAMILY) == family
+    n = 24
+    rng = np.random.default_rng(8)
+    q = rng.uniform(-0.9, 0.8, (n, cm.nq)); v = rng.standard_normal((n, cm.nv)) * 1.5
+    st = E.BatchState(hm, n)
+    ds = [O.OracleData(om) for _ in range(n)]
+    worst, rows = 0.0, set()
+    for k in range(50):
+        ctrl = rng.uniform(-1, 1, (n, cm.nu)).astype(np.float32)
+        st.qpos.copy_(torch.from_numpy(q.astype(np.float32))); st.qvel.copy_(torch.from_numpy(v.astype(np.float32)))
+        c = torch.from_numpy(ctrl).cuda()
+        if k % 10 == 0:
+            dump = E.debug_dump(hm, st, c).cpu().numpy().astype(np.float64)
+        E.step(hm, st, c, 1)
+        vg = st.qvel.cpu().numpy().astype(np.float64)
+        for e, d in enumerate(ds):
+            d.qpos[:] = q[e].astype(np.float32); d.qvel[:] = v[e].astype(np.float32); d.ctrl[:] = ctrl[e]
+            if k % 10 == 0:
+                d.forward()
+                M = dump[e, hm.layout("M"):hm.layout("M") + cm.nv * cm.nv].reshape(cm.nv, cm.nv)
+                assert np.abs(M - d.full_M()).max() < 2e-5 * np.abs(d.full_M()).max()
+                for nm, ref in (("qaccsm", d.qacc_smooth), ("qacc", d.qacc)):
+                    got = dump[e, hm.layout(nm):hm.layout(nm) + cm.nv]
+                    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), (nm, e)
+            d.step(1)
+            rows.add(d.nefc)
+            worst = max(worst, float(np.abs(vg[e] - d.qvel).max() / max(1.0, np.abs(d.qvel).max())))
+            q[e] = d.qpos; v[e] = d.qvel
+    assert worst < 2e-4, worst
+    assert len(rows) >= 3 and int(st.status.max()) == 0
