@@ -30,7 +30,11 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 # BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288, and the MuJoCo-default leg on the
 # implicitfast integrator) reported next to the headline line
 EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
-                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"})]
+                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
+                 # the step of the reference's own GPU path: mjx_env.step = n_substeps x mjx.step, observation straight from the
+                 # stepped data (envs/myo/mjx/mjx_base_env.py:74-91) -- no trailing mj_forward as in the CPU path
+                 # (robot.py:595-607), whose outputs the Pose observation / reward do not read.  NOT the headline protocol.
+                 ("myoHandPoseRandom-v0", 4096, {"do_forward": False})]
 
 
 def algorithmic_bytes(env) -> int:
