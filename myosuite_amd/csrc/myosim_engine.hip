@@ -1,5 +1,7 @@
 // myosim_engine.hip -- host side of the C ABI (include/myosim.h): model upload, LDS layout, kernel selection / launch,
 // reset and Philox kernels.  The fused physics kernel template is in myosim_engine_kernel.hpp.
+#include <array>
+#include <algorithm>
 #include <atomic>
 #include "myosim_engine_kernel.hpp"
 #include "myosim_inst_list.hpp"
@@ -178,7 +180,7 @@ struct mm_model {
   size_t lds_per_env = 0;
   int device = 0;
   float origin[3] = {0.f, 0.f, 0.f};   // internal world-frame origin (see Dims::ox)
-  std::vector<int32_t> desc_all, seg_tab;   // Aux::dof_desc / dof_seg, built with the dims
+  std::vector<int32_t> desc_all, seg_tab, anc_tab;   // Aux::dof_desc / dof_seg / dof_anc, built with the dims
   int nseg = 0;                             // segments of the dof tree (SP kernels)
   int nwrapitem = 0;                        // tendon path items that wrap a geom (tangent points kept in LDS)
 };
@@ -220,11 +222,12 @@ static void build_layout(mm_model* m) {
   // 12 words (cvel, cacc) + 1 pointer-jumping word per body | dense tile | SP kernels: published rows [nvp][12], x [nvp], update
   // matrices [nseg][36]
   m->d.seg_u = 13 * m->nvp;
-  L.u1 = take(std::max(std::max(13 * d.nbody, m->nvp * m->nvp), m->d.seg_u + 36 * m->nseg));
+  const int u1_words = std::max(std::max(13 * d.nbody, m->nvp * m->nvp), m->d.seg_u + 36 * m->nseg);
+  L.u1 = take(u1_words);
   L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
   L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
-  L.wrapw = take(7 * m->nwrapitem);
+  L.wrapw = (7 * m->nwrapitem <= u1_words) ? L.u1 : take(7 * m->nwrapitem);   // u1 is free between FK and the velocity stage
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
   o = (o + 3) & ~3;
@@ -318,6 +321,10 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     const size_t nvs = (size_t)(d.nv > 0 ? d.nv : 1);
     m->desc_all.assign(nvs * 8, -1);
     m->seg_tab.assign(nvs * 6, -1);
+    for (int i = 0; i < d.nv; i++) m->seg_tab[(size_t)i * 6 + 5] = dep[i];
+    m->anc_tab.assign(nvs * 2, 0);
+    for (int i = 0; i < d.nv && fits; i++)
+      for (int k = dpar[i]; k >= 0; k = dpar[k]) m->anc_tab[(size_t)i * 2 + (dep[k] >> 2)] |= (int32_t)((uint32_t)k << (8 * (dep[k] & 3)));
     d.seg_nlevel = 0; d.seg_lvinfo[0] = d.seg_lvinfo[1] = 0; d.seg_lvtb[0] = d.seg_lvtb[1] = 0; d.seg_zero = 0; d.desc_words = 0; m->nseg = 0;
     if (fits) {
       std::vector<int> ndesc(d.nv, 0);
@@ -348,31 +355,41 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
       }
       if (segs.size() > 255) fits = false;
       if (fits) {
-        int mch[8] = {0}, lt[8], lb[8];
-        for (int l = 0; l < 8; l++) lt[l] = lb[l] = -1;
-        for (size_t si = 0; si < segs.size(); si++) {
+        // elimination steps: the kernel's segment code is scalar in (t, b), so the segments of one step must be alike: a step is
+        // a group (tree level, t, b); children sit at a deeper level, i.e. in a later step, and are eliminated first
+        std::vector<std::array<int, 3>> groups;
+        for (const Seg& sg : segs) {
+          std::array<int, 3> k{sg.level, dep[sg.top], dep[sg.bottom]};
+          if (std::find(groups.begin(), groups.end(), k) == groups.end()) groups.push_back(k);
+        }
+        std::sort(groups.begin(), groups.end());
+        if (groups.size() > 8) fits = false;
+        int mch[8] = {0};
+        for (size_t si = 0; si < segs.size() && fits; si++) {
           const Seg& sg = segs[si];
           const int t = dep[sg.top], b = dep[sg.bottom];
-          d.seg_nlevel = std::max(d.seg_nlevel, sg.level + 1);
-          mch[sg.level] = std::max(mch[sg.level], sg.nch);
-          if (lt[sg.level] < 0) { lt[sg.level] = t; lb[sg.level] = b; }
-          else if (lt[sg.level] != t || lb[sg.level] != b) fits = false;   // the kernel's segment code is scalar in (t, b) per level
+          const int step = (int)(std::find(groups.begin(), groups.end(), std::array<int, 3>{sg.level, t, b}) - groups.begin());
+          mch[step] = std::max(mch[step], sg.nch);
           uint32_t path[2] = {0, 0}, ch[2] = {0xffffffffu, 0xffffffffu};
           for (int k = sg.bottom; k >= 0; k = dpar[k]) path[dep[k] >> 2] |= (uint32_t)k << (8 * (dep[k] & 3));
           for (int c = 0; c < sg.nch; c++) ch[c >> 2] = (ch[c >> 2] & ~(255u << (8 * (c & 3)))) | ((uint32_t)sg.ch[c] << (8 * (c & 3)));
           int32_t* e = &m->seg_tab[(size_t)sg.top * 6];
-          e[0] = t | (b << 4) | (sg.level << 8) | ((int)si << 16);
-          e[1] = (int32_t)path[0]; e[2] = (int32_t)path[1]; e[3] = (int32_t)ch[0]; e[4] = (int32_t)ch[1]; e[5] = 0;
+          e[0] = t | (b << 4) | (step << 8) | ((int)si << 16);
+          e[1] = (int32_t)path[0]; e[2] = (int32_t)path[1]; e[3] = (int32_t)ch[0]; e[4] = (int32_t)ch[1];
         }
         d.seg_lvtb[0] = d.seg_lvtb[1] = 0;
-        for (int l = 0; l < 8; l++) {
-          d.seg_lvinfo[l >> 2] |= mch[l] << (8 * (l & 3));
-          if (lt[l] >= 0) d.seg_lvtb[l >> 2] |= (lt[l] | (lb[l] << 4)) << (8 * (l & 3));
+        if (fits) {
+          d.seg_nlevel = (int)groups.size();
+          for (size_t l = 0; l < groups.size(); l++) {
+            d.seg_lvinfo[l >> 2] |= mch[l] << (8 * (l & 3));
+            d.seg_lvtb[l >> 2] |= (groups[l][1] | (groups[l][2] << 4)) << (8 * (l & 3));
+          }
         }
         m->nseg = (int)segs.size() + 1;   // + the all-zero slot
         d.seg_zero = (int)segs.size();
       }
     }
+    if (!fits) { d.seg_nlevel = 0; m->nseg = 0; }
     if (!d.gen && d.nv > 4 && !fits && d.integrator != MM_INT_IMPLICITFAST) d.gen = 1;
   }
   {
@@ -626,7 +643,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
       for (int i = bdofadr[b]; i >= 0 && i < bdofadr[b] + bdofnum[b]; i++) bm[2 * b + (i >> 5)] |= (int32_t)(1u << (i & 31));
     }
     m->x.body_dofmask = append(bm);
-    m->x.dof_desc = append(m->desc_all); m->x.dof_seg = append(m->seg_tab);
+    m->x.dof_desc = append(m->desc_all); m->x.dof_seg = append(m->seg_tab); m->x.dof_anc = append(m->anc_tab);
   }
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS

@@ -83,7 +83,7 @@ struct Layout {
   int u1;   // union: xquat[4nb] during FK | (cvel,cacc)[12nb] then cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
-  int wrapw;   // per wrapping path item: the two tangent points and a wrapped flag (7 words)
+  int wrapw;   // per wrapping path item: the two tangent points and a wrapped flag (7 words); inside u1 (free between FK and the velocity stage) when it fits
   int vec;  // nv: joint-transmission actuator forces
   int xvec; // NVP (16-byte aligned): operand vector of M x products routed through LDS
   int rk_qpos0, rk_act0, rk_adot;   // RK4: state at the start of the step, weighted act_dot sum (RK4 models only)
@@ -108,7 +108,8 @@ struct Aux {
   int dof_rel;           // per dof: 64-bit mask (2 words) of the dofs on its kinematic chain (ancestors, descendants, itself)
   int body_dofmask;      // per body: 64-bit mask (2 words) of the dofs between the body and the root of its tree (its chain)
   int dof_desc;          // per dof: ids of all its descendants, one byte each, 0xff-padded to 8 words
-  int dof_seg;           // per dof, 6 words: segment owned by the dof's lane (the segment's top dof) or -1; path and child bytes
+  int dof_seg;           // per dof, 6 words: segment owned by the dof's lane (the segment's top dof) or -1; path and child bytes; the dof's depth
+  int dof_anc;           // per dof, 2 words: ids of its ancestor dofs by depth, one byte each
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)
@@ -633,6 +634,10 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 #define MM_STAGE_PROF 0   /* 1: in-kernel stage timers (mm_debug_set_prof); a tools build (tools/build_variant.py prof -DMM_STAGE_PROF=1): \
                              the 26 SGPRs of the timer array and the clock reads cost the product kernels 1-2 % */
 #endif
+#ifndef MM_SPARSE_GEN
+#define MM_SPARSE_GEN 0   /* 1: the general-row kernels use the tree-sparse solve for the two M solves of a pass (solve0, Euler).  Measured: \
+                             the extra live state tips these 256-VGPR kernels into 80 spills; reorient -3 %, self-contact hand -5 % */
+#endif
 #ifndef MM_SPARSE_LDL
 #define MM_SPARSE_LDL 1   /* 0: dense register Cholesky in every kernel (A/B switch) */
 #endif
@@ -640,6 +645,13 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 #define PIN_S(x) asm volatile("" : "+s"(x))   /* keep a wave-uniform value in an SGPR: opaque to rematerialisation (an s_load + s_waitcnt at every use) */
 #define AI_(o) (reinterpret_cast<const int*>(mb + (o)))
 #define AF_(o) (reinterpret_cast<const float*>(mb + (o)))
+// What a lane knows about the dof-tree segment it owns (sp_factor_solve): depth range [t, b] of the segment, its step in the
+// elimination order (-1: the lane owns none), its index (slot of its update matrix), the dof ids on the path root .. bottom by
+// depth, the child segment indices (0xff = none); depth = depth of the lane's own dof (-1: no dof).
+struct SegLane {
+  int t, b, lv, id, depth;
+  unsigned path_lo, path_hi, ch_lo, ch_hi;
+};
 // All member functions are collective over the G lanes of one env group.  NVP = padded nv (compile time).
 // INTEG: 0 semi-implicit Euler (eulerdamp), 1 RK4, 2 implicitfast (compile-time variants: each one's state machine would cost
 // the others registers)
@@ -680,10 +692,7 @@ struct Engine {
   float Ms[SD], Md;
   unsigned anc_lo, anc_hi;   // ancestor dof ids by absolute depth, one byte each: depth 0..3 | 4..6
   int d_depth;               // depth of dof g in the dof tree (0 = no parent dof); -1 on lanes without a dof
-  // segment owned by this lane (lane of the segment's top dof): depth range [sg_t, sg_b], level in the segment tree (-1: none),
-  // index (slot of its update matrix), dof ids on the path root .. bottom by depth, child segment indices (0xff = none)
-  int sg_t, sg_b, sg_lv, sg_id;
-  unsigned sg_path_lo, sg_path_hi, sg_ch_lo, sg_ch_hi;
+  SegLane sgl;
   // ---- joint-limit row owned by this lane (lower side: lanes < G/2, upper side: lanes >= G/2)
   bool r_active;
   float r_D, r_aref, r_sign, r_jar;
@@ -726,7 +735,7 @@ struct Engine {
     for (int k = 0; k < SD; k++) Ms[k] = 0.f;
     Md = 1.f;
     anc_lo = anc_hi = 0u; d_depth = -1;
-    sg_t = sg_b = 0; sg_lv = -1; sg_id = 0; sg_path_lo = sg_path_hi = 0u; sg_ch_lo = sg_ch_hi = 0xffffffffu;
+    sgl = seg_lane_none();
     if constexpr (SP) {
       if (g < KD().nv) {
         const int* dpar = MI_(DOF_PARENTID);
@@ -745,14 +754,27 @@ struct Engine {
             if (e < 4) anc_lo |= (unsigned)j << (8 * e); else anc_hi |= (unsigned)j << (8 * (e - 4));
             j = dpar[j];
           }
-        const int* sg = AUXI(dof_seg) + 6 * g;
-        const int w = sg[0];
-        if (w >= 0) {
-          sg_t = w & 15; sg_b = (w >> 4) & 15; sg_lv = (w >> 8) & 15; sg_id = (w >> 16) & 255;
-          sg_path_lo = (unsigned)sg[1]; sg_path_hi = (unsigned)sg[2]; sg_ch_lo = (unsigned)sg[3]; sg_ch_hi = (unsigned)sg[4];
-        }
+        sgl = seg_lane_load();
       }
     }
+  }
+  __device__ __forceinline__ static SegLane seg_lane_none() {
+    SegLane q; q.t = q.b = 0; q.lv = -1; q.id = 0; q.depth = -1; q.path_lo = q.path_hi = 0u; q.ch_lo = q.ch_hi = 0xffffffffu;
+    return q;
+  }
+  // this lane's row of Aux.dof_seg (lanes without a dof own nothing)
+  __device__ __forceinline__ SegLane seg_lane_load() const {
+    SegLane q = seg_lane_none();
+    if (g < KD().nv) {
+      const int* sg = AUXI(dof_seg) + 6 * g;
+      const int w = sg[0];
+      q.depth = sg[5];
+      if (w >= 0) {
+        q.t = w & 15; q.b = (w >> 4) & 15; q.lv = (w >> 8) & 15; q.id = (w >> 16) & 255;
+        q.path_lo = (unsigned)sg[1]; q.path_hi = (unsigned)sg[2]; q.ch_lo = (unsigned)sg[3]; q.ch_hi = (unsigned)sg[4];
+      }
+    }
+    return q;
   }
   // dof id of this lane's ancestor at absolute depth E_ (valid for E_ < d_depth)
   template <int E_>
@@ -1387,8 +1409,8 @@ struct Engine {
   // lanes against 8 for a ds_write_b32).
   static constexpr int tri(int d) { return d * (d + 1) / 2; }
   template <int D_>
-  __device__ __forceinline__ int sg_path() const {
-    return (int)(D_ < 4 ? (sg_path_lo >> (8 * D_)) & 255u : (sg_path_hi >> (8 * (D_ - 4))) & 255u);
+  __device__ __forceinline__ static int sg_path(const SegLane& q) {
+    return (int)(D_ < 4 ? (q.path_lo >> (8 * D_)) & 255u : (q.path_hi >> (8 * (D_ - 4))) & 255u);
   }
   __device__ __forceinline__ static unsigned byte_of(unsigned w0, unsigned w1, int c) {
     return ((c < 4 ? w0 >> (8 * c) : w1 >> (8 * (c - 4))) & 255u);
@@ -1396,10 +1418,10 @@ struct Engine {
   // (t, b): depth range of the segments of the level at hand -- the same for every segment of one level of an SP model (the
   // host routes other trees to the general-row kernels), so these are scalar branches around straight-line code
   template <int D_>
-  __device__ __forceinline__ void sg_load_rows(const float* T, float (&F)[36], float (&r)[SD], int t, int b) const {
+  __device__ __forceinline__ void sg_load_rows(const SegLane& q, const float* T, float (&F)[36], float (&r)[SD], int t, int b) const {
     if constexpr (D_ < SD) {
       if (D_ >= t && D_ <= b) {
-        const float* P = T + sg_path<D_>() * TS;
+        const float* P = T + sg_path<D_>(q) * TS;
         const float4 p0 = *reinterpret_cast<const float4*>(P);
         const float v0[4] = {p0.x, p0.y, p0.z, p0.w};
 #pragma unroll
@@ -1412,7 +1434,7 @@ struct Engine {
         }
         r[D_] = P[8];
       }
-      sg_load_rows<D_ + 1>(T, F, r, t, b);
+      sg_load_rows<D_ + 1>(q, T, F, r, t, b);
     }
   }
   template <int D_>
@@ -1434,26 +1456,26 @@ struct Engine {
     }
   }
   template <int D_>
-  __device__ __forceinline__ void sg_back(float* X, const float (&F)[36], const float (&r)[SD], const float (&iv)[SD], float (&x)[SD], int t, int b) const {
+  __device__ __forceinline__ void sg_back(const SegLane& q, float* X, const float (&F)[36], const float (&r)[SD], const float (&iv)[SD], float (&x)[SD], int t, int b) const {
     if constexpr (D_ < SD) {
-      if (D_ < t) x[D_] = X[sg_path<D_>()];
+      if (D_ < t) x[D_] = X[sg_path<D_>(q)];
       else if (D_ <= b) {
         float v = r[D_] * iv[D_];
 #pragma unroll
         for (int e = 0; e < D_; e++) v -= F[tri(D_) + e] * x[e];
         x[D_] = v;
-        X[sg_path<D_>()] = v;
+        X[sg_path<D_>(q)] = v;
       }
-      sg_back<D_ + 1>(X, F, r, iv, x, t, b);
+      sg_back<D_ + 1>(q, X, F, r, iv, x, t, b);
     }
   }
   // add the update matrices of the child segments (nq quads of the triangle + the rhs); slots of absent children read zeros.
   // SHALLOW (parents no deeper than depth 2, the hand's wrist): two quads + rhs in flight per child; otherwise one quad at a
   // time -- the 36-word front and a whole child matrix in flight do not fit the register file next to the engine's state.
   template <bool SHALLOW>
-  __device__ __forceinline__ void sg_children(const float* U, int mch, int nq, int zslot, float (&F)[36], float (&r)[SD]) const {
+  __device__ __forceinline__ void sg_children(const SegLane& q, const float* U, int mch, int nq, int zslot, float (&F)[36], float (&r)[SD]) const {
     for (int c = 0; c < mch; c++) {
-      const unsigned id = byte_of(sg_ch_lo, sg_ch_hi, c);
+      const unsigned id = byte_of(q.ch_lo, q.ch_hi, c);
       const float* Uc = U + (id == 255u ? zslot : (int)id) * 36;
       if constexpr (SHALLOW) {
         const float4 u0 = *reinterpret_cast<const float4*>(Uc), u1 = *reinterpret_cast<const float4*>(Uc + 4);
@@ -1462,10 +1484,10 @@ struct Engine {
         r[0] += r0.x; r[1] += r0.y; r[2] += r0.z;
       } else {
 #pragma unroll
-        for (int q = 0; q < 7; q++)
-          if (q < nq) {
-            const float4 u = *reinterpret_cast<const float4*>(Uc + 4 * q);
-            F[4 * q] += u.x; F[4 * q + 1] += u.y; F[4 * q + 2] += u.z; F[4 * q + 3] += u.w;
+        for (int k4 = 0; k4 < 7; k4++)
+          if (k4 < nq) {
+            const float4 u = *reinterpret_cast<const float4*>(Uc + 4 * k4);
+            F[4 * k4] += u.x; F[4 * k4 + 1] += u.y; F[4 * k4 + 2] += u.z; F[4 * k4 + 3] += u.w;
           }
         const float4 r0 = *reinterpret_cast<const float4*>(Uc + 28), r1 = *reinterpret_cast<const float4*>(Uc + 32);
         r[0] += r0.x; r[1] += r0.y; r[2] += r0.z; r[3] += r0.w; r[4] += r1.x; r[5] += r1.y; r[6] += r1.z; r[7] += r1.w;
@@ -1479,19 +1501,15 @@ struct Engine {
     *reinterpret_cast<float4*>(Us + 28) = make_float4(r[0], r[1], r[2], r[3]);
     *reinterpret_cast<float4*>(Us + 32) = make_float4(r[4], r[5], r[6], r[7]);
   }
-  // x = (A + diag(dadd))^-1 rhs for the matrix whose sparse rows are (Ms, Md)
-  __device__ __forceinline__ float sp_factor_solve(float dadd, float rhs) {
-    float* T = W + KL().u1;            // published rows [NVP][TS]: row by absolute depth (diagonal at the dof's depth), rhs at [8]
+  // x = A^-1 rhs; P = this lane's row of A by absolute depth (diagonal at the dof's depth), q = its segment data
+  __device__ __forceinline__ float sp_solve_rows(const SegLane& q, const float (&P)[SD], float rhs) {
+    float* T = W + KL().u1;            // published rows [NVP][TS]: row by absolute depth, rhs at [8]
     float* X = T + NVP * TS;           // solution by dof
     float* U = T + KD().seg_u;         // update matrices [segment][36]: lower triangle over depths (28 words), rhs (8 words)
     const int nsl = KD().seg_nlevel, zslot = KD().seg_zero;
     const unsigned info_lo = (unsigned)KD().seg_lvinfo[0], info_hi = (unsigned)KD().seg_lvinfo[1];
     const unsigned tb_lo = (unsigned)KD().seg_lvtb[0], tb_hi = (unsigned)KD().seg_lvtb[1];
-    const int di = d_depth;
-    if (di >= 0) {
-      float P[SD];
-#pragma unroll
-      for (int e = 0; e < SD; e++) P[e] = e == di ? Md + dadd : Ms[e];
+    if (q.depth >= 0) {
       float* Pg = T + g * TS;
       *reinterpret_cast<float4*>(Pg) = make_float4(P[0], P[1], P[2], P[3]);
       *reinterpret_cast<float4*>(Pg + 4) = make_float4(P[4], P[5], P[6], P[7]);
@@ -1507,17 +1525,17 @@ struct Engine {
     for (int sl = nsl - 1; sl >= 0; sl--) {
       const unsigned tb = byte_of(tb_lo, tb_hi, sl);
       const int t = (int)(tb & 15u), b = (int)(tb >> 4);
-      if (sg_lv == sl) {
-        sg_load_rows<0>(T, F, r, t, b);
+      if (q.lv == sl) {
+        sg_load_rows<0>(q, T, F, r, t, b);
         // child segments: their update matrices cover the depths 0 .. b, a linear prefix of the triangle
         const int mch = (int)(byte_of(info_lo, info_hi, sl) & 15u);
         if (mch > 0) {
-          if (b <= 2) sg_children<true>(U, mch, 2, zslot, F, r);
-          else sg_children<false>(U, mch, (tri(b + 1) + 3) >> 2, zslot, F, r);
+          if (b <= 2) sg_children<true>(q, U, mch, 2, zslot, F, r);
+          else sg_children<false>(q, U, mch, (tri(b + 1) + 3) >> 2, zslot, F, r);
         }
         sg_pivots<SD - 1>(F, r, iv, t, b);
-        if (sl > 0) {   // update matrix over the ancestors: depths 0 .. t - 1
-          float* Us = U + sg_id * 36;
+        if (t > 0) {   // update matrix over the ancestors: depths 0 .. t - 1
+          float* Us = U + q.id * 36;
           if (t <= 3) sg_publish<2>(Us, F, r);
           else sg_publish<7>(Us, F, r);
         }
@@ -1529,12 +1547,48 @@ struct Engine {
     for (int k = 0; k < SD; k++) x[k] = 0.f;
     for (int sl = 0; sl < nsl; sl++) {
       const unsigned tb = byte_of(tb_lo, tb_hi, sl);
-      if (sg_lv == sl) sg_back<0>(X, F, r, iv, x, (int)(tb & 15u), (int)(tb >> 4));
+      if (q.lv == sl) sg_back<0>(q, X, F, r, iv, x, (int)(tb & 15u), (int)(tb >> 4));
       GSYNC();
     }
-    const float out = di >= 0 ? X[g] : 0.f;
+    const float out = q.depth >= 0 ? X[g] : 0.f;
     GSYNC();
     return out;
+  }
+  // x = (A + diag(dadd))^-1 rhs for the matrix whose sparse rows are (Ms, Md): the limit-rows-only kernels
+  __device__ __forceinline__ float sp_factor_solve(float dadd, float rhs) {
+    float P[SD];
+#pragma unroll
+    for (int e = 0; e < SD; e++) P[e] = e == d_depth ? Md + dadd : Ms[e];
+    return sp_solve_rows(sgl, P, rhs);
+  }
+  // the same for the general-row kernels (solve0 and the implicit-damping solve of the Euler step, whose matrices have M's
+  // pattern; the Newton Hessian M + J'DJ does not).  These kernels hold M as dense rows (Mrow); the row by absolute ancestor
+  // depth is picked out of it through the (dead) dense LDS tile, and the lane's segment data is re-read from the model tables
+  // instead of held in registers across the constraint stages.
+  __device__ __forceinline__ float spg_factor_solve(float dadd, float rhs) {
+    const SegLane q = seg_lane_load();
+    float* T = W + KL().u1;
+    const int row = g < NVP ? g : 0;
+    if (g < NVP)
+#pragma unroll
+      for (int k4 = 0; k4 < NVP / 4; k4++)
+        *reinterpret_cast<float4*>(T + row * NVP + 4 * k4) = make_float4(Mrow[4 * k4], Mrow[4 * k4 + 1], Mrow[4 * k4 + 2], Mrow[4 * k4 + 3]);
+    float P[SD];
+    {
+      const int* pa = AUXI(dof_seg) + 6 * (q.depth >= 0 ? g : 0);
+      // the dof's own path: ancestors by depth, then itself (words 1, 2 of an owner row describe the segment's BOTTOM dof;
+      // a dof's own ancestors are the same bytes up to its depth)
+      const unsigned a_lo = (unsigned)AUXI(dof_anc)[2 * (q.depth >= 0 ? g : 0)], a_hi = (unsigned)AUXI(dof_anc)[2 * (q.depth >= 0 ? g : 0) + 1];
+      (void)pa;
+#pragma unroll
+      for (int e = 0; e < SD; e++) {
+        const int col = e == q.depth ? g : (int)byte_of(a_lo, a_hi, e);
+        const float v = T[row * NVP + (e <= q.depth ? col : row)];
+        P[e] = e < q.depth ? v : (e == q.depth ? v + dadd : 0.f);
+      }
+    }
+    GSYNC();   // the rows are read: the tile region becomes the sparse solve's work area
+    return sp_solve_rows(q, P, rhs);
   }
   // y = M x: the diagonal and ancestor entries are this lane's row; the descendant entries M[k][g] x_k are published by the
   // descendants (their row times their x) and summed through the dof's descendant list
@@ -1594,7 +1648,10 @@ struct Engine {
   // (A + diag(dadd))^-1 rhs: the one entry point of every factor + solve pair
   __device__ __forceinline__ float factor_solve(float dadd, float rhs) {
     if constexpr (SP) return sp_factor_solve(dadd, rhs);
-    else { factor(dadd); return solve(rhs); }
+    else {
+      if constexpr (GEN && MM_SPARSE_LDL && MM_SPARSE_GEN && NVP >= 8 && INTEG != 2) { if (KD().seg_nlevel > 0) return spg_factor_solve(dadd, rhs); }
+      factor(dadd); return solve(rhs);
+    }
   }
 
   // dense Cholesky H = L L' with lane i holding row i; `dadd` is added to this lane's diagonal element.
@@ -2427,10 +2484,15 @@ struct Engine {
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
-    if constexpr (!SP) PFT(PF_FACTOR, factor(0.f));
+    constexpr bool SPG = GEN && MM_SPARSE_LDL && MM_SPARSE_GEN && NVP >= 8 && INTEG != 2;
+    const bool spg = SPG && KD().seg_nlevel > 0;   // general-row kernel on a model whose dof tree the sparse solve handles
+    if constexpr (!SP) { if (!spg) PFT(PF_FACTOR, factor(0.f)); }
     PFT(PF_ACT, passive_actuation());
     if constexpr (SP) PFT(PF_SOLVE0, d_qaccsm = sp_factor_solve(0.f, d_smooth));
-    else PFT(PF_SOLVE0, d_qaccsm = solve(d_smooth));
+    else {
+      if (spg) { if constexpr (SPG) PFT(PF_SOLVE0, d_qaccsm = spg_factor_solve(0.f, d_smooth)); }
+      else PFT(PF_SOLVE0, d_qaccsm = solve(d_smooth));
+    }
     PFT(PF_NEWTON, solve_constraints());
   }
 
