@@ -438,14 +438,6 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   for (int i = 0; i < d.nv; i++) dofslot[i] = rootslot[dofbody[i]];
   const int32_t* tj_adr = (const int32_t*)(blob + m->sec[MM_SEC_TENJ_ADR]);
   const int32_t* tj_dof = (const int32_t*)(blob + m->sec[MM_SEC_TENJ_DOF]);
-  std::vector<int32_t> dj_adr(d.nv + 1, 0), dj_entry, dj_tendon;
-  for (int i = 0; i < d.nv; i++) {
-    dj_adr[i] = (int)dj_entry.size();
-    for (int t = 0; t < d.ntendon; t++)
-      for (int e = tj_adr[t]; e < tj_adr[t + 1]; e++)
-        if (tj_dof[e] == i) { dj_entry.push_back(e); dj_tendon.push_back(t); }
-  }
-  dj_adr[d.nv] = (int)dj_entry.size();
   const int32_t* wt = (const int32_t*)(blob + m->sec[MM_SEC_WRAP_TYPE]);
   const int32_t* wo = (const int32_t*)(blob + m->sec[MM_SEC_WRAP_OBJID]);
   const int32_t* tadr = (const int32_t*)(blob + m->sec[MM_SEC_TENDON_ADR]);
@@ -512,11 +504,11 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     m->nwrapitem = (int)wraps.size();
   }
   // Tendon Jacobian by ENTRY (see Engine::tendon): every sparse-J entry (tendon, dof) gets the list of path segments that cross
-  // its dof, one 8-word row per segment: S a site-site segment; a wrap item contributes its unwrapped segment A (site - site)
+  // its dof, one 4-word row per segment: S a site-site segment; a wrap item contributes its unwrapped segment A (site - site)
   // or, when the tendon touches the geom, B (site - tangent point) and / or C (tangent point - site): rows A_OR_B, A_OR_C (the
   // usual case: the dof lies between one site's body and the geom's body), B_ONLY, C_ONLY, A_ONLY; J a fixed-tendon coefficient;
   // NONE pads an entry nothing crosses.  Row: [entry | joint word << 16, site0 | site1 << 16, body0 | body1 << 8 | mode << 16 |
-  // ep_unwrapped << 20 | ep_wrapped << 21, wrap slot, bits(1/divisor or coef), 0, 0, 0]; joint word = joint id | 1 (hinge) or
+  // ep_unwrapped << 20 | ep_wrapped << 21 | wrap slot << 22, bits(1/divisor or coef)]; joint word = joint id | 1 (hinge) or
   // 2 (slide) << 8 -- the kernel reads anchor / axis straight from the joint -- or dof id for ball / free dofs (via cdof).
   // jent[i] = first row | rows << 24 of the i-th entry in processing order.
   std::vector<int32_t> jent, jrow;
@@ -572,17 +564,17 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     for (int e : order) {
       const int dof = tj_dof[e], j = dofjnt[dof], ty = jtype[j];
       const bool direct = (ty == MM_JNT_HINGE || ty == MM_JNT_SLIDE) && j < 256;
-      if ((!direct && dof >= 256) || e >= 65536 || per_ent[e].size() > 127 || jrow.size() / 8 >= (1u << 24)) {
+      if ((!direct && dof >= 256) || e >= 65536 || per_ent[e].size() > 127 || jrow.size() / 4 >= (1u << 24)) {
         delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian beyond the engine's table limits");
       }
       const int32_t jw = (direct ? j : dof) | ((direct ? (ty == MM_JNT_HINGE ? 1 : 2) : 0) << 8);
-      jent.push_back((int32_t)(jrow.size() / 8) | ((int32_t)per_ent[e].size() << 24));
+      jent.push_back((int32_t)(jrow.size() / 4) | ((int32_t)per_ent[e].size() << 24));
       for (const Rec& r : per_ent[e]) {
-        const int32_t row[8] = {e | (jw << 16), r.sites, r.bm, r.wi, r.f2, 0, 0, 0};
-        for (int k = 0; k < 8; k++) jrow.push_back(row[k]);
+        if (r.wi >= 1024) { delete m; return fail(MM_EUNSUPPORTED, "more than 1024 wrapping tendon path items"); }
+        const int32_t row[4] = {e | (jw << 16), r.sites, r.bm | (r.wi << 22), r.f2};
+        for (int k = 0; k < 4; k++) jrow.push_back(row[k]);
       }
     }
-    while (jrow.size() % 4) jrow.push_back(0);
   }
 
   std::vector<uint32_t> dev(m->h_blob);
@@ -622,12 +614,26 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     d.ox = m->origin[0]; d.oy = m->origin[1]; d.oz = m->origin[2];
   }
   m->x.body_depth = append(depth); m->x.body_rootslot = append(rootslot); m->x.dof_rootslot = append(dofslot);
-  m->x.dofj_adr = append(dj_adr); m->x.dofj_entry = append(dj_entry); m->x.dofj_tendon = append(dj_tendon);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
   m->x.jent = append(jent);
   while (dev.size() % 4) dev.push_back(0u);   // 16-byte rows
   m->x.jrec = append(jrow);
-  m->x.item_tab = append(item_tab); m->x.nitem = (int)item_tab.size() / 8;
+  {
+    // 4-word device rows: [tendon | kind << 16, site0 | site1 << 16 (kind 3: joint id), geom | (sidesite + 1) << 16 (kind 3:
+    // bits(coef)), bits(1 / divisor)]
+    std::vector<int32_t> packed;
+    const int nit = (int)item_tab.size() / 8;
+    for (int ii = 0; ii < nit; ii++) {
+      const int32_t* I = &item_tab[8 * (size_t)ii];
+      if (I[0] >= 65536 || (I[1] != 3 && (I[5] >= 65536 || I[6] + 1 >= 65536))) { delete m; return fail(MM_EUNSUPPORTED, "tendon path beyond the engine's table limits"); }
+      packed.push_back(I[0] | (I[1] << 16));
+      packed.push_back(I[1] == 3 ? I[3] : (I[3] | (I[4] << 16)));
+      packed.push_back(I[1] == 3 ? I[4] : (I[5] | ((I[6] + 1) << 16)));
+      packed.push_back(I[7]);
+    }
+    while (dev.size() % 4) dev.push_back(0u);   // 16-byte rows
+    m->x.item_tab = append(packed); m->x.nitem = nit;
+  }
   {
     const int32_t* dpar = (const int32_t*)(blob + m->sec[MM_SEC_DOF_PARENTID]);
     std::vector<int32_t> rel(2 * (size_t)d.nv, 0);
@@ -725,6 +731,7 @@ extern "C" int mm_model_info(const mm_model* m, int which) {
     case MM_INFO_LDS_BYTES_PER_ENV: return (int)m->lds_per_env;
     case MM_INFO_ENVS_PER_BLOCK: return (64 / m->lanes) * (m->waves_per_block > 0 ? m->waves_per_block : 1);
     case MM_INFO_NGEOM: return m->d.ngeom; case MM_INFO_WAVES_PER_BLOCK: return m->waves_per_block;
+    case MM_INFO_MODEL_WORDS: return m->blob_words;
     case MM_INFO_KERNEL_FAMILY: return m->d.gen ? 2 : ((MM_SPARSE_LDL && m->nvp >= 8 && m->d.integrator != MM_INT_IMPLICITFAST) ? 1 : 0);
   }
   return MM_EARG;

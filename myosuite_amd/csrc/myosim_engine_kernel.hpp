@@ -101,10 +101,9 @@ struct DbgLayout {
 // engine-private tables appended behind the model blob on the device
 struct Aux {
   int body_depth, body_rootslot, dof_rootslot;
-  int dofj_adr, dofj_entry, dofj_tendon;   // transpose of the sparse tendon Jacobian
   int root_list, nroot;
   int jent, jrec;        // tendon Jacobian by entry: [ntenJ][4] {entry, joint word, first record, records}, records [..][4] (host: mm_model_create)
-  int item_tab, nitem;   // flattened tendon path items (8 words each), wraps first: see tendon()
+  int item_tab, nitem;   // flattened tendon path items (4 words each), wraps first: see tendon()
   int dof_rel;           // per dof: 64-bit mask (2 words) of the dofs on its kinematic chain (ancestors, descendants, itself)
   int body_dofmask;      // per body: 64-bit mask (2 words) of the dofs between the body and the root of its tree (its chain)
   int dof_desc;          // per dof: ids of all its descendants, one byte each, 0xff-padded to 8 words
@@ -675,6 +674,8 @@ struct Engine {
   // integer model constants of the owned body and of its first two joints (loaded once per kernel); the float constants
   // (body / joint frames) are read from the LDS-resident model where they are used: holding them cost 23 VGPRs and spills
   int c_jn, c_ja;
+  int c_rowj;         // joint of dof g (its limit row lives in lane c_rowj); c_rowj_mine: dof g is that joint's (first) dof
+  bool c_rowj_mine;
   // ---- dof-lane registers (valid for g < nv)
   float d_cdof[6];
   float d_qvel, d_warm, d_bias, d_smooth, d_qaccsm, d_qacc, d_qfrccon;
@@ -717,6 +718,8 @@ struct Engine {
       const bool isb = g > 0 && g < KD().nbody;
       c_ja = isb ? MI_(BODY_JNTADR)[g] : 0;
       c_jn = isb ? MI_(BODY_JNTNUM)[g] : 0;
+      c_rowj = g < KD().nv ? MI_(DOF_JNTID)[g] : 0;
+      c_rowj_mine = g < KD().nv && MI_(JNT_DOFADR)[c_rowj] == g;
     }
     r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; r_floss = 0.f; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
@@ -982,8 +985,8 @@ struct Engine {
   }
 
   // ---------------------------------------------------------------- A2 tendons
-  // Two sweeps.  (1) Path items, flattened over ALL tendons on the host (Aux.item_tab, 8 words each: {tendon, kind, k0, site0,
-  // site1, geom, sidesite, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site, 2 = site-cylinder-site, 3 = fixed-tendon
+  // Two sweeps.  (1) Path items, flattened over ALL tendons on the host (Aux.item_tab, 4 words each: {tendon | kind << 16,
+  // site0 | site1 << 16, geom | (sidesite + 1) << 16, bits(1/divisor)}; kind 0 = site-site, 1 = site-sphere-site, 2 = site-cylinder-site, 3 = fixed-tendon
   // joint term) and sorted so that the expensive wrap items come first (a sweep of G lanes then executes one kind of item
   // instead of every lane walking its own tendon): lengths, and for wrap items the two tangent points + a wrapped flag into LDS.
   // (2) Jacobian entries, one lane per sparse-J entry (Aux.jent / jrec): the lane recomputes the end points of the segment(s)
@@ -1013,24 +1016,22 @@ struct Engine {
     int o_items = KX().item_tab, nitem = KX().nitem, o_jent = KX().jent, o_jrec = KX().jrec, d_ntenJ = KD().ntenJ;
     PIN_S(o.xpos); PIN_S(o.xmat); PIN_S(o.tenlen); PIN_S(o.tenj); PIN_S(o.xaxis); PIN_S(o.xanchor); PIN_S(o.site_body);
     PIN_S(o.site_pos); PIN_S(o.wrapw); PIN_S(o_items); PIN_S(nitem); PIN_S(o_jent); PIN_S(o_jrec); PIN_S(d_ntenJ);
-    const int* items = reinterpret_cast<const int*>(mb + o_items);
+    const int4* items = reinterpret_cast<const int4*>(mb + o_items);
     for (int t = g; t < KD().ntendon; t += G) W[o.tenlen + t] = 0.f;
     GSYNC();
     for (int it = g; it < nitem; it += G) {
-      const int* I = items + 8 * it;
-      const int t = I[0], kind = I[1];
-      const float inv_div = __int_as_float(I[7]);
-      if (kind == 3) {   // fixed tendon: coef * q_joint
-        const int jn = I[3];
-        const float coef = __int_as_float(I[4]);
-        atomicAdd(&W[o.tenlen + t], coef * W[o.qpos + MI_(JNT_QPOSADR)[jn]]);
+      const int4 I = items[it];   // [tendon | kind << 16, site0 | site1 << 16, geom | (sidesite + 1) << 16, bits(1 / divisor)]
+      const int t = I.x & 0xffff, kind = I.x >> 16;
+      const float inv_div = __int_as_float(I.w);
+      if (kind == 3) {   // fixed tendon: coef * q_joint   [.., joint id, bits(coef), ..]
+        atomicAdd(&W[o.tenlen + t], __int_as_float(I.z) * W[o.qpos + MI_(JNT_QPOSADR)[I.y]]);
         continue;
       }
-      V3 p0 = site_pos_o(o, I[3]), p1 = site_pos_o(o, I[4]);
+      V3 p0 = site_pos_o(o, I.y & 0xffff), p1 = site_pos_o(o, (I.y >> 16) & 0xffff);
       float wlen = -1.f;
       V3 w0, w1;
       if (kind != 0) {
-        const int gi = I[5], sideid = I[6];
+        const int gi = I.z & 0xffff, sideid = ((I.z >> 16) & 0xffff) - 1;
         V3 side = v3(0.f, 0.f, 0.f);
         if (sideid >= 0) side = site_pos_o(o, sideid);
         const int gb = reinterpret_cast<const int*>(mb + o.geom_body)[gi];
@@ -1066,13 +1067,13 @@ struct Engine {
       int e = 0;
       for (int r = r0; r < r0 + nr; r++) {
         // one row, then every load it addresses at once (both sites, both tangent points, the joint): two round trips per row
-        const int4 ra = jrow[2 * r];
-        const float f2 = __int_as_float(reinterpret_cast<const int*>(jrow + 2 * r + 1)[0]);
+        const int4 ra = jrow[r];   // [entry | joint word << 16, site0 | site1 << 16, body0 | body1 << 8 | mode << 16 | eps << 20 | wrap slot << 22, bits(f)]
+        const float f2 = __int_as_float(ra.w);
         e = ra.x & 0xffff;
         const int jw = ra.x >> 16, id = jw & 0xff, jk = (jw >> 8) & 3;
         const int mode = (ra.z >> 16) & 15;
         const int s0 = ra.y & 0xffff, s1 = (ra.y >> 16) & 0xffff, b0 = ra.z & 0xff, b1 = (ra.z >> 8) & 0xff;
-        const float* ws = W + o.wrapw + 7 * ra.w;
+        const float* ws = W + o.wrapw + 7 * ((ra.z >> 22) & 1023);
         const float wflag = ws[6];
         const V3 t0 = ld3(ws), t1 = ld3(ws + 3);
         const V3 q0 = ld3(W + o.xpos + 3 * b0) + mv(ldm(W + o.xmat + 9 * b0), ld3(reinterpret_cast<const float*>(mb + o.site_pos) + 3 * s0));
@@ -1161,10 +1162,8 @@ struct Engine {
 
   // value of the limit row of the joint that owns dof g (0 for dofs that are not a hinge/slide joint's dof)
   __device__ __forceinline__ float rows_to_dof(float val) const {
-    int j = g < KD().nv ? MI_(DOF_JNTID)[g] : 0;
-    float v = sh<G>(val, j);
-    bool mine = g < KD().nv && MI_(JNT_DOFADR)[j] == g;
-    return mine ? v : 0.f;
+    const float v = sh<G>(val, c_rowj);
+    return c_rowj_mine ? v : 0.f;
   }
 
   // ----------------------------------------------------- A5 velocity stage + bias forces
