@@ -1648,7 +1648,7 @@ struct Engine {
   __device__ __forceinline__ float factor_solve(float dadd, float rhs) {
     if constexpr (SP) return sp_factor_solve(dadd, rhs);
     else {
-      if constexpr (GEN && MM_SPARSE_LDL && MM_SPARSE_GEN && NVP >= 8 && INTEG != 2) { if (KD().seg_nlevel > 0) return spg_factor_solve(dadd, rhs); }
+      if constexpr (GEN && MM_SPARSE_LDL && MM_SPARSE_GEN && NVP >= 8 && INTEG != 2) { if (MM_SPARSE_GEN == 2 || KD().seg_nlevel > 0) return spg_factor_solve(dadd, rhs); }
       factor(dadd); return solve(rhs);
     }
   }
@@ -2484,7 +2484,7 @@ struct Engine {
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
     constexpr bool SPG = GEN && MM_SPARSE_LDL && MM_SPARSE_GEN && NVP >= 8 && INTEG != 2;
-    const bool spg = SPG && KD().seg_nlevel > 0;   // general-row kernel on a model whose dof tree the sparse solve handles
+    const bool spg = SPG && (MM_SPARSE_GEN == 2 || KD().seg_nlevel > 0);   // general-row kernel on a model whose dof tree the sparse solve handles
     if constexpr (!SP) { if (!spg) PFT(PF_FACTOR, factor(0.f)); }
     PFT(PF_ACT, passive_actuation());
     if constexpr (SP) PFT(PF_SOLVE0, d_qaccsm = sp_factor_solve(0.f, d_smooth));

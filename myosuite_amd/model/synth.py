@@ -924,8 +924,8 @@ def make_tree_toy(kind: str = "star") -> ModelSpec:
     """Limit-rows-only test models of different dof-tree shapes (hinges with ranges, damping, armature, one motor per joint; no
     contacts, tendons or equalities), for the three routes of the engine's factorisation: ``star`` -- a 2-dof stem carrying three
     equal 2-dof branches (regular segment tree: the tree-sparse L'DL kernels), ``chain`` -- a 10-link pendulum (deeper than the
-    sparse kernels' eight levels: general-row kernels, dense Cholesky), ``comb`` -- branches of unequal length (segment levels
-    that are not alike: general-row kernels).  Not reference assets."""
+    sparse kernels' eight levels: general-row kernels, dense Cholesky), ``comb`` -- branches of unequal length (more elimination steps), ``free`` -- a free-floating trunk with two arms
+    (eight levels, quaternion dofs).  Not reference assets."""
     s = ModelSpec(f"tree_toy_{kind}", timestep=0.002)
     n = [0]
 
@@ -938,6 +938,14 @@ def make_tree_toy(kind: str = "star") -> ModelSpec:
         return f"b{i}"
 
     ax = ((1, 0, 0), (0, 1, 0), (0.6, 0.8, 0))
+    if kind == "free":
+        # a free-floating trunk (6 dofs: depths 0..5) carrying two 2-link arms: eight tree levels, the deepest the sparse kernels take
+        s.add_body("trunk", "world", pos=(0, 0, 1.0), mass=2.0, inertia=(0.02, 0.03, 0.025))
+        s.add_joint("root", "trunk", "free")
+        for k in range(2):
+            q = link("trunk", ax[k], 0.15, (0.1 * (2 * k - 1), 0, -0.05))
+            link(q, ax[k + 1], 0.15, (0, 0, -0.15))
+        return s
     if kind == "chain":
         p = "world"
         for i in range(10):
@@ -1014,7 +1022,7 @@ def builders() -> dict:
             "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True),
             "leg_implicit": lambda: make_leg(implicit=True), "torso_exo": lambda: make_torso(exosuit=True),
             "tree_star": lambda: make_tree_toy("star"), "tree_chain": lambda: make_tree_toy("chain"),
-            "tree_comb": lambda: make_tree_toy("comb")}
+            "tree_comb": lambda: make_tree_toy("comb"), "tree_free": lambda: make_tree_toy("free")}
 
 
 def compile_spec(name: str, edit=None) -> CompiledModel:

@@ -331,7 +331,7 @@ def test_self_colliding_hand_gpu_matches_oracle(oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,family", [("star", 1), ("chain", 2), ("comb", 1)])
+@pytest.mark.parametrize("kind,family", [("star", 1), ("chain", 2), ("comb", 1), ("free", 1)])
 def test_dof_tree_shapes_route_and_match_oracle(oracle_lib, kind, family):
     """tree_toy models (limit rows only; dof trees of different shapes): the star and the comb (branches of unequal length:
     more elimination steps) take the tree-sparse L'DL kernels (one lane per segment of the dof tree), the 10-deep chain the
@@ -345,6 +345,8 @@ def test_dof_tree_shapes_route_and_match_oracle(oracle_lib, kind, family):
     n = 24
     rng = np.random.default_rng(8)
     q = rng.uniform(-0.9, 0.8, (n, cm.nq)); v = rng.standard_normal((n, cm.nv)) * 1.5
+    if kind == "free":
+        q[:, :3] = [0.0, 0.0, 1.0]; q[:, 3:7] /= np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
     st = E.BatchState(hm, n)
     ds = [O.OracleData(om) for _ in range(n)]
     worst, rows = 0.0, set()
