@@ -657,6 +657,15 @@ struct SegLane {
 template <int G, int NVP, bool GEN, int INTEG>
 struct Engine {
   static constexpr bool RK4 = INTEG == 1, IMPL = INTEG == 2;
+  // Dense Cholesky form.  Left-looking (row j of L from an LDS tile, one pivot broadcast per column) executes ~40 % fewer
+  // instructions than right-looking (NVP^2 / 2 cross-lane broadcasts) but adds an LDS round trip per column.  Groups narrower than
+  // the wave always take it (a broadcast costs ~5 issue slots there).  One env per wave: it wins where two or more waves per SIMD
+  // keep the issue ports busy (hand-family models at their batch sizes: reorient +3.4 %) and loses where a lone wave per SIMD
+  // waits on latency (leg-walk at 1024 envs: -7 %); the tile width stands in for that distinction.
+  static constexpr bool LEFT_LOOKING = NVP >= 8 && (G < 64 || NVP <= 32);
+  // M x and J x with x through an LDS vector (one write, NVP / 4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts:
+  // always for narrow groups; one env per wave, measured per tile width: 24-wide (self-contact hand) +1.2 %, 32-wide (reorient) -2.7 %
+  static constexpr bool LDS_VECTOR = NVP >= 8 && (G < 64 || NVP <= 24);
   const KArgs& a;
   const KConst& kc;    // model constants of the launch (see MM_CONST_IN_REGS)
   const uint32_t* mb;  // model words (LDS-resident copy or global)
@@ -1658,7 +1667,7 @@ struct Engine {
   // (instruction-level parallelism) instead of one serial dot-product chain per column.
   // Leaves Lrow (L[g][k]) and d_dinv (1/L[g][g]) in registers and L in the LDS tile (for the L' solve).
   __device__ __forceinline__ void factor(float dadd) {
-    if constexpr (G < 64 && NVP >= 8) { factor_core<true>(Mrow, dadd); return; }   // left-looking: reads M[g][j] once, no copy
+    if constexpr (LEFT_LOOKING) { factor_core<true>(Mrow, dadd); return; }   // left-looking: reads M[g][j] once, no copy
     float A[NVP];
 #pragma unroll
     for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == g ? dadd : 0.f);
@@ -1667,7 +1676,7 @@ struct Engine {
   template <bool DIAG>
   __device__ __forceinline__ void factor_core(float (&A)[NVP], float dadd = 0.f) {
     const auto& L = KL();
-    if constexpr (G < 64 && NVP >= 8) {
+    if constexpr (LEFT_LOOKING) {
       // Left-looking form for groups narrower than the wave.  A cross-lane broadcast costs ~5 issue slots there (two
       // v_readlane + v_mov + v_cndmask + hazard nops), and the right-looking update needs NVP^2/2 of them.  Here row j of L
       // comes from the LDS tile instead (one 128-bit load per four entries; the tile is written column by column as the
@@ -1735,7 +1744,7 @@ struct Engine {
   __device__ __forceinline__ float mul_m(float x) const {
     float y = 0.f;
     if constexpr (SP) return sp_mul_m(x);
-    if constexpr (G < 64 && NVP >= 8) {
+    if constexpr (LDS_VECTOR) {
       // x through LDS (one write, NVP/4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts
       float* X = W + KL().xvec;
       if (g < NVP) X[g] = x;
@@ -2265,6 +2274,17 @@ struct Engine {
   __device__ __forceinline__ float jac_mul(float x) const {
     const float4* J = reinterpret_cast<const float4*>(Jrow(g));
     float s = 0.f;
+    if constexpr (LDS_VECTOR) {
+      // x through LDS (one write, NVP/4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts
+      float* X = W + KL().xvec;
+      if (g < NVP) X[g] = x;
+#pragma unroll
+      for (int k = 0; k < NVP / 4; k++) {
+        const float4 j4 = J[k], x4 = *reinterpret_cast<const float4*>(X + 4 * k);
+        s += j4.x * x4.x + j4.y * x4.y + j4.z * x4.z + j4.w * x4.w;
+      }
+      return s;
+    }
 #pragma unroll
     for (int k = 0; k < NVP / 4; k++) {
       const float4 j4 = J[k];
