@@ -2296,7 +2296,12 @@ struct Engine {
   __device__ __forceinline__ float jacT_mul(float f) const {
     const float* Jc = W + KL().efcJ + (g < NVP ? g : 0);
     float s = 0.f;
-    for (int r = 0; r < nrows_wave; r++) s += Jc[r * RS] * bc<G>(f, r);
+    // four rows per turn: the column loads are independent of the running sum (one row per turn exposes an LDS round trip per
+    // row to a lone wave).  Rows past nefc hold zeros and carry no force; the table has a multiple of four rows.
+    for (int r = 0; r < nrows_wave; r += 4) {
+      const float j0 = Jc[r * RS], j1 = Jc[(r + 1) * RS], j2 = Jc[(r + 2) * RS], j3 = Jc[(r + 3) * RS];
+      s += j0 * bc<G>(f, r) + j1 * bc<G>(f, r + 1) + j2 * bc<G>(f, r + 2) + j3 * bc<G>(f, r + 3);
+    }
     return g < KD().nv ? s : 0.f;
   }
   // force -s'(x) of the row owned by this lane at x = J a - aref; quad = the row is in its quadratic state (contributes
