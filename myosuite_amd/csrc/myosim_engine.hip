@@ -650,6 +650,42 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     }
     m->x.body_dofmask = append(bm);
     m->x.dof_desc = append(m->desc_all); m->x.dof_seg = append(m->seg_tab); m->x.dof_anc = append(m->anc_tab);
+    {
+      // chains of the body tree (Engine::subtree_sum).  A body starts a chain when it hangs off the world or its parent has
+      // another child too; the bodies of a chain must have consecutive ids (MuJoCo's depth-first numbering gives that).
+      std::vector<int32_t> tab(3 * (size_t)std::max(d.nbody, 1), -1);
+      std::vector<int> nchb(d.nbody, 0), top_of(d.nbody, 0), lvl(d.nbody, 0);
+      for (int b = 1; b < d.nbody; b++) if (bpar[b] > 0) nchb[bpar[b]]++;
+      bool ok = d.nbody <= 255;
+      int nlev = 0;
+      for (int b = 1; b < d.nbody && ok; b++) {
+        const int p = bpar[b];
+        if (p > 0 && nchb[p] == 1) {             // continues its parent's chain
+          if (p != b - 1) { ok = false; break; }
+          top_of[b] = top_of[p];
+          tab[3 * (size_t)top_of[b]] = (tab[3 * (size_t)top_of[b]] & ~255) | b;   // new bottom
+          continue;
+        }
+        top_of[b] = b;
+        lvl[b] = p > 0 ? lvl[top_of[p]] + 1 : 0;
+        if (lvl[b] > 15) { ok = false; break; }
+        nlev = std::max(nlev, lvl[b] + 1);
+        tab[3 * (size_t)b] = b | (lvl[b] << 8);
+        tab[3 * (size_t)b + 1] = 0; tab[3 * (size_t)b + 2] = 0;
+        if (p > 0) {                             // register with the chain it hangs off (whose bottom is p)
+          int32_t* pt = &tab[3 * (size_t)top_of[p]];
+          const int c = (pt[0] >> 12) & 15;
+          if (c >= 8) { ok = false; break; }
+          pt[1 + (c >> 2)] |= (int32_t)((uint32_t)b << (8 * (c & 3)));
+          pt[0] = (pt[0] & ~(15 << 12)) | ((c + 1) << 12);
+        }
+      }
+      int maxch = 0, maxlen = 1;
+      for (int b = 1; b < d.nbody && ok; b++)
+        if (tab[3 * (size_t)b] >= 0) { maxch = std::max(maxch, (tab[3 * (size_t)b] >> 12) & 15); maxlen = std::max(maxlen, (tab[3 * (size_t)b] & 255) - b + 1); }
+      d.bchain_nlevel = ok ? (nlev | (maxch << 4) | (maxlen << 8)) : 0;
+      m->x.body_chain = append(tab);
+    }
   }
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS

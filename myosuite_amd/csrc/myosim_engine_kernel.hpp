@@ -60,6 +60,7 @@ struct Dims {
   int ntlim; // limited tendons (at most one limit row each, behind the joint-limit rows)
   int dof_nlevel;   // levels of the dof tree (1 + maximum number of ancestor dofs)
   // SP kernels: the dof tree cut into segments (maximal unbranched chains); one lane eliminates a whole segment
+  int bchain_nlevel;    // body chains (Engine::subtree_sum): levels of the chain tree | most child chains << 4 | longest chain << 8; 0: the host could not build the chains
   int seg_nlevel;       // levels of the segment tree
   int seg_lvinfo[2];    // one byte per segment level: [3:0] most child segments of a segment there
   int seg_lvtb[2];      // one byte per segment level: [3:0] top depth, [7:4] bottom depth of the segments there (all alike)
@@ -109,6 +110,7 @@ struct Aux {
   int dof_desc;          // per dof: ids of all its descendants, one byte each, 0xff-padded to 8 words
   int dof_seg;           // per dof, 6 words: segment owned by the dof's lane (the segment's top dof) or -1; path and child bytes; the dof's depth
   int dof_anc;           // per dof, 2 words: ids of its ancestor dofs by depth, one byte each
+  int body_chain;        // per body, 3 words: chain owned by the body's lane (its top body): bottom | level << 8 | children << 12, or -1; child chain tops, one byte each
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)
@@ -641,7 +643,10 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 #define MM_SPARSE_LDL 1   /* 0: dense register Cholesky in every kernel (A/B switch) */
 #endif
 // =========================================================================== engine
-#define PIN_S(x) asm volatile("" : "+s"(x))   /* keep a wave-uniform value in an SGPR: opaque to rematerialisation (an s_load + s_waitcnt at every use) */
+/* keep a wave-uniform value in an SGPR: opaque to rematerialisation (an s_load + s_waitcnt at every use).  The readfirstlane
+   folds away when the value already sits in an SGPR; without it the backend dies with "illegal VGPR to SGPR copy" in the
+   instantiations where it had moved the (uniform) value's computation to the vector ALU. */
+#define PIN_S(x) do { (x) = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); } while (0)
 #define AI_(o) (reinterpret_cast<const int*>(mb + (o)))
 #define AF_(o) (reinterpret_cast<const float*>(mb + (o)))
 // What a lane knows about the dof-tree segment it owns (sp_factor_solve): depth range [t, b] of the segment, its step in the
@@ -1175,6 +1180,51 @@ struct Engine {
     return c_rowj_mine ? v : 0.f;
   }
 
+  // Subtree sums of a K-vector per body, in place in an LDS table [nbody][K] (composite inertias, RNE forces): S[b] = V[b] +
+  // sum over the children c of S[c].  The body tree is cut into chains (maximal unbranched paths; bodies of a chain have
+  // consecutive ids in MuJoCo's depth-first order -- the host checks); the lane of a chain's top body walks its chain from the
+  // bottom up in registers, starting from its bottom body's value plus the finished totals of the chains hanging off it.  One
+  // step per level of the CHAIN tree (3 for the hand and the leg) instead of one per level of the body tree (9 / 12), and no LDS
+  // float atomics.  Falls back to the level-by-level atomic sweep when the host could not build the chains (bchain_nlevel = 0).
+  template <int K>
+  __device__ __forceinline__ void subtree_sum(int o_tab) {
+    const int ncl = KD().bchain_nlevel & 15, maxch = (KD().bchain_nlevel >> 4) & 15, maxlen = KD().bchain_nlevel >> 8;
+    int bottom = 0, lv = -1, nch = 0;
+    unsigned ch_lo = 0u, ch_hi = 0u;
+    if (g > 0 && g < KD().nbody) {
+      const int* bc = AUXI(body_chain) + 3 * g;
+      const int w = bc[0];
+      if (w >= 0) { bottom = w & 255; lv = (w >> 8) & 15; nch = (w >> 12) & 15; ch_lo = (unsigned)bc[1]; ch_hi = (unsigned)bc[2]; }
+    }
+    for (int cl = ncl - 1; cl >= 0; cl--) {
+      if (lv == cl) {
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = W[o_tab + K * bottom + k];
+        // wave-uniform trip counts (the most children / the longest chain of the model) with per-lane predicates: data-dependent
+        // per-lane loops here run into a backend error ("illegal VGPR to SGPR copy") in some instantiations
+        for (int c = 0; c < maxch; c++) {
+          if (c < nch) {
+            const int ct = (int)((c < 4 ? ch_lo >> (8 * c) : ch_hi >> (8 * (c - 4))) & 255u);
+#pragma unroll
+            for (int k = 0; k < K; k++) acc[k] += W[o_tab + K * ct + k];
+          }
+        }
+        if (nch > 0)
+#pragma unroll
+          for (int k = 0; k < K; k++) W[o_tab + K * bottom + k] = acc[k];
+        for (int st = 1; st < maxlen; st++) {
+          const int b = bottom - st;
+          if (b >= g) {
+#pragma unroll
+            for (int k = 0; k < K; k++) { acc[k] += W[o_tab + K * b + k]; W[o_tab + K * b + k] = acc[k]; }
+          }
+        }
+      }
+      GSYNC();
+    }
+  }
+
   // ----------------------------------------------------- A5 velocity stage + bias forces
   __device__ __forceinline__ void velocity_bias() {
     // offsets read once and pinned in SGPRs for this stage (see PIN_S)
@@ -1297,20 +1347,28 @@ struct Engine {
     }
     // backward accumulation through LDS (u1 region now holds cfrc[6*nbody]); deepest level first
     GSYNC();
-    if (g < nb)
+    if (KD().bchain_nlevel > 0) {
+      if (g < nb)
 #pragma unroll
-      for (int k = 0; k < 6; k++) W[o_u1 + 6 * g + k] = 0.f;
-    GSYNC();
-    for (int lv = d_nlevel_; lv >= 1; lv--) {
-      if (b_depth == lv) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          float tot = cf[k] + W[o_u1 + 6 * g + k];
-          W[o_u1 + 6 * g + k] = tot;
-          if (b_parent > 0) atomicAdd(&W[o_u1 + 6 * b_parent + k], tot);
-        }
-      }
+        for (int k = 0; k < 6; k++) W[o_u1 + 6 * g + k] = cf[k];
       GSYNC();
+      subtree_sum<6>(o_u1);
+    } else {
+      if (g < nb)
+#pragma unroll
+        for (int k = 0; k < 6; k++) W[o_u1 + 6 * g + k] = 0.f;
+      GSYNC();
+      for (int lv = d_nlevel_; lv >= 1; lv--) {
+        if (b_depth == lv) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            float tot = cf[k] + W[o_u1 + 6 * g + k];
+            W[o_u1 + 6 * g + k] = tot;
+            if (b_parent > 0) atomicAdd(&W[o_u1 + 6 * b_parent + k], tot);
+          }
+        }
+        GSYNC();
+      }
     }
     d_bias = 0.f;
     if (g < d_nv_) {
@@ -1334,12 +1392,14 @@ struct Engine {
     if constexpr (!SP)
       for (int e = g; e < NVP * NVP; e += G) W[o_u1 + e] = 0.f;
     GSYNC();
-    for (int lv = KD().nlevel; lv >= 2; lv--) {
-      if (b_depth == lv && b_parent > 0)
+    if (KD().bchain_nlevel > 0) subtree_sum<10>(o_crb);
+    else
+      for (int lv = KD().nlevel; lv >= 2; lv--) {
+        if (b_depth == lv && b_parent > 0)
 #pragma unroll
-        for (int k = 0; k < 10; k++) atomicAdd(&W[o_crb + 10 * b_parent + k], W[o_crb + 10 * g + k]);
-      GSYNC();
-    }
+          for (int k = 0; k < 10; k++) atomicAdd(&W[o_crb + 10 * b_parent + k], W[o_crb + 10 * g + k]);
+        GSYNC();
+      }
     if constexpr (SP) {
       // M[g][anc_d] = cdof_anc . (Ic_body(g) cdof_g): the ancestors' motion axes are independent LDS gathers
       if (g < nv) {
