@@ -56,7 +56,8 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
        MM_INFO_LANES_PER_ENV, MM_INFO_LDS_BYTES_PER_ENV, MM_INFO_ENVS_PER_BLOCK, MM_INFO_NGEOM,
        MM_INFO_WAVES_PER_BLOCK,
        MM_INFO_KERNEL_FAMILY,
-       MM_INFO_MODEL_WORDS };     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */   /* 0 limit rows only, dense Cholesky (nv <= 4); 1 limit rows only, tree-sparse L'DL; 2 general rows */
+       MM_INFO_MODEL_WORDS,
+       MM_INFO_BODY_CHAINS };     /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */   /* 0 limit rows only, dense Cholesky (nv <= 4); 1 limit rows only, tree-sparse L'DL; 2 general rows */
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
 typedef struct {

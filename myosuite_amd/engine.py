@@ -31,7 +31,8 @@ RWD_KEYS_KEYTURN = ["key_turn", "IFtip_approach", "THtip_approach", "act_reg", "
 RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", "done", "dense"]
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
- INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK, INFO_KERNEL_FAMILY, INFO_MODEL_WORDS) = range(14)
+ INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK, INFO_KERNEL_FAMILY, INFO_MODEL_WORDS,
+ INFO_BODY_CHAINS) = range(15)
 
 
 class EngineError(RuntimeError):
