@@ -1,6 +1,7 @@
 // myosim_engine.hip -- host side of the C ABI (include/myosim.h): model upload, LDS layout, kernel selection / launch,
 // reset and Philox kernels.  The fused physics kernel template is in myosim_engine_kernel.hpp.
 #include <array>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include "myosim_engine_kernel.hpp"
@@ -187,6 +188,7 @@ struct mm_model {
 
 static int upload_consts(mm_model* m);
 static thread_local std::string g_err;
+static int g_two_wave = 1;   // MYOSIM_TWO_WAVE=0 switches the helper waves off (A/B, debugging)
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x)                                                                                 \
   do {                                                                                            \
@@ -227,7 +229,10 @@ static void build_layout(mm_model* m) {
   L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
   L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
-  L.wrapw = (7 * m->nwrapitem <= u1_words) ? L.u1 : take(7 * m->nwrapitem);   // u1 is free between FK and the velocity stage
+  // u1 is free between FK and the velocity stage -- of the SAME wave: the general-row kernels may run the tendon stage in a
+  // helper wave next to the main wave's velocity stage (Engine::TW), so their tangent points get their own words
+  L.wrapw = (!d.gen && 7 * m->nwrapitem <= u1_words) ? L.u1 : take(7 * m->nwrapitem);
+  L.flags = take(2);
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
   o = (o + 3) & ~3;
@@ -263,6 +268,7 @@ static int check_lanes(const mm_model* m, int lanes) {
 }
 
 extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out) {
+  { const char* tw = getenv("MYOSIM_TWO_WAVE"); if (tw) g_two_wave = atoi(tw) != 0; }
   if (!blob || !out || nwords < MM_HEADER_WORDS + 2 * MM_NSEC) return fail(MM_EBADBLOB, "blob too short");
   if (blob[0] != MM_MAGIC || blob[1] != MM_VERSION || blob[2] != MM_NSEC || (int)blob[3] != nwords)
     return fail(MM_EBADBLOB, "bad magic/version/section count");
@@ -873,7 +879,10 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   const int epb = epw * wpb;
   const size_t lds = model_bytes + (size_t)epb * m->lds_per_env;
   if (lds > kLds) return fail(MM_ELDS, "per-block LDS tables exceed 160 KiB");
-  dim3 grid((a.s.nenv + epb - 1) / epb), block(64 * wpb);
+  // Two waves per env (Engine::TW): general-row Euler kernels with one env per wave, when the batch leaves at least half of the
+  // SIMDs without a wave (<= 4 env waves per CU: the block still fits the 512-thread launch bound with the helpers in it)
+  a.two_wave = (g_two_wave && G == 64 && m->d.gen && integ_kernel(m->d.integrator) == 0 && wpb <= 4 && want <= 4) ? 1 : 0;
+  dim3 grid((a.s.nenv + epb - 1) / epb), block(64 * wpb * (a.two_wave ? 2 : 1));
   hipStream_t st = (hipStream_t)stream;
   a.blob_words = m->blob_words;
   a.prof = g_prof;

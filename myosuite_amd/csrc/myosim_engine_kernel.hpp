@@ -84,6 +84,7 @@ struct Layout {
   int u1;   // union: xquat[4nb] during FK | (cvel,cacc)[12nb] then cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
+  int flags;   // two-wave launches: [0] passes the main wave has opened (kinematics done), [1] passes the helper wave has finished
   int wrapw;   // per wrapping path item: the two tangent points and a wrapped flag (7 words); inside u1 (free between FK and the velocity stage) when it fits
   int vec;  // nv: joint-transmission actuator forces
   int xvec; // NVP (16-byte aligned): operand vector of M x products routed through LDS
@@ -130,6 +131,7 @@ struct KArgs {
   mm_derived o;
   mm_rollout ro;         // rollout bookkeeping folded into the launch (mm_rollout_step); has_ro = 0: plain mm_env_step
   int has_ro;
+  int two_wave;          // every env is run by two waves of the block (Engine::TW): see k_engine
   int has_derived;
   int mode;              // 0: step(s) only, 1: forward only, 2: env step
   float* dbg;
@@ -662,6 +664,14 @@ struct SegLane {
 template <int G, int NVP, bool GEN, int INTEG>
 struct Engine {
   static constexpr bool RK4 = INTEG == 1, IMPL = INTEG == 2;
+  // Two waves per env (a.two_wave; general-row Euler kernels, one env per wave): when the batch leaves SIMDs empty -- leg-walk at
+  // 1024 envs is one wave per SIMD, all of them waiting on dependent latency most of the time -- a second wave of the block
+  // runs the stages that need no per-lane register state (tendon paths + Jacobian, tendon velocities, muscle / actuator forces,
+  // J'f) concurrently with the main wave's constraint assembly, velocity / RNE stage, CRB and factorisation.  The two meet
+  // through two LDS counters per env with bounded spin waits (a lost partner raises status bit 16 instead of hanging).
+  static constexpr bool TW = GEN && G == 64 && INTEG == 0;
+  static constexpr int TW_DONE = 0x7fffffff;
+  int tw_n;     // forward passes opened so far (two-wave launches)
   // Dense Cholesky form.  Left-looking (row j of L from an LDS tile, one pivot broadcast per column) executes ~40 % fewer
   // instructions than right-looking (NVP^2 / 2 cross-lane broadcasts) but adds an LDS round trip per column.  Groups narrower than
   // the wave always take it (a broadcast costs ~5 issue slots there).  One env per wave: it wins where two or more waves per SIMD
@@ -722,7 +732,7 @@ struct Engine {
   int env;                  // env index (per-env model deltas on a body: mm_state.body_mass_env / body_pos_env)
 
   __device__ __forceinline__ Engine(const KArgs& a_, const KConst& kc_, const uint32_t* mb_, float* W_, int g_)
-      : a(a_), kc(kc_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0) {
+      : a(a_), kc(kc_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0), tw_n(0) {
 #pragma unroll
     for (int i = 0; i < (MM_STAGE_PROF ? NPROF : 1); i++) pf[i] = 0;
     d_warm = 0.f; d_qvel = 0.f;
@@ -802,6 +812,30 @@ struct Engine {
 
   __device__ __forceinline__ V3 origin() const { return v3(KD().ox, KD().oy, KD().oz); }
   __device__ __forceinline__ float com_of_body(int b, int k) const { return W[KL().com + 3 * AUXI(body_rootslot)[b] + k]; }
+
+  __device__ __forceinline__ void tw_signal(int idx, int n) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (g == 0) reinterpret_cast<volatile int*>(W + KL().flags)[idx] = n;
+  }
+  __device__ __forceinline__ int tw_wait(int idx, int n) {
+    volatile int* f = reinterpret_cast<volatile int*>(W + KL().flags);
+    int v = f[idx];
+    for (int it = 0; v < n && it < (1 << 22); it++) { __builtin_amdgcn_s_sleep(1); v = f[idx]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (v < n) status |= 16;   // the partner wave never arrived
+    return v;
+  }
+  // the helper wave of a two-wave launch: for every forward pass the main wave opens, the tendon and actuation stages
+  __device__ __forceinline__ void helper_loop() {
+    for (int n = 1;; n++) {
+      const int v = tw_wait(0, n);
+      if (v == TW_DONE || v < n) break;
+      tendon();
+      tendon_velocity();
+      actuation();
+      tw_signal(1, n);
+    }
+  }
 
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
@@ -1180,6 +1214,22 @@ struct Engine {
     return c_rowj_mine ? v : 0.f;
   }
 
+  // tendon velocities J qvel (sparse rows)
+  __device__ __forceinline__ void tendon_velocity() {
+    const auto& L = KL();
+    int o_qvel = L.qvel;
+    {
+      int s_ja = SECOFF_(TENJ_ADR), s_jd = SECOFF_(TENJ_DOF), o_tj = L.tenj, o_qv = o_qvel, o_tv = L.tenvel;
+      PIN_S(s_ja); PIN_S(s_jd); PIN_S(o_tj); PIN_S(o_qv); PIN_S(o_tv);
+      for (int t = g; t < KD().ntendon; t += G) {
+        float s = 0.f;
+        const int e0 = reinterpret_cast<const int*>(mb + s_ja)[t], e1 = reinterpret_cast<const int*>(mb + s_ja)[t + 1];
+        for (int e = e0; e < e1; e++) s += W[o_tj + e] * W[o_qv + reinterpret_cast<const int*>(mb + s_jd)[e]];
+        W[o_tv + t] = s;
+      }
+    }
+  }
+
   // Subtree sums of a K-vector per body, in place in an LDS table [nbody][K] (composite inertias, RNE forces): S[b] = V[b] +
   // sum over the children c of S[c].  The body tree is cut into chains (maximal unbranched paths; bodies of a chain have
   // consecutive ids in MuJoCo's depth-first order -- the host checks); the lane of a chain's top body walks its chain from the
@@ -1231,16 +1281,7 @@ struct Engine {
     int o_cdof = KL().cdof; PIN_S(o_cdof); int o_u1 = KL().u1; PIN_S(o_u1); int o_qvel = KL().qvel; PIN_S(o_qvel); int s_JNT_TYPE = SECOFF_(JNT_TYPE); PIN_S(s_JNT_TYPE); int s_JNT_DOFADR = SECOFF_(JNT_DOFADR); PIN_S(s_JNT_DOFADR); int s_DOF_BODYID = SECOFF_(DOF_BODYID); PIN_S(s_DOF_BODYID); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_); int d_nv_ = KD().nv; PIN_S(d_nv_);
     const auto& L = KL();
     const int nb = d_nbody_;
-    {
-      int s_ja = SECOFF_(TENJ_ADR), s_jd = SECOFF_(TENJ_DOF), o_tj = L.tenj, o_qv = o_qvel, o_tv = L.tenvel;
-      PIN_S(s_ja); PIN_S(s_jd); PIN_S(o_tj); PIN_S(o_qv); PIN_S(o_tv);
-      for (int t = g; t < KD().ntendon; t += G) {
-        float s = 0.f;
-        const int e0 = reinterpret_cast<const int*>(mb + s_ja)[t], e1 = reinterpret_cast<const int*>(mb + s_ja)[t + 1];
-        for (int e = e0; e < e1; e++) s += W[o_tj + e] * W[o_qv + reinterpret_cast<const int*>(mb + s_jd)[e]];
-        W[o_tv + t] = s;
-      }
-    }
+    if (!(TW && a.two_wave)) tendon_velocity();
     // Forward pass by pointer jumping (see kinematics): cvel of a body is the SUM of cdof * qvel over the dofs of its
     // ancestors and itself (everything is expressed about the subtree COM: no frame change along the chain), so it is a
     // prefix sum over the chain: ceil(log2(depth)) rounds of "add what my pointer holds, point where it points".  The bias
@@ -1822,6 +1863,12 @@ struct Engine {
 
   // ------------------------------------------- A5/A6 passive + actuation -> qfrc_smooth
   __device__ __forceinline__ void passive_actuation() {
+    if (!(TW && a.two_wave)) actuation();
+    else tw_wait(1, tw_n);
+    smooth_force();
+  }
+  // tendon springs / dampers, actuator dynamics and forces, J'f: LDS in, LDS out (a two-wave launch runs it in the helper wave)
+  __device__ __forceinline__ void actuation() {
     const auto& L = KL();
     if constexpr (IMPL) {   // implicitfast: start the velocity-derivative weights from the passive dampers (mjd_passive_vel)
       for (int t = g; t < KD().ntendon; t += G) W[L.tenw + t] = MF_(TENDON_DAMPING)[t];
@@ -1916,6 +1963,10 @@ struct Engine {
       }
     }
     GSYNC();
+  }
+  // qfrc_smooth of dof g: passive joint forces - bias + actuation
+  __device__ __forceinline__ void smooth_force() {
+    const auto& L = KL();
     d_smooth = 0.f;
     if (g < KD().nv) {
       float s = -MF_(DOF_DAMPING)[g] * d_qvel - d_bias + W[L.vec + g];
@@ -2564,7 +2615,11 @@ struct Engine {
   __device__ __forceinline__ void forward() {
     PFT(PF_KIN, kinematics());
     PFT(PF_COM, com_pos());
-    PFT(PF_TENDON, tendon());
+    const bool tw = TW && a.two_wave;
+    if (tw) {
+      tw_signal(0, ++tw_n);                       // poses are final: the helper wave starts on the tendons
+      if (KD().ntlim) tw_wait(1, tw_n);           // tendon-limit rows need its lengths and Jacobian
+    } else PFT(PF_TENDON, tendon());
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
@@ -2831,15 +2886,19 @@ template <int G, int NVP, bool LM, bool GEN, int INTEG>
 __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   extern __shared__ float lds[];
   constexpr int EPW = 64 / G;  // envs per wave
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wpb = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // two-wave launches (Engine::TW): waves [0, wpb) are the main waves of the block's envs, waves [wpb, 2 wpb) their helpers
+  const bool two_wave = Engine<G, NVP, GEN, INTEG>::TW && a.two_wave;
+  const int wpb = two_wave ? (blockDim.x >> 7) : (blockDim.x >> 6);
+  const bool helper = two_wave && (int)(threadIdx.x >> 6) >= wpb;
+  const int wave = (int)(threadIdx.x >> 6) - (helper ? wpb : 0);
   const int g = lane % G;
   unsigned long long t_start = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
   // reset-observation pass (mm_task.obs_only with an env mask): a block none of whose envs is flagged leaves before the model
   // is staged -- every wave scans the block's whole env range, so the decision is block-uniform and nobody is left waiting at
   // the barrier (the pass is launched after every step of the non-Pose tasks and usually has nothing to do)
   if (a.mode == 2 && KA().t.obs_only && KA().t.env_mask) {
-    const int epb = (blockDim.x >> 6) * EPW, e0 = blockIdx.x * epb;
+    const int epb = wpb * EPW, e0 = blockIdx.x * epb;
     bool any = false;
     for (int i = lane; i < epb; i += 64) any |= (e0 + i < a.s.nenv) && KA().t.env_mask[e0 + i] != 0;
     if (__ballot(any) == 0ull) return;
@@ -2853,6 +2912,13 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     __syncthreads();
     mb = lm;
     wsbase = lds + ((a.blob_words + 3) & ~3);
+  }
+  if (two_wave) {   // the meeting counters of the block's envs start at zero
+    if ((int)threadIdx.x < wpb * EPW) {
+      float* Wf = wsbase + (size_t)threadIdx.x * KL().total + KL().flags;
+      reinterpret_cast<int*>(Wf)[0] = 0; reinterpret_cast<int*>(Wf)[1] = 0;
+    }
+    __syncthreads();
   }
   KConst kc;
 #if MM_CONST_IN_REGS
@@ -2884,6 +2950,9 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
   if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
   E.env = e;
+  if constexpr (Engine<G, NVP, GEN, INTEG>::TW) {
+    if (helper) { E.helper_loop(); return; }   // everything it needs and leaves lives in the env's LDS tables
+  }
 
   // ---- load state (HBM -> LDS tables / owner registers)
   for (int i = g; i < d.nq; i += G) W[L.qpos + i] = a.s.qpos[(size_t)e * d.nq + i];
@@ -2952,6 +3021,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   int nsub = (a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
   bool fwd = a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
   E.run(nsub, fwd, time);
+  if constexpr (Engine<G, NVP, GEN, INTEG>::TW) { if (two_wave) E.tw_signal(0, Engine<G, NVP, GEN, INTEG>::TW_DONE); }
 
   if (dup) return;   // surplus groups never write
 
