@@ -168,7 +168,7 @@ struct mm_model {
   std::vector<uint32_t> h_blob;
   int sec[MM_NSEC];
   Dims d;
-  Layout L;
+  Layout L, Ltw;   // LDS tables of an env in a one-wave / two-wave launch (env_layout)
   DbgLayout D;
   Aux x;
   int lanes = 64;
@@ -177,8 +177,8 @@ struct mm_model {
   int waves_per_block = 0;   // 0 = auto
   int lds_model = 1;
   int blob_words = 0;
-  int cofs = 0;              // word offset of the ConstBlock behind the blob (device copy only)
-  size_t lds_per_env = 0;
+  int cofs = 0, cofs_tw = 0; // word offsets of the ConstBlocks (one-wave / two-wave launches) behind the blob (device copy only)
+  size_t lds_per_env = 0, lds_per_env_tw = 0;   // bytes of LDS tables per env (one-wave / two-wave launches)
   int device = 0;
   float origin[3] = {0.f, 0.f, 0.f};   // internal world-frame origin (see Dims::ox)
   std::vector<int32_t> desc_all, seg_tab, anc_tab;   // Aux::dof_desc / dof_seg / dof_anc, built with the dims
@@ -211,10 +211,13 @@ static bool have_kernel(int G, int nvp, int gen, int rk4 = 0) {
   return false;
 }
 
-static void build_layout(mm_model* m) {
-  m->d.efc_rows = std::min(m->lanes, (m->d.njmax + 3) & ~3);
+// LDS tables of one env.  two_wave: the layout of a launch that gives every env a helper wave (Engine::TW): tables that share words
+// in a one-wave launch because ONE wave never needs both at a time (joint anchors / axes vs the composite inertias, the tendons'
+// tangent points vs the u1 scratch) get their own words, plus a second dense tile and the meeting counters.
+static Layout env_layout(const mm_model* m, bool two_wave) {
   const Dims& d = m->d;
-  Layout& L = m->L;
+  Layout L;
+  memset(&L, 0, sizeof(L));
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n > 0 ? n : 0); return r; };
   L.qpos = take(d.nq); L.qvel = take(d.nv); L.act = take(d.na); L.ctrl = take(d.nu); L.actdot = take(d.na);
@@ -223,32 +226,38 @@ static void build_layout(mm_model* m) {
   o = (o + 3) & ~3;
   // 12 words (cvel, cacc) + 1 pointer-jumping word per body | dense tile | SP kernels: published rows [nvp][12], x [nvp], update
   // matrices [nseg][36]
-  m->d.seg_u = 13 * m->nvp;
-  const int u1_words = std::max(std::max(13 * d.nbody, m->nvp * m->nvp), m->d.seg_u + 36 * m->nseg);
+  const int u1_words = std::max(std::max(13 * d.nbody, m->nvp * m->nvp), d.seg_u + 36 * m->nseg);
   L.u1 = take(u1_words);
-  L.crb = take(std::max(10 * d.nbody, 6 * d.njnt));
-  L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt;   // joint anchors/axes die before the composite inertias are written
+  if (two_wave) { L.crb = take(10 * d.nbody); L.xanchor = take(3 * d.njnt); L.xaxis = take(3 * d.njnt); }
+  else { L.crb = take(std::max(10 * d.nbody, 6 * d.njnt)); L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt; }   // anchors / axes die before crb
   L.tenlen = take(d.ntendon); L.tenvel = take(d.ntendon); L.tenj = take(d.ntenJ); L.tenfrc = take(d.ntendon);
-  // u1 is free between FK and the velocity stage -- of the SAME wave: the general-row kernels may run the tendon stage in a
-  // helper wave next to the main wave's velocity stage (Engine::TW), so their tangent points get their own words
-  L.wrapw = (!d.gen && 7 * m->nwrapitem <= u1_words) ? L.u1 : take(7 * m->nwrapitem);
-  L.flags = take(2);
+  L.wrapw = (!two_wave && 7 * m->nwrapitem <= u1_words) ? L.u1 : take(7 * m->nwrapitem);   // u1 is free between FK and the velocity stage
+  L.flags = take(two_wave ? 4 : 0);
   L.actlen = take(d.nu); L.actvel = take(d.nu); L.actfrc = take(d.nu);
   L.vec = take(d.nv);
   o = (o + 3) & ~3;
   L.xvec = take(m->nvp);
-  L.efcJ = L.rowtab = 0;
-  L.rk_qpos0 = L.rk_act0 = L.rk_adot = 0;
   if (d.integrator == MM_INT_RK4) { L.rk_qpos0 = take(d.nq); L.rk_act0 = take(d.na); L.rk_adot = take(d.na); }
-  L.tenw = L.dofw = 0;
   if (d.integrator == MM_INT_IMPLICITFAST) { L.tenw = take(d.ntendon); L.dofw = take(d.nv); }
   if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(d.efc_rows * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
+  if (two_wave) { o = (o + 3) & ~3; L.mtile = take(m->nvp * m->nvp + m->nvp); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
   o = (o + 3) & ~3;
   if ((o & 31) == 0) o += 4;
   L.total = o;
-  m->lds_per_env = (size_t)o * 4;
+  return L;
+}
+static void build_layout(mm_model* m) {
+  m->d.efc_rows = std::min(m->lanes, (m->d.njmax + 3) & ~3);
+  m->d.seg_u = 13 * m->nvp;
+  const Dims& d = m->d;
+  m->L = env_layout(m, false);
+  m->Ltw = env_layout(m, true);
+  m->lds_per_env = (size_t)m->L.total * 4;
+  m->lds_per_env_tw = (size_t)m->Ltw.total * 4;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += (n > 0 ? n : 0); return r; };
   DbgLayout& D = m->D;
   o = 0;
   D.xpos = take(3 * d.nbody); D.xquat = take(4 * d.nbody); D.xipos = take(3 * d.nbody); D.cdof = take(6 * d.nv);
@@ -696,6 +705,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   m->blob_words = (int)dev.size();
   m->cofs = (int)dev.size();          // ConstBlock (dims / LDS layout / aux offsets): global-only tail, not staged into LDS
   dev.resize(dev.size() + (sizeof(ConstBlock) + 3) / 4, 0u);
+  m->cofs_tw = (int)dev.size();       // the same for two-wave launches (their LDS layout differs)
+  dev.resize(dev.size() + (sizeof(ConstBlock) + 3) / 4, 0u);
 
   // default group width: the smallest that can own every body / dof / constraint row and has a compiled kernel
   m->lanes = 0;
@@ -733,6 +744,8 @@ static int upload_consts(mm_model* m) {
   cb.d = m->d; cb.L = m->L; cb.x = m->x;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(m->d_blob + m->cofs, &cb, sizeof(cb), hipMemcpyHostToDevice));
+  cb.L = m->Ltw;   // the const block of two-wave launches: the same dims and tables, the other LDS layout
+  HIPCHK(hipMemcpy(m->d_blob + m->cofs_tw, &cb, sizeof(cb), hipMemcpyHostToDevice));
   return MM_OK;
 }
 
@@ -855,33 +868,43 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   const size_t kLds = 160 * 1024;
   const size_t blob_bytes = (size_t)((m->blob_words + 3) & ~3) * 4;
   const int waves_needed = (a.s.nenv + epw - 1) / epw;
-  auto fit_waves = [&](size_t model_bytes) {   // waves of one block that fit in LDS next to the model copy (<= 8)
-    int fit = 8;                               // __launch_bounds__(512)
-    while (fit > 1 && model_bytes + (size_t)fit * epw * m->lds_per_env > kLds) fit--;
-    return fit;
-  };
   // lds_model: 1 = stage the model tables in LDS unless that costs resident waves the batch needs (then read them through
   // L2 instead: a graceful step instead of an occupancy cliff when a model grows past the LDS budget), 0 = never, 2 = always
   int want = (waves_needed + 255) / 256;       // waves per CU that spread the batch over all 256 CUs in one round
   if (want < 1) want = 1;
   if (want > 8) want = 8;
-  int lm = m->lds_model ? 1 : 0;
-  if (m->lds_model == 1 && fit_waves(blob_bytes) < want && fit_waves(0) > fit_waves(blob_bytes)) lm = 0;
-  if (m->lds_model == 1 && blob_bytes + (size_t)epw * m->lds_per_env > kLds) lm = 0;   // not even one wave fits next to the model copy
-  const size_t model_bytes = lm ? blob_bytes : 0;
-  int wpb = m->waves_per_block;
-  if (wpb <= 0) {
-    // one block per CU sharing one model copy: as many waves as fit in LDS, but no fatter than needed
-    wpb = want;
-    const int fit = fit_waves(model_bytes);
-    if (wpb > fit) wpb = fit;
+  // Two waves per env (Engine::TW): general-row Euler kernels with one env per wave, when the batch leaves at least half of the
+  // SIMDs without a wave (<= 4 env waves per CU: the block still fits the 512-thread launch bound with the helpers in it) and
+  // the larger per-env tables (a second dense tile) do not cost env waves
+  int two_wave = (g_two_wave && G == 64 && m->d.gen && integ_kernel(m->d.integrator) == 0 && want <= 4 && m->waves_per_block <= 0) ? 1 : 0;
+  int lm = 0, wpb = 0;
+  size_t per_env = 0, model_bytes = 0;
+  for (;;) {
+    per_env = two_wave ? m->lds_per_env_tw : m->lds_per_env;
+    auto fit_waves = [&](size_t mbytes) {   // waves of one block that fit in LDS next to the model copy (<= 8)
+      int fit = 8;                             // __launch_bounds__(512)
+      while (fit > 1 && mbytes + (size_t)fit * epw * per_env > kLds) fit--;
+      return fit;
+    };
+    lm = m->lds_model ? 1 : 0;
+    if (m->lds_model == 1 && fit_waves(blob_bytes) < want && fit_waves(0) > fit_waves(blob_bytes)) lm = 0;
+    if (m->lds_model == 1 && blob_bytes + (size_t)epw * per_env > kLds) lm = 0;   // not even one wave fits next to the model copy
+    model_bytes = lm ? blob_bytes : 0;
+    wpb = m->waves_per_block;
+    if (wpb <= 0) {
+      // one block per CU sharing one model copy: as many waves as fit in LDS, but no fatter than needed
+      wpb = want;
+      const int fit = fit_waves(model_bytes);
+      if (wpb > fit) wpb = fit;
+    }
+    if (two_wave && (wpb < want || wpb > 4)) { two_wave = 0; continue; }   // the extra tile would cost env waves: one wave per env
+    break;
   }
   const int epb = epw * wpb;
-  const size_t lds = model_bytes + (size_t)epb * m->lds_per_env;
+  const size_t lds = model_bytes + (size_t)epb * per_env;
   if (lds > kLds) return fail(MM_ELDS, "per-block LDS tables exceed 160 KiB");
-  // Two waves per env (Engine::TW): general-row Euler kernels with one env per wave, when the batch leaves at least half of the
-  // SIMDs without a wave (<= 4 env waves per CU: the block still fits the 512-thread launch bound with the helpers in it)
-  a.two_wave = (g_two_wave && G == 64 && m->d.gen && integ_kernel(m->d.integrator) == 0 && wpb <= 4 && want <= 4) ? 1 : 0;
+  a.two_wave = two_wave;
+  if (two_wave) { a.cofs = m->cofs_tw; a.L = m->Ltw; }
   dim3 grid((a.s.nenv + epb - 1) / epb), block(64 * wpb * (a.two_wave ? 2 : 1));
   hipStream_t st = (hipStream_t)stream;
   a.blob_words = m->blob_words;

@@ -84,6 +84,7 @@ struct Layout {
   int u1;   // union: xquat[4nb] during FK | (cvel,cacc)[12nb] then cfrc[6nb] during the velocity stage | dense NVP*NVP tile afterwards
   int crb;
   int tenlen, tenvel, tenj, tenfrc, actlen, actvel, actfrc;
+  int mtile;   // two-wave launches: a second dense NVP x NVP tile (M for the helper wave, which leaves Euler's factor in it) + NVP words (1 / diagonal)
   int flags;   // two-wave launches: [0] passes the main wave has opened (kinematics done), [1] passes the helper wave has finished
   int wrapw;   // per wrapping path item: the two tangent points and a wrapped flag (7 words); inside u1 (free between FK and the velocity stage) when it fits
   int vec;  // nv: joint-transmission actuator forces
@@ -672,6 +673,7 @@ struct Engine {
   static constexpr bool TW = GEN && G == 64 && INTEG == 0;
   static constexpr int TW_DONE = 0x7fffffff;
   int tw_n;     // forward passes opened so far (two-wave launches)
+  int o_tile;   // LDS word offset of the dense tile factor_core / solve work on (u1; the helper wave's own tile in two-wave launches)
   // Dense Cholesky form.  Left-looking (row j of L from an LDS tile, one pivot broadcast per column) executes ~40 % fewer
   // instructions than right-looking (NVP^2 / 2 cross-lane broadcasts) but adds an LDS round trip per column.  Groups narrower than
   // the wave always take it (a broadcast costs ~5 issue slots there).  One env per wave: it wins where two or more waves per SIMD
@@ -732,7 +734,8 @@ struct Engine {
   int env;                  // env index (per-env model deltas on a body: mm_state.body_mass_env / body_pos_env)
 
   __device__ __forceinline__ Engine(const KArgs& a_, const KConst& kc_, const uint32_t* mb_, float* W_, int g_)
-      : a(a_), kc(kc_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0), tw_n(0) {
+      : a(a_), kc(kc_), mb(mb_), W(W_), g(g_), status(0), nefc(0), niter(0), tw_n(0), o_tile(0) {
+    o_tile = KL().u1;   // (not in the initialiser list: the member is declared ahead of the references KL() goes through)
 #pragma unroll
     for (int i = 0; i < (MM_STAGE_PROF ? NPROF : 1); i++) pf[i] = 0;
     d_warm = 0.f; d_qvel = 0.f;
@@ -834,6 +837,23 @@ struct Engine {
       tendon_velocity();
       actuation();
       tw_signal(1, n);
+      if (KD().any_damping && KD().eulerdamp) {
+        // the factor of M + h B the Euler step will need (mj_Euler's implicit joint damping) does not depend on the constraint
+        // solve: computed here while the main wave is in Newton.  M arrives in the second tile and L leaves in it.
+        tw_wait(2, n);
+        const float* Mg = W + KL().mtile + (g < NVP ? g : 0) * NVP;
+#pragma unroll
+        for (int k4 = 0; k4 < NVP / 4; k4++) {
+          const float4 r = *reinterpret_cast<const float4*>(Mg + 4 * k4);
+          Mrow[4 * k4] = g < NVP ? r.x : 0.f; Mrow[4 * k4 + 1] = g < NVP ? r.y : 0.f;
+          Mrow[4 * k4 + 2] = g < NVP ? r.z : 0.f; Mrow[4 * k4 + 3] = g < NVP ? r.w : 0.f;
+        }
+        GSYNC();
+        o_tile = KL().mtile;
+        factor(g < KD().nv ? KD().timestep * MF_(DOF_DAMPING)[g] : 0.f);
+        if (g < NVP) W[KL().mtile + NVP * NVP + g] = d_dinv;   // 1 / L[g][g] as computed (not re-derived from L: bit-identical solves)
+        tw_signal(3, n);
+      }
     }
   }
 
@@ -1782,7 +1802,7 @@ struct Engine {
       // v_readlane + v_mov + v_cndmask + hazard nops), and the right-looking update needs NVP^2/2 of them.  Here row j of L
       // comes from the LDS tile instead (one 128-bit load per four entries; the tile is written column by column as the
       // factor proceeds, LDS ops of a wave execute in order) and only the pivot is broadcast: NVP broadcasts in total.
-      float* T = W + L.u1;
+      float* T = W + o_tile;
       const int row = g < NVP ? g : 0;
 #pragma unroll
       for (int j = 0; j < NVP; j++) {
@@ -1820,7 +1840,7 @@ struct Engine {
     // leave L in the dense LDS tile: the backward substitution reads its columns (= rows of L') from there
     if (g < NVP)
 #pragma unroll
-      for (int k = 0; k < NVP; k++) W[L.u1 + g * NVP + k] = Lrow[k];
+      for (int k = 0; k < NVP; k++) W[o_tile + g * NVP + k] = Lrow[k];
     else d_dinv = 1.f;
     GSYNC();
   }
@@ -1832,7 +1852,7 @@ struct Engine {
       float yj = bc<G>(x * d_dinv, j);
       x = (g == j) ? yj : (g > j ? x - Lrow[j] * yj : x);
     }
-    const float* LT = W + KL().u1 + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
+    const float* LT = W + o_tile + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
 #pragma unroll
     for (int i = NVP - 1; i >= 0; i--) {
       float zi = bc<G>(x * d_dinv, i);
@@ -2623,6 +2643,15 @@ struct Engine {
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
+    if (tw && KD().any_damping && KD().eulerdamp) {   // M for the helper wave's Euler factor
+      if (g < NVP) {
+        float* Mg = W + KL().mtile + g * NVP;
+#pragma unroll
+        for (int k4 = 0; k4 < NVP / 4; k4++)
+          *reinterpret_cast<float4*>(Mg + 4 * k4) = make_float4(Mrow[4 * k4], Mrow[4 * k4 + 1], Mrow[4 * k4 + 2], Mrow[4 * k4 + 3]);
+      }
+      tw_signal(2, tw_n);
+    }
     constexpr bool SPG = GEN && MM_SPARSE_LDL && MM_SPARSE_GEN && NVP >= 8 && INTEG != 2;
     const bool spg = SPG && (MM_SPARSE_GEN == 2 || KD().seg_nlevel > 0);   // general-row kernel on a model whose dof tree the sparse solve handles
     if constexpr (!SP) { if (!spg) PFT(PF_FACTOR, factor(0.f)); }
@@ -2661,7 +2690,21 @@ struct Engine {
     d_warm = d_qacc;
     float qa_ = d_qacc;
     if (KD().any_damping && KD().eulerdamp) {
-      qa_ = factor_solve(g < KD().nv ? h * MF_(DOF_DAMPING)[g] : 0.f, g < KD().nv ? d_smooth + d_qfrccon : 0.f);
+      if (TW && a.two_wave) {
+        // the helper wave factorised M + h B while this wave was in Newton: fetch row g of L, solve
+        tw_wait(3, tw_n);
+        const float* Lg = W + KL().mtile + (g < NVP ? g : 0) * NVP;
+#pragma unroll
+        for (int k4 = 0; k4 < NVP / 4; k4++) {
+          const float4 r = *reinterpret_cast<const float4*>(Lg + 4 * k4);
+          Lrow[4 * k4] = g < NVP ? r.x : 0.f; Lrow[4 * k4 + 1] = g < NVP ? r.y : 0.f;
+          Lrow[4 * k4 + 2] = g < NVP ? r.z : 0.f; Lrow[4 * k4 + 3] = g < NVP ? r.w : 0.f;
+        }
+        d_dinv = g < NVP ? W[KL().mtile + NVP * NVP + g] : 1.f;
+        o_tile = KL().mtile;
+        qa_ = solve(g < KD().nv ? d_smooth + d_qfrccon : 0.f);
+        o_tile = KL().u1;
+      } else qa_ = factor_solve(g < KD().nv ? h * MF_(DOF_DAMPING)[g] : 0.f, g < KD().nv ? d_smooth + d_qfrccon : 0.f);
     }
     for (int u = g; u < KD().nu; u += G) {
       int aa = MI_(ACT_ACTADR)[u];
@@ -2916,7 +2959,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (two_wave) {   // the meeting counters of the block's envs start at zero
     if ((int)threadIdx.x < wpb * EPW) {
       float* Wf = wsbase + (size_t)threadIdx.x * KL().total + KL().flags;
-      reinterpret_cast<int*>(Wf)[0] = 0; reinterpret_cast<int*>(Wf)[1] = 0;
+      reinterpret_cast<int*>(Wf)[0] = 0; reinterpret_cast<int*>(Wf)[1] = 0; reinterpret_cast<int*>(Wf)[2] = 0; reinterpret_cast<int*>(Wf)[3] = 0;
     }
     __syncthreads();
   }
