@@ -665,12 +665,14 @@ struct SegLane {
 template <int G, int NVP, bool GEN, int INTEG>
 struct Engine {
   static constexpr bool RK4 = INTEG == 1, IMPL = INTEG == 2;
-  // Two waves per env (a.two_wave; general-row Euler kernels, one env per wave): when the batch leaves SIMDs empty -- leg-walk at
-  // 1024 envs is one wave per SIMD, all of them waiting on dependent latency most of the time -- a second wave of the block
-  // runs the stages that need no per-lane register state (tendon paths + Jacobian, tendon velocities, muscle / actuator forces,
-  // J'f) concurrently with the main wave's constraint assembly, velocity / RNE stage, CRB and factorisation.  The two meet
-  // through two LDS counters per env with bounded spin waits (a lost partner raises status bit 16 instead of hanging).
-  static constexpr bool TW = GEN && G == 64 && INTEG == 0;
+  // Two waves per env group (a.two_wave; the Euler kernels): when the batch leaves SIMDs empty -- leg-walk at 1024 envs is one
+  // wave per SIMD, the elbow at 4096 envs half a wave, all of them waiting on dependent latency most of the time -- a second
+  // wave of the block (same lanes, same envs) runs the stages that need no per-lane register state (tendon paths + Jacobian,
+  // tendon velocities, muscle / actuator forces, J'f) concurrently with the main wave's constraint assembly, velocity / RNE
+  // stage, CRB and factorisation, and -- dense kernels -- factorises M + h B for the Euler step while the main wave is in
+  // Newton.  The two meet through LDS counters per env with bounded spin waits (a lost partner raises status bit 16
+  // instead of hanging).
+  static constexpr bool TW = INTEG == 0;
   static constexpr int TW_DONE = 0x7fffffff;
   int tw_n;     // forward passes opened so far (two-wave launches)
   int o_tile;   // LDS word offset of the dense tile factor_core / solve work on (u1; the helper wave's own tile in two-wave launches)
@@ -837,7 +839,7 @@ struct Engine {
       tendon_velocity();
       actuation();
       tw_signal(1, n);
-      if (KD().any_damping && KD().eulerdamp) {
+      if (!SP && KD().any_damping && KD().eulerdamp) {
         // the factor of M + h B the Euler step will need (mj_Euler's implicit joint damping) does not depend on the constraint
         // solve: computed here while the main wave is in Newton.  M arrives in the second tile and L leaves in it.
         tw_wait(2, n);
@@ -2643,7 +2645,7 @@ struct Engine {
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
-    if (tw && KD().any_damping && KD().eulerdamp) {   // M for the helper wave's Euler factor
+    if (tw && !SP && KD().any_damping && KD().eulerdamp) {   // M for the helper wave's Euler factor
       if (g < NVP) {
         float* Mg = W + KL().mtile + g * NVP;
 #pragma unroll
@@ -2690,7 +2692,7 @@ struct Engine {
     d_warm = d_qacc;
     float qa_ = d_qacc;
     if (KD().any_damping && KD().eulerdamp) {
-      if (TW && a.two_wave) {
+      if (TW && !SP && a.two_wave) {
         // the helper wave factorised M + h B while this wave was in Newton: fetch row g of L, solve
         tw_wait(3, tw_n);
         const float* Lg = W + KL().mtile + (g < NVP ? g : 0) * NVP;
