@@ -241,3 +241,30 @@ def test_rollout_step_other_tasks_and_sharded_streams():
     u = torch.empty(n // 2, full.cm.nu, device="cuda"); v = torch.empty(n, full.cm.nu, device="cuda")
     E.uniform(v, 3, 1); E.uniform(u, 3, 1, first_index=(n // 2) * full.cm.nu)
     assert torch.equal(v[n // 2:], u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,n", [("myoLegWalk-v0", 96), ("myoElbowPose1D6MRandom-v0", 256), ("myoHandReorient8-v0", 64),
+                                      ("myoHandPoseRandom-v0", 128)])
+def test_two_wave_launch_is_bit_identical_to_one_wave(env_id, n, monkeypatch):
+    """Small batches leave SIMDs empty, so every env group gets a helper wave (tendon / actuation stages, Euler's factor) next
+    to its main wave (Engine::TW).  The split changes who computes, not what: observations, rewards and flags of a rollout are
+    bit-identical to the one-wave launch (MYOSIM_TWO_WAVE=0), and no wave ever gives up waiting for its partner (status bit 16)."""
+    recs = []
+    for tw in ("1", "0"):
+        monkeypatch.setenv("MYOSIM_TWO_WAVE", tw)       # read by mm_model_create; applies to every launch after it
+        env = registry.make(env_id, num_envs=n, seed=5, max_episode_steps=6)
+        env.reset(seed=5)
+        a = torch.empty(n, env.cm.nu, device="cuda")
+        rec = []
+        for s in range(9):                              # crosses an episode boundary (auto-reset)
+            E.uniform(a, 31, s)
+            o, r, t, u, _ = env.step(a)
+            rec.append((o.clone(), r.clone(), t.clone(), u.clone()))
+        assert int(env.state.status.max()) & 16 == 0
+        recs.append(rec)
+        del env
+    for (o1, r1, t1, u1), (o0, r0, t0, u0) in zip(*recs):
+        assert torch.equal(o1, o0) and torch.equal(r1, r0) and torch.equal(t1, t0) and torch.equal(u1, u0)
+    monkeypatch.setenv("MYOSIM_TWO_WAVE", "1")
+    registry.make("myoElbowPose1D6MRandom-v0", num_envs=4)   # leave the switch on for the tests that follow
