@@ -873,10 +873,10 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   int want = (waves_needed + 255) / 256;       // waves per CU that spread the batch over all 256 CUs in one round
   if (want < 1) want = 1;
   if (want > 8) want = 8;
-  // Two waves per env group (Engine::TW): the Euler kernels, when the batch leaves at least half of the
+  // Two waves per env group (Engine::TW): the Euler and implicitfast kernels, when the batch leaves at least half of the
   // SIMDs without a wave (<= 4 env waves per CU: the block still fits the 512-thread launch bound with the helpers in it) and
   // the larger per-env tables (a second dense tile) do not cost env waves
-  int two_wave = (g_two_wave && integ_kernel(m->d.integrator) == 0 && want <= 4 && m->waves_per_block <= 0) ? 1 : 0;
+  int two_wave = (g_two_wave && integ_kernel(m->d.integrator) != 1 && want <= 4 && m->waves_per_block <= 0) ? 1 : 0;
   int lm = 0, wpb = 0;
   size_t per_env = 0, model_bytes = 0;
   for (;;) {

@@ -672,7 +672,7 @@ struct Engine {
   // stage, CRB and factorisation, and -- dense kernels -- factorises M + h B for the Euler step while the main wave is in
   // Newton.  The two meet through LDS counters per env with bounded spin waits (a lost partner raises status bit 16
   // instead of hanging).
-  static constexpr bool TW = INTEG == 0;
+  static constexpr bool TW = INTEG != 1;   // Euler and implicitfast (RK4's four forward passes per step would need the helper's pass logic)
   static constexpr int TW_DONE = 0x7fffffff;
   int tw_n;     // forward passes opened so far (two-wave launches)
   int o_tile;   // LDS word offset of the dense tile factor_core / solve work on (u1; the helper wave's own tile in two-wave launches)
@@ -839,7 +839,7 @@ struct Engine {
       tendon_velocity();
       actuation();
       tw_signal(1, n);
-      if (!SP && KD().any_damping && KD().eulerdamp) {
+      if (!SP && !IMPL && KD().any_damping && KD().eulerdamp) {
         // the factor of M + h B the Euler step will need (mj_Euler's implicit joint damping) does not depend on the constraint
         // solve: computed here while the main wave is in Newton.  M arrives in the second tile and L leaves in it.
         tw_wait(2, n);
@@ -2645,7 +2645,7 @@ struct Engine {
     PFT(PF_CONSTR, make_constraint());
     PFT(PF_VEL, velocity_bias());
     PFT(PF_CRB, crb());
-    if (tw && !SP && KD().any_damping && KD().eulerdamp) {   // M for the helper wave's Euler factor
+    if (tw && !SP && !IMPL && KD().any_damping && KD().eulerdamp) {   // M for the helper wave's Euler factor
       if (g < NVP) {
         float* Mg = W + KL().mtile + g * NVP;
 #pragma unroll
