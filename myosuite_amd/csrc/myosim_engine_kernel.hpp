@@ -839,6 +839,7 @@ struct Engine {
       tendon_velocity();
       actuation();
       tw_signal(1, n);
+      if constexpr (IMPL) { implicit_w(KL().mtile); tw_signal(3, n); }
       if (!SP && !IMPL && KD().any_damping && KD().eulerdamp) {
         // the factor of M + h B the Euler step will need (mj_Euler's implicit joint damping) does not depend on the constraint
         // solve: computed here while the main wave is in Newton.  M arrives in the second tile and L leaves in it.
@@ -2728,12 +2729,11 @@ struct Engine {
   // mjINT_IMPLICITFAST (oracle: mmo_implicitfast): (M + h W) qacc* = qfrc_smooth + qfrc_constraint with
   // W = diag(dofw) + sum_t tenw_t J_t'J_t restricted to dof pairs on one kinematic chain (the pattern of M), then mj_advance.
   // Lane i builds row i of W in its own row of the dense LDS tile (the factor of M in there is dead once Newton is done).
-  __device__ __forceinline__ void implicit_step(float& time) {
+  // W's tendon part sum_t w_t J_t'J_t (on-chain pairs) into the dense tile at word offset o_t: LDS in (tenw from the actuation
+  // stage, the tendon Jacobian), LDS out -- a two-wave launch runs it in the helper wave while the main wave is in Newton
+  __device__ __forceinline__ void implicit_w(int o_t) {
     const auto& L = KL();
-    const float h = KD().timestep;
-    const int nv = KD().nv;
-    d_warm = d_qacc;
-    float* T = W + L.u1;
+    float* T = W + o_t;
     const int row = g < NVP ? g : 0;
     if (g < NVP)
 #pragma unroll
@@ -2789,6 +2789,17 @@ struct Engine {
       }
     }
     GSYNC();
+  }
+  __device__ __forceinline__ void implicit_step(float& time) {
+    const auto& L = KL();
+    const float h = KD().timestep;
+    const int nv = KD().nv;
+    d_warm = d_qacc;
+    const bool twi = TW && a.two_wave;
+    if (twi) tw_wait(3, tw_n);          // the helper wave assembled W's tendon part in the second tile
+    else implicit_w(L.u1);
+    float* T = W + (twi ? L.mtile : L.u1);
+    const int row = g < NVP ? g : 0;
     float A[NVP];
 #pragma unroll
     for (int k4 = 0; k4 < NVP / 4; k4++) {

@@ -244,16 +244,17 @@ def test_rollout_step_other_tasks_and_sharded_streams():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_id,n", [("myoLegWalk-v0", 96), ("myoElbowPose1D6MRandom-v0", 256), ("myoHandReorient8-v0", 64),
-                                      ("myoHandPoseRandom-v0", 128)])
-def test_two_wave_launch_is_bit_identical_to_one_wave(env_id, n, monkeypatch):
+@pytest.mark.parametrize("env_id,n,kw", [("myoLegWalk-v0", 96, {}), ("myoElbowPose1D6MRandom-v0", 256, {}), ("myoHandReorient8-v0", 64, {}),
+                                         ("myoHandPoseRandom-v0", 128, {}), ("myoLegWalk-v0", 64, {"model": "leg_implicit"})],
+                         ids=["leg", "elbow", "reorient", "hand", "leg_implicitfast"])
+def test_two_wave_launch_is_bit_identical_to_one_wave(env_id, n, kw, monkeypatch):
     """Small batches leave SIMDs empty, so every env group gets a helper wave (tendon / actuation stages, Euler's factor) next
-    to its main wave (Engine::TW).  The split changes who computes, not what: observations, rewards and flags of a rollout are
+    to its main wave (Engine::TW; implicitfast: the helper also assembles the W matrix).  The split changes who computes, not what: observations, rewards and flags of a rollout are
     bit-identical to the one-wave launch (MYOSIM_TWO_WAVE=0), and no wave ever gives up waiting for its partner (status bit 16)."""
     recs = []
     for tw in ("1", "0"):
         monkeypatch.setenv("MYOSIM_TWO_WAVE", tw)       # read by mm_model_create; applies to every launch after it
-        env = registry.make(env_id, num_envs=n, seed=5, max_episode_steps=6)
+        env = registry.make(env_id, num_envs=n, seed=5, max_episode_steps=6, **kw)
         env.reset(seed=5)
         a = torch.empty(n, env.cm.nu, device="cuda")
         rec = []
