@@ -67,8 +67,9 @@ typedef struct {
   float* act;             /* [nenv][na]                                   */
   float* qacc_warmstart;  /* [nenv][nv]                                   */
   float* time;            /* [nenv]                                       */
-  int32_t* status;        /* [nenv] bit0: bad-state auto reset, bit1: constraint rows overflowed,
-                                    bit2: solver hit the iteration cap (sticky; cleared by reset) */
+  int32_t* status;        /* [nenv] sticky bits, cleared by reset: 1 bad-state auto reset (mj_step's mj_checkPos / checkVel / checkAcc),
+                                    4 the solver hit its iteration cap, 8 more constraint rows than the engine holds (surplus
+                                    rows dropped), 16 a two-wave launch lost a partner wave (a bounded wait gave up: engine bug) */
   /* per-env model delta (the reference mutates mjModel at reset: reorient_sar_v0.py:407-409): size of ONE geom */
   const float* geom_size_env; /* [nenv][3] or NULL: replaces geom_size[geom_env_id] in collision           */
   int    geom_env_id;         /* geom id the per-env size applies to (-1 = none)                           */
