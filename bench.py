@@ -5,6 +5,7 @@
     python bench.py --gpus 8                       # no launcher: re-executes itself under torch.distributed.run, 8 ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --oversubscribe       # TEST ONLY: N ranks share the visible GPU(s) (gloo group), exercises the N > 1 path
 
 One "step" = one env.step over the whole per-GPU batch, as ONE kernel launch (mm_rollout_step): draw actions U[0,1) on the
 device (benchmarks/mjx_benchmark.py:29), muscle ctrl map, frame_skip physics substeps, the post-step mj_forward, obs /
@@ -29,6 +30,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 
 # BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288, and the MuJoCo-default leg on the
 # implicitfast integrator) reported next to the headline line
+EXTRA_MIN_TIMED_MS = 60.0   # an extra line times at least this much kernel work (a 1.5 ms timed region is launch-noise bound)
 EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
                  ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
                  # the step of the reference's own GPU path: mjx_env.step = n_substeps x mjx.step, observation straight from the
@@ -54,18 +56,69 @@ def algorithmic_bytes(env) -> int:
     return 4 * (2 * (cm.nq + cm.nv + cm.na) + cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
 
 
-def algorithmic_flops(env_id: str):
+def workload_key(env_id: str, n: int, overrides=None) -> str:
+    """Key of one measured workload in the committed tables (profiles/r*_pmc.json, profiles/flops_per_env_step.json): the env id
+    and batch PLUS every override that changes the kernel or the work (`model=`, `do_forward=`), e.g.
+    "myoHandPoseRandom-v0@4096|model=hand_contact".  (Keyed by env id and batch alone, the self-contact hand would be
+    priced with the contact-free hand's counters.)"""
+    ov = "".join(f"|{k}={v}" for k, v in sorted((overrides or {}).items()))
+    return f"{env_id}@{n}{ov}"
+
+
+def algorithmic_flops(env_id: str, overrides=None):
     """fp operations of ONE env-step of the reference algorithm, counted by the instrumented oracle (tests/tools/count_flops.py
-    -> profiles/flops_per_env_step.json); None when the table has no entry for the workload."""
+    -> profiles/flops_per_env_step.json); None when the table has no entry for this workload (env id + overrides)."""
     try:
         tab = json.load(open(os.path.join(ROOT, "profiles", "flops_per_env_step.json")))
-        return tab.get(env_id)
+        ov = "".join(f"|{k}={v}" for k, v in sorted((overrides or {}).items()))
+        return tab.get(env_id + ov)
     except (OSError, ValueError):
         return None
 
 
-def cpu_baseline(env_id: str, nenv: int, nsteps: int):
-    """fp64 oracle ("port": CPU restatement, NOT libmujoco) on the host cores, bounded sample."""
+def host_topology():
+    """CPUs this process may use: logical CPUs (affinity mask), physical cores behind them (/proc/cpuinfo: distinct
+    (physical id, core id) pairs of the allowed CPUs), and the cgroup CPU quota when the container has one."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except (OSError, ValueError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    phys = len(cores) or len(allowed)
+    if quota is not None:
+        phys = max(1, min(phys, int(quota)))
+    return {"logical_cpus": len(allowed), "physical_cores": phys, "cgroup_cpu_quota": quota}
+
+
+def _cpu_envs(env_id: str, nenv: int):
+    """oracle model + `nenv` oracle envs in the task's reset state (same draws as the GPU batch) + frame_skip"""
     import numpy as np
     from myosuite_amd.envs import registry
     from myosuite_amd.model import synth
@@ -74,7 +127,6 @@ def cpu_baseline(env_id: str, nenv: int, nsteps: int):
     spec = registry.spec(env_id)
     cm = synth.get_model(spec["kwargs"]["model"])
     om = O.OracleModel(cm)
-    cores = os.cpu_count() or 1
     lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
     ds = []
     for e in range(nenv):
@@ -90,12 +142,49 @@ def cpu_baseline(env_id: str, nenv: int, nsteps: int):
             uq, _ = EO.pose_reset_draws(cm.nq, e, 0, 0)
             d.qpos[:] = (lo + (hi - lo) * uq).astype(np.float32)
         ds.append(d)
-    acts = np.stack([EO.uniform_stream(nenv * cm.nu, 0, s).reshape(nenv, cm.nu) for s in range(nsteps)]).astype(np.float64)
-    t0 = time.perf_counter()
-    O.batch_rollout(om, ds, acts, nsub=spec["kwargs"].get("frame_skip", 10), nthreads=cores, normalize=True, do_forward=True)
-    dt = time.perf_counter() - t0
-    return {"value": nenv * nsteps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{nenv} envs x {nsteps} env-steps of {env_id} (fp64 C oracle, {cores} threads, {dt:.1f} s)"}
+    return om, ds, cm, spec["kwargs"].get("frame_skip", 10)
+
+
+def cpu_rollout_rate(env_id: str, nthreads: int, target_s: float = 4.0, per_thread_rate: float = None):
+    """env-steps/s of the fp64 C oracle ("port": CPU restatement, NOT libmujoco) on `nthreads` host threads, one env at a time
+    per thread (oracle/mmo_batch.c), random actions through the muscle ctrl map, frame_skip substeps + the final forward per
+    env-step.  The sample is sized for ~`target_s` of wall time from a short calibration run (or `per_thread_rate`)."""
+    import numpy as np
+    from oracle import oracle as O
+    from oracle import env_oracle as EO
+    nenv = max(2 * nthreads, 8)
+    om, ds, cm, nsub = _cpu_envs(env_id, nenv)
+
+    def run(nsteps, first_stream):
+        acts = np.stack([EO.uniform_stream(nenv * cm.nu, 0, first_stream + s_).reshape(nenv, cm.nu) for s_ in range(nsteps)]).astype(np.float64)
+        t0 = time.perf_counter()
+        O.batch_rollout(om, ds, acts, nsub=nsub, nthreads=nthreads, normalize=True, do_forward=True)
+        return time.perf_counter() - t0
+
+    if per_thread_rate is None:
+        dt = run(2, 0)                      # calibration (also touches every page once)
+        per_thread_rate = nenv * 2 / dt / min(nthreads, nenv)
+    else:
+        run(1, 0)
+    nsteps = int(max(4, min(400, round(target_s * per_thread_rate * nthreads / nenv))))
+    dt = run(nsteps, 2)
+    return {"value": nenv * nsteps / dt, "threads": nthreads, "envs": nenv, "env_steps_each": nsteps, "seconds": dt}
+
+
+def cpu_baseline(env_id: str):
+    """The fp64 oracle on the host cores, two points: ONE thread -- the reference's own CPU protocol is one env on one core
+    (benchmarks/mjx_benchmark_baseline.py:8-25) -- and one thread per PHYSICAL core (`value`, `cores`).  Bounded sample: ~4 s
+    + ~8 s of wall time."""
+    topo = host_topology()
+    one = cpu_rollout_rate(env_id, 1, target_s=4.0)
+    cores = topo["physical_cores"]
+    allc = cpu_rollout_rate(env_id, cores, target_s=8.0, per_thread_rate=one["value"]) if cores > 1 else one
+    return {"value": allc["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{allc['envs']} envs x {allc['env_steps_each']} env-steps of {env_id} (fp64 C oracle, one thread per physical "
+                      f"core = {cores} threads, {allc['seconds']:.1f} s)",
+            "single_thread": {"value": one["value"], "unit": "env-steps/s", "cores": 1,
+                              "sample": f"{one['envs']} envs x {one['env_steps_each']} env-steps, one at a time on one thread ({one['seconds']:.1f} s)"},
+            "parallel_efficiency": allc["value"] / (one["value"] * cores), "host": topo}
 
 
 def respawn_under_launcher(args) -> int:
@@ -110,6 +199,13 @@ def respawn_under_launcher(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def status_or(status) -> int:
+    """bitwise OR of the per-env status words (the max of bit flags would hide bits: 1 | 4 has max 4)"""
+    import functools
+    import operator
+    return functools.reduce(operator.or_, (int(v) for v in status.unique().tolist()), 0)
 
 
 def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=None):
@@ -136,12 +232,12 @@ def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=No
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, device="cuda" if world > 1 else None)
+    elapsed = D.max_over_ranks(elapsed, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     return elapsed, kern_ms, env, stats
 
 
-def roofline(env, env_id, n, kern_ms):
+def roofline(env, env_id, n, kern_ms, overrides=None):
     """HBM roofline of the fused kernel (the contract's definition) + the views that actually bound it: fp32 vector issue
     (PMC counters of the committed profile of this command) and algorithmic flops against the fp32 vector peak."""
     from myosuite_amd import engine as E
@@ -150,7 +246,7 @@ def roofline(env, env_id, n, kern_ms):
     traffic = issue = None
     try:   # PMC counters cannot be read in-process: the committed rocprofv3 summary of this same command is reported
         pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
-        pm = json.load(open(pmc_file)).get(f"{env_id}@{n}")
+        pm = json.load(open(pmc_file)).get(workload_key(env_id, n, overrides))
         if pm:
             traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
             waves_per_simd = pm["sq_waves"] / 1024.0
@@ -164,7 +260,7 @@ def roofline(env, env_id, n, kern_ms):
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
            "algorithmic_bytes_per_launch": b_alg * n, "valu_issue": issue}
-    fl = algorithmic_flops(env_id)
+    fl = algorithmic_flops(env_id, overrides)
     if fl:
         tf = fl["flops"] * n / (kern_ms * 1e-3) / 1e12
         out["flops"] = {"algorithmic_flops_per_env_step": fl["flops"], "achieved_tflops": tf, "peak_tflops": FP32_PEAK_TFLOPS,
@@ -182,6 +278,12 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs lines (elbow / reorient / leg-walk / self-contact hand)")
+    ap.add_argument("--model", default=None, help="model override of the headline env (e.g. hand_contact): profile collection")
+    ap.add_argument("--no-forward", action="store_true", help="do_forward=False override of the headline env: profile collection")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: rank r runs on cuda:(r %% visible devices) and the process group is gloo, so that the N > 1 code "
+                         "path (launcher respawn, barrier, max over ranks, stats gather, sharded Philox streams) can be exercised on a "
+                         "one-GPU box.  The printed line is marked oversubscribed and is NOT a scaling measurement.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -191,7 +293,9 @@ def main():
     from myosuite_amd import dist as D
     from myosuite_amd import engine as E
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(backend="gloo" if args.oversubscribe else None)
+    if args.oversubscribe:
+        local = local % max(1, torch.cuda.device_count())
     if world != args.gpus:
         # never print a line whose n_gpus differs from the request
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
@@ -199,7 +303,12 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local)
     n = args.envs_per_gpu
-    elapsed, kern_ms, env, stats = measure(args.env, n, args.steps, args.warmup, rank, world, args.lanes)
+    head_ov = {}
+    if args.model:
+        head_ov["model"] = args.model
+    if args.no_forward:
+        head_ov["do_forward"] = False
+    elapsed, kern_ms, env, stats = measure(args.env, n, args.steps, args.warmup, rank, world, args.lanes, overrides=head_ov)
     cm = env.cm
 
     if rank == 0:
@@ -215,10 +324,14 @@ def main():
                                    f"(synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
                        "envs_per_gpu": n, "lanes_per_env": env.hm.launch_lanes(n), "launches_per_step": 1 if env._ro.autoreset else "1 + the task's masked reset",
                        "parallelism": f"env-shard x{world}"},
-            "roofline": roofline(env, args.env, n, kern_ms),
+            "roofline": roofline(env, args.env, n, kern_ms, head_ov),
             "stats": {"mean_episode_return": float(stats[:, 0].mean()), "solved_frac": float(stats[:, 2].mean()),
-                      "status_or": int(env.state.status.max())},
+                      "envs_in_stats": int(stats.shape[0]), "status_or": status_or(env.state.status)},
         }
+        if head_ov:
+            out["config"]["overrides"] = {k: str(v) for k, v in head_ov.items()}
+        if args.oversubscribe:
+            out["config"]["oversubscribed"] = f"{world} ranks on {torch.cuda.device_count()} device(s), gloo group: a test of the N > 1 path, not a scaling point"
         del env
         if world == 1 and not args.no_extra:
             # driver-visible numbers for the other BASELINE.json configs (same timed loop, shorter): not the headline value
@@ -226,19 +339,22 @@ def main():
             for env_id, ne, ov in EXTRA_CONFIGS:
                 tag = f"{env_id}, {ne} envs/GPU" + (f", {ov}" if ov else "")
                 try:
-                    el, km, ev, st = measure(env_id, ne, max(8, args.steps // 2), max(2, args.warmup // 2), 0, 1, overrides=ov)
-                    extra.append({"workload": tag, "value": ne * max(8, args.steps // 2) / el, "unit": "env-steps/s",
-                                  "ms_per_step": 1e3 * el / max(8, args.steps // 2), "lanes_per_env": ev.hm.launch_lanes(ne),
-                                  "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": roofline(ev, env_id, ne, km),
-                                  "status_or": int(ev.state.status.max())})
+                    # a short probe sizes the timed region: at least EXTRA_MIN_TIMED_MS of kernel work (and >= steps // 2 steps)
+                    _, km0, ev0, _ = measure(env_id, ne, 4, 2, 0, 1, overrides=ov)
+                    del ev0
+                    ks = int(max(8, args.steps // 2, min(2000, EXTRA_MIN_TIMED_MS / max(km0, 1e-3))))
+                    el, km, ev, st = measure(env_id, ne, ks, max(2, args.warmup // 2), 0, 1, overrides=ov)
+                    extra.append({"workload": tag, "key": workload_key(env_id, ne, ov), "value": ne * ks / el, "unit": "env-steps/s", "steps": ks,
+                                  "ms_per_step": 1e3 * el / ks, "lanes_per_env": ev.hm.launch_lanes(ne),
+                                  "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": roofline(ev, env_id, ne, km, ov),
+                                  "status_or": status_or(ev.state.status)})
                     del ev
                 except Exception as exc:      # an extra line must never take the headline line down
                     extra.append({"workload": tag, "error": repr(exc)})
             out["extra_configs"] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            # a few seconds of wall time on the host cores
-            nb, ns = (8192, 200) if cm.nv <= 4 else ((4096, 60) if cm.nv < 25 else (1024, 40))
-            out["cpu_baseline"] = cpu_baseline(args.env, nb, ns)
+        if not args.no_cpu_baseline:
+            # ~12 s of wall time on rank 0's host cores, after the timed region (the other ranks wait in destroy_process_group)
+            out["cpu_baseline"] = cpu_baseline(args.env)
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

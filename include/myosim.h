@@ -55,9 +55,18 @@ enum { MM_TASK_NONE = 0, MM_TASK_POSE = 1, MM_TASK_REACH = 2, MM_TASK_REORIENT =
 enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INFO_NSITE, MM_INFO_NTENDON,
        MM_INFO_LANES_PER_ENV, MM_INFO_LDS_BYTES_PER_ENV, MM_INFO_ENVS_PER_BLOCK, MM_INFO_NGEOM,
        MM_INFO_WAVES_PER_BLOCK,
-       MM_INFO_KERNEL_FAMILY,
-       MM_INFO_MODEL_WORDS,
-       MM_INFO_BODY_CHAINS };     /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */   /* 0 limit rows only, dense Cholesky (nv <= 4); 1 limit rows only, tree-sparse L'DL; 2 general rows */
+       MM_INFO_KERNEL_FAMILY,   /* 0 limit rows only, dense Cholesky (nv <= 4); 1 limit rows only, tree-sparse L'DL; 2 general rows */
+       MM_INFO_MODEL_WORDS,     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */
+       MM_INFO_BODY_CHAINS };   /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */
+
+/* ABI version of this header: bumped whenever a struct below gains / loses / reorders a field, an entry point changes its
+ * signature or a status / enum value is renumbered.  A caller compares MM_ABI_VERSION (what it was built against) with
+ * mm_abi_version() (what the library was built from) and, for bindings that restate the structs (ctypes, cgo, JNI), its own
+ * struct sizes with mm_struct_size().  History: 1 = round 1; 2 = mm_state.env_index_base, mm_env_draw(env_index_base), status
+  * bits renumbered, the mm_rollout struct -- round 2, shipped under the version STRING of round 1; 3 = this constant + mm_abi_version /
+ * mm_struct_size. */
+#define MM_ABI_VERSION 3
+enum { MM_STRUCT_STATE = 0, MM_STRUCT_DERIVED, MM_STRUCT_TASK, MM_STRUCT_ROLLOUT };
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
 typedef struct {
@@ -321,6 +330,8 @@ int  mm_uniform_at(float* out, size_t n, uint64_t seed, uint64_t stream_id, size
 
 const char* mm_last_error(void);
 const char* mm_version(void);
+int  mm_abi_version(void);                 /* MM_ABI_VERSION of the header the library was compiled from */
+int  mm_struct_size(int which);            /* sizeof of the MM_STRUCT_* struct as the library sees it (negative: unknown selector) */
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 #include "myosim_engine_kernel.hpp"
 #include "myosim_inst_list.hpp"
 MM_KERNEL_LIST(MM_DECLARE)
+MM_KERNELS_OBS(MM_DECLARE_OBS)
 
 // Philox4x32-10 / u01: myosim_engine_kernel.hpp
 // out[i] = word (first+i)%4 of Philox counter ((first+i)/4, stream_id): one thread per counter
@@ -197,7 +198,15 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mm_version(void) { return "myosim-hip 0.2 (gfx950, lane=item engine)"; }
+extern "C" const char* mm_version(void) { return "myosim-hip 0.3 (gfx950, lane=item engine, ABI 3)"; }
+extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
+extern "C" int mm_struct_size(int which) {
+  switch (which) {
+    case MM_STRUCT_STATE: return (int)sizeof(mm_state); case MM_STRUCT_DERIVED: return (int)sizeof(mm_derived);
+    case MM_STRUCT_TASK: return (int)sizeof(mm_task); case MM_STRUCT_ROLLOUT: return (int)sizeof(mm_rollout);
+  }
+  return MM_EARG;
+}
 
 static const int kNvpChoices[] = {4, 24, 32, 36, 40};
 // integrator -> kernel variant (template argument INTEG)
@@ -824,6 +833,25 @@ static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t l
   return MM_OK;
 }
 
+static bool have_obs_kernel(int G, int nvp, int gen, int rk4) {
+#define X(G_, N_, GN_, RK_) if (G == G_ && nvp == N_ && gen == GN_ && rk4 == RK_) return true;
+  MM_KERNELS_OBS(X)
+#undef X
+  return false;
+}
+template <int G, int NVP, bool GEN, int RK4>
+static int launch_obs_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  static std::atomic<unsigned> attr_done{0u};
+  const unsigned bit = m->device < 32 ? (1u << m->device) : 0u;
+  if (!(attr_done.load(std::memory_order_acquire) & bit) || !bit) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false, GEN, RK4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((k_engine<G, NVP, false, GEN, RK4, true>), grid, block, lds, st, a);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
 // group width (lanes per env) a launch over `nenv` envs uses: the pinned / default width, or -- for models without general
 // constraint rows, whose LDS tables do not depend on the width -- the narrowest group (most envs per wave) that still yields
 // >= 2 waves per CU, else the widest available
@@ -877,6 +905,8 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   // SIMDs without a wave (<= 4 env waves per CU: the block still fits the 512-thread launch bound with the helpers in it) and
   // the larger per-env tables (a second dense tile) do not cost env waves
   int two_wave = (g_two_wave && integ_kernel(m->d.integrator) != 1 && want <= 4 && m->waves_per_block <= 0) ? 1 : 0;
+  // the reset-observation pass of a task (mm_task.obs_only) has its own kernel symbol where one is compiled (model through L2)
+  const bool obs_kernel = a.mode == 2 && a.t.obs_only && have_obs_kernel(G, m->nvp, m->d.gen, integ_kernel(m->d.integrator));
   int lm = 0, wpb = 0;
   size_t per_env = 0, model_bytes = 0;
   for (;;) {
@@ -886,7 +916,7 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
       while (fit > 1 && mbytes + (size_t)fit * epw * per_env > kLds) fit--;
       return fit;
     };
-    lm = m->lds_model ? 1 : 0;
+    lm = (m->lds_model && !obs_kernel) ? 1 : 0;
     if (m->lds_model == 1 && fit_waves(blob_bytes) < want && fit_waves(0) > fit_waves(blob_bytes)) lm = 0;
     if (m->lds_model == 1 && blob_bytes + (size_t)epw * per_env > kLds) lm = 0;   // not even one wave fits next to the model copy
     model_bytes = lm ? blob_bytes : 0;
@@ -910,6 +940,12 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   a.blob_words = m->blob_words;
   a.prof = g_prof;
   const int rk4 = integ_kernel(m->d.integrator);
+  if (obs_kernel) {
+#define X(G_, N_, GN_, RK_) \
+    if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_obs_t<G_, N_, GN_ != 0, RK_>(m, a, grid, block, lds, st);
+    MM_KERNELS_OBS(X)
+#undef X
+  }
 #define X(G_, N_, GN_, RK_) \
   if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_t<G_, N_, GN_ != 0, RK_>(m, a, grid, block, lds, st, lm);
   MM_KERNEL_LIST(X)

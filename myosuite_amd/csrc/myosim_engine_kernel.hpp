@@ -250,9 +250,38 @@ __device__ __forceinline__ V3 mtv(const M3& m, V3 v) {
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// sin/cos for |x| <= ~8 (joint half-angles): Cody-Waite reduction to [-pi/4, pi/4] + minimax polynomials
-// (max abs error ~1.5e-7: at the fp32 rounding level of the quaternion it feeds).
+// sin/cos of a joint half-angle (|x| <= ~8), evaluated in fp64 and rounded ONCE to fp32 (<= 0.5 ulp).  Round 2 used an fp32
+// Cody-Waite + minimax form with ~1.5e-7 absolute error: 2.5 ulp on the quaternion of EVERY joint, i.e. ~3e-7 rad of
+// orientation error per joint, which a 0.2 m lever arm and a 9-joint chain turn into ~1.5e-7 m of position error -- 3x what
+// fp32 storage alone costs, and the largest term in the kernel's tendon moment-arm error (moment arms are ~5 mm, path
+// segments as short as that).  v_fma_f64 issues at the fp32 FMA rate on gfx950 and this runs once per joint per pass.
+#ifndef MM_SINCOS_F64
+#define MM_SINCOS_F64 1
+#endif
 __device__ __forceinline__ void sincos_small(float x, float* s, float* c) {
+#if MM_SINCOS_F64
+  const double xd = (double)x;
+  const double k = __builtin_rint(xd * 0.63661977236758134308);
+  const double r = __builtin_fma(-k, 1.57079632679489661923, xd);   // |k| <= 6: the product is exact to 1e-15
+  const double r2 = r * r;
+  double sp = -2.5052108385441718775e-08;                            // Taylor to r^11 / r^12 on |r| <= pi/4: error < 1e-11
+  sp = __builtin_fma(sp, r2, 2.7557319223985890653e-06);
+  sp = __builtin_fma(sp, r2, -1.9841269841269841270e-04);
+  sp = __builtin_fma(sp, r2, 8.3333333333333333333e-03);
+  sp = __builtin_fma(sp, r2, -1.6666666666666666667e-01);
+  const double sn = __builtin_fma(sp * r2, r, r);
+  double cp = 2.0876756987868098979e-09;
+  cp = __builtin_fma(cp, r2, -2.7557319223985890653e-07);
+  cp = __builtin_fma(cp, r2, 2.4801587301587301587e-05);
+  cp = __builtin_fma(cp, r2, -1.3888888888888888889e-03);
+  cp = __builtin_fma(cp, r2, 4.1666666666666666667e-02);
+  cp = __builtin_fma(cp, r2, -0.5);
+  const double cs = __builtin_fma(cp, r2, 1.0);
+  const int q = (int)k & 3;
+  const double ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+  *s = (float)((q & 2) ? -ss : ss);
+  *c = (float)(((q + 1) & 2) ? -cc : cc);
+#else
   float k = rintf(x * 0.636619772367581f);
   float r = fmaf(-k, 1.5707963705062866f, x);
   r = fmaf(-k, -4.371138828673793e-8f, r);
@@ -265,6 +294,7 @@ __device__ __forceinline__ void sincos_small(float x, float* s, float* c) {
   float ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
   *s = (q & 2) ? -ss : ss;
   *c = ((q + 1) & 2) ? -cc : cc;
+#endif
 }
 
 // spatial inertia (Ixx Iyy Izz Ixy Ixz Iyz, m*r[3], m) times motion vector [w; v]
@@ -552,21 +582,39 @@ __device__ __forceinline__ float seg_dg(int type, V3 s, V3 a0, V3 u, float t, fl
   sd_shape(type, s, a0 + t * u, g, tw);
   return dot(g, u);
 }
-__device__ __forceinline__ float seg_bisect(int type, V3 s, V3 a0, V3 u, float lo, float hi, float thr, int iters, float& tw) {
-  if (seg_dg(type, s, a0, u, lo, tw) > thr) return lo;
-  if (seg_dg(type, s, a0, u, hi, tw) <= thr) return hi;
+// POLISH: after the bisection, bracketed false-position steps on g' (monotone: g is convex) using the values at the ends of the
+// bracket.  13 bisection steps leave t within h * 2^-13 ~ 4e-6 m of the root; the oracle bisects 40 times in fp64, and a contact
+// point that sits 4e-6 m off moves the pyramid rows by ~1e-4 relative (round 2: constrained acceleration of the reorient batch
+// only 3e-3 from the oracle).  Two secant steps inside the bracket take a smooth g' (ellipsoid, rounded edges) to fp32
+// resolution; at a kink of g' (box / cylinder edge) they stay inside the bracket, so they are never worse than the bisection.
+__device__ __forceinline__ float seg_bisect(int type, V3 s, V3 a0, V3 u, float lo, float hi, float thr, int iters, float& tw, int polish = 0) {
+  float dlo = seg_dg(type, s, a0, u, lo, tw) - thr;
+  if (dlo > 0.f) return lo;
+  float dhi = seg_dg(type, s, a0, u, hi, tw) - thr;
+  if (dhi <= 0.f) return hi;
   for (int it = 0; it < iters; it++) {
     const float mid = 0.5f * (lo + hi);
-    if (seg_dg(type, s, a0, u, mid, tw) > thr) hi = mid; else lo = mid;
+    const float dm = seg_dg(type, s, a0, u, mid, tw) - thr;
+    if (dm > 0.f) { hi = mid; dhi = dm; } else { lo = mid; dlo = dm; }
   }
-  return 0.5f * (lo + hi);
+  float t = 0.5f * (lo + hi);
+  for (int it = 0; it < polish; it++) {
+    const float den = dhi - dlo;
+    if (!(den > 1e-12f)) break;
+    float tn = lo - dlo * (hi - lo) / den;
+    tn = fminf(fmaxf(tn, lo), hi);
+    const float dn = seg_dg(type, s, a0, u, tn, tw) - thr;
+    t = tn;
+    if (dn > 0.f) { hi = tn; dhi = dn; } else { lo = tn; dlo = dn; }
+  }
+  return t;
 }
 // same rule as the oracle's seg_shape (mmo_collision.inc): root of g', flat minima of box / cylinder replaced by the
-// midpoint of their +-tau interval; 13 bisection steps resolve t to h * 2^-13 ~ 4e-6 m
+// midpoint of their +-tau interval; 12 bisection steps + 3 bracketed secant steps on the root of g'
 __device__ __forceinline__ float seg_shape(int type, V3 s, V3 a0, V3 u, float h, float& tbest, V3& grad) {
   const float tau = 1e-4f;
   float tw = __builtin_nanf("");
-  float t = seg_bisect(type, s, a0, u, -h, h, 0.f, 13, tw);
+  float t = seg_bisect(type, s, a0, u, -h, h, 0.f, 12, tw, 3);
   if (type != MM_GEOM_ELLIPSOID) {
     const float dl = 0.02f * h;
     float tl = t, tr = t;
@@ -2908,7 +2956,12 @@ struct Engine {
         if (stepping && !redo && bad_state(false)) { reset_data(); time = 0.f; status |= 1; }
         forward();
         if (stepping) {
-          if (!redo && bad_state(true)) { reset_data(); time = 0.f; status |= 1; redo = true; continue; }
+          if (!redo && bad_state(true)) {
+            // two-wave launches: the helper may still be factorising the aborted pass's M + h B (implicitfast: assembling W) in
+            // the second tile, which the redone forward pass rewrites -- let it finish first
+            if constexpr (TW) { if (a.two_wave && (IMPL || (!SP && KD().any_damping && KD().eulerdamp))) tw_wait(3, tw_n); }
+            reset_data(); time = 0.f; status |= 1; redo = true; continue;
+          }
           if constexpr (IMPL) { PFT(PF_EULER, implicit_step(time)); }
           else { PFT(PF_EULER, euler(time)); }
           redo = false;
@@ -2938,7 +2991,10 @@ struct Engine {
 };
 
 // =========================================================================== kernels
-template <int G, int NVP, bool LM, bool GEN, int INTEG>
+// OBS: the reset-observation pass (mm_task.obs_only: forward pass + observation for the envs of a mask, no stepping) as its own
+// kernel symbol for the workloads whose reset is not folded into the env-step launch -- rocprofv3's per-kernel statistics then
+// separate the env-step from the (mostly early-exiting) pass that follows it, and the pass sheds the integrator code.
+template <int G, int NVP, bool LM, bool GEN, int INTEG, bool OBS = false>
 __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   extern __shared__ float lds[];
   constexpr int EPW = 64 / G;  // envs per wave
@@ -2953,7 +3009,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   // reset-observation pass (mm_task.obs_only with an env mask): a block none of whose envs is flagged leaves before the model
   // is staged -- every wave scans the block's whole env range, so the decision is block-uniform and nobody is left waiting at
   // the barrier (the pass is launched after every step of the non-Pose tasks and usually has nothing to do)
-  if (a.mode == 2 && KA().t.obs_only && KA().t.env_mask) {
+  if (a.mode == 2 && (OBS || KA().t.obs_only) && KA().t.env_mask) {
     const int epb = wpb * EPW, e0 = blockIdx.x * epb;
     bool any = false;
     for (int i = lane; i < epb; i += 64) any |= (e0 + i < a.s.nenv) && KA().t.env_mask[e0 + i] != 0;
@@ -2997,7 +3053,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   bool dup = e >= nenv;
   if (dup) e = nenv - 1;  // surplus groups recompute the last env (they never store)
   if (a.mode == 2 && KA().t.env_mask && !KA().t.env_mask[e]) dup = true;   // masked-out envs are left untouched
-  const bool obs_only = a.mode == 2 && KA().t.obs_only;
+  const bool obs_only = OBS || (a.mode == 2 && KA().t.obs_only);
   if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * KL().total;
   const auto& L = KL();
@@ -3074,8 +3130,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   if (a.mode == 2 && t.ctrl_out && !dup)
     for (int u = g; u < d.nu; u += G) t.ctrl_out[(size_t)e * d.nu + u] = W[L.ctrl + u];
 
-  int nsub = (a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
-  bool fwd = a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
+  int nsub = (OBS || a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
+  bool fwd = OBS || a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
   E.run(nsub, fwd, time);
   if constexpr (Engine<G, NVP, GEN, INTEG>::TW) { if (two_wave) E.tw_signal(0, Engine<G, NVP, GEN, INTEG>::TW_DONE); }
 

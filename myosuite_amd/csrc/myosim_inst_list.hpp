@@ -12,6 +12,9 @@
 #define MM_KERNELS_H(X) X(64, 36, 1, 0)   /* leg models: 34 dofs (the 40-wide tile wastes 20 % of the dense linear algebra) */
 #define MM_KERNELS_I(X) X(64, 24, 1, 0)   /* row-rich models with <= 24 dofs (key turn, torso) */
 #define MM_KERNELS_J(X) X(4, 4, 0, 2) X(32, 24, 0, 2) X(64, 36, 1, 2)   /* implicitfast: elbow, hand, leg at their default widths */
+/* reset-observation pass as its own kernel (k_engine<..., OBS = true>, model through L2): the BASELINE workloads whose reset is not
+   folded into the env-step launch -- reorient, leg-walk (Euler and implicitfast) */
+#define MM_KERNELS_OBS(X) X(64, 32, 1, 0) X(64, 36, 1, 0) X(64, 36, 1, 2)
 #define MM_KERNEL_LIST(X) MM_KERNELS_J(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X) MM_KERNELS_H(X) MM_KERNELS_I(X)
 #define MM_INSTANTIATE(G_, N_, GN_, RK_)                                        \
   template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_>(KArgs);   \
@@ -19,3 +22,5 @@
 #define MM_DECLARE(G_, N_, GN_, RK_)                                                   \
   extern template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_>(KArgs);   \
   extern template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_>(KArgs);
+#define MM_INSTANTIATE_OBS(G_, N_, GN_, RK_) template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_, true>(KArgs);
+#define MM_DECLARE_OBS(G_, N_, GN_, RK_) extern template __global__ void k_engine<G_, N_, false, GN_ != 0, RK_, true>(KArgs);

@@ -29,6 +29,11 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def backend() -> str:
+    """backend of the default process group ("nccl" = RCCL on ROCm, "gloo"), or "" without a group"""
+    return dist.get_backend() if dist.is_initialized() else ""
+
+
 def shard_envs(total_envs: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous shard [start, start+count) of a global env index range (remainder to the low ranks)."""
     base, rem = divmod(total_envs, world)
@@ -44,6 +49,11 @@ def gather_episode_stats(stats: torch.Tensor, always_collective: bool = False) -
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not always_collective):
         return stats
     world = dist.get_world_size()
+    if stats.is_cuda and dist.get_backend() == "gloo":
+        # gloo group over device tensors (bench.py --oversubscribe, CPU-only launch tests): stage through the host
+        parts = [torch.empty(stats.shape, dtype=stats.dtype) for _ in range(world)]
+        dist.all_gather(parts, stats.detach().cpu().contiguous())
+        return torch.cat(parts, 0).to(stats.device)
     out = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype, device=stats.device)
     dist.all_gather_into_tensor(out, stats.contiguous())
     return out

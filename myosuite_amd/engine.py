@@ -35,6 +35,9 @@ RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_
  INFO_BODY_CHAINS) = range(15)
 
 
+MM_ABI_VERSION = 3   # include/myosim.h
+
+
 class EngineError(RuntimeError):
     pass
 
@@ -199,6 +202,14 @@ def lib():
         L.mm_debug_set_dump.argtypes = [C.c_void_p]
         L.mm_debug_set_prof.argtypes = [C.c_void_p]
         L.mm_model_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        # the binding restates the header's structs: refuse a library built from another ABI or with other struct layouts
+        L.mm_struct_size.argtypes = [C.c_int]
+        if L.mm_abi_version() != MM_ABI_VERSION:
+            raise EngineError(f"{LIB_PATH} speaks ABI {L.mm_abi_version()}, this binding ABI {MM_ABI_VERSION}: rebuild the library")
+        for which, st in enumerate((mm_state, mm_derived, mm_task, mm_rollout)):
+            if L.mm_struct_size(which) != C.sizeof(st):
+                raise EngineError(f"struct layout mismatch: {st.__name__} is {L.mm_struct_size(which)} bytes in the library, "
+                                  f"{C.sizeof(st)} in the binding (include/myosim.h changed without engine.py)")
         _lib = L
     return _lib
 

@@ -168,9 +168,17 @@ class BaseV0:
             MA, MR, MF = nf * ap, nf * (1 - ap), 1 - nf
         else:
             # deterministic reset (to rest, or to fatigue_reset_vec): one launch, no temporaries
-            if self.fatigue_reset_vec is not None and getattr(self, "_fat_vec", None) is None:
-                self._fat_vec = torch.as_tensor(np.asarray(self.fatigue_reset_vec, np.float32), device=self.device).expand(na).contiguous()
-            E.fatigue_reset(self.fat_MA, self.fat_MR, self.fat_MF, mask, getattr(self, "_fat_vec", None))
+            # (the attribute is read on every reset, as the reference does -- fatigue.py:82-99, base_v0.py:124 -- so a vector
+            # assigned later, e.g. through MyoVecEnv.set_attr, takes effect; the device copy is rebuilt only when it changed)
+            vec = None
+            if self.fatigue_reset_vec is not None:
+                src = np.broadcast_to(np.asarray(self.fatigue_reset_vec, np.float32), (na,)).copy()
+                cached = getattr(self, "_fat_vec_src", None)
+                if cached is None or not np.array_equal(cached, src):
+                    self._fat_vec_src = src
+                    self._fat_vec = torch.from_numpy(src).to(self.device)
+                vec = self._fat_vec
+            E.fatigue_reset(self.fat_MA, self.fat_MR, self.fat_MF, mask, vec)
             return
         if mask is None:
             self.fat_MA.copy_(MA); self.fat_MR.copy_(MR); self.fat_MF.copy_(MF)

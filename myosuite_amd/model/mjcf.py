@@ -609,6 +609,101 @@ def _f(v):
 _GT = {0: "plane", 2: "sphere", 3: "capsule", 4: "ellipsoid", 5: "cylinder", 6: "box"}
 
 
+def dry_run(source: str, include_map: Optional[Dict[str, str]] = None) -> dict:
+    """What would `load` reject?  Walks an MJCF file (includes expanded where they resolve, recorded where they do not -- the
+    reference's task XMLs point into the empty ``simhive/myo_sim`` submodule) and lists EVERY construct outside the subset the
+    engine implements instead of stopping at the first, so that whoever gets hold of the real ``myo_sim`` tree sees the whole
+    gap at once.  Returns {"file", "missing_includes": [...], "unsupported": {construct: [locations...]}, "ignored": {...},
+    "counts": {tag: n}, "loadable": bool}.  `unsupported` mirrors the MjcfError sites of `load`; `ignored` lists elements that
+    `load` skips on purpose because they do not touch the physics step (visuals, cameras, lights, sensors, keyframes beyond qpos /
+    qvel / act / ctrl)."""
+    if include_map is None and os.environ.get("MYOSUITE_MYO_SIM_ROOT"):
+        include_map = {"simhive/myo_sim": os.environ["MYOSUITE_MYO_SIM_ROOT"]}
+    if os.path.exists(source):
+        root = ET.parse(source).getroot(); base = os.path.dirname(os.path.abspath(source)); fname = source
+    else:
+        root = ET.fromstring(source); base = os.getcwd(); fname = "<string>"
+    missing: List[str] = []
+
+    def note_missing(node, b):
+        for ch in list(node):
+            if ch.tag == "include":
+                fn = ch.attrib.get("file", "")
+                for old, new_ in (include_map or {}).items():
+                    if old in fn:
+                        fn = os.path.join(new_, fn[fn.index(old) + len(old):].lstrip("/"))
+                        break
+                path = fn if os.path.isabs(fn) else os.path.join(b, fn)
+                if not os.path.exists(path):
+                    missing.append(ch.attrib.get("file", ""))
+            else:
+                note_missing(ch, b)
+    note_missing(root, base)
+    _expand_includes(root, base, "skip", include_map)
+    unsupported: Dict[str, List[str]] = {}
+    ignored: Dict[str, int] = {}
+    counts: Dict[str, int] = {}
+
+    def bad(kind, where):
+        unsupported.setdefault(kind, []).append(where)
+
+    def where(el, parents):
+        nm = el.attrib.get("name") or el.attrib.get("class") or ""
+        return "/".join(p.tag + (f"[{p.attrib.get('name')}]" if p.attrib.get("name") else "") for p in parents[-2:]) + f"/{el.tag}" + (f"[{nm}]" if nm else "")
+
+    defaults_geom_type: Dict[str, str] = {}
+
+    def walk(el, parents):
+        counts[el.tag] = counts.get(el.tag, 0) + 1
+        a, w = el.attrib, where(el, parents)
+        t = el.tag
+        top = parents[1].tag if len(parents) > 1 else (parents[0].tag if parents else "")
+        if t == "compiler" and a.get("coordinate", "local") != "local":
+            bad("compiler coordinate=global", w)
+        if t == "option":
+            if a.get("integrator", "Euler") not in ("Euler", "RK4", "implicitfast"):
+                bad(f"integrator {a['integrator']}", w)
+            if a.get("cone", "pyramidal") != "pyramidal":
+                bad("elliptic friction cone", w)
+            if a.get("solver", "Newton") != "Newton":
+                bad(f"solver {a['solver']}", w)
+        if t == "geom" and "default" not in [p.tag for p in parents]:
+            gtype = a.get("type")
+            if gtype in ("mesh", "hfield", "sdf") or ("mesh" in a and gtype is None):
+                # collides unless contype == conaffinity == 0 (class defaults are not resolved here: reported as "may collide")
+                if a.get("contype", None) == "0" and a.get("conaffinity", None) == "0":
+                    ignored["visual mesh geom"] = ignored.get("visual mesh geom", 0) + 1
+                else:
+                    bad(f"{gtype or 'mesh'} geom that may collide (contype/conaffinity not both 0 on the element)", w)
+        if t == "joint" and "default" not in [p.tag for p in parents]:
+            if a.get("type") == "ball" and (a.get("limited") == "true" or "range" in a):
+                bad("limited ball joint", w)
+        if t in ("weld", "connect", "tendon", "distance", "flex") and top == "equality":
+            bad(f"equality <{t}>", w)
+        if top == "actuator" and t in ("general", "motor", "position", "velocity", "muscle", "cylinder", "adhesion", "damper", "intvelocity", "plugin"):
+            if not ("joint" in a or "tendon" in a):
+                bad("actuator transmission other than joint / tendon (" + ", ".join(k for k in ("site", "body", "slidersite", "cranksite", "jointinparent") if k in a) + ")", w)
+            if t in ("cylinder", "adhesion", "plugin"):
+                bad(f"actuator <{t}>", w)
+            if t == "general" and a.get("dyntype", "none") not in ("none", "integrator", "filter", "filterexact", "muscle"):
+                bad(f"actuator dyntype {a['dyntype']}", w)
+        if t in ("composite", "flexcomp", "flex", "skin", "plugin", "extension", "replicate", "attach", "frame") and t != "frame":
+            bad(f"<{t}>", w)
+        if t == "spatial" and top == "tendon":
+            for ch in el:
+                if ch.tag == "pulley":
+                    pass   # pulleys are implemented (divisor)
+        if t in ("camera", "light", "visual", "asset", "texture", "material", "sensor", "custom", "statistic", "headlight", "rgba", "global", "quality", "map", "scale"):
+            ignored[t] = ignored.get(t, 0) + 1
+            if t in ("asset", "sensor", "visual", "custom"):
+                return
+        for ch in el:
+            walk(ch, parents + [el])
+    walk(root, [])
+    return {"file": fname, "missing_includes": missing, "unsupported": unsupported, "ignored": ignored, "counts": counts,
+            "loadable": not unsupported and not missing}
+
+
 def dump(spec: ModelSpec) -> str:
     """ModelSpec -> MJCF text (radians, explicit inertials, collision through explicit <pair>s only)."""
     root = ET.Element("mujoco", model=spec.name)

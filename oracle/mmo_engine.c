@@ -43,6 +43,13 @@
 typedef MMO_REAL real;
 #endif
 
+/* stage markers (no-ops here): tests/tools/precision_study.py compiles this file with a scalar type that rounds to fp32 inside
+   the stages it selects, to see which stage's precision the 1000-step divergence hangs on */
+#ifndef MMO_STAGE
+#define MMO_STAGE(k)
+#endif
+enum { MMO_ST_KIN = 0, MMO_ST_COM, MMO_ST_TENDON, MMO_ST_CRB, MMO_ST_CONSTR, MMO_ST_VEL, MMO_ST_ACT, MMO_ST_ACC, MMO_ST_SOLVE, MMO_ST_INTEG, MMO_ST_NONE };
+
 /* ------------------------------------------------------------------ model */
 typedef struct {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, neq, npair, nM, njmax, nconmax;
@@ -133,6 +140,11 @@ typedef struct {
   real *con_dist, *con_pos, *con_frame;
   /* scratch */
   real *cacc, *cfrc, *tmp_nv, *qH, *qHDiagInv;
+  /* scratch stack for the temporaries of the step path (salloc / srelease): no heap traffic per call, so that many
+     threads stepping their own mmo_data never meet in the allocator (bench.py's cpu_baseline leg) */
+  real* scratch; int scratch_cap, scratch_top;
+  /* fp32-state twin (tests): round qpos / qvel / act / qacc_warmstart to float after every mmo_step */
+  int round_state_f32;
   /* per-user task parameters the engine does not interpret */
   int solver_niter, warn_bad;
   /* profiling counters */
@@ -140,6 +152,17 @@ typedef struct {
 } mmo_data;
 
 static real* ralloc(int n) { return (real*)calloc(n > 0 ? n : 1, sizeof(real)); }
+/* zeroed temporaries from the data's scratch stack; release in LIFO order with the mark taken before the first salloc */
+static real* salloc(mmo_data* d, int n) {
+  if (n < 1) n = 1;
+  if (d->scratch_top + n > d->scratch_cap) { fprintf(stderr, "mmo: scratch stack overflow (%d + %d > %d)\n", d->scratch_top, n, d->scratch_cap); abort(); }
+  real* p = d->scratch + d->scratch_top;
+  d->scratch_top += n;
+  memset((void*)p, 0, sizeof(real) * (size_t)n);
+  return p;
+}
+static int smark(const mmo_data* d) { return d->scratch_top; }
+static void srelease(mmo_data* d, int mark) { d->scratch_top = mark; }
 
 void mmo_reset(const mmo_model* m, mmo_data* d);
 
@@ -174,6 +197,10 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   }
   d->cacc = ralloc(6 * nb); d->cfrc = ralloc(6 * nb); d->tmp_nv = ralloc(nv);
   d->qH = ralloc(m->nM); d->qHDiagInv = ralloc(nv);
+  /* deepest nesting: mmo_rk4 (nq + nv + 5 na + 8 nv) -> forward -> mmo_solve (5 nv + 3 njmax + nv^2) or mmo_implicitfast (2 nv^2);
+     mmo_collide_and_add 9 nv, mmo_tendon 6 nv, mmo_com_pos nbody */
+  d->scratch_cap = m->nq + 24 * nv + 5 * m->na + 4 * nj + 2 * nv * nv + nb + 64;
+  d->scratch = ralloc(d->scratch_cap); d->scratch_top = 0;
   d->gsize_id = -1; d->gtype = -1; d->bmass_id = -1; d->bpos_id = -1;
   mmo_reset(m, d);
   return d;
@@ -191,7 +218,7 @@ void mmo_data_free(mmo_data* d) {
                 &d->efc_D, &d->efc_vel, &d->efc_aref, &d->efc_force, &d->qfrc_constraint, &d->qacc, &d->cacc,
                 &d->cfrc, &d->tmp_nv, &d->qH, &d->qHDiagInv, &d->con_dist, &d->con_pos, &d->con_frame, &d->efc_floss};
   for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(*p[i]);
-  free(d->efc_type); free(d->efc_id); free(d->con_pair);
+  free(d->efc_type); free(d->efc_id); free(d->con_pair); free(d->scratch);
   free(d);
 }
 
@@ -362,9 +389,8 @@ static void mmo_kinematics(const mmo_model* m, mmo_data* d) {
 /* subtree COM, body inertias about the tree's COM (world axes), dof motion axes */
 static void mmo_com_pos(const mmo_model* m, mmo_data* d) {
   int nb = m->nbody;
-  real* mass = d->tmp_nv; /* not big enough in general: use local */
-  real* sm = (real*)calloc(nb, sizeof(real));
-  (void)mass;
+  const int mk = smark(d);
+  real* sm = salloc(d, nb);
   for (int b = 0; b < nb; b++) {
     sm[b] = b == d->bmass_id ? d->bmass_val : MF(m, BODY_MASS)[b];
     for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = sm[b] * d->xipos[3 * b + k];
@@ -378,7 +404,7 @@ static void mmo_com_pos(const mmo_model* m, mmo_data* d) {
     if (sm[b] < MINVAL) for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = d->xipos[3 * b + k];
     else for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] /= sm[b];
   }
-  free(sm);
+  srelease(d, mk);
   for (int b = 1; b < nb; b++) {
     const real* c = d->subtree_com + 3 * MI(m, BODY_ROOTID)[b];
     const real* R = d->ximat + 9 * b;
@@ -585,7 +611,8 @@ static real mmo_wrap(real wpnt[6], const real* x0, const real* x1, const real* g
 
 static void mmo_tendon(const mmo_model* m, mmo_data* d) {
   int nv = m->nv;
-  real* j0 = (real*)malloc(sizeof(real) * 3 * nv * 2);
+  const int mk = smark(d);
+  real* j0 = salloc(d, 3 * nv * 2);
   real* j1 = j0 + 3 * nv;
   memset(d->ten_J, 0, sizeof(real) * m->ntendon * nv);
   const int32_t *wt = MI(m, WRAP_TYPE), *wo = MI(m, WRAP_OBJID);
@@ -663,7 +690,7 @@ static void mmo_tendon(const mmo_model* m, mmo_data* d) {
     }
     d->ten_length[t] = L;
   }
-  free(j0);
+  srelease(d, mk);
 }
 
 /* A3 */
@@ -1097,10 +1124,11 @@ static void mmo_solve(const mmo_model* m, mmo_data* d) {
     memset(d->qfrc_constraint, 0, sizeof(real) * nv);
     return;
   }
-  real* Ma = ralloc(nv); real* grad = ralloc(nv); real* Mgrad = ralloc(nv); real* search = ralloc(nv);
-  real* Mv = ralloc(nv); real* jar = ralloc(nefc); real* jv = ralloc(nefc);
-  real* Hd = ralloc(nv * nv);
-  int* active = (int*)calloc(nefc, sizeof(int));
+  const int mk = smark(d);
+  real* Ma = salloc(d, nv); real* grad = salloc(d, nv); real* Mgrad = salloc(d, nv); real* search = salloc(d, nv);
+  real* Mv = salloc(d, nv); real* jar = salloc(d, nefc); real* jv = salloc(d, nefc);
+  real* Hd = salloc(d, nv * nv);
+  int* active = (int*)(void*)salloc(d, nefc);   /* sizeof(real) >= sizeof(int) */
   real scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
 
 #define EVAL_COST(qa, out)                                                            \
@@ -1229,23 +1257,30 @@ static void mmo_solve(const mmo_model* m, mmo_data* d) {
     }
   }
 #undef EVAL_COST
-  free(Ma); free(grad); free(Mgrad); free(search); free(Mv); free(jar); free(jv); free(Hd); free(active);
+  srelease(d, mk);
 }
 
 /* ------------------------------------------------------ pipeline */
 void mmo_fwd_position(const mmo_model* m, mmo_data* d) {
+  MMO_STAGE(MMO_ST_KIN);
   mmo_kinematics(m, d);
+  MMO_STAGE(MMO_ST_COM);
   mmo_com_pos(m, d);
+  MMO_STAGE(MMO_ST_TENDON);
   mmo_tendon(m, d);
   mmo_transmission(m, d);
+  MMO_STAGE(MMO_ST_CRB);
   mmo_crb(m, d);
   memcpy(d->qLD, d->qM, sizeof(real) * m->nM);
   mmo_factor(m, d->qLD, d->qLDiagInv);
+  MMO_STAGE(MMO_ST_CONSTR);
   mmo_make_constraint(m, d);
+  MMO_STAGE(MMO_ST_NONE);
 }
 
 void mmo_fwd_velocity(const mmo_model* m, mmo_data* d) {
   int nv = m->nv;
+  MMO_STAGE(MMO_ST_VEL);
   for (int t = 0; t < m->ntendon; t++) {
     real s = 0;
     for (int i = 0; i < nv; i++) s += d->ten_J[t * nv + i] * d->qvel[i];
@@ -1259,7 +1294,9 @@ void mmo_fwd_velocity(const mmo_model* m, mmo_data* d) {
   mmo_com_vel(m, d);
   mmo_passive(m, d);
   mmo_rne(m, d);
+  MMO_STAGE(MMO_ST_CONSTR);
   mmo_reference_constraint(m, d);
+  MMO_STAGE(MMO_ST_NONE);
 }
 
 void mmo_fwd_acceleration(const mmo_model* m, mmo_data* d) {
@@ -1273,9 +1310,13 @@ void mmo_fwd_acceleration(const mmo_model* m, mmo_data* d) {
 void mmo_forward(const mmo_model* m, mmo_data* d) {
   mmo_fwd_position(m, d);
   mmo_fwd_velocity(m, d);
+  MMO_STAGE(MMO_ST_ACT);
   mmo_actuation(m, d);
+  MMO_STAGE(MMO_ST_ACC);
   mmo_fwd_acceleration(m, d);
+  MMO_STAGE(MMO_ST_SOLVE);
   mmo_solve(m, d);
+  MMO_STAGE(MMO_ST_NONE);
 }
 
 static int bad_state(const mmo_model* m, const mmo_data* d, int check_acc) {
@@ -1379,8 +1420,9 @@ static real actuator_dforce_dvel(const mmo_model* m, const mmo_data* d, int a) {
 static void mmo_implicitfast(const mmo_model* m, mmo_data* d) {
   int nv = m->nv;
   real h = m->timestep;
-  real* MM = ralloc(nv * nv);
-  real* Dm = ralloc(nv * nv);
+  const int mk = smark(d);
+  real* MM = salloc(d, nv * nv);
+  real* Dm = salloc(d, nv * nv);
   mmo_full_m(m, d, MM);
   for (int i = 0; i < nv; i++) Dm[i * nv + i] -= MF(m, DOF_DAMPING)[i];
   for (int t = 0; t < m->ntendon; t++) {
@@ -1419,7 +1461,7 @@ static void mmo_implicitfast(const mmo_model* m, mmo_data* d) {
   }
   for (int i = 0; i < nv; i++) { real v = qacc[i]; for (int k = 0; k < i; k++) v -= MM[i * nv + k] * qacc[k]; qacc[i] = v / MM[i * nv + i]; }
   for (int i = nv - 1; i >= 0; i--) { real v = qacc[i]; for (int k = i + 1; k < nv; k++) v -= MM[k * nv + i] * qacc[k]; qacc[i] = v / MM[i * nv + i]; }
-  free(MM); free(Dm);
+  srelease(d, mk);
   mmo_advance(m, d, qacc);
 }
 
@@ -1452,8 +1494,9 @@ static void mmo_rk4(const mmo_model* m, mmo_data* d) {
   int nv = m->nv, nq = m->nq, na = m->na;
   real h = m->timestep, t0 = d->time;
   static const real A[3] = {0.5, 0.5, 1.0}, B[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
-  real* q0 = ralloc(nq); real* v0 = ralloc(nv); real* a0 = ralloc(na);
-  real* vel = ralloc(4 * nv); real* acc = ralloc(4 * nv); real* adot = ralloc(4 * (na > 0 ? na : 1));
+  const int mk = smark(d);
+  real* q0 = salloc(d, nq); real* v0 = salloc(d, nv); real* a0 = salloc(d, na);
+  real* vel = salloc(d, 4 * nv); real* acc = salloc(d, 4 * nv); real* adot = salloc(d, 4 * (na > 0 ? na : 1));
   memcpy(q0, d->qpos, sizeof(real) * nq); memcpy(v0, d->qvel, sizeof(real) * nv); memcpy(a0, d->act, sizeof(real) * na);
   for (int i = 0; i < 4; i++) {
     memcpy(vel + i * nv, d->qvel, sizeof(real) * nv); memcpy(acc + i * nv, d->qacc, sizeof(real) * nv);
@@ -1482,7 +1525,7 @@ static void mmo_rk4(const mmo_model* m, mmo_data* d) {
     d->act[aa] = x;
   }
   d->time = t0 + h;
-  free(q0); free(v0); free(a0); free(vel); free(acc); free(adot);
+  srelease(d, mk);
 }
 
 /* mj_step: forward + integrate, with MuJoCo's bad-state auto-reset semantics */
@@ -1494,9 +1537,18 @@ void mmo_step(const mmo_model* m, mmo_data* d) {
     memcpy(c, d->ctrl, sizeof(real) * nu); mmo_reset(m, d); memcpy(d->ctrl, c, sizeof(real) * nu); d->warn_bad |= 1;
     mmo_forward(m, d); }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * m->nv);
+  MMO_STAGE(MMO_ST_INTEG);
   if (m->integrator == MM_INT_RK4) mmo_rk4(m, d);
   else if (m->integrator == MM_INT_IMPLICITFAST) mmo_implicitfast(m, d);
   else mmo_euler(m, d);
+  MMO_STAGE(MMO_ST_NONE);
+  if (d->round_state_f32) {
+    /* the fp32-STATE twin: all arithmetic in this file's precision, but the state handed from one substep to the next carries
+       only a float's 24 bits -- the floor of any engine that stores its state in fp32 (tests/test_oracle_invariants.py) */
+    for (int i = 0; i < m->nq; i++) d->qpos[i] = (real)(float)d->qpos[i];
+    for (int i = 0; i < m->nv; i++) { d->qvel[i] = (real)(float)d->qvel[i]; d->qacc_warmstart[i] = (real)(float)d->qacc_warmstart[i]; }
+    for (int i = 0; i < m->na; i++) d->act[i] = (real)(float)d->act[i];
+  }
 }
 
 /* ---------------------------------------------------------- accessors */
@@ -1520,6 +1572,7 @@ real* mmo_field(mmo_data* d, const char* name) {
 }
 void mmo_set_geom_size(mmo_data* d, int geom, double a, double b, double c) { d->gsize_id = geom; d->gsize_val[0] = a; d->gsize_val[1] = b; d->gsize_val[2] = c; }
 void mmo_set_geom_type(mmo_data* d, int type) { d->gtype = type; }
+void mmo_set_round_state_f32(mmo_data* d, int on) { d->round_state_f32 = on; }
 void mmo_set_body_mass(mmo_data* d, int body, double mass) { d->bmass_id = body; d->bmass_val = mass; }
 void mmo_set_body_pos(mmo_data* d, int body, double x, double y, double z) { d->bpos_id = body; d->bpos_val[0] = x; d->bpos_val[1] = y; d->bpos_val[2] = z; }
 /* test hook: capsule-axis segment vs convex primitive in the primitive's frame -> signed distance, t, outward normal */

@@ -47,6 +47,7 @@ def lib():
         L.mmo_set_time.argtypes = [C.c_void_p, C.c_double]
         L.mmo_set_geom_size.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         L.mmo_set_geom_type.argtypes = [C.c_void_p, C.c_int]
+        L.mmo_set_round_state_f32.argtypes = [C.c_void_p, C.c_int]
         L.mmo_set_body_mass.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.mmo_set_body_pos.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         L.mmo_test_seg_shape.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_double, C.c_void_p, C.c_void_p]
@@ -176,6 +177,11 @@ class OracleData:
     def set_body_pos(self, body: int, pos):
         """per-env model delta (key_turn_v0.py:164): frame position of one body in its parent"""
         lib().mmo_set_body_pos(self.ptr, int(body), float(pos[0]), float(pos[1]), float(pos[2]))
+
+    def round_state_f32(self, on: bool = True):
+        """the fp32-STATE twin: fp64 arithmetic, but qpos / qvel / act / qacc_warmstart are rounded to float after every
+        mmo_step -- the accuracy floor of any engine that keeps its state in fp32"""
+        lib().mmo_set_round_state_f32(self.ptr, int(bool(on)))
 
     def forward(self):
         lib().mmo_forward(self.model.ptr, self.ptr)

@@ -39,3 +39,39 @@ def test_bench_defaults_are_the_baseline_workload():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'default="myoHandPoseRandom-v0"' in src and "default=4096" in src            # BASELINE.json configs[2], 4096 envs/GPU
     assert "cpu_baseline" in src and "barrier" in src and "max_over_ranks" in src
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_n_gt_1_path_runs_oversubscribed_on_one_gpu():
+    """`python bench.py --gpus 2 --oversubscribe`: the whole N > 1 path -- respawn_under_launcher (torch.distributed.run, two
+    ranks), sharded Philox streams (env_index_base = rank * E), barrier + max-over-ranks timing, the episode-stats gather -- on
+    ONE GPU with a gloo group (RCCL refuses two ranks on one device).  One JSON line, n_gpus = 2, marked oversubscribed; its
+    gathered statistics are those of an UNSHARDED rollout of 2 E envs (rank r's envs are rows [r E, (r + 1) E))."""
+    import subprocess, sys
+    import torch
+    from myosuite_amd.envs import registry
+    E_, W, K = 256, 2, 6
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", str(K), "--warmup", str(W),
+                          "--envs-per-gpu", str(E_), "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "oversubscribed" in d["config"] and d["config"]["parallelism"] == "env-shard x2"
+    assert d["stats"]["envs_in_stats"] == 2 * E_                      # the gather returned both shards
+    assert abs(d["ms_per_step"] - 1e3 * 2 * E_ / d["value"]) < 1e-6 * d["ms_per_step"] + 1e-9
+    assert d["cpu_baseline"]["single_thread"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    # the same rollout unsharded, in this process
+    full = registry.make("myoHandPoseRandom-v0", num_envs=2 * E_, seed=0)
+    stats = full.rollout_setup(action_seed=0)
+    for s in range(W + K):
+        full.rollout_step(None, stream_id=s)
+    torch.cuda.synchronize()
+    assert abs(float(stats[:, 0].mean()) - d["stats"]["mean_episode_return"]) < 1e-4 * max(1.0, abs(float(stats[:, 0].mean())))
+    assert abs(float(stats[:, 2].mean()) - d["stats"]["solved_frac"]) < 1e-6

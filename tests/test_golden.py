@@ -137,6 +137,18 @@ def _mujoco_fixtures():
     return sorted(glob.glob(os.path.join(G, "mujoco_*.npz")))
 
 
+def fixture_model(g):
+    """the compiled model a libmujoco fixture was written for: imported from the MJCF text the fixture carries (ids in MuJoCo's
+    document order), or -- fixtures of multi-file models -- the synthetic model of that name, hash-checked"""
+    from myosuite_amd.model import mjcf, synth
+    if "xml" in g.files and str(g["xml"]):
+        cm = mjcf.load(str(g["xml"])).compile()
+    else:
+        cm = synth.get_model(str(g["model"]))
+    assert cm.hash() == str(g["model_hash"]), "fixture was written for another revision of the model / importer"
+    return cm
+
+
 def test_libmujoco_fixture_hook_is_wired():
     """tests/tools/validate_against_mujoco.py --write-fixture (run by anyone with `pip install mujoco`) drops
     tests/golden/mujoco_<model>.npz; this test and the two below it pick every such file up.  None is committed yet: the
@@ -157,8 +169,7 @@ def test_oracle_matches_libmujoco_fixture(oracle_lib, path):
     from myosuite_amd.model import synth
     from oracle import oracle as O
     g = np.load(path)
-    cm = synth.get_model(str(g["model"]))
-    assert cm.hash() == str(g["model_hash"]), "fixture was written for another revision of the synthetic model"
+    cm = fixture_model(g)
     A = cm.arrays
     np.testing.assert_allclose(A["DOF_INVWEIGHT0"], g["c_dof_invweight0"], rtol=1e-5)
     np.testing.assert_allclose(A["ACT_ACC0"], g["c_actuator_acc0"], rtol=1e-5)
@@ -169,8 +180,51 @@ def test_oracle_matches_libmujoco_fixture(oracle_lib, path):
     for k in g.files:
         if k.startswith("f_") and k != "f_nefc":
             ref = g[k].ravel(); got = np.asarray(getattr(d, k[2:])).ravel()[:ref.size]
-            assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), k
+            if ref.size == 0:          # (a model without tendons / actuators: found by the fake-mujoco round trip)
+                continue
+            assert got.size == ref.size and np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), k
     assert d.nefc == int(g["f_nefc"])
     for s in range(g["ctrl"].shape[0]):
         d.ctrl[:] = g["ctrl"][s]; d.step()
         assert np.abs(d.qpos - g["t_qpos"][s]).max() < 1e-6 * max(1.0, np.abs(g["t_qpos"][s]).max()), s
+
+
+def test_libmujoco_validation_tool_round_trips_through_a_fake_mujoco(oracle_lib, tmp_path, monkeypatch, capsys):
+    """tests/tools/validate_against_mujoco.py has never met a real `mujoco` module (none in this image).  So that its first real
+    run cannot fail on plumbing, drive the whole tool -- MJCF dump, MjModel.from_xml_path, compile-time constants, the forward
+    field mapping, the stepping loop, --write-fixture -- through tests/tools/fake_mujoco.py (the mujoco entry points it uses,
+    implemented on the fp64 oracle), then feed the fixture it wrote to the reader the committed fixtures go through
+    (test_oracle_matches_libmujoco_fixture).  The numbers are the oracle's own, so every difference must be ~0: what is tested
+    is the writer / reader pair, the field names and shapes."""
+    import importlib.util
+    import json
+    import sys
+    tools = os.path.join(os.path.dirname(G), "tools")
+    sys.path.insert(0, tools)
+    try:
+        import fake_mujoco
+        fake_mujoco.install()
+        spec = importlib.util.spec_from_file_location("validate_against_mujoco", os.path.join(tools, "validate_against_mujoco.py"))
+        tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+        written = []
+        real_savez = np.savez_compressed
+        monkeypatch.setattr(np, "savez_compressed", lambda path, **kw: (written.append(str(tmp_path / os.path.basename(path))),
+                                                                           real_savez(str(tmp_path / os.path.basename(path)), **kw))[1])
+        for model in ("hand", "contact_toy"):
+            monkeypatch.setattr(sys, "argv", ["validate_against_mujoco.py", "--model", model, "--steps", "12", "--write-fixture"])
+            assert tool.main() == 0
+            out = capsys.readouterr().out
+            rep = json.loads(out[out.index("{"):out.rindex("}") + 1])
+            assert rep["dims"]["nq"][0] == rep["dims"]["nq"][1] and rep["dims"]["ntendon"][0] == rep["dims"]["ntendon"][1]
+            assert max(rep["compile_constants_maxabs_diff"].values()) < 1e-6, rep["compile_constants_maxabs_diff"]
+            assert all(v < 1e-9 for k, v in rep["forward_rel_diff"].items() if k != "nefc") and rep["forward_rel_diff"]["nefc"][0] == rep["forward_rel_diff"]["nefc"][1]
+            assert rep["qpos_divergence"]["oracle_vs_mujoco"]["max"] < 1e-9
+        assert len(written) == 2 and all(os.path.exists(w) for w in written)
+        g = np.load(written[0])
+        assert str(g["mujoco_version"]) == "fake-oracle" and g["t_qpos"].shape[0] == 12
+        assert {"q0", "v0", "a0", "ctrl", "t_qpos", "model_hash", "f_qacc", "f_nefc", "c_meaninertia"} <= set(g.files)
+        for w in written:                                  # the reader of committed fixtures accepts what the writer wrote
+            test_oracle_matches_libmujoco_fixture(oracle_lib, w)
+    finally:
+        sys.modules.pop("mujoco", None)
+        sys.path.remove(tools)

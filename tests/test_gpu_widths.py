@@ -20,12 +20,35 @@ from oracle import oracle as O
 from test_gpu_parity import STAGE_NAMES, STAGE_OMAP, _rel   # noqa: E402  (same directory)
 
 NSAMPLE = 32
-CONFIGS = [  # env id, envs per GPU (BASELINE.json configs 2-5), expected lanes per env, stage tolerance
-    ("myoElbowPose1D6MRandom-v0", 4096, 8, 2e-4),
-    ("myoHandPoseRandom-v0", 4096, 32, 2e-4),
-    ("myoHandReorient100-v0", 2048, 64, 5e-4),
-    ("myoFatiLegWalk-v0", 1024, 64, 5e-4),
+CONFIGS = [  # env id, envs per GPU (BASELINE.json configs 2-5 + bench.py's extra lines), expected lanes per env, stage tolerance, overrides
+    ("myoElbowPose1D6MRandom-v0", 4096, 8, 2e-4, {}),
+    ("myoHandPoseRandom-v0", 4096, 32, 2e-4, {}),
+    ("myoHandReorient100-v0", 2048, 64, 5e-4, {}),
+    ("myoFatiLegWalk-v0", 1024, 64, 5e-4, {}),
+    ("myoHandPoseRandom-v0", 4096, 64, 5e-4, {"model": "hand_contact"}),     # the self-colliding hand (one env per wave, general rows)
+    ("myoFatiLegWalk-v0", 1024, 64, 5e-4, {"model": "leg_implicit"}),        # MuJoCo-default leg on implicitfast (two-wave launch)
 ]
+
+
+def _cfg_id(c):
+    return f"{c[0]}@{c[1]}-G{c[2]}" + ("".join(f"-{v}" for v in c[4].values()))
+
+
+def _oracle_flips_under_fp32_rounding(om, cm, env, e, qpos, qvel, act, ctrl, warm, nefc_ref, is_reorient):
+    """Is env `e` marginal?  True when the fp64 oracle ITSELF changes its row count under perturbations of qpos of the size of
+    one fp32 rounding (3e-7 relative): a contact / limit sits within rounding of its activation threshold.  Only such envs may
+    differ from the GPU in their row count."""
+    rng = np.random.default_rng(1000 + int(e))
+    for _ in range(12):
+        d = O.OracleData(om)
+        if is_reorient:
+            d.set_geom_size(cm.names["geom"]["obj"], env.geom_size[e].cpu().numpy().astype(np.float64), int(env.geom_type[e]))
+        d.qpos[:] = qpos + 3e-7 * np.maximum(1.0, np.abs(qpos)) * rng.choice([-1.0, 1.0], size=qpos.shape)
+        d.qvel[:] = qvel; d.act[:] = act; d.ctrl[:] = ctrl; d.qacc_warmstart[:] = warm
+        d.forward()
+        if d.nefc != nefc_ref:
+            return True
+    return False
 
 
 def _env_oracle(env, e):
@@ -54,9 +77,9 @@ def _env_oracle(env, e):
     return o
 
 
-@pytest.mark.parametrize("env_id,nenv,lanes,stage_tol", CONFIGS, ids=[f"{c[0]}@{c[1]}-G{c[2]}" for c in CONFIGS])
-def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stage_tol):
-    env = registry.make(env_id, num_envs=nenv, seed=17, autoreset=False)
+@pytest.mark.parametrize("env_id,nenv,lanes,stage_tol,overrides", CONFIGS, ids=[_cfg_id(c) for c in CONFIGS])
+def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stage_tol, overrides):
+    env = registry.make(env_id, num_envs=nenv, seed=17, autoreset=False, **overrides)
     cm, hm = env.cm, env.hm
     assert hm.launch_lanes(nenv) == lanes, "the benchmarked launch does not use the width this test is named after"
     env.reset(seed=17)
@@ -85,9 +108,14 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
         d.qacc_warmstart[:] = st.qacc_warmstart[e].cpu().numpy()
         d.forward()
         # a contact / limit whose distance sits within fp32 rounding of its activation threshold can be a row in one engine and
-        # not in the other: such an env is compared up to the unconstrained stages only, and at most 2 of the 32 may be marginal
+        # not in the other.  Such an env is compared up to the unconstrained stages only -- but ONLY when the oracle itself flips
+        # the row under a perturbation of the size of one fp32 rounding; a row-count mismatch anywhere else fails the test
         rows_gpu = int(round(float(dump[e, hm.layout("efc_active"):hm.layout("efc_active") + 64].sum())))
         is_marginal = rows_gpu != d.nefc
+        if is_marginal:
+            assert _oracle_flips_under_fp32_rounding(om, cm, env, e, qpos[e].astype(np.float64), qvel[e], act[e], ctrl[e],
+                                                     st.qacc_warmstart[e].cpu().numpy(), d.nefc, "Reorient" in env_id), \
+                (int(e), rows_gpu, d.nefc, "row counts differ and the oracle's does not depend on fp32-sized perturbations")
         marginal += int(is_marginal)
         for n in STAGE_NAMES:
             if is_marginal and n == "qacc":
@@ -101,10 +129,9 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
         M = dump[e, hm.layout("M"):hm.layout("M") + cm.nv * cm.nv].reshape(cm.nv, cm.nv)
         worst["M"] = max(worst.get("M", 0.0), _rel(M, d.full_M()))
     print("stage errors", env_id, {k: f"{v:.1e}" for k, v in worst.items()}, "marginal envs", marginal, "worst qacc env", worst_qacc_env)
-    # the constrained acceleration of the reorient model goes through the capsule-vs-convex narrow phase (bisection to 4e-6 m on
-    # the capsule axis; the contact point moves by that much between fp32 and fp64): looser bound on that one stage
-    qacc_tol = 5e-3 if "Reorient" in env_id else stage_tol
-    bad = {k: v for k, v in worst.items() if v >= (2e-5 if k == "M" else (qacc_tol if k == "qacc" else stage_tol))}
+    # (round 2 allowed the reorient batch 5e-3 on qacc: the capsule-vs-convex narrow phase stopped at a 4e-6 m bracket; with the
+    # secant polish of the root every stage of every config is held to the same bound)
+    bad = {k: v for k, v in worst.items() if v >= (2e-5 if k == "M" else stage_tol)}
     assert not bad and marginal <= 2, (bad, marginal, worst_qacc_env)
 
     # ---- (ii) one teacher-forced env-step through the gym-level API (ctrl map / fatigue, frame_skip substeps, final
@@ -119,9 +146,9 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
         got = obs[e].cpu().numpy()
         scale = np.maximum(1.0, np.abs(ob))
         if env_id.startswith(("myoElbowPose", "myoHandPose")):
-            tol = np.full(got.shape, 5e-4 if cm.nq > 1 else 5e-5)
+            tol = np.full(got.shape, (2e-3 if cm.npair > 0 else 5e-4) if cm.nq > 1 else 5e-5)   # (self-contact hand: contact onsets)
         elif "Reorient" in env_id:
-            tol = np.full(200, 2e-3); tol[26:32] = 2e-2; tol[44 + 39:44 + 78] = 2e-2; tol[44 + 78:44 + 117] = 0.5
+            tol = np.full(200, 2e-3); tol[26:32] = 2e-2; tol[44 + 39:44 + 78] = 2e-2; tol[44 + 78:44 + 117] = 2e-2
         else:
             tol = np.full(403, 2e-3); tol[33:69] = 1e-2; tol[83 + 80:83 + 160] = 2e-2; tol[83 + 160:83 + 240] = 1e-2
         badi = np.abs(got - ob) / scale > tol
@@ -131,56 +158,75 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
     assert int((env.state.status & 0xA).max()) == 0
 
 
-@pytest.mark.parametrize("name,lanes,nsub", [("elbow", 8, 10), ("hand", 32, 10), ("hand", 64, 10)],
-                         ids=["elbow-G8", "hand-G32", "hand-G64"])
-def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
-    """BASELINE.json: "state divergence vs CPU mj_step < 1e-4 rel over 1000 steps".  100 env-steps x 10 substeps, random
-    actions through the muscle ctrl map, free running from the Pose task's random reset, on the group widths the 4096-env
-    benchmark launches; error = max|qpos_gpu - qpos_oracle| / max(1, max|qpos|), MAXIMUM over the whole run, per env.
+NORTH_STAR_ENVS = 64
 
-    Elbow: every env < 1e-4 (measured ~1e-6).  Hand: the bound on the maximum over the run cannot hold for every env for ANY
-    fp32 state -- tests/test_oracle_invariants.py::test_north_star_tolerance_is_at_the_sensitivity_of_the_reference_algorithm
-    shows the fp64 oracle against itself exceeding 1e-4 from a 1e-7 perturbation (limit rows switching on one substep apart).
-    Gated here: the typical env (median of the per-env maxima < 2e-5), at least 12 of 16 envs below 1e-4 over their whole run
-    (the fp64 twin at a 1e-6 perturbation has 13), and every env back under 2e-3 at the end of the run."""
-    nenv = 16
+
+def north_star_run(name, lanes, nsub=10, nenv=NORTH_STAR_ENVS, nsteps=100):
+    """100 env-steps x 10 substeps, random actions through the muscle ctrl map, free running from the Pose task's random reset:
+    per-env-step relative qpos error [step, env] of (i) the GPU and (ii) the fp64 oracle whose STATE is rounded to fp32 after
+    every substep (the floor of any engine that stores fp32 state), both against the plain fp64 oracle."""
     cm = synth.get_model(name); om = O.OracleModel(cm)
     hm = E.HipModel(cm, lanes_per_env=lanes)
     assert hm.launch_lanes(nenv) == lanes
     lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
     q0 = np.stack([(lo + (hi - lo) * EO.pose_reset_draws(cm.nq, e, 0, 0)[0]).astype(np.float32) for e in range(nenv)])
     st = E.BatchState(hm, nenv); st.qpos.copy_(torch.from_numpy(q0))
-    ds = []
+    ds, tw = [], []
     for e in range(nenv):
         d = O.OracleData(om); d.qpos[:] = q0[e]; ds.append(d)
+        t = O.OracleData(om); t.qpos[:] = q0[e]; t.round_state_f32(True); tw.append(t)
     a = torch.empty(nenv, cm.nu, device="cuda")
-    rel = np.zeros((100, nenv))
-    for s in range(100):
+    rel = np.zeros((nsteps, nenv)); rel_tw = np.zeros((nsteps, nenv))
+    for s in range(nsteps):
         E.uniform(a, 0, s)
         ctrl = (1.0 / (1.0 + torch.exp(-5.0 * (a - 0.5)))).contiguous()
         E.step(hm, st, ctrl, nsub)
         c = ctrl.cpu().numpy()
-        for e, d in enumerate(ds):
-            d.ctrl[:] = c[e]; d.step(nsub)
-        oq = np.stack([d.qpos for d in ds]); gq = st.qpos.cpu().numpy()
-        rel[s] = np.abs(gq - oq).max(axis=1) / max(1.0, np.abs(oq).max())
-    per_env = rel.max(axis=0)
+        for e in range(nenv):
+            ds[e].ctrl[:] = c[e]; ds[e].step(nsub)
+            tw[e].ctrl[:] = c[e]; tw[e].step(nsub)
+        oq = np.stack([d.qpos for d in ds]); gq = st.qpos.cpu().numpy(); tq = np.stack([d.qpos for d in tw])
+        scale = max(1.0, np.abs(oq).max())
+        rel[s] = np.abs(gq - oq).max(axis=1) / scale
+        rel_tw[s] = np.abs(tq - oq).max(axis=1) / scale
+    return rel, rel_tw, int(st.status.max())
+
+
+@pytest.mark.parametrize("name,lanes,nsub", [("elbow", 8, 10), ("hand", 32, 10), ("hand", 64, 10)],
+                         ids=["elbow-G8", "hand-G32", "hand-G64"])
+def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
+    """BASELINE.json: "state divergence vs CPU mj_step < 1e-4 rel over 1000 steps".  64 envs on the group widths the 4096-env
+    benchmark launches; error = max|qpos_gpu - qpos_oracle| / max(1, max|qpos|), MAXIMUM over the whole run, per env.
+
+    Elbow: every env < 1e-4 (measured ~1e-6).  Hand: a bound on every env's maximum cannot hold for ANY fp32 state -- the fp64
+    oracle whose state is merely ROUNDED to fp32 after every substep (`twin`) already has an env in 64 at 4e-3 (a joint-limit
+    row switching on one substep apart).  So the gate is (i) the north-star count, >= 60 of 64 envs below 1e-4 over their whole
+    run, and (ii) "no worse than the fp32-state floor": at most 2 more envs above 1e-4 than the twin, median of the per-env
+    maxima within 4x of the twin's."""
+    rel, rel_tw, status = north_star_run(name, lanes, nsub)
+    nenv = rel.shape[1]
+    per_env, per_env_tw = rel.max(axis=0), rel_tw.max(axis=0)
     run = rel.max(axis=1)
     print(f"1000-step divergence {name} G={lanes}: at 100/300/1000 steps {run[9]:.2e} {run[29]:.2e} {run[99]:.2e}, max over run "
-          f"{run.max():.2e}; per-env maxima median {np.median(per_env):.2e}, {int((per_env < 1e-4).sum())}/{nenv} envs < 1e-4")
+          f"{run.max():.2e}; per-env maxima median {np.median(per_env):.2e} (fp32-state twin {np.median(per_env_tw):.2e}), "
+          f"{int((per_env < 1e-4).sum())}/{nenv} envs < 1e-4 (twin {int((per_env_tw < 1e-4).sum())}/{nenv})")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", f"parity_1000_{name}_G{lanes}.json"), "w") as f:
         import json
         json.dump({"rel_err_per_env_step": run.tolist(), "per_env_max_over_run": per_env.tolist(), "max_over_run": float(run.max()),
                    "median_env_max": float(np.median(per_env)), "envs_below_1e-4": int((per_env < 1e-4).sum()), "nenv": nenv,
-                   "lanes": lanes}, f)
-    assert int(st.status.max()) == 0
+                   "lanes": lanes,
+                   "fp32_state_twin": {"per_env_max_over_run": per_env_tw.tolist(), "median_env_max": float(np.median(per_env_tw)),
+                                       "envs_below_1e-4": int((per_env_tw < 1e-4).sum()),
+                                       "what": "fp64 oracle, qpos/qvel/act/qacc_warmstart rounded to fp32 after every substep"}}, f)
+    assert status == 0
     if name == "elbow":
         assert run.max() < 1e-4, run.max()
     else:
-        assert np.median(per_env) < 2e-5, np.sort(per_env)
-        assert (per_env < 1e-4).sum() >= 12, np.sort(per_env)
-        assert rel[-1].max() < 2e-3, rel[-1]
+        below, below_tw = int((per_env < 1e-4).sum()), int((per_env_tw < 1e-4).sum())
+        assert below >= 60, np.sort(per_env)[-8:]
+        assert below >= below_tw - 2, (below, below_tw)
+        assert np.median(per_env) < 4.0 * max(np.median(per_env_tw), 5e-7), (np.median(per_env), np.median(per_env_tw))
 
 
 @pytest.mark.parametrize("env_id,n", [("myoElbowPose1D6MRandom-v0", 256), ("myoHandPoseRandom-v0", 96), ("myoHandPoseFixed-v0", 64)])

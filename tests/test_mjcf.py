@@ -280,3 +280,43 @@ def test_mjcf_imported_models_step_on_the_hip_path(oracle_lib, tmp_path, monkeyp
         d = O.OracleData(om); d.qpos[:] = q0[e]; d.ctrl[:] = ctrl[e].cpu().numpy(); d.step(20)
         assert np.abs(st.qpos[e].cpu().numpy() - d.qpos).max() < 2e-4, e
     assert int(st.status.max()) == 0
+
+
+def test_dry_run_lists_every_construct_the_importer_would_reject():
+    """mjcf.dry_run: the whole gap of a file at once (load stops at the first MjcfError), plus the includes that do not resolve.
+    On the reference's own task XMLs -- whose bodies live in the EMPTY simhive/myo_sim submodule -- it names the missing
+    includes, and for the chase-tag leg scene the height-field terrain geom (assets/leg/myolegs_chasetag.xml)."""
+    from myosuite_amd.model import mjcf
+    xml = """<mujoco model="gap">
+      <option integrator="implicit" cone="elliptic" solver="CG"/>
+      <asset><mesh name="m" file="x.stl"/></asset>
+      <worldbody>
+        <geom name="floor" type="hfield" hfield="h"/>
+        <body name="a"><joint name="ja" type="ball" limited="true" range="0 1"/><geom name="ga" type="mesh" mesh="m"/>
+          <geom name="vis" type="mesh" mesh="m" contype="0" conaffinity="0"/><geom name="ok" type="capsule" size="0.01 0.02"/>
+          <body name="b"><joint name="jb" type="hinge"/><geom type="sphere" size="0.01"/><site name="s"/></body></body>
+      </worldbody>
+      <equality><weld body1="a" body2="b"/><joint joint1="jb" joint2="jb"/></equality>
+      <actuator><general name="u1" site="s"/><motor name="u2" joint="jb"/><adhesion name="u3" body="b"/></actuator>
+      <sensor><jointpos joint="jb"/></sensor>
+    </mujoco>"""
+    r = mjcf.dry_run(xml)
+    kinds = set(r["unsupported"])
+    for expect in ("integrator implicit", "elliptic friction cone", "solver CG", "limited ball joint", "equality <weld>", "actuator <adhesion>"):
+        assert expect in kinds, (expect, kinds)
+    assert any(k.startswith("hfield geom") for k in kinds) and any(k.startswith("mesh geom") for k in kinds)
+    assert any(k.startswith("actuator transmission other than joint / tendon") for k in kinds)
+    assert len(r["unsupported"][[k for k in kinds if k.startswith("mesh geom")][0]]) == 1          # the visual mesh is not a gap
+    assert r["ignored"].get("visual mesh geom") == 1 and r["ignored"].get("sensor") == 1 and not r["loadable"]
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.load(xml)
+    # a file of the supported subset is reported loadable, and loads
+    ok = mjcf.dump(synth.make_hand())
+    r2 = mjcf.dry_run(ok)
+    assert r2["loadable"] and not r2["unsupported"] and not r2["missing_includes"]
+    ref = "/root/reference/myosuite/envs/myo/assets"
+    if os.path.isdir(ref):
+        sar = mjcf.dry_run(os.path.join(ref, "hand", "myohand_sar.xml"))
+        assert len(sar["missing_includes"]) == 3 and all("simhive/myo_sim" in f for f in sar["missing_includes"]) and not sar["unsupported"]
+        leg = mjcf.dry_run(os.path.join(ref, "leg", "myolegs_chasetag.xml"))
+        assert any(k.startswith("hfield geom") for k in leg["unsupported"]) and len(leg["missing_includes"]) == 7

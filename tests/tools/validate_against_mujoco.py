@@ -59,6 +59,9 @@ def main():
                 "elbow_exo": synth.make_elbow_exo}[args.model]()
         path = os.path.join(tempfile.mkdtemp(), f"{args.model}.xml")
         open(path, "w").write(mjcf.dump(spec))
+        # everything below uses the model AS IMPORTED FROM THE XML libmujoco reads: MuJoCo numbers sites / geoms / tendons in
+        # document order, the builder in insertion order (found by the fake-mujoco round trip: site_xpos rows did not line up)
+        spec = mjcf.load(path)
     cm = spec.compile()
     mjm = mujoco.MjModel.from_xml_path(path); mjd = mujoco.MjData(mjm)
     rep = {"xml": path, "dims": {"nq": [cm.nq, mjm.nq], "nv": [cm.nv, mjm.nv], "nu": [cm.nu, mjm.nu], "ntendon": [cm.ntendon, mjm.ntendon]}}
@@ -81,7 +84,11 @@ def main():
     mujoco.mj_forward(mjm, mjd); d.forward()
     fix = None
     if args.write_fixture:
+        # the fixture carries the MJCF text itself: its readers import exactly the model libmujoco compiled (include-free XML
+        # only; for --xml files with <include> the readers need the same tree, so the text is stored for single-file models)
+        xml_text = open(path).read()
         fix = dict(model=np.array(args.model if not args.xml else os.path.basename(args.xml)), model_hash=np.array(cm.hash()),
+                   xml=np.array(xml_text if "<include" not in xml_text else ""),
                    mujoco_version=np.array(mujoco.__version__), q0=q0, v0=v0, a0=a0, ctrl=ctrl,
                    c_dof_invweight0=np.array(mjm.dof_invweight0), c_body_invweight0=np.array(mjm.body_invweight0),
                    c_tendon_invweight0=np.array(mjm.tendon_invweight0), c_actuator_acc0=np.array(mjm.actuator_acc0),
