@@ -152,22 +152,22 @@ def cpu_rollout_rate(env_id: str, nthreads: int, target_s: float = 4.0, per_thre
     import numpy as np
     from oracle import oracle as O
     from oracle import env_oracle as EO
-    nenv = max(2 * nthreads, 8)
-    om, ds, cm, nsub = _cpu_envs(env_id, nenv)
-
-    def run(nsteps, first_stream):
-        acts = np.stack([EO.uniform_stream(nenv * cm.nu, 0, first_stream + s_).reshape(nenv, cm.nu) for s_ in range(nsteps)]).astype(np.float64)
-        t0 = time.perf_counter()
-        O.batch_rollout(om, ds, acts, nsub=nsub, nthreads=nthreads, normalize=True, do_forward=True)
-        return time.perf_counter() - t0
-
+    # the sample grows in ENVS (one env at a time per thread, ~40 env-steps each), sized for ~target_s of wall time from the
+    # single-thread rate (given, or measured on a few envs first)
+    nsteps = 40
     if per_thread_rate is None:
-        dt = run(2, 0)                      # calibration (also touches every page once)
-        per_thread_rate = nenv * 2 / dt / min(nthreads, nenv)
-    else:
-        run(1, 0)
-    nsteps = int(max(4, min(400, round(target_s * per_thread_rate * nthreads / nenv))))
-    dt = run(nsteps, 2)
+        om, ds, cm, nsub = _cpu_envs(env_id, 2)
+        acts = np.stack([EO.uniform_stream(2 * cm.nu, 0, s_).reshape(2, cm.nu) for s_ in range(10)]).astype(np.float64)
+        t0 = time.perf_counter()
+        O.batch_rollout(om, ds, acts, nsub=nsub, nthreads=1, normalize=True, do_forward=True)
+        per_thread_rate = 2 * 10 / (time.perf_counter() - t0)
+    nenv = int(round(target_s * per_thread_rate * nthreads / nsteps))
+    nenv = max(2 * nthreads, min(8192, ((nenv + nthreads - 1) // nthreads) * nthreads))
+    om, ds, cm, nsub = _cpu_envs(env_id, nenv)
+    acts = np.stack([EO.uniform_stream(nenv * cm.nu, 0, s_).reshape(nenv, cm.nu) for s_ in range(nsteps)]).astype(np.float64)
+    t0 = time.perf_counter()
+    O.batch_rollout(om, ds, acts, nsub=nsub, nthreads=nthreads, normalize=True, do_forward=True)
+    dt = time.perf_counter() - t0
     return {"value": nenv * nsteps / dt, "threads": nthreads, "envs": nenv, "env_steps_each": nsteps, "seconds": dt}
 
 

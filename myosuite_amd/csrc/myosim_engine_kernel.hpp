@@ -690,6 +690,12 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 #define MM_SPARSE_GEN 0   /* 1: the general-row kernels use the tree-sparse solve for the two M solves of a pass (solve0, Euler).  Measured: \
                              the extra live state tips these 256-VGPR kernels into 80 spills; reorient -3 %, self-contact hand -5 % */
 #endif
+#ifndef MM_NEWTON_POLISH
+#define MM_NEWTON_POLISH 0   /* experiment (limit-rows-only kernels): one extra Newton step after the convergence test fires */
+#endif
+#ifndef MM_NEWTON_TRUE_MV
+#define MM_NEWTON_TRUE_MV 0  /* experiment (tree-sparse kernels): M search as an explicit product instead of -grad - D search */
+#endif
 #ifndef MM_SPARSE_LDL
 #define MM_SPARSE_LDL 1   /* 0: dense register Cholesky in every kernel (A/B switch) */
 #endif
@@ -2082,6 +2088,9 @@ struct Engine {
     // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull;
+#if MM_NEWTON_POLISH
+    bool polished = false;
+#endif
     for (int iter = 0; iter < KD().iterations; iter++) {
       const bool on = r_active && r_jar < 0.f;
       const unsigned long long set_now = __ballot(on);
@@ -2094,7 +2103,14 @@ struct Engine {
         // compare the active sets of THIS group only
         const int lane = threadIdx.x & 63;
         const unsigned long long gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane - g);
-        if (((set_now ^ set_prev) & gm) == 0ull) break;
+        if (((set_now ^ set_prev) & gm) == 0ull) {
+#if MM_NEWTON_POLISH
+          if (polished) break;
+          polished = true;     // experiment: one more Newton step from the (nominally exact) minimiser
+#else
+          break;
+#endif
+        }
       }
       set_prev = set_now;
       float dadd = rows_to_dof(on ? r_D : 0.f);
@@ -2105,7 +2121,7 @@ struct Engine {
       // (M + diag(dadd)) search = -grad, so M search needs no product: the residual of the solve is of the order of the
       // rounding of an explicit product
       float Mv;
-      if constexpr (SP) Mv = g < nv ? -grad - dadd * search : 0.f;
+      if constexpr (SP && !MM_NEWTON_TRUE_MV) Mv = g < nv ? -grad - dadd * search : 0.f;
       else Mv = mul_m(search);
       float jv = r_sign * sh<G>(search, r_dof);
       float dm = Ma - d_smooth;
