@@ -2378,16 +2378,17 @@ struct Engine {
     int myrows = 0;
     for (int c = 0; c < 2; c++) if (c < nc && cdist[c] < incl) myrows += rowsper;
     int base = neq + nfr + nlim + ntl + gscan_excl(myrows);
-    const int ncrows = gsum_i(myrows);
     // Row table entries by the pair's lane; the Jacobian rows by ALL lanes of the group, one dof each: lane i holds its dof's
     // motion axis in registers and knows from a per-body chain mask (Aux.body_dofmask) whether dof i moves geom1's or geom2's
     // body, so a contact costs a handful of broadcasts + 4 stores per lane instead of one lane walking two kinematic chains
     // with two dependent LDS round trips per dof (11 k cycles per forward pass for the leg's foot contacts).
     int cbase[2] = {-1, -1};
+    int made = 0;      // contact rows this lane actually created (a contact that does not fit is dropped whole)
     for (int c = 0; c < 2; c++) {
       if (!(c < nc && cdist[c] < incl)) continue;
       if (base + rowsper > KD().efc_rows) { over = 1; continue; }
       cbase[c] = base;
+      made += rowsper;
       const float tran = MF_(BODY_INVWEIGHT0)[2 * b1] + MF_(BODY_INVWEIGHT0)[2 * b2];
       for (int k = 0; k < rowsper; k++) {
         RT[3 * (base + k)] = __int_as_float(MM_CON_CONTACT | (g << 3));
@@ -2428,8 +2429,13 @@ struct Engine {
       }
     }
     if (gor<G>(over)) status |= 8;   // more rows than lanes: surplus rows dropped (njmax-style warning)
-    nefc = neq + nfr + nlim + ntl + ncrows;
-    if (nefc > KD().efc_rows) nefc = KD().efc_rows;
+    // rows that exist: everything ahead of the contacts up to the table size, plus the contact rows that were created.  (Counting
+    // the rows of a DROPPED contact -- round 2: min(sum, efc_rows) -- left the tail rows active with whatever the row table
+    // held: a garbage row descriptor indexes the solimp / solref tables out of bounds, a memory fault with the model in HBM.)
+    {
+      const int pre = neq + nfr + nlim + ntl;
+      nefc = (pre < KD().efc_rows ? pre : KD().efc_rows) + gsum_i(made);
+    }
     {
       int w = nefc;
 #pragma unroll
