@@ -37,8 +37,11 @@ def main():
     L = O.lib()
     L.mmo_flops_get.argtypes = [C.c_void_p]
     res = {}
-    for env_id, model, warm in (("myoElbowPose1D6MRandom-v0", None, 5), ("myoHandPoseRandom-v0", None, 5), ("myoHandReorient100-v0", None, 3),
-                                ("myoFatiLegWalk-v0", None, 5), ("myoLegWalk-v0", None, 5)):
+    # keys = bench.workload_key without the batch: env id + the overrides that change the work
+    for env_id, model, warm, fwd in (("myoElbowPose1D6MRandom-v0", None, 5, True), ("myoHandPoseRandom-v0", None, 5, True),
+                                     ("myoHandReorient100-v0", None, 3, True), ("myoFatiLegWalk-v0", None, 5, True), ("myoLegWalk-v0", None, 5, True),
+                                     ("myoHandPoseRandom-v0", "hand_contact", 5, True), ("myoFatiLegWalk-v0", "leg_implicit", 5, True),
+                                     ("myoHandPoseRandom-v0", None, 5, False)):
         sp = registry.spec(env_id)
         cm = synth.get_model(model or sp["kwargs"]["model"])
         fs = sp["kwargs"].get("frame_skip", 10)
@@ -60,16 +63,19 @@ def main():
                 d.ctrl[:] = 1.0 / (1.0 + np.exp(-5.0 * (a - 0.5)))
                 if s >= warm:
                     L.mmo_flops_reset()
-                d.step(fs); d.forward()
+                d.step(fs)
+                if fwd:
+                    d.forward()
                 if s >= warm:
                     c = (C.c_uint64 * 6)(); L.mmo_flops_get(c)
                     tot += np.array(list(c), np.uint64); n += 1
         add, mul, div, sq, tr, cmp_ = (tot / n).tolist()
-        res[env_id] = {"flops": add + mul + div + sq + tr, "add": add, "mul": mul, "div": div, "sqrt": sq, "transcendental": tr,
+        key = env_id + (f"|model={model}" if model else "") + ("" if fwd else "|do_forward=False")
+        res[key] = {"flops": add + mul + div + sq + tr, "add": add, "mul": mul, "div": div, "sqrt": sq, "transcendental": tr,
                        "compare_minmax": cmp_, "frame_skip": fs,
                        "source": "tests/tools/count_flops.py: fp64 oracle compiled with an operation-counting scalar, mean of 48 env-steps "
-                                 "(frame_skip substeps + final forward), random actions"}
-        print(env_id, json.dumps(res[env_id]))
+                                 "(frame_skip substeps" + (" + final forward" if fwd else ", no final forward") + "), random actions"}
+        print(key, json.dumps(res[key]))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "profiles", "flops_per_env_step.json"), "w"), indent=1)
 

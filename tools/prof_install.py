@@ -27,15 +27,19 @@ for spec in sys.argv[2:]:
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, "profiles", f"{tag}_{wl}_pmc_summary.txt"))
     shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(ROOT, "profiles", f"{tag}_{wl}_bench_under_rocprof.json"))
     e = {}
+    def is_step_kernel(name):     # the fused env-step kernel, not the reset-observation variant (last template argument true)
+        return "k_engine" in name and not re.search(r",\s*true\s*>", name.split("(")[0])
     for line in open(os.path.join(src, "summary.txt")):
         m = re.match(r"pmc_\w+ \| (.*?) \| (\w+) \| mean/dispatch ([0-9.eE+-]+) \| dispatches (\d+)", line)
-        if m and "k_engine" in m.group(1) and m.group(2) in KEYS:
+        if m and is_step_kernel(m.group(1)) and m.group(2) in KEYS:
             e["kernel"] = m.group(1).replace("void ", "").replace("(KArgs)", "")
             e["dispatches"] = int(m.group(4))
             e[KEYS[m.group(2)]] = float(m.group(3))
     for row in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
-        if "k_engine" in row["Name"]:
+        if is_step_kernel(row["Name"]):
             e["kernel_trace_avg_ns"] = float(row["AverageNs"]); e["kernel_trace_calls"] = int(row["Calls"])
+        elif "k_engine" in row["Name"]:
+            e["reset_obs_kernel_trace_avg_ns"] = float(row["AverageNs"]); e["reset_obs_kernel_trace_calls"] = int(row["Calls"])
     b = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
     e["bench_kernel_ms_same_run"] = b.get("roofline", {}).get("kernel_ms")
     out[key] = e

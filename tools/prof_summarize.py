@@ -4,7 +4,7 @@ out = sys.argv[1]
 for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True):
     print("# kernel stats:", os.path.relpath(f, out))
     for i, row in enumerate(csv.reader(open(f))):
-        if i < 6:
+        if i < 8:
             print(",".join(row))
 for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(d):
@@ -17,4 +17,4 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             if "k_engine" not in k and "k_uniform" not in k and "k_reset" not in k:
                 continue
             for c, v in cs.items():
-                print(f"{os.path.basename(d)} | {k[:60]} | {c} | mean/dispatch {sum(v)/len(v):.1f} | dispatches {len(v)}")
+                print(f"{os.path.basename(d)} | {k[:90]} | {c} | mean/dispatch {sum(v)/len(v):.1f} | dispatches {len(v)}")
