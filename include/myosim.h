@@ -64,8 +64,8 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
  * mm_abi_version() (what the library was built from) and, for bindings that restate the structs (ctypes, cgo, JNI), its own
  * struct sizes with mm_struct_size().  History: 1 = round 1; 2 = mm_state.env_index_base, mm_env_draw(env_index_base), status
   * bits renumbered, the mm_rollout struct -- round 2, shipped under the version STRING of round 1; 3 = this constant + mm_abi_version /
- * mm_struct_size. */
-#define MM_ABI_VERSION 3
+ * mm_struct_size; 4 = mm_task.size / mm_rollout.size (append-only growth of the two structs that gain fields per task). */
+#define MM_ABI_VERSION 4
 enum { MM_STRUCT_STATE = 0, MM_STRUCT_DERIVED, MM_STRUCT_TASK, MM_STRUCT_ROLLOUT };
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
@@ -116,8 +116,13 @@ typedef struct {
   int32_t* solver_niter;    /* [nenv] Newton iterations of the last solve     */
 } mm_derived;
 
-/* Per-call description of the env-level (MyoBase) work fused around the physics. */
+/* Per-call description of the env-level (MyoBase) work fused around the physics.
+ * Forward compatibility: `size` = sizeof(mm_task) AS THE CALLER WAS COMPILED (first field, always set).  New tasks append
+ * their parameters at the END of the struct; the library copies min(size, its own sizeof) bytes and zero-fills the rest, so a
+ * caller built against an older, shorter struct keeps working (zero = "feature off" for every appended field), and a caller
+ * built against a NEWER header is refused (MM_EARG) instead of having its tail silently ignored. */
 typedef struct {
+  uint32_t size;            /* sizeof(mm_task) in the caller's build (0 is refused) */
   int   task;               /* MM_TASK_*                                       */
   int   nsubsteps;          /* frame_skip                                      */
   int   normalize_act;      /* 1: muscle ctrl = 1/(1+exp(-5(a-0.5)))  (base_v0.py:86-90) */
@@ -197,6 +202,7 @@ typedef struct {
  * step -- benchmarks/mjx_benchmark.py:29 draws actions, gym's autoreset wrapper / playground's TrainingWrapper re-arm
  * finished episodes, RecordEpisodeStatistics accumulates returns -- without extra kernel launches. */
 typedef struct {
+  uint32_t size;            /* sizeof(mm_rollout) in the caller's build (same rule as mm_task.size) */
   const float* action;      /* [nenv][nu], or NULL: draw action ~ U[0,1) in the kernel (Philox4x32-10, mm_uniform's scheme:
                                element i = (env_index_base + e) * nu + u is word i%4 of counter (i/4, action_stream), key action_seed) */
   uint64_t action_seed, action_stream;

@@ -198,7 +198,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mm_version(void) { return "myosim-hip 0.3 (gfx950, lane=item engine, ABI 3)"; }
+extern "C" const char* mm_version(void) { return "myosim-hip 0.3 (gfx950, lane=item engine, ABI 4)"; }
 extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
 extern "C" int mm_struct_size(int which) {
   switch (which) {
@@ -235,7 +235,10 @@ static Layout env_layout(const mm_model* m, bool two_wave) {
   o = (o + 3) & ~3;
   // 12 words (cvel, cacc) + 1 pointer-jumping word per body | dense tile | SP kernels: published rows [nvp][12], x [nvp], update
   // matrices [nseg][36]
-  const int u1_words = std::max(std::max(13 * d.nbody, m->nvp * m->nvp), d.seg_u + 36 * m->nseg);
+  // row stride of the dense tile(s): Engine::TD (the 32-wide tile of the dense kernels is padded against LDS bank conflicts)
+  const bool sp_kernel = MM_SPARSE_LDL && !d.gen && m->nvp >= 8 && d.integrator != MM_INT_IMPLICITFAST;
+  const int td = (!sp_kernel && m->nvp == 32) ? 36 : m->nvp;
+  const int u1_words = std::max(std::max(13 * d.nbody, m->nvp * td), d.seg_u + 36 * m->nseg);
   L.u1 = take(u1_words);
   if (two_wave) { L.crb = take(10 * d.nbody); L.xanchor = take(3 * d.njnt); L.xaxis = take(3 * d.njnt); }
   else { L.crb = take(std::max(10 * d.nbody, 6 * d.njnt)); L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt; }   // anchors / axes die before crb
@@ -249,7 +252,7 @@ static Layout env_layout(const mm_model* m, bool two_wave) {
   if (d.integrator == MM_INT_RK4) { L.rk_qpos0 = take(d.nq); L.rk_act0 = take(d.na); L.rk_adot = take(d.na); }
   if (d.integrator == MM_INT_IMPLICITFAST) { L.tenw = take(d.ntendon); L.dofw = take(d.nv); }
   if (d.gen) { o = (o + 3) & ~3; L.efcJ = take(d.efc_rows * (m->nvp + 4)); L.rowtab = take(3 * m->lanes); }
-  if (two_wave) { o = (o + 3) & ~3; L.mtile = take(m->nvp * m->nvp + m->nvp); }
+  if (two_wave) { o = (o + 3) & ~3; L.mtile = take(m->nvp * td + m->nvp); }
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
   o = (o + 3) & ~3;
@@ -979,6 +982,18 @@ extern "C" int mm_forward(const mm_model* m, const mm_state* s, const float* ctr
   return launch(m, a, stream);
 }
 
+// mm_task / mm_rollout grow by appending fields: take min(caller's size, ours) bytes, zero the rest (include/myosim.h)
+template <typename T>
+static int sized_copy(T* dst, const T* src, const char* what) {
+  if (!src) return fail(MM_EARG, what);
+  const uint32_t sz = *reinterpret_cast<const uint32_t*>(src);
+  if (sz < 8 || sz > sizeof(T)) return fail(MM_EARG, "mm_task / mm_rollout: .size is unset or larger than this library's struct (caller built against a newer header)");
+  memset(dst, 0, sizeof(T));
+  memcpy(dst, src, sz);
+  dst->size = (uint32_t)sizeof(T);
+  return MM_OK;
+}
+
 static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
   if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
@@ -1012,6 +1027,9 @@ static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
 
 extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* action, const mm_task* t,
                            const mm_derived* out, void* stream) {
+  mm_task tt;
+  { const int rc = sized_copy(&tt, t, "mm_env_step: null task"); if (rc != MM_OK) return rc; }
+  t = &tt;
   { const int rc = check_task(m, s, t); if (rc != MM_OK) return rc; }
   KArgs a; fill_common(m, a, s);
   a.ctrl = action; a.mode = 2; a.t = *t;
@@ -1022,6 +1040,10 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
 
 extern "C" int mm_rollout_step(const mm_model* m, const mm_state* s, const mm_task* t, const mm_rollout* r,
                                const mm_derived* out, void* stream) {
+  mm_task tt; mm_rollout rr;
+  { const int rc = sized_copy(&tt, t, "mm_rollout_step: null task"); if (rc != MM_OK) return rc; }
+  { const int rc = sized_copy(&rr, r, "mm_rollout_step: null rollout description"); if (rc != MM_OK) return rc; }
+  t = &tt; r = &rr;
   { const int rc = check_task(m, s, t); if (rc != MM_OK) return rc; }
   if (!r) return fail(MM_EARG, "mm_rollout_step: null rollout description");
   if (t->obs_only) return fail(MM_EARG, "mm_rollout_step: obs_only passes go through mm_env_step");

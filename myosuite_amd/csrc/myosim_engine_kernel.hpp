@@ -772,6 +772,14 @@ struct Engine {
   static constexpr int SD = 8;     // maximum depth of the dof tree of an SP model (host routes deeper ones to the GEN kernels)
   static constexpr int TS = 12;    // row stride of the published rows: [row 0..7, 1/D, rhs, -, -]
   static constexpr bool SP = MM_SPARSE_LDL && !GEN && NVP >= 8 && INTEG != 2;
+  // Row stride of the dense NVP x NVP LDS tile(s).  Lane i works on ROW i, so a row stride that is a multiple of 32 words puts the
+  // lanes of a wave on one bank: with NVP = 32 the left-looking factor's column store T[i][j] was a 32-way conflict and the row
+  // read-backs (M after CRB, J'DJ after the MFMA product) 8-way; rocprofv3 had 47 % of the reorient kernel's LDS cycles as
+  // bank-conflict cycles (profiles/r03a_pmc.json).  Stride 36 (stride / 4 odd): a 128-bit row access of 16 lanes covers all 64
+  // banks once, the column store is 4-way: reorient kernel 0.761 -> 0.719 ms.  Only the 32-wide tile is padded: for the 24- and
+  // 36-wide ones (8-way / 4-way conflicts) the extra LDS words cost the self-contact hand its LDS-resident model copy and the
+  // leg its two-wave launch (measured: -4 % / -3 %), which outweighs the conflicts.
+  static constexpr int TD = (!SP && NVP == 32) ? 36 : NVP;
   float Ms[SD], Md;
   unsigned anc_lo, anc_hi;   // ancestor dof ids by absolute depth, one byte each: depth 0..3 | 4..6
   int d_depth;               // depth of dof g in the dof tree (0 = no parent dof); -1 on lanes without a dof
@@ -898,7 +906,7 @@ struct Engine {
         // the factor of M + h B the Euler step will need (mj_Euler's implicit joint damping) does not depend on the constraint
         // solve: computed here while the main wave is in Newton.  M arrives in the second tile and L leaves in it.
         tw_wait(2, n);
-        const float* Mg = W + KL().mtile + (g < NVP ? g : 0) * NVP;
+        const float* Mg = W + KL().mtile + (g < NVP ? g : 0) * TD;
 #pragma unroll
         for (int k4 = 0; k4 < NVP / 4; k4++) {
           const float4 r = *reinterpret_cast<const float4*>(Mg + 4 * k4);
@@ -908,7 +916,7 @@ struct Engine {
         GSYNC();
         o_tile = KL().mtile;
         factor(g < KD().nv ? KD().timestep * MF_(DOF_DAMPING)[g] : 0.f);
-        if (g < NVP) W[KL().mtile + NVP * NVP + g] = d_dinv;   // 1 / L[g][g] as computed (not re-derived from L: bit-identical solves)
+        if (g < NVP) W[KL().mtile + NVP * TD + g] = d_dinv;   // 1 / L[g][g] as computed (not re-derived from L: bit-identical solves)
         tw_signal(3, n);
       }
     }
@@ -1508,7 +1516,7 @@ struct Engine {
       for (int k = 0; k < 10; k++) W[o_crb + 10 * g + k] = b_cinert[k];
     // zero the dense tile (u1 region; cfrc is dead now) and put 1 on the padded diagonal
     if constexpr (!SP)
-      for (int e = g; e < NVP * NVP; e += G) W[o_u1 + e] = 0.f;
+      for (int e = g; e < NVP * TD; e += G) W[o_u1 + e] = 0.f;
     GSYNC();
     if (KD().bchain_nlevel > 0) subtree_sum<10>(o_crb);
     else
@@ -1548,17 +1556,20 @@ struct Engine {
 #pragma unroll
         for (int k = 0; k < 6; k++) s += W[o_cdof + 6 * j + k] * buf[k];
         if (j == g) s += AF_(s_DOF_ARMATURE)[g];
-        W[o_u1 + g * NVP + j] = s;
-        W[o_u1 + j * NVP + g] = s;
+        W[o_u1 + g * TD + j] = s;
+        W[o_u1 + j * TD + g] = s;
         j = dpar[j];
       }
     } else if (g < NVP) {
-      W[o_u1 + g * NVP + g] = 1.f;
+      W[o_u1 + g * TD + g] = 1.f;
     }
     GSYNC();
     if (g < NVP) {
 #pragma unroll
-      for (int k = 0; k < NVP; k++) Mrow[k] = W[o_u1 + g * NVP + k];
+      for (int k4 = 0; k4 < NVP / 4; k4++) {
+        const float4 r = *reinterpret_cast<const float4*>(W + o_u1 + g * TD + 4 * k4);
+        Mrow[4 * k4] = r.x; Mrow[4 * k4 + 1] = r.y; Mrow[4 * k4 + 2] = r.z; Mrow[4 * k4 + 3] = r.w;
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < NVP; k++) Mrow[k] = 0.f;
@@ -1758,7 +1769,7 @@ struct Engine {
     if (g < NVP)
 #pragma unroll
       for (int k4 = 0; k4 < NVP / 4; k4++)
-        *reinterpret_cast<float4*>(T + row * NVP + 4 * k4) = make_float4(Mrow[4 * k4], Mrow[4 * k4 + 1], Mrow[4 * k4 + 2], Mrow[4 * k4 + 3]);
+        *reinterpret_cast<float4*>(T + row * TD + 4 * k4) = make_float4(Mrow[4 * k4], Mrow[4 * k4 + 1], Mrow[4 * k4 + 2], Mrow[4 * k4 + 3]);
     float P[SD];
     {
       const int* pa = AUXI(dof_seg) + 6 * (q.depth >= 0 ? g : 0);
@@ -1769,7 +1780,7 @@ struct Engine {
 #pragma unroll
       for (int e = 0; e < SD; e++) {
         const int col = e == q.depth ? g : (int)byte_of(a_lo, a_hi, e);
-        const float v = T[row * NVP + (e <= q.depth ? col : row)];
+        const float v = T[row * TD + (e <= q.depth ? col : row)];
         P[e] = e < q.depth ? v : (e == q.depth ? v + dadd : 0.f);
       }
     }
@@ -1819,16 +1830,16 @@ struct Engine {
   template <int E_>
   __device__ __forceinline__ void sp_dense_entry(float* T) const {
     if constexpr (E_ < SD - 1) {
-      if (E_ < d_depth) { const int ja = anc<E_>(); T[g * NVP + ja] = Ms[E_]; T[ja * NVP + g] = Ms[E_]; }
+      if (E_ < d_depth) { const int ja = anc<E_>(); T[g * TD + ja] = Ms[E_]; T[ja * TD + g] = Ms[E_]; }
       sp_dense_entry<E_ + 1>(T);
     }
   }
   // tests only: M as a dense symmetric NVP x NVP tile in the u1 region
   __device__ __forceinline__ void sp_dense_tile() const {
     float* T = W + KL().u1;
-    for (int e = g; e < NVP * NVP; e += G) T[e] = 0.f;
+    for (int e = g; e < NVP * TD; e += G) T[e] = 0.f;
     GSYNC();
-    if (d_depth >= 0) { T[g * NVP + g] = Md; sp_dense_entry<0>(T); }
+    if (d_depth >= 0) { T[g * TD + g] = Md; sp_dense_entry<0>(T); }
     GSYNC();
   }
   // (A + diag(dadd))^-1 rhs: the one entry point of every factor + solve pair
@@ -1867,7 +1878,7 @@ struct Engine {
         if constexpr (DIAG) s += (g == j) ? dadd : 0.f;
 #pragma unroll
         for (int k4 = 0; k4 < (j + 3) / 4; k4++) {
-          const float4 r = *reinterpret_cast<const float4*>(T + j * NVP + 4 * k4);
+          const float4 r = *reinterpret_cast<const float4*>(T + j * TD + 4 * k4);
           if (4 * k4 + 0 < j) s -= Lrow[4 * k4 + 0] * r.x;
           if (4 * k4 + 1 < j) s -= Lrow[4 * k4 + 1] * r.y;
           if (4 * k4 + 2 < j) s -= Lrow[4 * k4 + 2] * r.z;
@@ -1878,7 +1889,7 @@ struct Engine {
         const float lj = (g >= j) ? s * inv : 0.f;
         Lrow[j] = lj;
         if (g == j) d_dinv = inv;
-        if (g < NVP) T[row * NVP + j] = lj;
+        if (g < NVP) T[row * TD + j] = lj;
       }
       if (g >= NVP) d_dinv = 1.f;
       GSYNC();
@@ -1895,10 +1906,11 @@ struct Engine {
       for (int k = j + 1; k < NVP; k++) A[k] -= lj * bc<G>(lj, k);
     }
     // leave L in the dense LDS tile: the backward substitution reads its columns (= rows of L') from there
-    if (g < NVP)
+    if (g < NVP) {
 #pragma unroll
-      for (int k = 0; k < NVP; k++) W[o_tile + g * NVP + k] = Lrow[k];
-    else d_dinv = 1.f;
+      for (int k4 = 0; k4 < NVP / 4; k4++)
+        *reinterpret_cast<float4*>(W + o_tile + g * TD + 4 * k4) = make_float4(Lrow[4 * k4], Lrow[4 * k4 + 1], Lrow[4 * k4 + 2], Lrow[4 * k4 + 3]);
+    } else d_dinv = 1.f;
     GSYNC();
   }
 
@@ -1913,7 +1925,7 @@ struct Engine {
 #pragma unroll
     for (int i = NVP - 1; i >= 0; i--) {
       float zi = bc<G>(x * d_dinv, i);
-      x = (g == i) ? zi : (g < i ? x - LT[i * NVP] * zi : x);
+      x = (g == i) ? zi : (g < i ? x - LT[i * TD] * zi : x);
     }
     return x;
   }
@@ -2607,8 +2619,8 @@ struct Engine {
             for (int v = 0; v < 4; v++) {
               const int i = 16 * ti + 4 * lk + v, j = 16 * tj + lr;
               if (i < NVP && j < NVP) {
-                T[i * NVP + j] = acc[tj][v];
-                if (ti != tj) T[j * NVP + i] = acc[tj][v];
+                T[i * TD + j] = acc[tj][v];
+                if (ti != tj) T[j * TD + i] = acc[tj][v];
               }
             }
         }
@@ -2616,7 +2628,7 @@ struct Engine {
         const int row = g < NVP ? g : 0;
 #pragma unroll
         for (int k4 = 0; k4 < NVP / 4; k4++) {
-          const float4 r = *reinterpret_cast<const float4*>(T + row * NVP + 4 * k4);
+          const float4 r = *reinterpret_cast<const float4*>(T + row * TD + 4 * k4);
           A[4 * k4] = Mrow[4 * k4] + r.x; A[4 * k4 + 1] = Mrow[4 * k4 + 1] + r.y;
           A[4 * k4 + 2] = Mrow[4 * k4 + 2] + r.z; A[4 * k4 + 3] = Mrow[4 * k4 + 3] + r.w;
         }
@@ -2718,7 +2730,7 @@ struct Engine {
     PFT(PF_CRB, crb());
     if (tw && !SP && !IMPL && KD().any_damping && KD().eulerdamp) {   // M for the helper wave's Euler factor
       if (g < NVP) {
-        float* Mg = W + KL().mtile + g * NVP;
+        float* Mg = W + KL().mtile + g * TD;
 #pragma unroll
         for (int k4 = 0; k4 < NVP / 4; k4++)
           *reinterpret_cast<float4*>(Mg + 4 * k4) = make_float4(Mrow[4 * k4], Mrow[4 * k4 + 1], Mrow[4 * k4 + 2], Mrow[4 * k4 + 3]);
@@ -2766,14 +2778,14 @@ struct Engine {
       if (TW && !SP && a.two_wave) {
         // the helper wave factorised M + h B while this wave was in Newton: fetch row g of L, solve
         tw_wait(3, tw_n);
-        const float* Lg = W + KL().mtile + (g < NVP ? g : 0) * NVP;
+        const float* Lg = W + KL().mtile + (g < NVP ? g : 0) * TD;
 #pragma unroll
         for (int k4 = 0; k4 < NVP / 4; k4++) {
           const float4 r = *reinterpret_cast<const float4*>(Lg + 4 * k4);
           Lrow[4 * k4] = g < NVP ? r.x : 0.f; Lrow[4 * k4 + 1] = g < NVP ? r.y : 0.f;
           Lrow[4 * k4 + 2] = g < NVP ? r.z : 0.f; Lrow[4 * k4 + 3] = g < NVP ? r.w : 0.f;
         }
-        d_dinv = g < NVP ? W[KL().mtile + NVP * NVP + g] : 1.f;
+        d_dinv = g < NVP ? W[KL().mtile + NVP * TD + g] : 1.f;
         o_tile = KL().mtile;
         qa_ = solve(g < KD().nv ? d_smooth + d_qfrccon : 0.f);
         o_tile = KL().u1;
@@ -2807,7 +2819,7 @@ struct Engine {
     const int row = g < NVP ? g : 0;
     if (g < NVP)
 #pragma unroll
-      for (int k4 = 0; k4 < NVP / 4; k4++) *reinterpret_cast<float4*>(T + row * NVP + 4 * k4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k4 = 0; k4 < NVP / 4; k4++) *reinterpret_cast<float4*>(T + row * TD + 4 * k4) = make_float4(0.f, 0.f, 0.f, 0.f);
     GSYNC();
     {
       // one lane per tendon: its (<= 8 x 8) on-chain entry pairs go into the tile with LDS float atomics (a lane per dof walking
@@ -2851,7 +2863,7 @@ struct Engine {
               for (int b_ = 0; b_ < 8; b_++) {
                 if (d2[b_] < 0) continue;
                 const bool rel = d2[b_] < 32 ? (rl[a_] >> d2[b_]) & 1u : (rh[a_] >> (d2[b_] - 32)) & 1u;
-                if (rel) atomicAdd(&T[dd[a_] * NVP + d2[b_]], w1 * j2[b_]);
+                if (rel) atomicAdd(&T[dd[a_] * TD + d2[b_]], w1 * j2[b_]);
               }
             }
           }
@@ -2873,7 +2885,7 @@ struct Engine {
     float A[NVP];
 #pragma unroll
     for (int k4 = 0; k4 < NVP / 4; k4++) {
-      const float4 r = *reinterpret_cast<const float4*>(T + row * NVP + 4 * k4);
+      const float4 r = *reinterpret_cast<const float4*>(T + row * TD + 4 * k4);
       A[4 * k4] = Mrow[4 * k4] + h * r.x; A[4 * k4 + 1] = Mrow[4 * k4 + 1] + h * r.y;
       A[4 * k4 + 2] = Mrow[4 * k4 + 2] + h * r.z; A[4 * k4 + 3] = Mrow[4 * k4 + 3] + h * r.w;
     }
@@ -3185,7 +3197,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     float* D = a.dbg + (size_t)e * a.D.total;
     if constexpr (Engine<G, NVP, GEN, INTEG>::SP) {
       E.sp_dense_tile();
-      if (g < d.nv) for (int k = 0; k < d.nv; k++) D[a.D.M + g * d.nv + k] = W[L.u1 + g * NVP + k];
+      if (g < d.nv) for (int k = 0; k < d.nv; k++) D[a.D.M + g * d.nv + k] = W[L.u1 + g * Engine<G, NVP, GEN, INTEG>::TD + k];
     }
     if (g < d.nbody) {
       st3(D + a.D.xpos + 3 * g, E.b_xpos + E.origin()); st3(D + a.D.xipos + 3 * g, E.b_xipos + E.origin());

@@ -35,7 +35,7 @@ RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_
  INFO_BODY_CHAINS) = range(15)
 
 
-MM_ABI_VERSION = 3   # include/myosim.h
+MM_ABI_VERSION = 4   # include/myosim.h
 
 
 class EngineError(RuntimeError):
@@ -123,7 +123,11 @@ class mm_derived(C.Structure):
 
 
 class mm_task(C.Structure):
-    _fields_ = [("task", C.c_int), ("nsubsteps", C.c_int), ("normalize_act", C.c_int), ("do_forward", C.c_int),
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.size = C.sizeof(mm_task)      # the library copies min(size, its sizeof) bytes: see include/myosim.h
+
+    _fields_ = [("size", C.c_uint32), ("task", C.c_int), ("nsubsteps", C.c_int), ("normalize_act", C.c_int), ("do_forward", C.c_int),
                 ("fatigue", C.c_int), ("max_episode_steps", C.c_int),
                 ("pose_thd", C.c_float), ("far_th", C.c_float),
                 ("w_pose", C.c_float), ("w_bonus", C.c_float), ("w_act_reg", C.c_float), ("w_penalty", C.c_float),
@@ -145,7 +149,11 @@ class mm_task(C.Structure):
 
 
 class mm_rollout(C.Structure):
-    _fields_ = [("action", C.c_void_p), ("action_seed", C.c_uint64), ("action_stream", C.c_uint64), ("action_out", C.c_void_p),
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.size = C.sizeof(mm_rollout)
+
+    _fields_ = [("size", C.c_uint32), ("action", C.c_void_p), ("action_seed", C.c_uint64), ("action_stream", C.c_uint64), ("action_out", C.c_void_p),
                 ("ep_stats", C.c_void_p), ("reset_mask", C.c_void_p), ("autoreset", C.c_int), ("random_qpos", C.c_int),
                 ("qlo", C.c_void_p), ("qhi", C.c_void_p), ("tlo", C.c_void_p), ("thi", C.c_void_p), ("target", C.c_void_p),
                 ("episode", C.c_void_p), ("reset_seed", C.c_uint64)]

@@ -621,3 +621,29 @@ def test_hip_matches_libmujoco_fixture(path):
         ref = g["t_qpos"][s]
         worst = max(worst, float(np.abs(st.qpos[0].cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max())))
     assert worst < 1e-4, worst
+
+
+@pytest.mark.gpu
+def test_task_struct_size_field_gives_append_only_compatibility():
+    """mm_task.size / mm_rollout.size (include/myosim.h): the library copies min(size, its sizeof) bytes and zero-fills the rest.
+    A caller built against an OLDER, shorter mm_task (here: cut in front of the reset-observation fields, which it leaves at
+    zero anyway) gets the same result as the full struct; size = 0 (unset) and size > sizeof (a NEWER header) are refused
+    with MM_EARG instead of being misread."""
+    import ctypes as C
+    from myosuite_amd.envs import registry
+    envs = [registry.make("myoElbowPose1D6MRandom-v0", num_envs=32, seed=3, autoreset=False) for _ in range(2)]
+    a = torch.empty(32, envs[0].cm.nu, device="cuda")
+    E.uniform(a, 1, 0)
+    full, cut = envs
+    assert full._task.size == C.sizeof(E.mm_task)
+    cut._task.size = E.mm_task.env_mask.offset          # an "old" caller whose struct ended before env_mask / obs_only
+    for _ in range(3):
+        E.env_step(full.hm, full.state, a, full._task)
+        E.env_step(cut.hm, cut.state, a, cut._task)
+    assert torch.equal(full.obs, cut.obs) and torch.equal(full.state.qpos, cut.state.qpos)
+    for bad in (0, C.sizeof(E.mm_task) + 8):
+        cut._task.size = bad
+        with pytest.raises(E.EngineError):
+            E.env_step(cut.hm, cut.state, a, cut._task)
+    cut._task.size = C.sizeof(E.mm_task)
+    E.env_step(cut.hm, cut.state, a, cut._task)
