@@ -140,7 +140,9 @@ struct KArgs {
   unsigned long long* prof;
 };
 enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_ACT, PF_SOLVE0, PF_NEWTON, PF_EULER,
-       PF_IO, PF_TOTAL, NPROF };
+       PF_IO, PF_TOTAL,
+       PF_N_WARM, PF_N_GRAD, PF_N_HBUILD, PF_N_FACTOR, PF_N_SOLVE, PF_N_PROD, PF_N_LS,   // inside the general-row Newton solve (tools build)
+       NPROF };
 
 // section offsets come from the blob header in global memory through the scalar cache (s_load at use) instead of ~100
 // kernel-argument words that live in (spilled) SGPRs for the whole kernel
@@ -1893,6 +1895,7 @@ struct Engine {
       }
       if (g >= NVP) d_dinv = 1.f;
       GSYNC();
+      scale_rows();
       return;
     }
 #pragma unroll
@@ -1912,20 +1915,32 @@ struct Engine {
         *reinterpret_cast<float4*>(W + o_tile + g * TD + 4 * k4) = make_float4(Lrow[4 * k4], Lrow[4 * k4 + 1], Lrow[4 * k4 + 2], Lrow[4 * k4 + 3]);
     } else d_dinv = 1.f;
     GSYNC();
+    scale_rows();
+  }
+  // After a factorisation the row registers are rewritten for the substitution: Lrow[k] <- L[g][k] / L[g][g] (k < g), 0 on and above
+  // the diagonal.  With the lane's own 1 / L[g][g] folded into its row (and into its right-hand side), step j of the forward
+  // substitution is "broadcast x_j, one fma" for every lane -- no multiply ahead of the broadcast and no selects behind it.
+  // The dependent chain of a substitution step was mul -> readlane -> fma -> cndmask -> cndmask (~100 cycles for a lone wave, 72
+  // steps per solve: a solve cost as much as the factorisation, 7 k cycles for the 36-dof leg, three to four solves per pass).
+  __device__ __forceinline__ void scale_rows() {
+#pragma unroll
+    for (int k = 0; k < NVP; k++) Lrow[k] = (k >= g) ? 0.f : Lrow[k] * d_dinv;
   }
 
-  // x <- (L L')^-1 x ; lane i holds x_i
+  // x <- (L L')^-1 x ; lane i holds x_i.  Lrow = the scaled rows (scale_rows), the LDS tile = L itself.
   __device__ __forceinline__ float solve(float x) const {
+    // L y = b:  x'_g = b_g / L_gg - sum_{k < g} (L_gk / L_gg) y_k, and y_j is lane j's x' once the steps k < j are in
+    x *= d_dinv;
 #pragma unroll
-    for (int j = 0; j < NVP; j++) {
-      float yj = bc<G>(x * d_dinv, j);
-      x = (g == j) ? yj : (g > j ? x - Lrow[j] * yj : x);
-    }
-    const float* LT = W + o_tile + (g < NVP ? g : 0);   // LT[i*NVP] = L[i][g]
+    for (int j = 0; j < NVP; j++) x = fmaf(-Lrow[j], bc<G>(x, j), x);
+    // L' z = y:  x''_g = y_g / L_gg - sum_{k > g} (L_kg / L_gg) z_k; the column entries come from the tile, scaled by the lane's own
+    // 1 / L_gg off the dependent chain
+    const float* LT = W + o_tile + (g < NVP ? g : 0);   // LT[i*TD] = L[i][g]
+    x *= d_dinv;
 #pragma unroll
     for (int i = NVP - 1; i >= 0; i--) {
-      float zi = bc<G>(x * d_dinv, i);
-      x = (g == i) ? zi : (g < i ? x - LT[i * TD] * zi : x);
+      const float c = (g < i) ? LT[i * TD] * d_dinv : 0.f;
+      x = fmaf(-c, bc<G>(x, i), x);
     }
     return x;
   }
@@ -2548,12 +2563,15 @@ struct Engine {
     d_qfrccon = 0.f;
     if (nrows_wave == 0) { d_qacc = d_qaccsm; return; }
     const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
+#define PFN(stage, t0_) do { if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? stage : 0] += t1_ - t0_; t0_ = t1_; } } while (0)
+    unsigned long long tn_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_gen(d_warm, Ma_ws);
     float cost_sm = cost_gen(d_qaccsm, d_smooth);
     float Ma;
     if (cost_ws < cost_sm) { d_qacc = d_warm; Ma = Ma_ws; (void)cost_gen(d_qacc, Ma); }
     else { d_qacc = d_qaccsm; Ma = d_smooth; }
+    PFN(PF_N_WARM, tn_);
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull, sat_prev = 0ull;
     bool done = nefc == 0;     // envs of the wave that have no rows idle through the loop (wave-collective code below)
@@ -2573,6 +2591,7 @@ struct Engine {
       }
       if (__ballot(!done) == 0ull) break;
       set_prev = set_now; sat_prev = sat_now;
+      PFN(PF_N_GRAD, tn_);
       // H = M + J_A' D J_A
       float A[NVP];
 #if MM_MFMA_HBUILD
@@ -2658,13 +2677,17 @@ struct Engine {
           }
         }
       }
+      PFN(PF_N_HBUILD, tn_);
       factor_core<false>(A);
+      PFN(PF_N_FACTOR, tn_);
       float search = -solve(grad);
       if (g >= nv || done) search = 0.f;
+      PFN(PF_N_SOLVE, tn_);
       float sn = sqrtf(gsum<G>(search * search));
       if (sn < MINVALF) done = true;
       float Mv = mul_m(search);
       float jv = jac_mul(search);
+      PFN(PF_N_PROD, tn_);
       float dm = Ma - d_smooth;
       float q1 = gsum<G>(search * dm), q2 = gsum<G>(0.5f * search * Mv);
       const float gtol = KD().tolerance * KD().ls_tolerance * sn / scale;
@@ -2705,9 +2728,12 @@ struct Engine {
         if (!done && stepmax <= 2e-7f * fmaxf(qmax, 1.f)) done = true;
       }
       if (iter == KD().iterations - 1 && !done) status |= 4;
+      PFN(PF_N_LS, tn_);
     }
     bool on2;
     d_qfrccon = jacT_mul(row_force(r_jar, on2));
+    PFN(PF_N_GRAD, tn_);
+#undef PFN
   }
 
   // ------------------------------------------------------------------ pipeline
@@ -2786,6 +2812,7 @@ struct Engine {
           Lrow[4 * k4 + 2] = g < NVP ? r.z : 0.f; Lrow[4 * k4 + 3] = g < NVP ? r.w : 0.f;
         }
         d_dinv = g < NVP ? W[KL().mtile + NVP * TD + g] : 1.f;
+        scale_rows();
         o_tile = KL().mtile;
         qa_ = solve(g < KD().nv ? d_smooth + d_qfrccon : 0.f);
         o_tile = KL().u1;

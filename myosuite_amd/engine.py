@@ -511,7 +511,8 @@ def debug_dump(model: HipModel, state: BatchState, ctrl: Optional[torch.Tensor] 
     return buf
 
 
-PROF_STAGES = ["kin", "com", "tendon", "constr", "vel", "crb", "factor", "act", "solve0", "newton", "euler", "io", "total"]
+PROF_STAGES = ["kin", "com", "tendon", "constr", "vel", "crb", "factor", "act", "solve0", "newton", "euler", "io", "total",
+               "n_warm", "n_grad", "n_hbuild", "n_factor", "n_solve", "n_prod", "n_ls"]   # the last seven: inside the general-row Newton solve
 
 
 def profile_stages(fn):
