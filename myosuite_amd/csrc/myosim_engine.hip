@@ -256,7 +256,15 @@ static Layout env_layout(const mm_model* m, bool two_wave) {
   // 16-byte aligned env stride (wide ds_read/ds_write never straddle), skewed by 4 words so that neighbouring
   // envs of a wave do not start on the same LDS bank
   o = (o + 3) & ~3;
-  if ((o & 31) == 0) o += 4;
+#ifndef MM_ENV_SKEW
+#define MM_ENV_SKEW 1
+#endif
+  if (MM_ENV_SKEW && m->nvp <= 4) {
+    // tiny models run 4 .. 16 envs per wave (8 lanes per env for the elbow at 4096 envs): a ds_read_b32 is serviced in groups of
+    // 32 lanes over 32 banks, i.e. four 8-lane envs at a time -- an env stride of 8 (mod 32) words puts their same-offset
+    // accesses on disjoint banks (rocprofv3: 32 % of the elbow kernel's LDS cycles were conflict cycles with the old skew of 4)
+    while ((o & 31) != 8) o += 4;
+  } else if ((o & 31) == 0) o += 4;
   L.total = o;
   return L;
 }
