@@ -150,21 +150,37 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
     act_in = (0.1 + 0.8 * a).contiguous()
     obs, rwd, term, trunc, info = env.step(act_in)
     an = act_in.cpu().numpy()
+    obs_err = None
     for e, o in oracles.items():
         ob, r, done, rd = o.step(an[e].astype(np.float64))
         got = obs[e].cpu().numpy()
         scale = np.maximum(1.0, np.abs(ob))
+        # bounds = ~25x what the kernels measure on these batches (profiles/r03_full_batch_stage_errors.json: elbow 4e-7, hand 7e-7,
+        # self-contact hand 1.4e-6, reorient 1.9e-5 -- its muscle-force entries --, leg walk 4e-6); round 2 allowed reorient's
+        # muscle forces 0.5 and the walk's muscle velocities / forces 2e-2 / 1e-2
         if env_id.startswith(("myoElbowPose", "myoHandPose")):
-            tol = np.full(got.shape, (2e-3 if cm.npair > 0 else 5e-4) if cm.nq > 1 else 5e-5)   # (self-contact hand: contact onsets)
+            tol = np.full(got.shape, (5e-5 if cm.npair > 0 else 2e-5) if cm.nq > 1 else 1e-5)
         elif "Reorient" in env_id:
-            tol = np.full(200, 2e-3); tol[26:32] = 2e-2; tol[44 + 39:44 + 78] = 2e-2; tol[44 + 78:44 + 117] = 2e-2
+            tol = np.full(200, 5e-4)
         else:
-            tol = np.full(403, 2e-3); tol[33:69] = 1e-2; tol[83 + 80:83 + 160] = 2e-2; tol[83 + 160:83 + 240] = 1e-2
-        badi = np.abs(got - ob) / scale > tol
-        assert not badi.any(), (e, np.nonzero(badi)[0][:5], (np.abs(got - ob) / scale)[badi][:5])
-        assert abs(float(rwd[e]) - r) < 5e-3 * max(1.0, abs(r)), (e, float(rwd[e]), r)
+            tol = np.full(403, 1e-4)
+        nerr = np.abs(got - ob) / scale
+        obs_err = np.maximum(obs_err, nerr) if obs_err is not None else nerr
+        badi = nerr > tol
+        assert not badi.any(), (e, np.nonzero(badi)[0][:5], nerr[badi][:5])
+        assert abs(float(rwd[e]) - r) < 5e-4 * max(1.0, abs(r)), (e, float(rwd[e]), r)
         assert bool(term[e]) == done
     assert int((env.state.status & 0xA).max()) == 0
+    try:      # teacher-forced observation error (relative to max(1, |obs|)) by observation index, for profiles/
+        import json
+        fn = os.path.join("gpurun_out", "full_batch_stage_errors.json")
+        rec = json.load(open(fn)) if os.path.exists(fn) else {}
+        key = _cfg_id((env_id, nenv, lanes, stage_tol, overrides))
+        rec.setdefault(key, {})["teacher_forced_env_step_obs_err_max"] = float(obs_err.max())
+        rec[key]["teacher_forced_env_step_obs_err_by_index"] = [float(f"{v:.3e}") for v in obs_err]
+        json.dump(rec, open(fn, "w"), indent=1)
+    except OSError:
+        pass
 
 
 NORTH_STAR_ENVS = 64

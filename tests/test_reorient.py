@@ -12,6 +12,21 @@ RK = ("pos_align", "rot_align", "act_reg", "drop", "bonus", "sparse", "solved", 
 WT = {"pos_align": 1.0, "rot_align": 1.0, "act_reg": 5.0, "drop": 5.0, "bonus": 10.0}
 
 
+
+_ERR = {}
+
+
+def _record_err(nerr):
+    """worst teacher-forced observation error by index, per test (printed at exit with -s; evidence for the tolerances)"""
+    import inspect
+    name = inspect.stack()[1].function
+    cur = _ERR.get(name)
+    _ERR[name] = nerr.copy() if cur is None or cur.shape != nerr.shape else np.maximum(cur, nerr)
+    import atexit
+    if not getattr(_record_err, "_hooked", False):
+        _record_err._hooked = True
+        atexit.register(lambda: [print("TEACHER-FORCED-ERR", k, len(v), f"max {v.max():.3e} at {int(v.argmax())}", "top", np.sort(v)[-5:][::-1].round(7).tolist()) for k, v in _ERR.items()])
+
 def test_reorient_oracle_arithmetic_matches_reference_vectors():
     g = np.load(os.path.join(G, "ref_reorient_env.npz"))
     n = g["qpos"].shape[0]
@@ -129,13 +144,14 @@ def test_gpu_reorient_env_matches_oracle_env(oracle_lib):
         for e in range(n):
             o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
             got = obs[e].cpu().numpy()
-            tol = np.full(200, 2e-3); tol[26:32] = 2e-2; tol[44 + 39:44 + 78] = 2e-2; tol[44 + 78:44 + 117] = 0.5   # obj_vel, mvel, mforce (N)
+            tol = np.full(200, 5e-4)   # measured worst over the run 3.9e-5 (a muscle-force entry); round 2 allowed mforce 0.5, mvel / obj_vel 2e-2
             scale = np.maximum(1.0, np.abs(o))
+            _record_err(np.abs(got - o) / scale)
             bad = np.abs(got - o) / scale > tol
             assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], (np.abs(got - o) / scale)[bad][:5])
             for i, k in enumerate(E.RWD_KEYS_REORIENT):
                 ref = float(rd[k])
-                assert abs(float(env.rwd[e, i]) - ref) < 5e-3 * max(1.0, abs(ref)), (k, s, e)
+                assert abs(float(env.rwd[e, i]) - ref) < 5e-4 * max(1.0, abs(ref)), (k, s, e)
             assert bool(term[e]) == done
     assert list(info["rwd_dict"].keys()) == E.RWD_KEYS_REORIENT
 
@@ -215,10 +231,11 @@ def test_gpu_pen_twirl_env_matches_oracle_env(oracle_lib, env_id):
         for e in range(n):
             o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
             got = obs[e].cpu().numpy()
-            tol = np.full(83, 2e-3); tol[26:32] = 2e-2
+            tol = np.full(83, 5e-5)   # measured worst 1.6e-6
+            _record_err(np.abs(got - o) / np.maximum(1.0, np.abs(o)))
             bad = np.abs(got - o) / np.maximum(1.0, np.abs(o)) > tol
             assert not bad.any(), (s, e, np.nonzero(bad)[0][:5])
             for i, k in enumerate(E.RWD_KEYS_REORIENT):
                 ref = float(rd[k])
-                assert abs(float(env.rwd[e, i]) - ref) < 5e-3 * max(1.0, abs(ref)), (k, s, e)
+                assert abs(float(env.rwd[e, i]) - ref) < 5e-4 * max(1.0, abs(ref)), (k, s, e)
             assert bool(term[e]) == done

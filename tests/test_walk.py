@@ -12,6 +12,21 @@ RK = ("vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "spar
 WT = {"vel_reward": 5.0, "done": -100, "cyclic_hip": -10, "ref_rot": 10.0, "joint_angle_rew": 5.0}
 
 
+
+_ERR = {}
+
+
+def _record_err(nerr):
+    """worst teacher-forced observation error by index, per test (printed at exit with -s; evidence for the tolerances)"""
+    import inspect
+    name = inspect.stack()[1].function
+    cur = _ERR.get(name)
+    _ERR[name] = nerr.copy() if cur is None or cur.shape != nerr.shape else np.maximum(cur, nerr)
+    import atexit
+    if not getattr(_record_err, "_hooked", False):
+        _record_err._hooked = True
+        atexit.register(lambda: [print("TEACHER-FORCED-ERR", k, len(v), f"max {v.max():.3e} at {int(v.argmax())}", "top", np.sort(v)[-5:][::-1].round(7).tolist()) for k, v in _ERR.items()])
+
 def test_walk_oracle_arithmetic_matches_reference_vectors():
     """oracle/env_oracle.walk_obs_reward against vectors produced by executing the reference's walk_v0.py."""
     g = np.load(os.path.join(G, "ref_walk_env.npz"))
@@ -79,15 +94,15 @@ def test_gpu_walk_env_matches_oracle_env(oracle_lib):
         for e in range(n):
             o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
             got = obs[e].cpu().numpy()
-            # fp32 vs fp64 after 10 contact-rich substeps; velocity-like entries (qvel*dt, com_vel, muscle_velocity, and the force-velocity part of muscle_force) carry
-            # the fp32 moment-arm cancellation error times joint speeds of several rad/s: looser bound there
-            tol = np.full(403, 2e-3); tol[33:69] = 1e-2; tol[83 + 80:83 + 160] = 2e-2; tol[83 + 160:83 + 240] = 1e-2
+            # fp32 vs fp64 after 10 contact-rich substeps (teacher forced)
+            tol = np.full(403, 2e-4)   # measured worst over the run 1.9e-5 (a muscle-velocity entry); round 2 allowed 1e-2 ... 2e-2 there
             scale = np.maximum(1.0, np.abs(o))
+            _record_err(np.abs(got - o) / scale)
             bad = np.abs(got - o) / scale > tol
             assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], (np.abs(got - o) / scale)[bad][:5])
             for i, k in enumerate(E.RWD_KEYS_WALK):
                 ref = float(rd[k])
-                assert abs(float(env.rwd[e, i]) - ref) < 2e-3 * max(1.0, abs(ref)), (k, s, e)
+                assert abs(float(env.rwd[e, i]) - ref) < 5e-4 * max(1.0, abs(ref)), (k, s, e)
             assert bool(term[e]) == done
     assert int(env.step_count[0]) == nsteps
     assert list(info["rwd_dict"].keys()) == E.RWD_KEYS_WALK
@@ -233,10 +248,11 @@ def test_gpu_stand_env_matches_oracle_env(oracle_lib):
         for e in range(n):
             o, dense, done, rd = orc[e].step(an[e].astype(np.float64))
             got = obs[e].cpu().numpy()
-            tol = np.full(got.shape, 2e-3); tol[cm.nq:cm.nq + cm.nv] = 1e-2
+            tol = np.full(got.shape, 5e-5)   # measured worst 2.3e-6
+            _record_err(np.abs(got - o) / np.maximum(1.0, np.abs(o)))
             bad = np.abs(got - o) / np.maximum(1.0, np.abs(o)) > tol
             assert not bad.any(), (s, e, np.nonzero(bad)[0][:5], (np.abs(got - o))[bad][:5])
             for i, k in enumerate(E.RWD_KEYS_REACH):
                 ref = float(rd[k])
-                assert abs(float(env.rwd[e, i]) - ref) < 1e-2 * max(1.0, abs(ref)), (k, s, e, float(env.rwd[e, i]), ref)
+                assert abs(float(env.rwd[e, i]) - ref) < 1e-3 * max(1.0, abs(ref)), (k, s, e, float(env.rwd[e, i]), ref)
             assert bool(term[e]) == done
