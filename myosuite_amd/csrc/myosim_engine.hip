@@ -238,7 +238,7 @@ static Layout env_layout(const mm_model* m, bool two_wave) {
   // row stride of the dense tile(s): Engine::TD (the 32-wide tile of the dense kernels is padded against LDS bank conflicts)
   const bool sp_kernel = MM_SPARSE_LDL && !d.gen && m->nvp >= 8 && d.integrator != MM_INT_IMPLICITFAST;
   const int td = (!sp_kernel && m->nvp == 32) ? 36 : m->nvp;
-  const int u1_words = std::max(std::max(13 * d.nbody, m->nvp * td), d.seg_u + 36 * m->nseg);
+  const int u1_words = std::max(std::max(14 * d.nbody, m->nvp * td), d.seg_u + 36 * m->nseg);   // (CVS + 1) * nbody: Engine::CVS
   L.u1 = take(u1_words);
   if (two_wave) { L.crb = take(10 * d.nbody); L.xanchor = take(3 * d.njnt); L.xaxis = take(3 * d.njnt); }
   else { L.crb = take(std::max(10 * d.nbody, 6 * d.njnt)); L.xanchor = L.crb; L.xaxis = L.crb + 3 * d.njnt; }   // anchors / axes die before crb

@@ -774,6 +774,14 @@ struct Engine {
   static constexpr int SD = 8;     // maximum depth of the dof tree of an SP model (host routes deeper ones to the GEN kernels)
   static constexpr int TS = 12;    // row stride of the published rows: [row 0..7, 1/D, rhs, -, -]
   static constexpr bool SP = MM_SPARSE_LDL && !GEN && NVP >= 8 && INTEG != 2;
+  // Per-body records that live in the u1 scratch get ODD strides: lane g touches record g, and a ds_read_b32 of 32 lanes hits 32
+  // banks -- stride 4 (quaternions) and 12 (cvel | cacc) were 4-way bank conflicts on every access of the pointer-jumping rounds
+  // (8 of them per forward pass).  u1 has the room (host: >= (CVS + 1) * nbody words), so this costs no LDS.
+#ifndef MM_QS
+#define MM_QS 5
+#define MM_CVS 13
+#endif
+  static constexpr int QS = MM_QS, CVS = MM_CVS;
   // Row stride of the dense NVP x NVP LDS tile(s).  Lane i works on ROW i, so a row stride that is a multiple of 32 words puts the
   // lanes of a wave on one bank: with NVP = 32 the left-looking factor's column store T[i][j] was a 32-way conflict and the row
   // read-backs (M after CRB, J'DJ after the MFMA product) 8-way; rocprofv3 had 47 % of the reorient kernel's LDS cycles as
@@ -991,13 +999,13 @@ struct Engine {
     for (int r = 0; r < nround; r++) {
       if (g < nb) {
         st3(W + o_xpos + 3 * g, tp);
-        W[o_u1 + 4 * g] = tq.w; W[o_u1 + 4 * g + 1] = tq.x; W[o_u1 + 4 * g + 2] = tq.y; W[o_u1 + 4 * g + 3] = tq.z;
+        W[o_u1 + QS * g] = tq.w; W[o_u1 + QS * g + 1] = tq.x; W[o_u1 + QS * g + 2] = tq.y; W[o_u1 + QS * g + 3] = tq.z;
         UP[g] = up;
       }
       GSYNC();
       if (up > 0) {
         const V3 pp = ld3(W + o_xpos + 3 * up);
-        const Q4 pq = ldq(W + o_u1 + 4 * up);
+        const Q4 pq = ldq(W + o_u1 + QS * up);
         const int uu = UP[up];
         tp = pp + mv(q2m(pq), tp);
         tq = qmul(pq, tq);
@@ -1009,7 +1017,7 @@ struct Engine {
     if (isb) {
       tq = qnorm(tq);
       st3(W + o_xpos + 3 * g, tp);
-      W[o_u1 + 4 * g] = tq.w; W[o_u1 + 4 * g + 1] = tq.x; W[o_u1 + 4 * g + 2] = tq.y; W[o_u1 + 4 * g + 3] = tq.z;
+      W[o_u1 + QS * g] = tq.w; W[o_u1 + QS * g + 1] = tq.x; W[o_u1 + QS * g + 2] = tq.y; W[o_u1 + QS * g + 3] = tq.z;
       b_xpos = tp; b_xquat = tq;
     }
     GSYNC();
@@ -1020,7 +1028,7 @@ struct Engine {
       const int p = b_parent;
       if (p > 0) {
         const V3 pp = ld3(W + o_xpos + 3 * p);
-        const M3 pm = q2m(ldq(W + o_u1 + 4 * p));
+        const M3 pm = q2m(ldq(W + o_u1 + QS * p));
         for (int i = 0; i < c_jn; i++) {
           const int j = c_ja + i;
           st3(W + o_xanchor + 3 * j, pp + mv(pm, ld3(W + o_xanchor + 3 * j)));
@@ -1380,7 +1388,7 @@ struct Engine {
     const bool isb = g > 0 && g < nb;
     int nround = 0;
     for (int s_ = 1; s_ < d_nlevel_; s_ <<= 1) nround++;
-    int* UP = reinterpret_cast<int*>(W + o_u1 + 12 * nb);   // pointer scratch behind the (cvel, cacc) slots: u1 holds >= 13 nbody words
+    int* UP = reinterpret_cast<int*>(W + o_u1 + CVS * nb);   // pointer scratch behind the (cvel, cacc) slots: u1 holds >= (CVS + 1) nbody words
     if (isb) {      // own dofs: local velocity contribution
       for (int i = 0; i < c_jn; i++) {
         int type, da;
@@ -1401,13 +1409,13 @@ struct Engine {
       for (int r = 0; r < nround; r++) {
         if (g < nb) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) W[o_u1 + 12 * g + k] = cv[k];
+          for (int k = 0; k < 6; k++) W[o_u1 + CVS * g + k] = cv[k];
           UP[g] = up;
         }
         GSYNC();
         if (up > 0) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) cv[k] += W[o_u1 + 12 * up + k];
+          for (int k = 0; k < 6; k++) cv[k] += W[o_u1 + CVS * up + k];
           up = UP[up];
         }
         GSYNC();
@@ -1450,13 +1458,13 @@ struct Engine {
       for (int r = 0; r < nround; r++) {
         if (g < nb) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) W[o_u1 + 12 * g + 6 + k] = ca[k];
+          for (int k = 0; k < 6; k++) W[o_u1 + CVS * g + 6 + k] = ca[k];
           UP[g] = up;
         }
         GSYNC();
         if (up > 0) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) ca[k] += W[o_u1 + 12 * up + 6 + k];
+          for (int k = 0; k < 6; k++) ca[k] += W[o_u1 + CVS * up + 6 + k];
           up = UP[up];
         }
         GSYNC();
