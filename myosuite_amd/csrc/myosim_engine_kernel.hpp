@@ -692,6 +692,17 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 #define MM_SPARSE_GEN 0   /* 1: the general-row kernels use the tree-sparse solve for the two M solves of a pass (solve0, Euler).  Measured: \
                              the extra live state tips these 256-VGPR kernels into 80 spills; reorient -3 %, self-contact hand -5 % */
 #endif
+#ifndef MM_LS_RELSTOP
+/* Experiment, OFF: end the exact line search once a turn moves alpha by less than MM_LS_RELSTOP_TOL relative, instead of running the
+   safeguarded Newton on phi'(alpha) until its step vanishes in float resolution.  The stage timers put ~10 k of the hand's 32 k
+   Newton cycles per pass in the search, but the precision of alpha is not slack: qacc += alpha * search with |search| up to
+   1e2...1e3, and tolerance 1e-5 took the north-star count from 61 to 55 of 64 envs (median 3.6e-6 -> 1.2e-5) for +1.9 %
+   throughput; 1e-6: 58 of 64, +0.8 %; 3e-7: 61 of 64, +0.6 % (profiles/r03_north_star_ab.json).  Not worth a digit. */
+#define MM_LS_RELSTOP 0
+#endif
+#ifndef MM_LS_RELSTOP_TOL
+#define MM_LS_RELSTOP_TOL 3e-7f
+#endif
 #ifndef MM_NEWTON_POLISH
 #define MM_NEWTON_POLISH 0   /* experiment (limit-rows-only kernels): one extra Newton step after the convergence test fires */
 #endif
@@ -1160,6 +1171,7 @@ struct Engine {
     PIN_S(o.xpos); PIN_S(o.xmat); PIN_S(o.tenlen); PIN_S(o.tenj); PIN_S(o.xaxis); PIN_S(o.xanchor); PIN_S(o.site_body);
     PIN_S(o.site_pos); PIN_S(o.wrapw); PIN_S(o_items); PIN_S(nitem); PIN_S(o_jent); PIN_S(o_jrec); PIN_S(d_ntenJ);
     const int4* items = reinterpret_cast<const int4*>(mb + o_items);
+    unsigned long long tt_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
     for (int t = g; t < KD().ntendon; t += G) W[o.tenlen + t] = 0.f;
     GSYNC();
     for (int it = g; it < nitem; it += G) {
@@ -1200,6 +1212,7 @@ struct Engine {
       }
     }
     GSYNC();
+    if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? PF_N_HBUILD : 0] += t1_ - tt_; tt_ = t1_; }   // (tools build: item sweep)
     const int* jent = reinterpret_cast<const int*>(mb + o_jent);
     const int4* jrow = reinterpret_cast<const int4*>(mb + o_jrec);
     int jn = g < d_ntenJ ? jent[g] : 0;
@@ -1245,6 +1258,7 @@ struct Engine {
       W[o.tenj + e] = acc;
     }
     GSYNC();
+    if (MM_STAGE_PROF && a.prof) pf[MM_STAGE_PROF ? PF_N_FACTOR : 0] += clock64() - tt_;   // (tools build: Jacobian-entry sweep)
   }
 
   // ------------------------------------------------------------- A7 joint-limit rows (one per lane)
@@ -2110,6 +2124,8 @@ struct Engine {
     d_qfrccon = 0.f;
     if (nefc == 0) { d_qacc = d_qaccsm; return; }
     const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
+#define PFN(stage, t0_) do { if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? stage : 0] += t1_ - t0_; t0_ = t1_; } } while (0)
+    unsigned long long tn_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
     // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_of(d_warm, Ma_ws);
@@ -2121,6 +2137,7 @@ struct Engine {
     // tolerance, so "improvement < tol" would stop with a residual gradient.  The cost is piecewise quadratic:
     // a FULL Newton step (alpha = 1) that leaves the active set unchanged lands on the exact minimiser, which is
     // the convergence test used here (the gradient test is kept for the exact-arithmetic case).
+    PFN(PF_N_WARM, tn_);
     float alpha_prev = 0.f;
     unsigned long long set_prev = 0ull;
 #if MM_NEWTON_POLISH
@@ -2149,8 +2166,10 @@ struct Engine {
       }
       set_prev = set_now;
       float dadd = rows_to_dof(on ? r_D : 0.f);
+      PFN(PF_N_GRAD, tn_);
       float search = -factor_solve(dadd, grad);
       if (g >= nv) search = 0.f;
+      PFN(PF_N_SOLVE, tn_);
       float sn = sqrtf(gsum<G>(search * search));
       if (sn < MINVALF) break;
       // (M + diag(dadd)) search = -grad, so M search needs no product: the residual of the solve is of the order of the
@@ -2175,7 +2194,7 @@ struct Engine {
         float next = alpha - d1 / fmaxf(d2, MINVALF);
         if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
         else if (hi < 0.f && next <= lo) next = 2.f * lo + 1e-10f;
-        if (next == alpha) break;
+        if (MM_LS_RELSTOP ? fabsf(next - alpha) <= MM_LS_RELSTOP_TOL * fabsf(alpha) : next == alpha) { alpha = next; break; }
         alpha = next;
       }
       if (!(alpha > 0.f)) break;
@@ -2197,7 +2216,10 @@ struct Engine {
         d_qfrccon = rows_to_dof(r_sign * (on2 ? -r_D * r_jar : 0.f));
         status |= 4;
       }
+      PFN(PF_N_LS, tn_);
     }
+    PFN(PF_N_GRAD, tn_);
+#undef PFN
   }
 
 
@@ -2719,7 +2741,7 @@ struct Engine {
             float next = alpha - d1 / fmaxf(d2, MINVALF);
             if (hi >= 0.f && (next <= lo || next >= hi)) next = 0.5f * (lo + hi);
             else if (hi < 0.f && next <= lo) next = 2.f * lo + 1e-10f;
-            if (next == alpha) lsdone = true;
+            if (MM_LS_RELSTOP ? fabsf(next - alpha) <= MM_LS_RELSTOP_TOL * fabsf(alpha) : next == alpha) lsdone = true;
             alpha = next;
           }
         }
