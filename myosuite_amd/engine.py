@@ -58,10 +58,16 @@ EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
 #   hand pose   <32,24>      4.07 M -> 4.15 M  iterative-maxocc
 #   reorient    <64,32,GEN>  1.79 M -> 1.85 M  iterative-maxocc
 #   leg walk    <64,40,GEN>  0.71 M -> 0.79 M  iterative-ilp      (iterative-maxocc: 0.71 M; iterative-minreg loses 10-25 % everywhere)
-SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp", "myosim_inst_H.hip": "iterative-ilp"}
+#   implicitfast leg <64,36,GEN,2>  kernel 0.753 -> 0.724 ms  iterative-ilp   (round 3; the self-contact hand <64,24,GEN> loses 2 % with it)
+SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp", "myosim_inst_H.hip": "iterative-ilp",
+                  "myosim_inst_J.hip": "iterative-ilp"}
 # Extra per-file flags.  -sink-insts-to-avoid-spills: hand pose <32,24> 5.55 -> 5.67 M; within +-1 % (mostly -) on the others.
 FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
-              "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"]}   # leg <64,36,GEN>: +0.8 %
+              "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # leg <64,36,GEN>: +0.8 %
+              # reorient <64,32,GEN>: VGPR spills 74 -> 18 (model-in-LDS variant 47 -> 0), kernel 0.705 -> 0.686 ms (+3 %), and 4x
+              # less scratch traffic for a kernel whose time followed the box's memory clock.  The same flag on the 24-wide and
+              # implicitfast general-row units (inst_I, inst_J) loses 1 %: not set there.
+              "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"]}
 
 
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
