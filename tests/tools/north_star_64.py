@@ -1,6 +1,6 @@
 """North-star accuracy of the library at MYOSIM_LIB (default: the in-tree build), for A/B runs of kernel variants on the GPU box:
 per-stage relative error of one forward pass (hand, 64 random states) and the 64-env 1000-substep divergence statistics next to
-the fp32-state twin.   python tests/tools/north_star_64.py [tag] [lanes]   ->  gpurun_out/north_star_64_<tag>.json"""
+the fp32-state twin.   python tests/tools/north_star_64.py [tag] [lanes] [nenv]   ->  gpurun_out/north_star_64_<tag>.json"""
 import json
 import os
 import sys
@@ -17,10 +17,11 @@ import test_gpu_widths as TW
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "head"
 lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+nenv = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 cm = synth.get_model("hand")
 hm = E.HipModel(cm, lanes_per_env=lanes)
 out = {"lib": E.LIB_PATH, "lanes": lanes, "stage_rel_err": FS.stage_errors(cm, hm)}
-rel, rel_tw, status = TW.north_star_run("hand", lanes)
+rel, rel_tw, status = TW.north_star_run("hand", lanes, nenv=nenv)
 pe, pt = rel.max(axis=0), rel_tw.max(axis=0)
 out.update({"envs_below_1e-4": int((pe < 1e-4).sum()), "twin_envs_below_1e-4": int((pt < 1e-4).sum()), "nenv": int(pe.size),
             "median_env_max": float(np.median(pe)), "twin_median_env_max": float(np.median(pt)), "max_over_run": float(pe.max()),
