@@ -57,15 +57,17 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
        MM_INFO_WAVES_PER_BLOCK,
        MM_INFO_KERNEL_FAMILY,   /* 0 limit rows only, dense Cholesky (nv <= 4); 1 limit rows only, tree-sparse L'DL; 2 general rows */
        MM_INFO_MODEL_WORDS,     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */
-       MM_INFO_BODY_CHAINS };   /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */
+       MM_INFO_BODY_CHAINS,     /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */
+       MM_INFO_FOLDED_RESET };  /* 1: mm_rollout.autoreset is available for the WALK / REORIENT tasks on this model (64 lanes per env, a kernel of MM_KERNELS_OBS) */
 
 /* ABI version of this header: bumped whenever a struct below gains / loses / reorders a field, an entry point changes its
  * signature or a status / enum value is renumbered.  A caller compares MM_ABI_VERSION (what it was built against) with
  * mm_abi_version() (what the library was built from) and, for bindings that restate the structs (ctypes, cgo, JNI), its own
  * struct sizes with mm_struct_size().  History: 1 = round 1; 2 = mm_state.env_index_base, mm_env_draw(env_index_base), status
   * bits renumbered, the mm_rollout struct -- round 2, shipped under the version STRING of round 1; 3 = this constant + mm_abi_version /
- * mm_struct_size; 4 = mm_task.size / mm_rollout.size (append-only growth of the two structs that gain fields per task). */
-#define MM_ABI_VERSION 4
+ * mm_struct_size; 4 = mm_task.size / mm_rollout.size (append-only growth of the two structs that gain fields per task); 5 = mm_rollout gains the
+ * walk / reorient reset fields (appended: an ABI-4 caller's shorter struct is still accepted). */
+#define MM_ABI_VERSION 5
 enum { MM_STRUCT_STATE = 0, MM_STRUCT_DERIVED, MM_STRUCT_TASK, MM_STRUCT_ROLLOUT };
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
@@ -209,7 +211,8 @@ typedef struct {
   float* action_out;        /* optional [nenv][nu]: the actions that were applied (for the learner)                 */
   float* ep_stats;          /* optional [nenv][3] in/out: return += dense reward, length += 1, solved = max(solved, .) */
   uint8_t* reset_mask;      /* optional [nenv] out: done | truncated of this step                                  */
-  /* masked auto-reset folded into the same launch, MM_TASK_POSE only (pose_v0.py:174-257; same draws as mm_pose_reset):
+  /* masked auto-reset folded into the same launch, MM_TASK_POSE (pose_v0.py:174-257; same draws as mm_pose_reset; WALK / REORIENT:
+     see the fields at the end):
      envs whose episode ended get qpos ~ U(qlo,qhi) (random_qpos) or qpos0, target ~ U(tlo,thi), qvel = act = time = 0,
      step_count = 0, episode += 1, and their obs row holds the FIRST observation of the new episode (reward / done rows keep
      the terminal step's values).  Other tasks: autoreset = 0, reset through reset_mask + the task's reset call. */
@@ -219,6 +222,23 @@ typedef struct {
   float* target;            /* [nenv][nq]: == mm_task.target_jnt_value                                             */
   int32_t* episode;         /* [nenv] in/out                                                                        */
   uint64_t reset_seed;
+  /* --- appended in ABI 5: the masked auto-reset of the WALK and REORIENT tasks folded into the launch as well.  Their first
+     observation needs a forward pass on the reset state, so the launch makes a second pass (forward + observation) for the envs
+     it re-arms; available where an env is a whole wavefront (64 lanes per env: the leg and reorient models), MM_EUNSUPPORTED
+     otherwise.  Same draws, state and per-env model deltas as mm_walk_reset / mm_reorient_reset_typed (episode counter included);
+     the 3CC-r state of a re-armed env goes back to rest (MF = fat_reset_vec or 0, MR = 1 - MF, MA = 0: mm_fatigue_reset). */
+  const float *walk_ka_qpos, *walk_ka_qvel;   /* [nq] / [nv] key pose (walk_v0.py:354-365); kb_*: second stride key of the "random" reset */
+  const float *walk_kb_qpos, *walk_kb_qvel;
+  int   walk_random;
+  const float* reor_init_qpos;      /* [nq]                                                                         */
+  const float* reor_size_tables;    /* [4][reor_ntab][3]: capsule, ellipsoid, cylinder, box                         */
+  int   reor_ntab;
+  float reor_tar_length;
+  float*   reor_geom_size_env;      /* [nenv][3] = mm_state.geom_size_env (written)                                 */
+  int32_t* reor_geom_type_env;      /* [nenv]    = mm_state.geom_type_env (written)                                 */
+  float*   reor_axis_half;          /* [nenv]    = mm_task.reor_axis_half (written)                                 */
+  float*   reor_des_rot;            /* [nenv][3] = mm_task.reor_des_rot (written)                                   */
+  const float* fat_reset_vec;       /* [na] or NULL                                                                 */
 } mm_rollout;
 
 /* columns of mm_task.rwd for MM_TASK_POSE (pose_v0.py:120-139) */

@@ -198,7 +198,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mm_version(void) { return "myosim-hip 0.3 (gfx950, lane=item engine, ABI 4)"; }
+extern "C" const char* mm_version(void) { return "myosim-hip 0.3 (gfx950, lane=item engine, ABI 5)"; }
 extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
 extern "C" int mm_struct_size(int which) {
   switch (which) {
@@ -797,6 +797,7 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
   return fail(MM_EARG, "unknown option");
 }
 
+static bool have_obs_kernel(int G, int nvp, int gen, int rk4);
 extern "C" int mm_model_info(const mm_model* m, int which) {
   if (!m) return MM_EARG;
   switch (which) {
@@ -808,6 +809,7 @@ extern "C" int mm_model_info(const mm_model* m, int which) {
     case MM_INFO_NGEOM: return m->d.ngeom; case MM_INFO_WAVES_PER_BLOCK: return m->waves_per_block;
     case MM_INFO_MODEL_WORDS: return m->blob_words;
     case MM_INFO_BODY_CHAINS: return m->d.bchain_nlevel;
+    case MM_INFO_FOLDED_RESET: return (m->lanes == 64 && !m->lanes_auto && have_obs_kernel(64, m->nvp, m->d.gen, integ_kernel(m->d.integrator))) ? 1 : 0;
     case MM_INFO_KERNEL_FAMILY: return m->d.gen ? 2 : ((MM_SPARSE_LDL && m->nvp >= 8 && m->d.integrator != MM_INT_IMPLICITFAST) ? 1 : 0);
   }
   return MM_EARG;
@@ -1056,10 +1058,23 @@ extern "C" int mm_rollout_step(const mm_model* m, const mm_state* s, const mm_ta
   if (!r) return fail(MM_EARG, "mm_rollout_step: null rollout description");
   if (t->obs_only) return fail(MM_EARG, "mm_rollout_step: obs_only passes go through mm_env_step");
   if (r->autoreset) {
-    if (t->task != MM_TASK_POSE) return fail(MM_EUNSUPPORTED, "mm_rollout_step: the folded auto-reset exists for the POSE task only (reset the others through reset_mask)");
-    if (!r->tlo || !r->thi || !r->target || !r->episode || !t->step_count || (r->random_qpos && (!r->qlo || !r->qhi)))
-      return fail(MM_EARG, "mm_rollout_step: autoreset needs tlo/thi/target/episode/step_count (and qlo/qhi for random_qpos)");
-    if (r->target != t->target_jnt_value) return fail(MM_EARG, "mm_rollout_step: rollout.target must be the task's target_jnt_value buffer");
+    if (t->task == MM_TASK_POSE) {
+      if (!r->tlo || !r->thi || !r->target || !r->episode || !t->step_count || (r->random_qpos && (!r->qlo || !r->qhi)))
+        return fail(MM_EARG, "mm_rollout_step: autoreset needs tlo/thi/target/episode/step_count (and qlo/qhi for random_qpos)");
+      if (r->target != t->target_jnt_value) return fail(MM_EARG, "mm_rollout_step: rollout.target must be the task's target_jnt_value buffer");
+    } else if (t->task == MM_TASK_WALK || t->task == MM_TASK_REORIENT) {
+      // the second (reset-observation) pass is decided per wavefront: one env per wave, general-row kernels
+      if (!(pick_lanes(m, s->nenv) == 64 && have_obs_kernel(64, m->nvp, m->d.gen, integ_kernel(m->d.integrator))))
+        return fail(MM_EUNSUPPORTED, "mm_rollout_step: the folded walk / reorient reset exists in the 64-lane kernels of MM_KERNELS_OBS (reset through reset_mask instead)");
+      if (!r->episode || !t->step_count) return fail(MM_EARG, "mm_rollout_step: autoreset needs episode / step_count");
+      if (t->task == MM_TASK_WALK && (!r->walk_ka_qpos || !r->walk_ka_qvel || (r->walk_random && (!r->walk_kb_qpos || !r->walk_kb_qvel))))
+        return fail(MM_EARG, "mm_rollout_step: walk autoreset needs the key pose(s)");
+      if (t->task == MM_TASK_REORIENT && (!r->reor_init_qpos || !r->reor_size_tables || r->reor_ntab <= 0 || !r->reor_geom_size_env || !r->reor_geom_type_env ||
+                                          !r->reor_axis_half || !r->reor_des_rot || !(r->reor_tar_length > 0.f) || r->reor_geom_size_env != s->geom_size_env ||
+                                          r->reor_geom_type_env != s->geom_type_env || r->reor_axis_half != t->reor_axis_half || r->reor_des_rot != t->reor_des_rot))
+        return fail(MM_EARG, "mm_rollout_step: reorient autoreset needs init_qpos / size tables and the state's / task's per-env buffers");
+      if (t->fatigue && (!t->fat_MA || !t->fat_MR || !t->fat_MF)) return fail(MM_EARG, "mm_rollout_step: fatigue state missing");
+    } else return fail(MM_EUNSUPPORTED, "mm_rollout_step: the folded auto-reset exists for the POSE, WALK and REORIENT tasks (reset the others through reset_mask)");
   }
   KArgs a; fill_common(m, a, s);
   a.ctrl = r->action; a.mode = 2; a.t = *t; a.ro = *r; a.has_ro = 1;

@@ -813,7 +813,8 @@ struct Engine {
   bool r_eq;
   float r_floss;    // friction-loss row: bound of the row force (0 on every other row)
   int nrows_wave;   // wave-uniform upper bound of nefc over the envs of this wave
-  const float* env_gsize;   // this env's row of mm_state.geom_size_env (or null)
+  float env_gsv[3];         // this env's row of mm_state.geom_size_env (values: the folded reorient reset rewrites them)
+  bool env_has_gs;
   float rk_v0, rk_vsum, rk_asum;   // RK4: qvel at the start of the step, weighted sums of stage qvel / qacc
   int env_gtype;            // this env's entry of mm_state.geom_type_env (or -1)
   int env;                  // env index (per-env model deltas on a body: mm_state.body_mass_env / body_pos_env)
@@ -833,7 +834,7 @@ struct Engine {
       c_rowj = g < KD().nv ? MI_(DOF_JNTID)[g] : 0;
       c_rowj_mine = g < KD().nv && MI_(JNT_DOFADR)[c_rowj] == g;
     }
-    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; r_floss = 0.f; nrows_wave = 0; env_gsize = nullptr; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; r_floss = 0.f; nrows_wave = 0; env_has_gs = false; env_gsv[0] = env_gsv[1] = env_gsv[2] = 0.f; env_gtype = -1; rk_v0 = rk_vsum = rk_asum = 0.f;
     // lanes that own no body / dof still take part in reductions with zero weights: their registers must
     // hold finite values (0 * garbage could be NaN)
     b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
@@ -2382,9 +2383,9 @@ struct Engine {
       V3 x1 = geom_pos(g1), x2 = geom_pos(g2);
       float r1 = MF_(GEOM_SIZE)[3 * g1], h1 = MF_(GEOM_SIZE)[3 * g1 + 1];
       float r2 = MF_(GEOM_SIZE)[3 * g2], h2 = MF_(GEOM_SIZE)[3 * g2 + 1];
-      if (env_gsize) {   // per-env model delta: size of one geom (mm_state.geom_size_env)
-        if (g1 == a.s.geom_env_id) { r1 = env_gsize[0]; h1 = env_gsize[1]; }
-        if (g2 == a.s.geom_env_id) { r2 = env_gsize[0]; h2 = env_gsize[1]; }
+      if (env_has_gs) {   // per-env model delta: size of one geom (mm_state.geom_size_env)
+        if (g1 == a.s.geom_env_id) { r1 = env_gsv[0]; h1 = env_gsv[1]; }
+        if (g2 == a.s.geom_env_id) { r2 = env_gsv[0]; h2 = env_gsv[1]; }
       }
       if (t1 == MM_GEOM_PLANE && t2 == MM_GEOM_SPHERE) {
         nc = pln_sph(x1, geom_zaxis(g1), x2, r2, margin, cdist[0], cpos[0], cn[0]) ? 1 : 0;
@@ -2415,7 +2416,7 @@ struct Engine {
         const V3 xc = flip ? x2 : x1, xs = flip ? x1 : x2;
         const float rc = flip ? r2 : r1, hc = flip ? h2 : h1;
         V3 ss = ld3(MF_(GEOM_SIZE) + 3 * gs);
-        if (env_gsize && gs == a.s.geom_env_id) ss = ld3(env_gsize);
+        if (env_has_gs && gs == a.s.geom_env_id) ss = v3(env_gsv[0], env_gsv[1], env_gsv[2]);
         const V3 uc = geom_zaxis(gc);
         const M3 ms = geom_mat(gs);
         const SegHit hit = seg_shape_call(ts, ss, mtv(ms, xc - xs), mtv(ms, uc), hc);
@@ -3144,13 +3145,16 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   bool dup = e >= nenv;
   if (dup) e = nenv - 1;  // surplus groups recompute the last env (they never store)
   if (a.mode == 2 && KA().t.env_mask && !KA().t.env_mask[e]) dup = true;   // masked-out envs are left untouched
-  const bool obs_only = OBS || (a.mode == 2 && KA().t.obs_only);
+  bool obs_only = OBS || (a.mode == 2 && KA().t.obs_only);
   if (obs_only && __ballot(!dup) == 0ull) return;   // reset-observation pass: waves without a reset env do nothing
   float* W = wsbase + (size_t)(wave * EPW + lane / G) * KL().total;
   const auto& L = KL();
   const auto& d = KD();
   Engine<G, NVP, GEN, INTEG> E(a, kc, mb, W, g);
-  if (a.s.geom_size_env && a.s.geom_env_id >= 0) E.env_gsize = a.s.geom_size_env + (size_t)e * 3;
+  if (a.s.geom_size_env && a.s.geom_env_id >= 0) {
+    E.env_has_gs = true;
+    E.env_gsv[0] = a.s.geom_size_env[(size_t)e * 3]; E.env_gsv[1] = a.s.geom_size_env[(size_t)e * 3 + 1]; E.env_gsv[2] = a.s.geom_size_env[(size_t)e * 3 + 2];
+  }
   if (a.s.geom_type_env && a.s.geom_env_id >= 0) E.env_gtype = a.s.geom_type_env[e];
   E.env = e;
   if constexpr (Engine<G, NVP, GEN, INTEG>::TW) {
@@ -3223,10 +3227,19 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
 
   int nsub = (OBS || a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
   bool fwd = OBS || a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
+  // FOLD: the masked auto-reset of the WALK / REORIENT tasks inside this launch (mm_rollout.autoreset).  Their first observation
+  // needs a forward pass on the reset state: an env that ends its episode is re-armed in registers / LDS at the end of pass 0 and
+  // pass 1 runs the reset-observation pass (forward + observation, no stepping, no bookkeeping) before the state is stored.  One
+  // env per wavefront (G = 64), so the second pass is a wave-uniform decision.  Every other kernel: the loop is a single pass.
+  // (Compiled into the kernels that also exist as reset-observation kernels, MM_KERNELS_OBS: the 32- and 36-wide ones of the reorient
+  // and leg models; the loop keeps the engine's registers live across the task stage, which cost the 24-wide self-contact hand 2.7 %.)
+  constexpr bool FOLD = GEN && G == 64 && !OBS && (NVP == 32 || NVP == 36);
+#pragma nounroll
+  for (int pass = 0; pass < (FOLD ? 2 : 1); pass++) {   // (never unrolled: ONE copy of the pipeline, as before)
+  bool refold = false;
   E.run(nsub, fwd, time);
-  if constexpr (Engine<G, NVP, GEN, INTEG>::TW) { if (two_wave) E.tw_signal(0, Engine<G, NVP, GEN, INTEG>::TW_DONE); }
 
-  if (dup) return;   // surplus groups never write
+  if (dup) break;   // surplus groups never write
 
   // ---- derived outputs of the final forward
   if (fwd && a.has_derived) {
@@ -3292,7 +3305,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   bool rw_done = false, will_reset = false;
   if (a.mode == 2) {
     int sc = 0, sc0 = 0;
-    if (t.step_count) { sc0 = t.step_count[e]; sc = obs_only ? sc0 : sc0 + 1; }
+    if (t.step_count) { sc0 = (FOLD && pass == 1) ? 0 : t.step_count[e]; sc = obs_only ? sc0 : sc0 + 1; }
     if (t.task == MM_TASK_POSE) {
       const float dt = t.obs_dt;
       const int o_err = t.obs_layout == 1 ? d.nq + d.nv + d.na : d.nq + d.nv;
@@ -3588,9 +3601,15 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         if (t.done && !obs_only) t.done[e] = dropped ? 1 : 0;
       }
     }
+    if constexpr (FOLD) {
+      if (pass == 0 && has_ro && !obs_only && KA().ro.autoreset && (t.task == MM_TASK_WALK || t.task == MM_TASK_REORIENT)) {
+        const bool trunc_ = t.max_episode_steps > 0 && sc >= t.max_episode_steps;
+        refold = __builtin_amdgcn_readfirstlane((int)(rw_done || trunc_)) != 0;     // rw_done is lane 0's
+      }
+    }
     if (g == 0 && !obs_only) {
       const bool trunc = t.max_episode_steps > 0 && sc >= t.max_episode_steps;
-      if (t.step_count) t.step_count[e] = will_reset ? 0 : sc;
+      if (t.step_count) t.step_count[e] = (will_reset || refold) ? 0 : sc;
       if (t.truncated) t.truncated[e] = trunc ? 1 : 0;
       if (has_ro) {   // rollout bookkeeping (mm_rollout): what mm_episode_stats does in its own launch
         const __attribute__((address_space(4))) mm_rollout& ro = KA().ro;
@@ -3603,6 +3622,80 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     }
   }
 
+  if constexpr (FOLD) {
+    if (refold) {
+      // ---- re-arm this env inside the launch (mm_rollout.autoreset; WALK: mm_walk_reset, REORIENT: mm_reorient_reset_typed --
+      // same Philox counters, keyed by the global env index and the episode counter), then run the reset-observation pass.  The
+      // terminal step's reward / done / statistics are already written; its observation row is replaced by the new episode's.
+      const __attribute__((address_space(4))) mm_rollout& ro = KA().ro;
+      if constexpr (Engine<G, NVP, GEN, INTEG>::TW) {
+        // two-wave launches: nobody waited for the helper's last job of the final forward pass (Euler's factor / the W matrix in
+        // the second tile), which the next forward pass rewrites
+        if (two_wave && (Engine<G, NVP, GEN, INTEG>::IMPL || (!Engine<G, NVP, GEN, INTEG>::SP && d.any_damping && d.eulerdamp))) E.tw_wait(3, E.tw_n);
+      }
+      const int ep = ro.episode[e];
+      const uint32_t ge = (uint32_t)(a.s.env_index_base + e);
+      const uint64_t sd = ro.reset_seed;
+      if (t.task == MM_TASK_WALK) {
+        const float *kq = ro.walk_ka_qpos, *kv = ro.walk_ka_qvel;
+        if (ro.walk_random) {      // walk_v0.py:327-352: coin between the two stride keys, N(0, 0.02) on every coordinate but root height / quaternion
+          uint32_t c[4] = {0xFFFFu, 2u, ge, (uint32_t)ep};
+          philox4x32_10(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+          if (!(u01(c[0]) < 0.5f)) { kq = ro.walk_kb_qpos; kv = ro.walk_kb_qvel; }
+        }
+        for (int i = g; i < d.nq; i += G) {
+          float q = kq[i];
+          if (ro.walk_random && !(i >= 2 && i < 7)) {
+            uint32_t c[4] = {(uint32_t)i, 2u, ge, (uint32_t)ep};
+            philox4x32_10(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+            const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = u01(c[1]);
+            q += 0.02f * sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+          }
+          W[L.qpos + i] = q;
+        }
+        if (g < d.nv) { E.d_qvel = kv[g]; W[L.qvel + g] = E.d_qvel; }
+      } else {                     // MM_TASK_REORIENT (reorient_sar_v0.py:386-432)
+        uint32_t c[4] = {0u, 3u, ge, (uint32_t)ep};
+        philox4x32_10(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+        int idx = (int)(u01(c[0]) * (float)ro.reor_ntab);
+        if (idx >= ro.reor_ntab) idx = ro.reor_ntab - 1;
+        int ty = (int)(u01(c[3]) * 4.f);
+        if (ty > 3) ty = 3;
+        const float* sz = ro.reor_size_tables + 3 * (ty * ro.reor_ntab + idx);
+        const float s0 = sz[0], s1 = sz[1], s2 = sz[2];
+        const float ah = ty == 0 ? 1.3f * s1 : (ty == 2 ? s1 : s2);
+        const float e0 = -1.f + 2.f * u01(c[1]), e1 = -0.8f + 2.f * u01(c[2]);
+        const float aj = -0.5f * e1, ak = 0.5f * e0;
+        const float sj = sinf(aj), cj = cosf(aj), sk = sinf(ak), ck = cosf(ak);
+        const float qw = cj * ck, qx = cj * sk, qy = -(sj * ck), qz = -sj * sk;
+        const float sc_ = 2.f * ah / ro.reor_tar_length;
+        if (g == 0) {             // every lane computed the same draws; lane 0 publishes the per-env model deltas
+          ro.reor_geom_type_env[e] = MM_GEOM_CAPSULE + ty;
+          ro.reor_geom_size_env[(size_t)e * 3] = s0; ro.reor_geom_size_env[(size_t)e * 3 + 1] = s1; ro.reor_geom_size_env[(size_t)e * 3 + 2] = s2;
+          ro.reor_axis_half[e] = ah;
+          ro.reor_des_rot[(size_t)e * 3 + 0] = 2.f * (qx * qz + qw * qy) * sc_;
+          ro.reor_des_rot[(size_t)e * 3 + 1] = 2.f * (qy * qz - qw * qx) * sc_;
+          ro.reor_des_rot[(size_t)e * 3 + 2] = (1.f - 2.f * (qx * qx + qy * qy)) * sc_;
+        }
+        E.env_gtype = MM_GEOM_CAPSULE + ty; E.env_has_gs = true; E.env_gsv[0] = s0; E.env_gsv[1] = s1; E.env_gsv[2] = s2;
+        for (int i = g; i < d.nq; i += G) W[L.qpos + i] = ro.reor_init_qpos[i];
+        if (g < d.nv) { E.d_qvel = 0.f; W[L.qvel + g] = 0.f; }
+      }
+      if (g < d.nv) E.d_warm = 0.f;
+      for (int i = g; i < d.na; i += G) W[L.act + i] = 0.f;
+      if (t.fatigue)               // CumulativeFatigue.reset (fatigue.py:82-99): MF = fatigue_reset_vec (or 0), MR = 1 - MF, MA = 0
+        for (int i = g; i < d.na; i += G) {
+          const float mf = ro.fat_reset_vec ? ro.fat_reset_vec[i] : 0.f;
+          const size_t k = (size_t)e * d.na + i;
+          t.fat_MA[k] = 0.f; t.fat_MR[k] = 1.f - mf; t.fat_MF[k] = mf;
+        }
+      time = 0.f; E.status = 0;
+      if (g == 0) ro.episode[e] = ep + 1;
+      GSYNC();
+      obs_only = true; nsub = 0; fwd = true;
+      continue;
+    }
+  }
   // ---- store state
   if (!will_reset) {
     for (int i = g; i < d.nq; i += G) a.s.qpos[(size_t)e * d.nq + i] = W[L.qpos + i];
@@ -3639,5 +3732,8 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     for (int i = g; i < d.na; i += G) { a.s.act[(size_t)e * d.na + i] = 0.f; if (ob) ob[o_act + i] = 0.f; }
     if (g == 0) { a.s.time[e] = 0.f; if (a.s.status) a.s.status[e] = 0; ro.episode[e] = ep + 1; }
   }
+  break;
+  }   // pass
+  if constexpr (Engine<G, NVP, GEN, INTEG>::TW) { if (two_wave) E.tw_signal(0, Engine<G, NVP, GEN, INTEG>::TW_DONE); }
 }
 

@@ -32,10 +32,10 @@ RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "spar
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
  INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK, INFO_KERNEL_FAMILY, INFO_MODEL_WORDS,
- INFO_BODY_CHAINS) = range(15)
+ INFO_BODY_CHAINS, INFO_FOLDED_RESET) = range(16)
 
 
-MM_ABI_VERSION = 4   # include/myosim.h
+MM_ABI_VERSION = 5   # include/myosim.h
 
 
 class EngineError(RuntimeError):
@@ -162,7 +162,12 @@ class mm_rollout(C.Structure):
     _fields_ = [("size", C.c_uint32), ("action", C.c_void_p), ("action_seed", C.c_uint64), ("action_stream", C.c_uint64), ("action_out", C.c_void_p),
                 ("ep_stats", C.c_void_p), ("reset_mask", C.c_void_p), ("autoreset", C.c_int), ("random_qpos", C.c_int),
                 ("qlo", C.c_void_p), ("qhi", C.c_void_p), ("tlo", C.c_void_p), ("thi", C.c_void_p), ("target", C.c_void_p),
-                ("episode", C.c_void_p), ("reset_seed", C.c_uint64)]
+                ("episode", C.c_void_p), ("reset_seed", C.c_uint64),
+                ("walk_ka_qpos", C.c_void_p), ("walk_ka_qvel", C.c_void_p), ("walk_kb_qpos", C.c_void_p), ("walk_kb_qvel", C.c_void_p),
+                ("walk_random", C.c_int),
+                ("reor_init_qpos", C.c_void_p), ("reor_size_tables", C.c_void_p), ("reor_ntab", C.c_int), ("reor_tar_length", C.c_float),
+                ("reor_geom_size_env", C.c_void_p), ("reor_geom_type_env", C.c_void_p), ("reor_axis_half", C.c_void_p),
+                ("reor_des_rot", C.c_void_p), ("fat_reset_vec", C.c_void_p)]
 
 
 def lib():

@@ -86,6 +86,23 @@ class ReorientEnvV0(BaseV0):
         self.rwd_dict["solved"] = self.rwd_dict["solved"] > 0.5
         self.rwd_dict["done"] = self.rwd_dict["done"] > 0.5
 
+    def _rollout_fill_reset(self, ro):
+        """the Geometries reset (object type / size / desired orientation draws, open-hand pose) runs inside the env-step launch
+        where an env is a whole wavefront (mm_rollout; second, reset-observation pass for the envs the launch re-arms)"""
+        if not (self.autoreset and self.hm.info(E.INFO_FOLDED_RESET) == 1 and not getattr(self, "fatigue_reset_random", False)):
+            return
+        ro.autoreset = 1
+        ro.reor_init_qpos = self._init_qpos_dev.data_ptr()
+        ro.reor_size_tables = self._size_tables.data_ptr(); ro.reor_ntab = int(self._size_tables.shape[1])
+        ro.reor_tar_length = float(self.tar_length)
+        ro.reor_geom_size_env = self.state.geom_size_env.data_ptr(); ro.reor_geom_type_env = self.state.geom_type_env.data_ptr()
+        ro.reor_axis_half = self.axis_half.data_ptr(); ro.reor_des_rot = self.des_rot.data_ptr()
+        ro.episode = self.episode.data_ptr(); ro.reset_seed = self._seed_u64
+        if self.muscle_condition == "fatigue" and self.fatigue_reset_vec is not None:
+            import numpy as np
+            self._ro_fat_vec = torch.from_numpy(np.broadcast_to(np.asarray(self.fatigue_reset_vec, np.float32), (self.cm.na,)).copy()).to(self.device)
+            ro.fat_reset_vec = self._ro_fat_vec.data_ptr()
+
     def reset(self, seed=None, mask: Optional[torch.Tensor] = None, **kwargs):
         if seed is not None:
             self.seed(seed)
@@ -136,6 +153,9 @@ class PenTwirlEnvV0(ReorientEnvV0):
         self._task = t
         self._seed_u64 = int(self.input_seed) if self.input_seed is not None else 0
         self.reset()
+
+    def _rollout_fill_reset(self, ro):
+        """pen-twirl keeps its separate reset call (mm_pen_reset: fixed geometry, other draws)"""
 
     def reset(self, seed=None, mask: Optional[torch.Tensor] = None, **kwargs):
         if seed is not None:

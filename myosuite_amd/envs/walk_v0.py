@@ -90,6 +90,24 @@ class WalkEnvV0(BaseV0):
         self.rwd_dict["solved"] = self.rwd_dict["solved"] > 0.5
         self.rwd_dict["done"] = self.rwd_dict["done"] > 0.5
 
+    def _rollout_fill_reset(self, ro):
+        """the walk reset (key pose, optional stride coin + noise; 3CC-r state back to rest) runs inside the env-step launch
+        where an env is a whole wavefront (mm_rollout: the launch makes a second, reset-observation pass for the envs it
+        re-arms); random fatigue resets and narrower launches keep the separate reset calls"""
+        if not (self.autoreset and self.hm.info(E.INFO_FOLDED_RESET) == 1 and not self.fatigue_reset_random):
+            return
+        rnd = self.reset_type == "random"
+        k = 2 if (rnd or self.reset_type == "init") else 0
+        ro.autoreset = 1
+        ro.walk_ka_qpos, ro.walk_ka_qvel = self._keys_q[k].data_ptr(), self._keys_v[k].data_ptr()
+        ro.walk_kb_qpos = self._keys_q[3].data_ptr() if rnd else None
+        ro.walk_kb_qvel = self._keys_v[3].data_ptr() if rnd else None
+        ro.walk_random = int(rnd)
+        ro.episode = self.episode.data_ptr(); ro.reset_seed = self._seed_u64
+        if self.muscle_condition == "fatigue" and self.fatigue_reset_vec is not None:
+            self._ro_fat_vec = torch.from_numpy(np.broadcast_to(np.asarray(self.fatigue_reset_vec, np.float32), (self.cm.na,)).copy()).to(self.device)
+            ro.fat_reset_vec = self._ro_fat_vec.data_ptr()
+
     def reset(self, seed=None, mask: Optional[torch.Tensor] = None, **kwargs):
         if seed is not None:
             self.seed(seed)

@@ -344,3 +344,47 @@ def test_two_wave_launch_is_bit_identical_to_one_wave(env_id, n, kw, monkeypatch
         assert torch.equal(o1, o0) and torch.equal(r1, r0) and torch.equal(t1, t0) and torch.equal(u1, u0)
     monkeypatch.setenv("MYOSIM_TWO_WAVE", "1")
     registry.make("myoElbowPose1D6MRandom-v0", num_envs=4)   # leave the switch on for the tests that follow
+
+
+@pytest.mark.parametrize("env_id,n,kw", [("myoLegWalk-v0", 80, {}), ("myoFatiLegWalk-v0", 64, {}), ("myoHandReorient100-v0", 96, {}),
+                                         ("myoLegWalk-v0", 64, {"reset_type": "random"}), ("myoLegWalk-v0", 64, {"model": "leg_implicit"})],
+                         ids=["leg", "fati-leg", "reorient", "leg-random-reset", "leg-implicitfast"])
+def test_folded_walk_and_reorient_reset_matches_the_separate_reset(env_id, n, kw):
+    """mm_rollout.autoreset for the WALK / REORIENT tasks: an env that ends its episode is re-armed INSIDE the env-step launch
+    (reset state + per-env model deltas + 3CC-r state, then a second, reset-observation pass of the same wave) instead of by
+    three more launches (fatigue reset, task reset, reset-observation pass).  Against the stepwise path across several episode
+    boundaries: states, targets / geometry draws, counters, fatigue state and statistics bit-identical; the first observation
+    of a new episode to 1e-5 (another kernel instantiation computes it in the stepwise path)."""
+    kws = dict(num_envs=n, seed=11, max_episode_steps=5, **kw)
+    fused = registry.make(env_id, **kws)
+    ref = registry.make(env_id, **kws)
+    stats_f = fused.rollout_setup(action_seed=23)
+    assert fused._ro.autoreset == 1 and fused.hm.info(E.INFO_FOLDED_RESET) == 1
+    stats_r = torch.zeros(n, 3, device="cuda"); need = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    a = torch.empty(n, ref.cm.nu, device="cuda")
+    dense_col = ref.rwd.shape[1] - 1
+    crossed = 0
+    for s in range(13):
+        obs_f, rwd_f, mask_f = fused.rollout_step(None, stream_id=s)
+        E.uniform(a, 23, s)
+        E.env_step(ref.hm, ref.state, a, ref._task)
+        E.episode_stats(stats_r, need, ref.rwd, dense_col, dense_col - 2, ref.done, ref.truncated)
+        ref.reset(mask=need)
+        crossed += int(need.sum())
+        assert torch.equal(mask_f, need), s
+        assert torch.equal(rwd_f, ref.rwd), s
+        for k in ("qpos", "qvel", "act", "qacc_warmstart", "time"):
+            assert torch.equal(getattr(fused.state, k), getattr(ref.state, k)), (k, s)
+        assert torch.equal(fused.episode, ref.episode) and torch.equal(fused.step_count, ref.step_count)
+        if "Reorient" in env_id:
+            assert torch.equal(fused.geom_size, ref.geom_size) and torch.equal(fused.geom_type, ref.geom_type)
+            assert torch.equal(fused.axis_half, ref.axis_half) and torch.equal(fused.des_rot, ref.des_rot)
+        if fused.muscle_condition == "fatigue":
+            assert torch.equal(fused.fat_MA, ref.fat_MA) and torch.equal(fused.fat_MR, ref.fat_MR) and torch.equal(fused.fat_MF, ref.fat_MF)
+        keep = need == 0
+        assert torch.equal(obs_f[keep], ref.obs[keep]), s                      # envs that continue: the same launch path
+        err = (obs_f[~keep] - ref.obs[~keep]).abs() / ref.obs[~keep].abs().clamp(min=1.0)
+        assert err.numel() == 0 or float(err.max()) < 1e-5, (s, float(err.max()))
+        assert torch.equal(stats_f, stats_r)
+        assert int(fused.state.status.max()) & 16 == 0
+    assert crossed >= 2 * n
