@@ -809,7 +809,7 @@ extern "C" int mm_model_info(const mm_model* m, int which) {
     case MM_INFO_NGEOM: return m->d.ngeom; case MM_INFO_WAVES_PER_BLOCK: return m->waves_per_block;
     case MM_INFO_MODEL_WORDS: return m->blob_words;
     case MM_INFO_BODY_CHAINS: return m->d.bchain_nlevel;
-    case MM_INFO_FOLDED_RESET: return (m->lanes == 64 && !m->lanes_auto && have_obs_kernel(64, m->nvp, m->d.gen, integ_kernel(m->d.integrator))) ? 1 : 0;
+    case MM_INFO_FOLDED_RESET: return (MM_FOLD_RESET && m->lanes == 64 && !m->lanes_auto && have_obs_kernel(64, m->nvp, m->d.gen, integ_kernel(m->d.integrator))) ? 1 : 0;
     case MM_INFO_KERNEL_FAMILY: return m->d.gen ? 2 : ((MM_SPARSE_LDL && m->nvp >= 8 && m->d.integrator != MM_INT_IMPLICITFAST) ? 1 : 0);
   }
   return MM_EARG;

@@ -692,6 +692,9 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
 #define MM_SPARSE_GEN 0   /* 1: the general-row kernels use the tree-sparse solve for the two M solves of a pass (solve0, Euler).  Measured: \
                              the extra live state tips these 256-VGPR kernels into 80 spills; reorient -3 %, self-contact hand -5 % */
 #endif
+#ifndef MM_FOLD_RESET
+#define MM_FOLD_RESET 1   /* 0: no folded walk / reorient reset (A/B switch; MM_INFO_FOLDED_RESET then reports 0) */
+#endif
 #ifndef MM_LS_RELSTOP
 /* Experiment, OFF: end the exact line search once a turn moves alpha by less than MM_LS_RELSTOP_TOL relative, instead of running the
    safeguarded Newton on phi'(alpha) until its step vanishes in float resolution.  The stage timers put ~10 k of the hand's 32 k
@@ -873,6 +876,25 @@ struct Engine {
         sgl = seg_lane_load();
       }
     }
+  }
+  // Back to the constructor's values for everything a forward pass recomputes (the folded reset calls this before its second
+  // forward pass, so that none of these registers is live across the task stage and the reset block)
+  __device__ __forceinline__ void reinit_transients() {
+    r_dof = 0; r_active = false; r_sign = 1.f; r_D = 0.f; r_aref = 0.f; r_jar = 0.f; r_eq = false; r_floss = 0.f; nrows_wave = 0; rk_v0 = rk_vsum = rk_asum = 0.f;
+    b_xpos = v3(0.f, 0.f, 0.f); b_xipos = b_xpos;
+    Q4 qi = {1.f, 0.f, 0.f, 0.f};
+    b_xquat = qi;
+#pragma unroll
+    for (int k = 0; k < 10; k++) b_cinert[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { b_cvel[k] = 0.f; d_cdof[k] = 0.f; }
+    d_bias = d_smooth = d_qaccsm = d_qacc = d_qfrccon = 0.f; d_dinv = 1.f;
+#pragma unroll
+    for (int k = 0; k < NVP; k++) { Mrow[k] = 0.f; Lrow[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < SD; k++) Ms[k] = 0.f;
+    Md = 1.f;
+    nefc = 0; niter = 0;
   }
   __device__ __forceinline__ static SegLane seg_lane_none() {
     SegLane q; q.t = q.b = 0; q.lv = -1; q.id = 0; q.depth = -1; q.path_lo = q.path_hi = 0u; q.ch_lo = q.ch_hi = 0xffffffffu;
@@ -3228,19 +3250,25 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   int nsub = (OBS || a.mode == 1 || obs_only) ? 0 : t.nsubsteps;
   bool fwd = OBS || a.mode == 1 || obs_only || (a.mode == 2 && t.do_forward);
   // FOLD: the masked auto-reset of the WALK / REORIENT tasks inside this launch (mm_rollout.autoreset).  Their first observation
-  // needs a forward pass on the reset state: an env that ends its episode is re-armed in registers / LDS at the end of pass 0 and
-  // pass 1 runs the reset-observation pass (forward + observation, no stepping, no bookkeeping) before the state is stored.  One
-  // env per wavefront (G = 64), so the second pass is a wave-uniform decision.  Every other kernel: the loop is a single pass.
-  // (Compiled into the kernels that also exist as reset-observation kernels, MM_KERNELS_OBS: the 32- and 36-wide ones of the reorient
-  // and leg models; the loop keeps the engine's registers live across the task stage, which cost the 24-wide self-contact hand 2.7 %.)
-  constexpr bool FOLD = GEN && G == 64 && !OBS && (NVP == 32 || NVP == 36);
-#pragma nounroll
-  for (int pass = 0; pass < (FOLD ? 2 : 1); pass++) {   // (never unrolled: ONE copy of the pipeline, as before)
+  // needs a forward pass on the reset state: an env that ends its episode is re-armed in registers / LDS after the task stage and
+  // the same wave runs the reset-observation pass (forward + observation, no stepping, no bookkeeping) before the state is stored.
+  // One env per wavefront (G = 64), so the second pass is a wave-uniform branch.  It is a SECOND inlined copy of the forward
+  // pipeline and of the task stage (forward only, obs_only constant), not a loop around one copy: the loop kept everything the
+  // pipeline reads live across the task stage and the reset block (100+ VGPR spills in the 32- / 36-wide kernels, kernel time
+  // +1..3 %); the straight-line form has the spill count and the kernel time of the unfolded kernel (0 / 0 / 5 spills), and the
+  // cold copy is only fetched by a wave whose env resets.  Compiled into the kernels that also exist as reset-observation kernels
+  // (MM_KERNELS_OBS: the 32- and 36-wide ones of the reorient and leg models) -- the only models the two tasks run on.
+  constexpr bool FOLD = MM_FOLD_RESET && GEN && G == 64 && !OBS && (NVP == 32 || NVP == 36);
   bool refold = false;
+  // results of the task stage the rollout bookkeeping needs: dense reward / solved / done (valid in lane 0 of the group),
+  // and whether this env is re-armed inside this launch (group-uniform; POSE task with mm_rollout.autoreset)
+  float rw_dense = 0.f, rw_solved = 0.f;
+  bool rw_done = false, will_reset = false;
   E.run(nsub, fwd, time);
 
-  if (dup) break;   // surplus groups never write
-
+  // everything between the pipeline and the state store: derived outputs, task stage, bookkeeping.  `pass` 1 = the reset-observation
+  // pass of a folded reset (observation only: obs_only is true there)
+  auto stage = [&](const bool obs_only, const int pass) __attribute__((always_inline)) {
   // ---- derived outputs of the final forward
   if (fwd && a.has_derived) {
     const mm_derived& o = a.o;
@@ -3299,10 +3327,6 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   }
 
   // ---- task stage: obs_dict / reward_dict (pose_v0.py:100-140), TimeLimit counter
-  // results of the task stage the rollout bookkeeping needs: dense reward / solved / done (valid in lane 0 of the group),
-  // and whether this env is re-armed inside this launch (group-uniform; POSE task with mm_rollout.autoreset)
-  float rw_dense = 0.f, rw_solved = 0.f;
-  bool rw_done = false, will_reset = false;
   if (a.mode == 2) {
     int sc = 0, sc0 = 0;
     if (t.step_count) { sc0 = (FOLD && pass == 1) ? 0 : t.step_count[e]; sc = obs_only ? sc0 : sc0 + 1; }
@@ -3621,7 +3645,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
       }
     }
   }
+  };   // stage
 
+  if (!dup) {   // surplus groups never write
+  stage(obs_only, 0);
   if constexpr (FOLD) {
     if (refold) {
       // ---- re-arm this env inside the launch (mm_rollout.autoreset; WALK: mm_walk_reset, REORIENT: mm_reorient_reset_typed --
@@ -3691,9 +3718,10 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
         }
       time = 0.f; E.status = 0;
       if (g == 0) ro.episode[e] = ep + 1;
+      E.reinit_transients();
       GSYNC();
-      obs_only = true; nsub = 0; fwd = true;
-      continue;
+      E.run(0, true, time);
+      stage(true, 1);
     }
   }
   // ---- store state
@@ -3732,8 +3760,7 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
     for (int i = g; i < d.na; i += G) { a.s.act[(size_t)e * d.na + i] = 0.f; if (ob) ob[o_act + i] = 0.f; }
     if (g == 0) { a.s.time[e] = 0.f; if (a.s.status) a.s.status[e] = 0; ro.episode[e] = ep + 1; }
   }
-  break;
-  }   // pass
+  }   // !dup
   if constexpr (Engine<G, NVP, GEN, INTEG>::TW) { if (two_wave) E.tw_signal(0, Engine<G, NVP, GEN, INTEG>::TW_DONE); }
 }
 
