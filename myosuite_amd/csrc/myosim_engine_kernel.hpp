@@ -139,6 +139,17 @@ struct KArgs {
   int blob_words;
   unsigned long long* prof;
 };
+// Stage boundaries as scheduling fences: the machine scheduler works on basic blocks, and with the stage timers compiled out a
+// whole forward pass is a handful of very long blocks across which it hoists loads and lengthens live ranges until the 256-VGPR
+// kernels spill.  (Found because the tools build, whose timers end a block at every stage, ran the leg kernels 8-15 % FASTER.)
+#ifndef MM_STAGE_FENCE
+#define MM_STAGE_FENCE 1
+#endif
+#if MM_STAGE_FENCE
+#define MM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MM_FENCE() ((void)0)
+#endif
 enum { PF_KIN = 0, PF_COM, PF_TENDON, PF_CONSTR, PF_VEL, PF_CRB, PF_FACTOR, PF_ACT, PF_SOLVE0, PF_NEWTON, PF_EULER,
        PF_IO, PF_TOTAL,
        PF_N_WARM, PF_N_GRAD, PF_N_HBUILD, PF_N_FACTOR, PF_N_SOLVE, PF_N_PROD, PF_N_LS,   // inside the general-row Newton solve (tools build)
@@ -1933,7 +1944,7 @@ struct Engine {
         }
         const float piv = bc<G>(s, j);
         const float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
-        const float lj = (g >= j) ? s * inv : 0.f;
+        const float lj = (g > j) ? s * inv : 0.f;    // STRICTLY lower: the diagonal lives in d_dinv (see scale_rows)
         Lrow[j] = lj;
         if (g == j) d_dinv = inv;
         if (g < NVP) T[row * TD + j] = lj;
@@ -1947,7 +1958,9 @@ struct Engine {
     for (int j = 0; j < NVP; j++) {
       float piv = bc<G>(A[j], j);
       float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
-      float lj = (g >= j) ? A[j] * inv : 0.f;
+      // STRICTLY lower (the diagonal lives in d_dinv): the trailing update only needs L[k][j] of the rows k > j, and lane j's own
+      // row is finished -- what the update does to its entries right of the diagonal is never read
+      float lj = (g > j) ? A[j] * inv : 0.f;
       Lrow[j] = lj;
       if (g == j) d_dinv = inv;
 #pragma unroll
@@ -1962,31 +1975,38 @@ struct Engine {
     GSYNC();
     scale_rows();
   }
-  // After a factorisation the row registers are rewritten for the substitution: Lrow[k] <- L[g][k] / L[g][g] (k < g), 0 on and above
-  // the diagonal.  With the lane's own 1 / L[g][g] folded into its row (and into its right-hand side), step j of the forward
-  // substitution is "broadcast x_j, one fma" for every lane -- no multiply ahead of the broadcast and no selects behind it.
-  // The dependent chain of a substitution step was mul -> readlane -> fma -> cndmask -> cndmask (~100 cycles for a lone wave, 72
-  // steps per solve: a solve cost as much as the factorisation, 7 k cycles for the 36-dof leg, three to four solves per pass).
+  // After a factorisation the row registers are rewritten for the substitution: Lrow[k] <- L[g][k] / L[g][g].  The factor leaves
+  // STRICTLY lower rows (registers and LDS tile: zeros on and right of the diagonal, 1 / L[g][g] in d_dinv), so this is NVP plain
+  // multiplies -- no `k < g` selects, whose 36 lane masks the compiler kept in SGPR pairs, spilled, and restored with two
+  // v_readlane in every step of the substitution that follows.  With the lane's own 1 / L[g][g] folded into its row (and into its
+  // right-hand side), step j of the forward substitution is "broadcast x_j, one fma" for every lane.
   __device__ __forceinline__ void scale_rows() {
 #pragma unroll
-    for (int k = 0; k < NVP; k++) Lrow[k] = (k >= g) ? 0.f : Lrow[k] * d_dinv;
+    for (int k = 0; k < NVP; k++) Lrow[k] *= d_dinv;
   }
 
-  // x <- (L L')^-1 x ; lane i holds x_i.  Lrow = the scaled rows (scale_rows), the LDS tile = L itself.
+  // x <- (L L')^-1 x ; lane i holds x_i.  Lrow = the scaled rows (scale_rows), the LDS tile = the strictly lower part of L.
   __device__ __forceinline__ float solve(float x) const {
+    // The column entries of the back substitution (L' z = y needs L[i][g], i > g: column g of the LDS tile, zero for i <= g) are
+    // fetched FIRST, with unconditional loads pinned ahead of the forward chain: their LDS latency hides behind the forward
+    // substitution.  (`g < i ? LT[..] : 0` compiled to a branch around a ds_read with a full s_waitcnt in EVERY step -- one LDS
+    // round trip per step, 5.5 k of the 6.3 k cycles of a 36-wide solve; unconditional but unpinned loads still waited once per
+    // two steps.)
+    const float* LT = W + o_tile + (g < NVP ? g : 0);   // LT[i*TD] = L[i][g]
+    const float ds = g < NVP ? d_dinv : 0.f;            // (lanes without a row read column 0: scaled to zero)
+    float c[NVP];
+#pragma unroll
+    for (int i = 0; i < NVP; i++) c[i] = LT[i * TD];
+    __builtin_amdgcn_sched_barrier(0);
     // L y = b:  x'_g = b_g / L_gg - sum_{k < g} (L_gk / L_gg) y_k, and y_j is lane j's x' once the steps k < j are in
     x *= d_dinv;
 #pragma unroll
     for (int j = 0; j < NVP; j++) x = fmaf(-Lrow[j], bc<G>(x, j), x);
-    // L' z = y:  x''_g = y_g / L_gg - sum_{k > g} (L_kg / L_gg) z_k; the column entries come from the tile, scaled by the lane's own
-    // 1 / L_gg off the dependent chain
-    const float* LT = W + o_tile + (g < NVP ? g : 0);   // LT[i*TD] = L[i][g]
+    // L' z = y:  x''_g = y_g / L_gg - sum_{k > g} (L_kg / L_gg) z_k; the column entries are scaled by the lane's own 1 / L_gg off
+    // the dependent chain
     x *= d_dinv;
 #pragma unroll
-    for (int i = NVP - 1; i >= 0; i--) {
-      const float c = (g < i) ? LT[i * TD] * d_dinv : 0.f;
-      x = fmaf(-c, bc<G>(x, i), x);
-    }
+    for (int i = NVP - 1; i >= 0; i--) x = fmaf(-(c[i] * ds), bc<G>(x, i), x);
     return x;
   }
 
@@ -2147,7 +2167,7 @@ struct Engine {
     d_qfrccon = 0.f;
     if (nefc == 0) { d_qacc = d_qaccsm; return; }
     const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
-#define PFN(stage, t0_) do { if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? stage : 0] += t1_ - t0_; t0_ = t1_; } } while (0)
+#define PFN(stage, t0_) do { MM_FENCE(); if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? stage : 0] += t1_ - t0_; t0_ = t1_; } } while (0)
     unsigned long long tn_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
     // warm start: qacc_warmstart is kept only if it beats the unconstrained solution
     float Ma_ws = mul_m(d_warm);
@@ -2616,7 +2636,7 @@ struct Engine {
     d_qfrccon = 0.f;
     if (nrows_wave == 0) { d_qacc = d_qaccsm; return; }
     const float scale = 1.f / (KD().meaninertia * (float)(nv > 1 ? nv : 1));
-#define PFN(stage, t0_) do { if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? stage : 0] += t1_ - t0_; t0_ = t1_; } } while (0)
+#define PFN(stage, t0_) do { MM_FENCE(); if (MM_STAGE_PROF && a.prof) { const unsigned long long t1_ = clock64(); pf[MM_STAGE_PROF ? stage : 0] += t1_ - t0_; t0_ = t1_; } } while (0)
     unsigned long long tn_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;
     float Ma_ws = mul_m(d_warm);
     float cost_ws = cost_gen(d_warm, Ma_ws);
@@ -2793,7 +2813,9 @@ struct Engine {
 #define PFT(stage, call)                                   \
   do {                                                     \
     unsigned long long t0_ = (MM_STAGE_PROF && a.prof) ? clock64() : 0;       \
+    MM_FENCE();                                            \
     call;                                                  \
+    MM_FENCE();                                            \
     if (MM_STAGE_PROF && a.prof) pf[MM_STAGE_PROF ? stage : 0] += clock64() - t0_;              \
   } while (0)
   __device__ __forceinline__ void forward() {
