@@ -2692,18 +2692,34 @@ struct Engine {
           f4v acc[NT];
 #pragma unroll
           for (int q = 0; q < NT; q++) acc[q] = f4v{0.f, 0.f, 0.f, 0.f};
-          for (int kb = 0; kb < K4; kb++) {
+          // K sweep, software-pipelined by hand: the operands of step kb + 1 are requested before the MFMAs of step kb issue, so
+          // the LDS round trip (~100 cycles for a lone wave) hides behind the three 32-cycle matrix instructions instead of
+          // preceding them.  Clamped addresses + unconditional loads + a select: `ok ? table[i] : 0` compiles to a branch around
+          // the ds_read with a full s_waitcnt behind it.
+          auto fetch = [&](const int kb, float& dsc, float (&av)[NT]) __attribute__((always_inline)) {
             const int row = 4 * kb + lk;
             const bool rok = row < erows;
-            const float dsc = rok ? Dv[row] : 0.f;
-            float av[NT];
+            const int rr = rok ? row : 0;
+            const float* Jr = Jb + rr * RS;
+            const float dl = Dv[rr];
 #pragma unroll
             for (int t = ti; t < NT; t++) {
               const int col = 16 * t + lr;
-              av[t] = (rok && col < NVP) ? Jb[row * RS + col] : 0.f;
+              const float v = Jr[col < NVP ? col : 0];
+              av[t] = (rok && col < NVP) ? v : 0.f;
             }
+            dsc = rok ? dl : 0.f;
+          };
+          float dsc, av[NT];
+          fetch(0, dsc, av);
+          for (int kb = 0; kb < K4; kb++) {
+            float dsn, an[NT];
+            fetch(kb + 1, dsn, an);
 #pragma unroll
             for (int tj = ti; tj < NT; tj++) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ti], av[tj] * dsc, acc[tj], 0, 0, 0);
+            dsc = dsn;
+#pragma unroll
+            for (int t = ti; t < NT; t++) av[t] = an[t];
           }
 #pragma unroll
           for (int tj = ti; tj < NT; tj++)

@@ -59,8 +59,8 @@ EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
 #   reorient    <64,32,GEN>  1.79 M -> 1.85 M  iterative-maxocc
 #   leg walk    <64,40,GEN>  0.71 M -> 0.79 M  iterative-ilp      (iterative-maxocc: 0.71 M; iterative-minreg loses 10-25 % everywhere)
 #   implicitfast leg <64,36,GEN,2>  kernel 0.753 -> 0.724 ms  iterative-ilp   (round 3; the self-contact hand <64,24,GEN> loses 2 % with it)
-SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp", "myosim_inst_H.hip": "iterative-ilp",
-                  "myosim_inst_J.hip": "iterative-ilp"}
+SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp",
+                  "myosim_inst_J.hip": "iterative-ilp"}   # (inst_H, the Euler leg: iterative-ilp until the stage fences went in; since then maxocc +2 %)
 # Extra per-file flags.  -sink-insts-to-avoid-spills: hand pose <32,24> 5.55 -> 5.67 M; within +-1 % (mostly -) on the others.
 FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-mllvm", "-amdgpu-set-wave-priority=1"],   # wave priority: hand +0.6 %
               "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # leg <64,36,GEN>: +0.8 %

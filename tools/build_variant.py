@@ -14,9 +14,9 @@ def comp(src):
     obj = os.path.join(out, base + ".o")
     if only and not any(o in base for o in only.split(",")):
         return os.path.join(E.CSRC, "_build", base + ".o")
-    sched = E.SCHED_STRATEGY.get(os.path.basename(src), E.SCHED_STRATEGY["default"])
+    sched = os.environ.get("VARIANT_SCHED") or E.SCHED_STRATEGY.get(os.path.basename(src), E.SCHED_STRATEGY["default"])   # VARIANT_SCHED=none: the compiler's default
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + E.EXTRA_FLAGS + E.FILE_FLAGS.get(os.path.basename(src), []) + flags + \
-          (["-mllvm", f"-amdgpu-sched-strategy={sched}"] if "inst" in base else []) + ["-c", "-o", obj, src]
+          (["-mllvm", f"-amdgpu-sched-strategy={sched}"] if "inst" in base and sched != "none" else []) + ["-c", "-o", obj, src]
     subprocess.check_call(cmd)
     return obj
 with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count()) as ex:
