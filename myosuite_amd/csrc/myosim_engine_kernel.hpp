@@ -1711,9 +1711,16 @@ struct Engine {
     }
   }
   template <int D_>
-  __device__ __forceinline__ void sg_back(const SegLane& q, float* X, const float (&F)[36], const float (&r)[SD], const float (&iv)[SD], float (&x)[SD], int t, int b) const {
+  __device__ __forceinline__ void sg_anc_x(const SegLane& q, const float* X, float (&xa)[SD], int t) const {
+    if constexpr (D_ < SD - 1) {
+      xa[D_] = X[sg_path<D_>(q)];   // (unconditional: bytes beyond the path are 0 = dof 0)
+      sg_anc_x<D_ + 1>(q, X, xa, t);
+    } else xa[D_] = 0.f;
+  }
+  template <int D_>
+  __device__ __forceinline__ void sg_back(const SegLane& q, float* X, const float (&xa)[SD], const float (&F)[36], const float (&r)[SD], const float (&iv)[SD], float (&x)[SD], int t, int b) const {
     if constexpr (D_ < SD) {
-      if (D_ < t) x[D_] = X[sg_path<D_>(q)];
+      if (D_ < t) x[D_] = xa[D_];
       else if (D_ <= b) {
         float v = r[D_] * iv[D_];
 #pragma unroll
@@ -1721,7 +1728,7 @@ struct Engine {
         x[D_] = v;
         X[sg_path<D_>(q)] = v;
       }
-      sg_back<D_ + 1>(q, X, F, r, iv, x, t, b);
+      sg_back<D_ + 1>(q, X, xa, F, r, iv, x, t, b);
     }
   }
   // add the update matrices of the child segments (nq quads of the triangle + the rhs); slots of absent children read zeros.
@@ -1802,7 +1809,14 @@ struct Engine {
     for (int k = 0; k < SD; k++) x[k] = 0.f;
     for (int sl = 0; sl < nsl; sl++) {
       const unsigned tb = byte_of(tb_lo, tb_hi, sl);
-      if (q.lv == sl) sg_back<0>(q, X, F, r, iv, x, (int)(tb & 15u), (int)(tb >> 4));
+      if (q.lv == sl) {
+        // the ancestors' solution entries (depths < t), all requested at once: one uniform branch per depth with a ds_read in it
+        // was one LDS round trip per depth (path bytes beyond the segment's top point at dof 0: harmless reads)
+        const int t_ = (int)(tb & 15u);
+        float xa[SD];
+        sg_anc_x<0>(q, X, xa, t_);
+        sg_back<0>(q, X, xa, F, r, iv, x, t_, (int)(tb >> 4));
+      }
       GSYNC();
     }
     const float out = q.depth >= 0 ? X[g] : 0.f;
@@ -3172,7 +3186,14 @@ __global__ void __launch_bounds__(512) k_engine(KArgs a) {
   float* wsbase = lds;
   if (LM) {
     uint32_t* lm = reinterpret_cast<uint32_t*>(lds);
-    for (int i = threadIdx.x; i < a.blob_words; i += blockDim.x) lm[i] = a.blob[i];
+    // 128-bit copies, four in flight per thread (word by word this was one serialised HBM / L2 round trip per 2 KB of model: 16-22
+    // of them, ~1 % of the launch)
+    const uint4* src4 = reinterpret_cast<const uint4*>(a.blob);
+    uint4* dst4 = reinterpret_cast<uint4*>(lm);
+    const int n4 = a.blob_words >> 2;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) dst4[i] = src4[i];
+    for (int i = (n4 << 2) + threadIdx.x; i < a.blob_words; i += blockDim.x) lm[i] = a.blob[i];
     __syncthreads();
     mb = lm;
     wsbase = lds + ((a.blob_words + 3) & ~3);
