@@ -2521,12 +2521,14 @@ struct Engine {
           const int rb = (int)bc<G>((float)cbase[c], p);                  // row base of contact c of pair p in THIS group (-1: none)
           if (__ballot(rb >= 0) == 0ull) continue;
           const int pb1 = (int)bc<G>((float)b1, p), pb2 = (int)bc<G>((float)b2, p), prow = (int)bc<G>((float)rowsper, p);
+          // the two bodies' dof masks: one unconditional word load each, both in flight (`g < 32 ? lo : hi` was two branches
+          // with a load and a full wait apiece, ahead of every contact's Jacobian)
+          const int w1 = bmask[2 * pb1 + ((g >> 5) & 1)], w2 = bmask[2 * pb2 + ((g >> 5) & 1)];
           const V3 pn = v3(bc<G>(cn[c].x, p), bc<G>(cn[c].y, p), bc<G>(cn[c].z, p));
           const V3 pp = v3(bc<G>(cpos[c].x, p), bc<G>(cpos[c].y, p), bc<G>(cpos[c].z, p));
           const float pmu = bc<G>(mu, p);
           if (rb < 0 || g >= nv_) continue;
-          const bool in1 = g < 32 ? (bmask[2 * pb1] >> g) & 1 : (bmask[2 * pb1 + 1] >> (g - 32)) & 1;
-          const bool in2 = g < 32 ? (bmask[2 * pb2] >> g) & 1 : (bmask[2 * pb2 + 1] >> (g - 32)) & 1;
+          const bool in1 = (w1 >> (g & 31)) & 1, in2 = (w2 >> (g & 31)) & 1;
           if (in1 == in2) continue;                                       // on neither chain, or on both (the two terms cancel)
           // contact frame (mmo_collision.inc: make_frame)
           V3 y = (pn.y < 0.5f && pn.y > -0.5f) ? v3(0.f, 1.f, 0.f) : v3(0.f, 0.f, 1.f);
@@ -2563,14 +2565,19 @@ struct Engine {
       const int desc = __float_as_int(RT[3 * g]), kind = desc & 7, id = desc >> 3;
       const float x = RT[3 * g + 1], dA = RT[3 * g + 2];
       float vel = 0.f;
-      {   // J_row . qvel with 128-bit loads (rows and the qvel table are 16-byte aligned; columns >= nv of a row are zero)
+      {   // J_row . qvel (rows are 16-byte aligned: 128-bit loads; columns >= nv of a row are zero)
+        // Straight-line over the padded width, every load unconditional and in flight at once; the tail words behind qvel[nv - 1]
+        // are finite table words (act, ctrl) under zero columns of J, masked anyway.  (The trip count nv / 4 and the tail
+        // predicates made this nine blocks with an LDS round trip each.)
         const float4* J4 = reinterpret_cast<const float4*>(Jrow(g));
         const int nv_ = KD().nv;
-        for (int k4 = 0; 4 * k4 < nv_; k4++) {
+#pragma unroll
+        for (int k4 = 0; k4 < NVP / 4; k4++) {
           const float4 j4 = J4[k4];
-          const float* qv = W + L.qvel + 4 * k4;
-          vel += j4.x * qv[0] + (4 * k4 + 1 < nv_ ? j4.y * qv[1] : 0.f) + (4 * k4 + 2 < nv_ ? j4.z * qv[2] : 0.f) +
-                 (4 * k4 + 3 < nv_ ? j4.w * qv[3] : 0.f);
+          const float* qv = W + L.qvel + 4 * k4;      // (the qvel table itself is only word-aligned)
+          const float q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
+          vel += (4 * k4 < nv_ ? j4.x * q0 : 0.f) + (4 * k4 + 1 < nv_ ? j4.y * q1 : 0.f) + (4 * k4 + 2 < nv_ ? j4.z * q2 : 0.f) +
+                 (4 * k4 + 3 < nv_ ? j4.w * q3 : 0.f);
         }
       }
       const float *si, *sr;
