@@ -2516,7 +2516,18 @@ struct Engine {
       V3 off_c = v3(0.f, 0.f, 0.f);     // subtree COM of this lane's dof (cdof is expressed about it)
       if (g < nv_) off_c = ld3(W + L.com + 3 * AUXI(dof_rootslot)[g]);
       const int* bmask = AUXI(body_dofmask);
-      for (int p = 0; p < np_; p++) {
+      // pairs that made a contact in any env group of this wave (lane p = pair p): only those are visited -- the scan over all
+      // pairs cost a broadcast + ballot + branch per (pair, contact) slot, 40 of them per pass for the hand's 20 pairs
+      unsigned long long act = __ballot(cbase[0] >= 0 || cbase[1] >= 0);
+      if constexpr (G < 64) {
+#pragma unroll
+        for (int sft = G; sft < 64; sft <<= 1) act |= act >> sft;
+        act &= (1ull << G) - 1ull;
+      }
+      (void)np_;
+      while (act) {
+        const int p = __builtin_ctzll(act);
+        act &= act - 1ull;
         for (int c = 0; c < 2; c++) {
           const int rb = (int)bc<G>((float)cbase[c], p);                  // row base of contact c of pair p in THIS group (-1: none)
           if (__ballot(rb >= 0) == 0ull) continue;
@@ -2623,9 +2634,13 @@ struct Engine {
     float s = 0.f;
     // four rows per turn: the column loads are independent of the running sum (one row per turn exposes an LDS round trip per
     // row to a lone wave).  Rows past nefc hold zeros and carry no force; the table has a multiple of four rows.
+    // ... and the next four are requested before the current four are used (the last turn re-reads its own rows)
+    float j0 = Jc[0], j1 = Jc[RS], j2 = Jc[2 * RS], j3 = Jc[3 * RS];
     for (int r = 0; r < nrows_wave; r += 4) {
-      const float j0 = Jc[r * RS], j1 = Jc[(r + 1) * RS], j2 = Jc[(r + 2) * RS], j3 = Jc[(r + 3) * RS];
+      const int rn = r + 4 < nrows_wave ? r + 4 : r;
+      const float n0 = Jc[rn * RS], n1 = Jc[(rn + 1) * RS], n2 = Jc[(rn + 2) * RS], n3 = Jc[(rn + 3) * RS];
       s += j0 * bc<G>(f, r) + j1 * bc<G>(f, r + 1) + j2 * bc<G>(f, r + 2) + j3 * bc<G>(f, r + 3);
+      j0 = n0; j1 = n1; j2 = n2; j3 = n3;
     }
     return g < KD().nv ? s : 0.f;
   }
