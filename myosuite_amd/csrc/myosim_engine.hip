@@ -686,6 +686,21 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     m->x.body_dofmask = append(bm);
     m->x.dof_desc = append(m->desc_all); m->x.dof_seg = append(m->seg_tab); m->x.dof_anc = append(m->anc_tab);
     {
+      // one word pair per joint for the per-body joint loops (Engine::kinematics / velocity_bias): type | dofadr << 4 | qposadr << 14,
+      // bits(qpos0[qposadr])
+      const int32_t* jt = (const int32_t*)(blob + m->sec[MM_SEC_JNT_TYPE]);
+      const int32_t* jd = (const int32_t*)(blob + m->sec[MM_SEC_JNT_DOFADR]);
+      const int32_t* jq = (const int32_t*)(blob + m->sec[MM_SEC_JNT_QPOSADR]);
+      const uint32_t* q0 = blob + m->sec[MM_SEC_QPOS0];
+      std::vector<int32_t> jp(2 * (size_t)std::max(d.njnt, 1), 0);
+      for (int j = 0; j < d.njnt; j++) {
+        if (jd[j] < 0 || jd[j] >= 1024 || jq[j] < 0 || jq[j] >= 1024) { delete m; return fail(MM_EUNSUPPORTED, "joint addresses beyond the engine's packed joint word (1024 dofs / qpos words)"); }
+        jp[2 * j] = (int32_t)(jt[j] | (jd[j] << 4) | (jq[j] << 14));
+        jp[2 * j + 1] = (int32_t)q0[jq[j]];
+      }
+      m->x.jnt_pack = append(jp);
+    }
+    {
       // chains of the body tree (Engine::subtree_sum).  A body starts a chain when it hangs off the world or its parent has
       // another child too; the bodies of a chain must have consecutive ids (MuJoCo's depth-first numbering gives that).
       std::vector<int32_t> tab(3 * (size_t)std::max(d.nbody, 1), -1);

@@ -112,6 +112,7 @@ struct Aux {
   int dof_desc;          // per dof: ids of all its descendants, one byte each, 0xff-padded to 8 words
   int dof_seg;           // per dof, 6 words: segment owned by the dof's lane (the segment's top dof) or -1; path and child bytes; the dof's depth
   int dof_anc;           // per dof, 2 words: ids of its ancestor dofs by depth, one byte each
+  int jnt_pack;          // per joint, 2 words: type | dofadr << 4 | qposadr << 14, bits(qpos0[qposadr]) -- one load instead of type -> address -> qpos0
   int body_chain;        // per body, 3 words: chain owned by the body's lane (its top body): bottom | level << 8 | children << 12, or -1; child chain tops, one byte each
 };
 
@@ -980,7 +981,7 @@ struct Engine {
   // ---------------------------------------------------------------- A1 kinematics
   __device__ __forceinline__ void kinematics() {
     // offsets read once and pinned in SGPRs for this stage (see PIN_S)
-    int o_xpos = KL().xpos; PIN_S(o_xpos); int o_u1 = KL().u1; PIN_S(o_u1); int o_xmat = KL().xmat; PIN_S(o_xmat); int o_xanchor = KL().xanchor; PIN_S(o_xanchor); int o_xaxis = KL().xaxis; PIN_S(o_xaxis); int o_qpos = KL().qpos; PIN_S(o_qpos); int s_JNT_TYPE = SECOFF_(JNT_TYPE); PIN_S(s_JNT_TYPE); int s_JNT_QPOSADR = SECOFF_(JNT_QPOSADR); PIN_S(s_JNT_QPOSADR); int s_JNT_POS = SECOFF_(JNT_POS); PIN_S(s_JNT_POS); int s_JNT_AXIS = SECOFF_(JNT_AXIS); PIN_S(s_JNT_AXIS); int s_QPOS0 = SECOFF_(QPOS0); PIN_S(s_QPOS0); int s_BODY_POS = SECOFF_(BODY_POS); PIN_S(s_BODY_POS); int s_BODY_QUAT = SECOFF_(BODY_QUAT); PIN_S(s_BODY_QUAT); int s_BODY_IPOS = SECOFF_(BODY_IPOS); PIN_S(s_BODY_IPOS); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_);
+    int o_xpos = KL().xpos; PIN_S(o_xpos); int o_u1 = KL().u1; PIN_S(o_u1); int o_xmat = KL().xmat; PIN_S(o_xmat); int o_xanchor = KL().xanchor; PIN_S(o_xanchor); int o_xaxis = KL().xaxis; PIN_S(o_xaxis); int o_qpos = KL().qpos; PIN_S(o_qpos); int s_JNT_POS = SECOFF_(JNT_POS); PIN_S(s_JNT_POS); int s_JNT_AXIS = SECOFF_(JNT_AXIS); PIN_S(s_JNT_AXIS); int s_QPOS0 = SECOFF_(QPOS0); PIN_S(s_QPOS0); int s_BODY_POS = SECOFF_(BODY_POS); PIN_S(s_BODY_POS); int s_BODY_QUAT = SECOFF_(BODY_QUAT); PIN_S(s_BODY_QUAT); int s_BODY_IPOS = SECOFF_(BODY_IPOS); PIN_S(s_BODY_IPOS); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_);
     const auto& L = KL();
     const V3 org = origin();
     if (g == 0) {
@@ -1005,10 +1006,22 @@ struct Engine {
       V3 pos = (a.s.body_pos_env && b == a.s.body_pos_env_id) ? ld3(a.s.body_pos_env + (size_t)env * 3) : ld3(AF_(s_BODY_POS) + 3 * b);
       if (b_parent == 0) pos = pos - org;
       Q4 quat = ldq(AF_(s_BODY_QUAT) + 4 * b);
+      // The constants of joint i + 1 are requested before joint i is worked on (a body with several joints is a serial chain in
+      // one lane; with the model read through L2 every joint paid type -> qpos address -> qpos0 as dependent misses)
+      const int* JP = AUXI(jnt_pack);
+      const int j0_ = c_ja > 0 ? c_ja : 0;
+      int pk_ = JP[2 * j0_]; float pq0_ = __int_as_float(JP[2 * j0_ + 1]);
+      V3 pjpos_ = ld3(AF_(s_JNT_POS) + 3 * j0_), pjax_ = ld3(AF_(s_JNT_AXIS) + 3 * j0_);
       for (int i = 0; i < c_jn; i++) {
         const int j = c_ja + i;
-        int type, qa; V3 jpos, jax; float q0;
-        type = AI_(s_JNT_TYPE)[j]; qa = AI_(s_JNT_QPOSADR)[j]; jpos = ld3(AF_(s_JNT_POS) + 3 * j); jax = ld3(AF_(s_JNT_AXIS) + 3 * j); q0 = AF_(s_QPOS0)[qa];
+        const int type = pk_ & 15, qa = (pk_ >> 14) & 1023;
+        const V3 jpos = pjpos_, jax = pjax_;
+        const float q0 = pq0_;
+        {
+          const int jn_ = i + 1 < c_jn ? j + 1 : j;
+          pk_ = JP[2 * jn_]; pq0_ = __int_as_float(JP[2 * jn_ + 1]);
+          pjpos_ = ld3(AF_(s_JNT_POS) + 3 * jn_); pjax_ = ld3(AF_(s_JNT_AXIS) + 3 * jn_);
+        }
         if (type == MM_JNT_FREE) {      // child of the world: its frame is the world frame
           pos = ld3(W + o_qpos + qa) - org;
           quat = qnorm(ldq(W + o_qpos + qa + 3));
@@ -1421,7 +1434,7 @@ struct Engine {
   // ----------------------------------------------------- A5 velocity stage + bias forces
   __device__ __forceinline__ void velocity_bias() {
     // offsets read once and pinned in SGPRs for this stage (see PIN_S)
-    int o_cdof = KL().cdof; PIN_S(o_cdof); int o_u1 = KL().u1; PIN_S(o_u1); int o_qvel = KL().qvel; PIN_S(o_qvel); int s_JNT_TYPE = SECOFF_(JNT_TYPE); PIN_S(s_JNT_TYPE); int s_JNT_DOFADR = SECOFF_(JNT_DOFADR); PIN_S(s_JNT_DOFADR); int s_DOF_BODYID = SECOFF_(DOF_BODYID); PIN_S(s_DOF_BODYID); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_); int d_nv_ = KD().nv; PIN_S(d_nv_);
+    int o_cdof = KL().cdof; PIN_S(o_cdof); int o_u1 = KL().u1; PIN_S(o_u1); int o_qvel = KL().qvel; PIN_S(o_qvel); int s_DOF_BODYID = SECOFF_(DOF_BODYID); PIN_S(s_DOF_BODYID); int d_nlevel_ = KD().nlevel; PIN_S(d_nlevel_); int d_nbody_ = KD().nbody; PIN_S(d_nbody_); int d_nv_ = KD().nv; PIN_S(d_nv_);
     const auto& L = KL();
     const int nb = d_nbody_;
     if (!(TW && a.two_wave)) tendon_velocity();
@@ -1437,10 +1450,13 @@ struct Engine {
     int nround = 0;
     for (int s_ = 1; s_ < d_nlevel_; s_ <<= 1) nround++;
     int* UP = reinterpret_cast<int*>(W + o_u1 + CVS * nb);   // pointer scratch behind the (cvel, cacc) slots: u1 holds >= (CVS + 1) nbody words
+    const int* JP = AUXI(jnt_pack);
+    const int j0_ = c_ja > 0 ? c_ja : 0;
     if (isb) {      // own dofs: local velocity contribution
+      int pk_ = JP[2 * j0_];
       for (int i = 0; i < c_jn; i++) {
-        int type, da;
-        type = AI_(s_JNT_TYPE)[c_ja + i]; da = AI_(s_JNT_DOFADR)[c_ja + i];
+        int type = pk_ & 15, da = (pk_ >> 4) & 1023;
+        pk_ = JP[2 * (i + 1 < c_jn ? c_ja + i + 1 : c_ja + i)];     // (the next joint's word is in flight while this one's dofs are read)
         const int nd = type == MM_JNT_FREE ? 6 : (type == MM_JNT_BALL ? 3 : 1);
         for (int d3 = 0; d3 < nd; d3++) {
           const float qv = W[o_qvel + da + d3];
@@ -1474,9 +1490,10 @@ struct Engine {
       float run[6];
 #pragma unroll
       for (int k = 0; k < 6; k++) run[k] = cv[k] - own[k];
+      int pk_ = JP[2 * j0_];
       for (int i = 0; i < c_jn; i++) {
-        int type, da;
-        type = AI_(s_JNT_TYPE)[c_ja + i]; da = AI_(s_JNT_DOFADR)[c_ja + i];
+        int type = pk_ & 15, da = (pk_ >> 4) & 1023;
+        pk_ = JP[2 * (i + 1 < c_jn ? c_ja + i + 1 : c_ja + i)];
         if (type == MM_JNT_FREE) {     // translational dofs: cdof_dot = 0, they only move the running velocity
           for (int d3 = 0; d3 < 3; d3++) {
             const float qv = W[o_qvel + da + d3];
@@ -1608,15 +1625,23 @@ struct Engine {
       for (int k = 0; k < 10; k++) I[k] = W[o_crb + 10 * b + k];
       inert_mul(buf, I, d_cdof);
       const int* dpar = AI_(s_DOF_PARENTID);
-      int j = g;
+      // ancestor walk with the parent pointer fetched one step ahead: the motion axes of ancestor j and the pointer two above it
+      // are in flight together (pointer -> axes -> pointer was two dependent round trips per level, 17 levels for the leg)
+      const float arm = AF_(s_DOF_ARMATURE)[g];
+      int j = g, jn = dpar[g];
       while (j >= 0) {
+        float cj[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cj[k] = W[o_cdof + 6 * j + k];
+        int jnn = dpar[jn >= 0 ? jn : 0];
+        jnn = jn >= 0 ? jnn : -1;
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) s += W[o_cdof + 6 * j + k] * buf[k];
-        if (j == g) s += AF_(s_DOF_ARMATURE)[g];
+        for (int k = 0; k < 6; k++) s += cj[k] * buf[k];
+        if (j == g) s += arm;
         W[o_u1 + g * TD + j] = s;
         W[o_u1 + j * TD + g] = s;
-        j = dpar[j];
+        j = jn; jn = jnn;
       }
     } else if (g < NVP) {
       W[o_u1 + g * TD + g] = 1.f;
