@@ -1955,8 +1955,10 @@ struct Engine {
   __device__ __forceinline__ void factor(float dadd) {
     if constexpr (LEFT_LOOKING) { factor_core<true>(Mrow, dadd); return; }   // left-looking: reads M[g][j] once, no copy
     float A[NVP];
+    int gq = g;
+    asm volatile("" : "+v"(gq));   // (see factor_core: lane masks are not to be shared between the inlined copies)
 #pragma unroll
-    for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == g ? dadd : 0.f);
+    for (int k = 0; k < NVP; k++) A[k] = Mrow[k] + (k == gq ? dadd : 0.f);
     factor_core<false>(A, 0.f);
   }
   template <bool DIAG>
@@ -1969,10 +1971,12 @@ struct Engine {
       // factor proceeds, LDS ops of a wave execute in order) and only the pivot is broadcast: NVP broadcasts in total.
       float* T = W + o_tile;
       const int row = g < NVP ? g : 0;
+      int gq = g;                      // (opaque per call: see the right-looking branch below)
+      asm volatile("" : "+v"(gq));
 #pragma unroll
       for (int j = 0; j < NVP; j++) {
         float s = A[j];
-        if constexpr (DIAG) s += (g == j) ? dadd : 0.f;
+        if constexpr (DIAG) s += (gq == j) ? dadd : 0.f;
 #pragma unroll
         for (int k4 = 0; k4 < (j + 3) / 4; k4++) {
           const float4 r = *reinterpret_cast<const float4*>(T + j * TD + 4 * k4);
@@ -1983,9 +1987,9 @@ struct Engine {
         }
         const float piv = bc<G>(s, j);
         const float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
-        const float lj = (g > j) ? s * inv : 0.f;    // STRICTLY lower: the diagonal lives in d_dinv (see scale_rows)
+        const float lj = (gq > j) ? s * inv : 0.f;    // STRICTLY lower: the diagonal lives in d_dinv (see scale_rows)
         Lrow[j] = lj;
-        if (g == j) d_dinv = inv;
+        if (gq == j) d_dinv = inv;
         if (g < NVP) T[row * TD + j] = lj;
       }
       if (g >= NVP) d_dinv = 1.f;
@@ -1993,15 +1997,21 @@ struct Engine {
       scale_rows();
       return;
     }
+    // The lane index the 2 NVP comparisons below use is made opaque per call: the factorisation is inlined several times per
+    // pipeline copy, the compiler shared the (g > j), (g == j) lane masks between the copies, kept 72 of them alive in SGPR
+    // pairs across the stages in between, spilled them -- and every use became two v_readlane + s_nop (690 restores in the leg
+    // kernel, ~170 per factorisation of 1476 instructions).
+    int gq = g;
+    asm volatile("" : "+v"(gq));
 #pragma unroll
     for (int j = 0; j < NVP; j++) {
       float piv = bc<G>(A[j], j);
       float inv = __frsqrt_rn(fmaxf(piv, MINVALF));
       // STRICTLY lower (the diagonal lives in d_dinv): the trailing update only needs L[k][j] of the rows k > j, and lane j's own
       // row is finished -- what the update does to its entries right of the diagonal is never read
-      float lj = (g > j) ? A[j] * inv : 0.f;
+      float lj = (gq > j) ? A[j] * inv : 0.f;
       Lrow[j] = lj;
-      if (g == j) d_dinv = inv;
+      if (gq == j) d_dinv = inv;
 #pragma unroll
       for (int k = j + 1; k < NVP; k++) A[k] -= lj * bc<G>(lj, k);
     }
