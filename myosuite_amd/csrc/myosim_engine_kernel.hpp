@@ -2112,34 +2112,42 @@ struct Engine {
     PIN_S(s_cl); PIN_S(s_cr); PIN_S(s_aa); PIN_S(s_id); PIN_S(s_gr); PIN_S(s_tt); PIN_S(s_dt); PIN_S(s_dp); PIN_S(s_lr); PIN_S(s_a0);
     PIN_S(s_gt); PIN_S(s_gp); PIN_S(s_bt); PIN_S(s_bp); PIN_S(s_fl); PIN_S(s_fr);
     for (int u = g; u < KD().nu; u += G) {
+      // Every table word of actuator u is requested up front, unconditionally: flag by flag (`if (limited[u]) .. range[u]`,
+      // three looks at dyntype, gain / bias type, ...) the loop was a chain of a dozen load -> wait -> branch links per sweep.
+      const int f_cl = AI_(s_cl)[u], aa = AI_(s_aa)[u], id = AI_(s_id)[u], f_tt = AI_(s_tt)[u], f_dt = AI_(s_dt)[u],
+                f_gt = AI_(s_gt)[u], f_bt = AI_(s_bt)[u], f_fl = AI_(s_fl)[u];
+      const float cr0 = AF_(s_cr)[2 * u], cr1 = AF_(s_cr)[2 * u + 1], gear = AF_(s_gr)[u];
+      const float lr0 = AF_(s_lr)[2 * u], lr1 = AF_(s_lr)[2 * u + 1], acc0 = AF_(s_a0)[u];
+      const float flo = AF_(s_fr)[2 * u], fhi = AF_(s_fr)[2 * u + 1];
+      float dp[3], gp[9], bp[9];
+#pragma unroll
+      for (int k = 0; k < 3; k++) dp[k] = AF_(s_dp)[3 * u + k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { gp[k] = AF_(s_gp)[9 * u + k]; bp[k] = AF_(s_bp)[9 * u + k]; }
       float ctrl = W[L.ctrl + u];
-      if (AI_(s_cl)[u]) ctrl = clampf(ctrl, AF_(s_cr)[2 * u], AF_(s_cr)[2 * u + 1]);
-      int aa = AI_(s_aa)[u], id = AI_(s_id)[u];
-      float gear = AF_(s_gr)[u], len, vel, input = ctrl;
-      bool ten = AI_(s_tt)[u] == MM_TRN_TENDON;
+      const float actv = W[L.act + (aa >= 0 ? aa : 0)];
+      if (f_cl) ctrl = clampf(ctrl, cr0, cr1);
+      float len, vel, input = ctrl;
+      const bool ten = f_tt == MM_TRN_TENDON;
       if (ten) { len = gear * W[L.tenlen + id]; vel = gear * W[L.tenvel + id]; }
       else { len = gear * W[L.qpos + MI_(JNT_QPOSADR)[id]]; vel = gear * W[L.qvel + MI_(JNT_DOFADR)[id]]; }
-      if (AI_(s_dt)[u] == MM_DYN_MUSCLE) {
-        float act = W[L.act + aa];
-        W[L.actdot + aa] = muscle_dynamics(ctrl, act, AF_(s_dp) + 3 * u);
-        input = act;
-      } else if (AI_(s_dt)[u] == MM_DYN_INTEGRATOR) {
-        W[L.actdot + aa] = ctrl; input = W[L.act + aa];
-      } else if (AI_(s_dt)[u] == MM_DYN_FILTER) {
-        const float act = W[L.act + aa];
-        W[L.actdot + aa] = (ctrl - act) / fmaxf(MINVALF, AF_(s_dp)[3 * u]); input = act;
+      if (f_dt == MM_DYN_MUSCLE) {
+        W[L.actdot + aa] = muscle_dynamics(ctrl, actv, dp);
+        input = actv;
+      } else if (f_dt == MM_DYN_INTEGRATOR) {
+        W[L.actdot + aa] = ctrl; input = actv;
+      } else if (f_dt == MM_DYN_FILTER) {
+        W[L.actdot + aa] = (ctrl - actv) / fmaxf(MINVALF, dp[0]); input = actv;
       }
-      float lr0 = AF_(s_lr)[2 * u], lr1 = AF_(s_lr)[2 * u + 1], acc0 = AF_(s_a0)[u];
       float gain, bias = 0.f;
-      if (AI_(s_gt)[u] == MM_GAIN_MUSCLE) gain = muscle_gain(len, vel, lr0, lr1, acc0, AF_(s_gp) + 9 * u);
-      else gain = AF_(s_gp)[9 * u];
-      if (AI_(s_bt)[u] == MM_BIAS_MUSCLE) bias = muscle_bias(len, lr0, lr1, acc0, AF_(s_bp) + 9 * u);
-      else if (AI_(s_bt)[u] == MM_BIAS_AFFINE)   // position / velocity servos
-        bias = AF_(s_bp)[9 * u] + AF_(s_bp)[9 * u + 1] * len + AF_(s_bp)[9 * u + 2] * vel;
+      if (f_gt == MM_GAIN_MUSCLE) gain = muscle_gain(len, vel, lr0, lr1, acc0, gp);
+      else gain = gp[0];
+      if (f_bt == MM_BIAS_MUSCLE) bias = muscle_bias(len, lr0, lr1, acc0, bp);
+      else if (f_bt == MM_BIAS_AFFINE)   // position / velocity servos
+        bias = bp[0] + bp[1] * len + bp[2] * vel;
       float f = gain * input + bias;
       bool clamped = false;
-      if (AI_(s_fl)[u]) {
-        const float flo = AF_(s_fr)[2 * u], fhi = AF_(s_fr)[2 * u + 1];
+      if (f_fl) {
         f = clampf(f, flo, fhi);
         clamped = f <= flo || f >= fhi;
       }
@@ -2149,9 +2157,9 @@ struct Engine {
       if constexpr (IMPL) {
         // s = d force / d velocity (mjd_actuator_vel: bias_vel + gain_vel * input; none while the force sits on its range)
         float s = 0.f;
-        if (AI_(s_bt)[u] == MM_BIAS_AFFINE) s = AF_(s_bp)[9 * u + 2];
-        if (AI_(s_gt)[u] == MM_GAIN_MUSCLE) {
-          const float* prm = AF_(s_gp) + 9 * u;
+        if (f_bt == MM_BIAS_AFFINE) s = bp[2];
+        if (f_gt == MM_GAIN_MUSCLE) {
+          const float* prm = gp;
           const float force = muscle_f0(prm, acc0);
           const float L0 = (lr1 - lr0) / fmaxf(MINVALF, prm[1] - prm[0]);
           const float Ln = prm[0] + (len - lr0) / fmaxf(MINVALF, L0);
