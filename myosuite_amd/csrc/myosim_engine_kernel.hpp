@@ -2196,12 +2196,22 @@ struct Engine {
     d_smooth = 0.f;
     if (g < KD().nv) {
       float s = -MF_(DOF_DAMPING)[g] * d_qvel - d_bias + W[L.vec + g];
-      int j = MI_(DOF_JNTID)[g];
-      float ks = MF_(JNT_STIFFNESS)[j];
-      int type = MI_(JNT_TYPE)[j];
-      if (ks != 0.f && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
-        int qa = MI_(JNT_QPOSADR)[j];
-        s -= ks * (W[L.qpos + qa] - MF_(QPOS_SPRING)[qa]);
+      if constexpr (GEN) {
+        // (general-row kernels: the joint's words at once, position and spring reference unconditionally -- two round trips, no
+        // branch in between: leg +1 %.  The same form costs the 250-VGPR hand kernel 0.7 %: it keeps the chain.)
+        const int j = c_rowj;                       // = DOF_JNTID[g], held since the constructor
+        const float ks = MF_(JNT_STIFFNESS)[j];
+        const int type = MI_(JNT_TYPE)[j], qa = MI_(JNT_QPOSADR)[j];
+        const float qs = W[L.qpos + qa], q0s = MF_(QPOS_SPRING)[qa];
+        if (ks != 0.f && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) s -= ks * (qs - q0s);
+      } else {
+        int j = MI_(DOF_JNTID)[g];
+        float ks = MF_(JNT_STIFFNESS)[j];
+        int type = MI_(JNT_TYPE)[j];
+        if (ks != 0.f && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+          int qa = MI_(JNT_QPOSADR)[j];
+          s -= ks * (W[L.qpos + qa] - MF_(QPOS_SPRING)[qa]);
+        }
       }
       d_smooth = s;
     }
@@ -2415,12 +2425,14 @@ struct Engine {
     int lim = 0, ldof = 0;
     float ldist = 0.f, lsign = 1.f, lmargin = 0.f;
     if (g < KD().njnt) {
-      const int j = g, type = MI_(JNT_TYPE)[j];
-      if (MI_(JNT_LIMITED)[j] && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
-        ldof = MI_(JNT_DOFADR)[j];
-        float q = W[L.qpos + MI_(JNT_QPOSADR)[j]];
-        lmargin = MF_(JNT_MARGIN)[j];
-        float dlo = q - MF_(JNT_RANGE)[2 * j], dhi = MF_(JNT_RANGE)[2 * j + 1] - q;
+      // (all table words of the joint at once, then its position: no load -> branch -> load chain)
+      const int j = g, type = MI_(JNT_TYPE)[j], limited = MI_(JNT_LIMITED)[j], da = MI_(JNT_DOFADR)[j], qa = MI_(JNT_QPOSADR)[j];
+      const float mg = MF_(JNT_MARGIN)[j], rlo = MF_(JNT_RANGE)[2 * j], rhi = MF_(JNT_RANGE)[2 * j + 1];
+      const float q = W[L.qpos + qa];
+      if (limited && (type == MM_JNT_HINGE || type == MM_JNT_SLIDE)) {
+        ldof = da;
+        lmargin = mg;
+        float dlo = q - rlo, dhi = rhi - q;
         ldist = dlo;
         if (!(dlo < lmargin) && dhi < lmargin) { ldist = dhi; lsign = -1.f; }
         lim = ldist < lmargin ? 1 : 0;
@@ -2990,9 +3002,10 @@ struct Engine {
     }
     for (int u = g; u < KD().nu; u += G) {
       int aa = MI_(ACT_ACTADR)[u];
+      const int dt_ = GEN ? MI_(ACT_DYNTYPE)[u] : 0;     // (general-row kernels: both words at once)
       if (aa < 0) continue;
       float x = W[L.act + aa] + h * W[L.actdot + aa];
-      if (MI_(ACT_DYNTYPE)[u] == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
+      if ((GEN ? dt_ : MI_(ACT_DYNTYPE)[u]) == MM_DYN_MUSCLE) x = clampf(x, 0.f, 1.f);
       W[L.act + aa] = x;
     }
     if (g < KD().nv) {
