@@ -198,9 +198,25 @@ struct KConst { Dims d; Layout L; Aux x; int sec[MM_NSEC]; };
 #define KL() (KCB_().L)
 #define KX() (KCB_().x)
 #endif
-#define MI_(S) (reinterpret_cast<const int*>(mb + SECOFF_(S)))
-#define MF_(S) (reinterpret_cast<const float*>(mb + SECOFF_(S)))
-#define AUXI(f) (reinterpret_cast<const int*>(mb + KX().f))
+// A model table = (base of the model words, 32-bit word offset).  Element access builds the BYTE offset in 32 bits and adds it to
+// the base as an unsigned value: with the model read through L2 (LM = 0 kernels: `mb` is a uniform global pointer) that is the
+// `global_load v, v_off, s[base]` form -- one VGPR and one shift per load -- where indexing a `const T*` with an int index is a
+// sign extension + 64-bit add into a VGPR pair per load (659 such loads in the reorient kernel, 7 % of its VALU instructions and
+// most of its spills).  Converts to a plain pointer where a callee wants one (the old, slower path).
+template <class T>
+struct Tab {
+  const uint32_t* b;
+  uint32_t o;
+  __device__ __forceinline__ T operator[](int i) const {
+    const uint32_t byte = (o << 2) + (uint32_t)i * (uint32_t)sizeof(T);
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(b) + byte);
+  }
+  __device__ __forceinline__ Tab operator+(int i) const { return Tab{b, o + (uint32_t)i * (uint32_t)(sizeof(T) / 4)}; }
+  __device__ __forceinline__ operator const T*() const { return reinterpret_cast<const T*>(b + o); }
+};
+#define MI_(S) (Tab<int>{mb, (uint32_t)SECOFF_(S)})
+#define MF_(S) (Tab<float>{mb, (uint32_t)SECOFF_(S)})
+#define AUXI(f) (Tab<int>{mb, (uint32_t)KX().f})
 
 #define GSYNC()                                           \
   do {                                                    \
@@ -220,9 +236,11 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ V3 ld3(const float* p) { return v3(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 ld3(Tab<float> p) { return v3(p[0], p[1], p[2]); }
 __device__ __forceinline__ void st3(float* p, V3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
 struct Q4 { float w, x, y, z; };
 __device__ __forceinline__ Q4 ldq(const float* p) { Q4 q = {p[0], p[1], p[2], p[3]}; return q; }
+__device__ __forceinline__ Q4 ldq(Tab<float> p) { Q4 q = {p[0], p[1], p[2], p[3]}; return q; }
 __device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
   Q4 r;
   r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
@@ -732,8 +750,8 @@ __device__ __forceinline__ float muscle_dynamics(float ctrl, float act, const fl
    folds away when the value already sits in an SGPR; without it the backend dies with "illegal VGPR to SGPR copy" in the
    instantiations where it had moved the (uniform) value's computation to the vector ALU. */
 #define PIN_S(x) do { (x) = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); } while (0)
-#define AI_(o) (reinterpret_cast<const int*>(mb + (o)))
-#define AF_(o) (reinterpret_cast<const float*>(mb + (o)))
+#define AI_(o) (Tab<int>{mb, (uint32_t)(o)})
+#define AF_(o) (Tab<float>{mb, (uint32_t)(o)})
 // What a lane knows about the dof-tree segment it owns (sp_factor_solve): depth range [t, b] of the segment, its step in the
 // elimination order (-1: the lane owns none), its index (slot of its update matrix), the dof ids on the path root .. bottom by
 // depth, the child segment indices (0xff = none); depth = depth of the lane's own dof (-1: no dof).
