@@ -781,7 +781,10 @@ struct Engine {
   // the wave always take it (a broadcast costs ~5 issue slots there).  One env per wave: it wins where two or more waves per SIMD
   // keep the issue ports busy (hand-family models at their batch sizes: reorient +3.4 %) and loses where a lone wave per SIMD
   // waits on latency (leg-walk at 1024 envs: -7 %); the tile width stands in for that distinction.
-  static constexpr bool LEFT_LOOKING = NVP >= 8 && (G < 64 || NVP <= 32);
+#ifndef MM_LEFT_LOOKING_MAX
+#define MM_LEFT_LOOKING_MAX 32   /* widest one-env-per-wave tile factorised left-looking (A/B: 36 = the leg too) */
+#endif
+  static constexpr bool LEFT_LOOKING = NVP >= 8 && (G < 64 || NVP <= MM_LEFT_LOOKING_MAX);
   // M x and J x with x through an LDS vector (one write, NVP / 4 broadcast 128-bit reads) instead of NVP cross-lane broadcasts:
   // always for narrow groups; one env per wave, measured per tile width: 24-wide (self-contact hand) +1.2 %, 32-wide (reorient) -2.7 %
   static constexpr bool LDS_VECTOR = NVP >= 8 && (G < 64 || NVP <= 24);
