@@ -64,6 +64,7 @@ SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative
 # Extra per-file flags.  -sink-insts-to-avoid-spills: hand pose <32,24> 5.55 -> 5.67 M; within +-1 % (mostly -) on the others.
 FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-mllvm", "-amdgpu-set-wave-priority=1"],   # wave priority: hand +0.6 %
               "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # leg <64,36,GEN>: +0.8 %
+              "myosim_inst_I.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # self-contact hand <64,24,GEN>: VGPR spills 14 -> 0 (end of round 3)
               # reorient <64,32,GEN>: VGPR spills 74 -> 18 (model-in-LDS variant 47 -> 0), kernel 0.705 -> 0.686 ms (+3 %), and 4x
               # less scratch traffic for a kernel whose time followed the box's memory clock.  The same flag on the 24-wide and
               # implicitfast general-row units (inst_I, inst_J) loses 1 %: not set there.
