@@ -1,0 +1,68 @@
+"""Static resource ratchet of the shipped kernels (no GPU): the gfx950 code objects are pulled out of the built library's offload
+bundles and their AMDGPU metadata notes read -- the instantiations the BASELINE workloads launch must not spill vector registers
+(a spilled VGPR in these 250-VGPR kernels is scratch traffic to HBM in the hot loops: round 3 took reorient from 74 to 0, the
+self-contact hand from 26 to 0, and the SGPR spills of the general-row kernels from 420...570 to below 260)."""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from myosuite_amd import engine as E
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _device_objects(path):
+    d = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    i = d.find(magic)
+    while i >= 0:
+        p = i + len(magic)
+        (n,) = struct.unpack_from("<Q", d, p); p += 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", d, p); p += 24
+            triple = d[p:p + tl].decode(); p += tl
+            if "gfx950" in triple and size:
+                yield d[i + off:i + off + size]
+        i = d.find(magic, i + len(magic))
+
+
+def _kernel_table():
+    import isa_stats
+    tab = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, blob in enumerate(_device_objects(E.LIB_PATH)):
+            f = os.path.join(tmp, f"{k}.co")
+            open(f, "wb").write(blob)
+            for rec in isa_stats.notes(f):
+                tab[rec["name"]] = rec
+    return tab
+
+
+@pytest.mark.skipif(not (os.path.exists(E.LIB_PATH) and os.path.exists(READELF)), reason="needs the built library and llvm-readelf")
+def test_shipped_bench_kernels_do_not_spill_vector_registers():
+    tab = _kernel_table()
+    assert len(tab) >= 60, f"only {len(tab)} kernels found in {E.LIB_PATH}"
+    # <lanes, width, model in LDS, general rows, integrator, reset-observation>: what bench.py's seven workloads launch
+    def mangled(lanes, width, lds_model, gen, integ, obs=0):   # k_engine<lanes, width, lds_model, gen, integ, obs>(KArgs)
+        return f"_Z8k_engineILi{lanes}ELi{width}ELb{lds_model}ELb{gen}ELi{integ}ELb{obs}EEv5KArgs"
+    no_spill = [mangled(32, 24, 1, 0, 0),     # hand pose, 4096 envs (headline)
+                mangled(8, 4, 1, 0, 0),       # elbow, 4096 envs
+                mangled(64, 36, 1, 1, 0),     # leg walk, 1024 envs
+                mangled(64, 32, 0, 1, 0),     # reorient, 2048 envs (model through L2)
+                mangled(64, 24, 1, 1, 0)]     # self-contact hand, 4096 envs
+    for name in no_spill:
+        assert name in tab, (name, sorted(tab)[:4])
+        assert int(tab[name]["vgpr_spill_count"]) == 0, tab[name]
+        assert int(tab[name]["vgpr_count"]) <= 256
+    # ratchets: the implicitfast leg still spills (26), SGPR spills of the general-row kernels stay below 260
+    legi = mangled(64, 36, 1, 1, 2)
+    assert int(tab[legi]["vgpr_spill_count"]) <= 40, tab[legi]
+    for name in no_spill[2:] + [legi]:
+        assert int(tab[name]["sgpr_spill_count"]) < 260, tab[name]
