@@ -36,7 +36,13 @@ EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v
                  # the step of the reference's own GPU path: mjx_env.step = n_substeps x mjx.step, observation straight from the
                  # stepped data (envs/myo/mjx/mjx_base_env.py:74-91) -- no trailing mj_forward as in the CPU path
                  # (robot.py:595-607), whose outputs the Pose observation / reward do not read.  NOT the headline protocol.
-                 ("myoHandPoseRandom-v0", 4096, {"do_forward": False})]
+                 ("myoHandPoseRandom-v0", 4096, {"do_forward": False}),
+                 # precision mode (include/myosim.h MM_PREC_F64_STATE): the same launch over real = double with fp64 state rows --
+                 # the kernels that meet "state divergence < 1e-4 rel over 1000 steps" on every env (tests/test_gpu_widths.py)
+                 ("myoHandPoseRandom-v0", 4096, {"precision": "f64_state"}),
+                 ("myoElbowPose1D6MRandom-v0", 4096, {"precision": "f64_state"}),
+                 # the one workload the reference publishes GPU numbers for (MjxHandReachRandom-v0)
+                 ("myoHandReachRandom-v0", 4096, {})]
 
 
 def algorithmic_bytes(env) -> int:
@@ -53,7 +59,8 @@ def algorithmic_bytes(env) -> int:
         n_aux += 3 * cm.na          # MA / MR / MF
     if cm.npair > 0 or cm.neq > 0:
         n_aux += cm.nv              # qacc_warmstart
-    return 4 * (2 * (cm.nq + cm.nv + cm.na) + cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
+    sw = 8 if getattr(env, "precision", 0) == 2 else 4      # MM_PREC_F64_STATE: the state rows are fp64
+    return sw * 2 * (cm.nq + cm.nv + cm.na) + 4 * (cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
 
 
 def workload_key(env_id: str, n: int, overrides=None) -> str:
@@ -345,6 +352,7 @@ def main():
                     ks = int(max(8, args.steps // 2, min(2000, EXTRA_MIN_TIMED_MS / max(km0, 1e-3))))
                     el, km, ev, st = measure(env_id, ne, ks, max(2, args.warmup // 2), 0, 1, overrides=ov)
                     extra.append({"workload": tag, "key": workload_key(env_id, ne, ov), "value": ne * ks / el, "unit": "env-steps/s", "steps": ks,
+                                  "dtype": {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64"}[int(getattr(ev, "precision", 0))],
                                   "ms_per_step": 1e3 * el / ks, "lanes_per_env": ev.hm.launch_lanes(ne),
                                   "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": roofline(ev, env_id, ne, km, ov),
                                   "status_or": status_or(ev.state.status)})

@@ -66,8 +66,9 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
  * struct sizes with mm_struct_size().  History: 1 = round 1; 2 = mm_state.env_index_base, mm_env_draw(env_index_base), status
   * bits renumbered, the mm_rollout struct -- round 2, shipped under the version STRING of round 1; 3 = this constant + mm_abi_version /
  * mm_struct_size; 4 = mm_task.size / mm_rollout.size (append-only growth of the two structs that gain fields per task); 5 = mm_rollout gains the
- * walk / reorient reset fields (appended: an ABI-4 caller's shorter struct is still accepted). */
-#define MM_ABI_VERSION 5
+ * walk / reorient reset fields (appended: an ABI-4 caller's shorter struct is still accepted); 6 = the "precision" option: under
+ * MM_PREC_F64_STATE four mm_state pointers address fp64 rows (no struct changed: an ABI-5 caller that never sets the option is unaffected). */
+#define MM_ABI_VERSION 6
 enum { MM_STRUCT_STATE = 0, MM_STRUCT_DERIVED, MM_STRUCT_TASK, MM_STRUCT_ROLLOUT };
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
@@ -264,8 +265,20 @@ int  mm_model_info(const mm_model* m, int which);
 int  mm_model_set_lanes(mm_model* m, int lanes_per_env);
 /* tuning knobs: "lds_model" (1 = stage the model tables in LDS unless that costs resident waves the batch needs,
    0 = never, 2 = always), "waves_per_block" (0 = auto), "origin_shift" (1 = the kernel works in a frame centred on the
-   model; 0 = raw world coordinates, for the fp32 error study) */
+   model; 0 = raw world coordinates, for the fp32 error study),
+   "precision" (MM_PREC_*, below) */
 int  mm_model_set_option(mm_model* m, const char* name, int value);
+/* "precision": which kernel family steps the model.
+     MM_PREC_F32        the default: fp32 arithmetic, tables and state rows (the throughput kernels).
+     MM_PREC_F64        the same pipeline with fp64 arithmetic, registers and on-chip tables; every buffer of the ABI keeps its
+                        type (state rows fp32: the state is rounded once per launch, not per substep), so any caller can switch.
+     MM_PREC_F64_STATE  as MM_PREC_F64, and mm_state.qpos / qvel / act / qacc_warmstart point to FLOAT64 rows [nenv][n] (the
+                        pointers keep their declared type; time, actions, targets, observations, rewards stay fp32).  This is
+                        the mode that meets "state divergence vs CPU mj_step < 1e-4 rel over 1000 steps" on every env: MuJoCo's
+                        mjtNum is double, and an fp32 state row alone already breaks the bound on ~1.5 % of the hand's envs.
+   Available for limit-rows-only models (no contacts / equalities / friction loss) on the Euler integrator with nv <= 24 --
+   BASELINE.json's configs 2-3; MM_EUNSUPPORTED otherwise.  Model tables (the MYOB blob) are fp32 in every mode.  */
+enum { MM_PREC_F32 = 0, MM_PREC_F64 = 1, MM_PREC_F64_STATE = 2 };
 /* lanes per env a launch over `nenv` envs will use (the width is picked per launch from the batch size unless pinned
    with mm_model_set_lanes or fixed by the model's constraint tables) */
 int  mm_model_launch_lanes(const mm_model* m, int nenv);

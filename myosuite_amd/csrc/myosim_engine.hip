@@ -5,9 +5,13 @@
 #include <algorithm>
 #include <atomic>
 #include "myosim_engine_kernel.hpp"
+#include "myosim_engine_kernel_f64.hpp"
 #include "myosim_inst_list.hpp"
 MM_KERNEL_LIST(MM_DECLARE)
 MM_KERNELS_OBS(MM_DECLARE_OBS)
+namespace mm64 {
+MM_KERNELS_F64(MM_DECLARE)
+}
 
 // Philox4x32-10 / u01: myosim_engine_kernel.hpp
 // out[i] = word (first+i)%4 of Philox counter ((first+i)/4, stream_id): one thread per counter
@@ -34,7 +38,12 @@ struct ResetArgs {
   int32_t* reor_gtype;   // non-null: also draw the object type (tables [4][ntab][3])
   int pen; float pen_axis_half, pen_lo0, pen_hi0, pen_lo1, pen_hi1;   // pen-twirl reset: fixed geometry, euler ranges
   int hold; const float* hold_center; float hold_half, hold_slo, hold_shi; float* hold_goal; float* hold_gsize;
+  int state_f64;   // MM_PREC_F64_STATE: the four state rows of mm_state are fp64
 };
+// one element of a state row (fp32, or fp64 behind the same pointer in precision mode MM_PREC_F64_STATE)
+__device__ __forceinline__ void st_row(float* p, size_t i, float v, int f64) {
+  if (f64) reinterpret_cast<double*>(p)[i] = (double)v; else p[i] = v;
+}
 
 __global__ void k_reset(ResetArgs r) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,7 +63,7 @@ __global__ void k_reset(ResetArgs r) {
       if (r.random_qpos) q = r.qlo[i] + (r.qhi[i] - r.qlo[i]) * uq;
       if (r.target) r.target[(size_t)e * r.nq + i] = r.tlo[i] + (r.thi[i] - r.tlo[i]) * ut;
     }
-    r.s.qpos[(size_t)e * r.nq + i] = q;
+    st_row(r.s.qpos, (size_t)e * r.nq + i, q, r.state_f64);
     if (r.pose && r.obs) {  // first observation of the new episode: qvel = act = 0
       float* ob = r.obs + (size_t)e * r.obs_dim;
       ob[i] = q;
@@ -149,15 +158,15 @@ __global__ void k_reset(ResetArgs r) {
         float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = u01(c[1]);
         q += 0.02f * sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
       }
-      r.s.qpos[(size_t)e * r.nq + i] = q;
+      st_row(r.s.qpos, (size_t)e * r.nq + i, q, r.state_f64);
     }
-    for (int i = 0; i < r.nv; i++) r.s.qvel[(size_t)e * r.nv + i] = kv[i];
+    for (int i = 0; i < r.nv; i++) st_row(r.s.qvel, (size_t)e * r.nv + i, kv[i], r.state_f64);
   }
   for (int i = 0; i < r.nv; i++) {
-    if (!r.walk) r.s.qvel[(size_t)e * r.nv + i] = r.qvel_src ? r.qvel_src[(size_t)e * r.nv + i] : 0.f;
-    r.s.qacc_warmstart[(size_t)e * r.nv + i] = 0.f;
+    if (!r.walk) st_row(r.s.qvel, (size_t)e * r.nv + i, r.qvel_src ? r.qvel_src[(size_t)e * r.nv + i] : 0.f, r.state_f64);
+    st_row(r.s.qacc_warmstart, (size_t)e * r.nv + i, 0.f, r.state_f64);
   }
-  for (int i = 0; i < r.na; i++) r.s.act[(size_t)e * r.na + i] = 0.f;
+  for (int i = 0; i < r.na; i++) st_row(r.s.act, (size_t)e * r.na + i, 0.f, r.state_f64);
   r.s.time[e] = 0.f;
   if (r.s.status) r.s.status[e] = 0;
   if (r.step_count) r.step_count[e] = 0;
@@ -185,6 +194,7 @@ struct mm_model {
   std::vector<int32_t> desc_all, seg_tab, anc_tab;   // Aux::dof_desc / dof_seg / dof_anc, built with the dims
   int nseg = 0;                             // segments of the dof tree (SP kernels)
   int nwrapitem = 0;                        // tendon path items that wrap a geom (tangent points kept in LDS)
+  int precision = MM_PREC_F32;              // MM_PREC_*: which kernel family steps this model (mm_model_set_option "precision")
 };
 
 static int upload_consts(mm_model* m);
@@ -198,7 +208,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mm_version(void) { return "myosim-hip 0.3 (gfx950, lane=item engine, ABI 5)"; }
+extern "C" const char* mm_version(void) { return "myosim-hip 0.4 (gfx950, lane=item engine, ABI 6)"; }
 extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
 extern "C" int mm_struct_size(int which) {
   switch (which) {
@@ -218,6 +228,19 @@ static bool have_kernel(int G, int nvp, int gen, int rk4 = 0) {
   MM_KERNEL_LIST(X)
 #undef X
   return false;
+}
+
+// ... and of the precision-mode family (mm64::k_engine: limit-rows-only models, Euler)
+static bool have_kernel_f64(int G, int nvp, int gen, int rk4) {
+#define X(G_, N_, GN_, RK_) if (G == G_ && nvp == N_ && gen == GN_ && rk4 == RK_) return true;
+  MM_KERNELS_F64(X)
+#undef X
+  return false;
+}
+// the check every width decision goes through: a compiled instantiation of the model's kernel family
+static bool have_model_kernel(const mm_model* m, int G) {
+  const int rk = integ_kernel(m->d.integrator);
+  return m->precision != MM_PREC_F32 ? have_kernel_f64(G, m->nvp, m->d.gen, rk) : have_kernel(G, m->nvp, m->d.gen, rk);
 }
 
 // LDS tables of one env.  two_wave: the layout of a launch that gives every env a helper wave (Engine::TW): tables that share words
@@ -274,8 +297,9 @@ static void build_layout(mm_model* m) {
   const Dims& d = m->d;
   m->L = env_layout(m, false);
   m->Ltw = env_layout(m, true);
-  m->lds_per_env = (size_t)m->L.total * 4;
-  m->lds_per_env_tw = (size_t)m->Ltw.total * 4;
+  const size_t word = m->precision != MM_PREC_F32 ? 8 : 4;   // the tables hold `real`: precision mode doubles them
+  m->lds_per_env = (size_t)m->L.total * word;
+  m->lds_per_env_tw = (size_t)m->Ltw.total * word;
   int o = 0;
   auto take = [&](int n) { int r = o; o += (n > 0 ? n : 0); return r; };
   DbgLayout& D = m->D;
@@ -793,7 +817,7 @@ extern "C" void mm_model_destroy(mm_model* m) {
 extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
   if (!m) return MM_EARG;
   if (lanes == 0) return MM_OK;
-  if (!check_lanes(m, lanes) || !have_kernel(lanes, m->nvp, m->d.gen, integ_kernel(m->d.integrator)))
+  if (!check_lanes(m, lanes) || !have_model_kernel(m, lanes))
     return fail(MM_EARG, "lanes_per_env must be 4/8/16/32/64, >= nbody, nv, njnt, padded nv (and constraint rows), with a compiled kernel");
   m->lanes = lanes;
   m->lanes_auto = 0;
@@ -805,6 +829,24 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
   if (!m || !name) return MM_EARG;
   if (!strcmp(name, "lds_model")) { m->lds_model = value; return MM_OK; }
   if (!strcmp(name, "waves_per_block")) { m->waves_per_block = value; return MM_OK; }
+  if (!strcmp(name, "precision")) {
+    // MM_PREC_F32 (default): the fp32 kernels.  MM_PREC_F64: fp64 arithmetic, registers and LDS tables; state rows stay fp32 (a
+    // drop-in for every caller).  MM_PREC_F64_STATE: the four state rows of mm_state are fp64 as well.  (include/myosim.h)
+    if (value != MM_PREC_F32 && value != MM_PREC_F64 && value != MM_PREC_F64_STATE) return fail(MM_EARG, "precision: MM_PREC_F32 / MM_PREC_F64 / MM_PREC_F64_STATE");
+    if (value != MM_PREC_F32) {
+      bool any = false;
+      for (int c : {4, 8, 16, 32, 64}) any = any || (check_lanes(m, c) && have_kernel_f64(c, m->nvp, m->d.gen, integ_kernel(m->d.integrator)));
+      if (!any) return fail(MM_EUNSUPPORTED, "precision: the fp64 kernels cover limit-rows-only models (no contacts / equalities / friction loss) on the Euler integrator, nv <= 24");
+    }
+    const int old = m->precision;
+    m->precision = value;
+    if (!m->lanes_auto && !have_model_kernel(m, m->lanes)) { m->precision = old; return fail(MM_EUNSUPPORTED, "precision: no kernel of that family at the pinned lanes_per_env"); }
+    if (m->lanes_auto && !have_model_kernel(m, m->lanes)) {   // default width of the family
+      for (int c : {64, 32, 16, 8, 4}) if (check_lanes(m, c) && have_model_kernel(m, c)) m->lanes = c;
+    }
+    build_layout(m);
+    return upload_consts(m);
+  }
   if (!strcmp(name, "origin_shift")) {   // 0: the kernel works in raw world coordinates (A/B of the fp32 error study)
     m->d.ox = value ? m->origin[0] : 0.f; m->d.oy = value ? m->origin[1] : 0.f; m->d.oz = value ? m->origin[2] : 0.f;
     return upload_consts(m);
@@ -861,6 +903,21 @@ static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t l
   return MM_OK;
 }
 
+template <int G, int NVP, bool GEN, int RK4>
+static int launch_f64_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st, int lm) {
+  static std::atomic<unsigned> attr_done[2] = {{0u}, {0u}};
+  const unsigned bit = m->device < 32 ? (1u << m->device) : 0u;
+  if (!(attr_done[lm].load(std::memory_order_acquire) & bit) || !bit) {
+    if (lm) HIPCHK(hipFuncSetAttribute((const void*)mm64::k_engine<G, NVP, true, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    else HIPCHK(hipFuncSetAttribute((const void*)mm64::k_engine<G, NVP, false, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[lm].fetch_or(bit, std::memory_order_release);
+  }
+  if (lm) hipLaunchKernelGGL((mm64::k_engine<G, NVP, true, GEN, RK4>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((mm64::k_engine<G, NVP, false, GEN, RK4>), grid, block, lds, st, a);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
 static bool have_obs_kernel(int G, int nvp, int gen, int rk4) {
 #define X(G_, N_, GN_, RK_) if (G == G_ && nvp == N_ && gen == GN_ && rk4 == RK_) return true;
   MM_KERNELS_OBS(X)
@@ -888,7 +945,7 @@ static int pick_lanes(const mm_model* m, int nenv) {
   if (m->lanes_auto && !m->d.gen) {
     int best = 0;
     for (int c : {4, 8, 16, 32, 64}) {
-      if (!check_lanes(m, c) || !have_kernel(c, m->nvp, 0)) continue;
+      if (!check_lanes(m, c) || !have_model_kernel(m, c)) continue;
       best = c;
       if ((nenv + (64 / c) - 1) / (64 / c) >= 512) break;
     }
@@ -933,6 +990,11 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   // SIMDs without a wave (<= 4 env waves per CU: the block still fits the 512-thread launch bound with the helpers in it) and
   // the larger per-env tables (a second dense tile) do not cost env waves
   int two_wave = (g_two_wave && integ_kernel(m->d.integrator) != 1 && want <= 4 && m->waves_per_block <= 0) ? 1 : 0;
+  // precision-mode kernels: a lane's register state doubles, so they are built for one wave per SIMD (256-thread blocks, up to
+  // 512 VGPRs + AGPRs per lane); no helper waves
+  const bool f64 = m->precision != MM_PREC_F32;
+  const int max_wpb = f64 ? 4 : 8;              // __launch_bounds__ of the family
+  if (f64) { two_wave = 0; if (want > max_wpb) want = max_wpb; }
   // the reset-observation pass of a task (mm_task.obs_only) has its own kernel symbol where one is compiled (model through L2)
   const bool obs_kernel = a.mode == 2 && a.t.obs_only && have_obs_kernel(G, m->nvp, m->d.gen, integ_kernel(m->d.integrator));
   int lm = 0, wpb = 0;
@@ -940,7 +1002,7 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   for (;;) {
     per_env = two_wave ? m->lds_per_env_tw : m->lds_per_env;
     auto fit_waves = [&](size_t mbytes) {   // waves of one block that fit in LDS next to the model copy (<= 8)
-      int fit = 8;                             // __launch_bounds__(512)
+      int fit = max_wpb;                       // __launch_bounds__ (512 threads; 256 in precision mode)
       while (fit > 1 && mbytes + (size_t)fit * epw * per_env > kLds) fit--;
       return fit;
     };
@@ -948,7 +1010,7 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
     if (m->lds_model == 1 && fit_waves(blob_bytes) < want && fit_waves(0) > fit_waves(blob_bytes)) lm = 0;
     if (m->lds_model == 1 && blob_bytes + (size_t)epw * per_env > kLds) lm = 0;   // not even one wave fits next to the model copy
     model_bytes = lm ? blob_bytes : 0;
-    wpb = m->waves_per_block;
+    wpb = std::min(m->waves_per_block, max_wpb);
     if (wpb <= 0) {
       // one block per CU sharing one model copy: as many waves as fit in LDS, but no fatter than needed
       wpb = want;
@@ -968,6 +1030,14 @@ static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int
   a.blob_words = m->blob_words;
   a.prof = g_prof;
   const int rk4 = integ_kernel(m->d.integrator);
+  a.state_f64 = m->precision == MM_PREC_F64_STATE ? 1 : 0;
+  if (f64) {
+#define X(G_, N_, GN_, RK_) \
+    if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_f64_t<G_, N_, GN_ != 0, RK_>(m, a, grid, block, lds, st, lm);
+    MM_KERNELS_F64(X)
+#undef X
+    return fail(MM_EUNSUPPORTED, "no compiled precision-mode kernel for this (lanes_per_env, nv) combination");
+  }
   if (obs_kernel) {
 #define X(G_, N_, GN_, RK_) \
     if (G == G_ && m->nvp == N_ && m->d.gen == GN_ && rk4 == RK_) return launch_obs_t<G_, N_, GN_ != 0, RK_>(m, a, grid, block, lds, st);
@@ -1102,7 +1172,7 @@ extern "C" int mm_reset(const mm_model* m, const mm_state* s, const uint8_t* mas
                         const float* qvel_src, void* stream) {
   if (!m || !s) return fail(MM_EARG, "mm_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.qpos_src = qpos_src; r.qvel_src = qvel_src;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
   HIPCHK(hipGetLastError());
@@ -1116,7 +1186,7 @@ extern "C" int mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t
   if (!m || !s || !tlo || !thi || !target) return fail(MM_EARG, "mm_pose_reset: bad argument");
   if (random_qpos && (!qlo || !qhi)) return fail(MM_EARG, "mm_pose_reset: random_qpos needs qlo/qhi");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask;
   r.qlo = qlo; r.qhi = qhi; r.tlo = tlo; r.thi = thi; r.target = target; r.episode = episode;
   r.step_count = step_count; r.seed = seed; r.pose = 1; r.random_qpos = random_qpos;
@@ -1205,7 +1275,7 @@ extern "C" int mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_
                               uint64_t seed, float* obs, int obs_dim, void* stream) {
   if (!m || !s || !tlo || !thi || !target || !tip0 || ntip <= 0) return fail(MM_EARG, "mm_reach_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask;
   r.tlo = tlo; r.thi = thi; r.target = target; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.reach = 1; r.ntip = ntip; r.tip0 = tip0; r.obs = obs; r.obs_dim = obs_dim;
@@ -1220,7 +1290,7 @@ extern "C" int mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t
   if (!m || !s || !key_a_qpos || !key_a_qvel) return fail(MM_EARG, "mm_walk_reset: bad argument");
   if (random && (!key_b_qpos || !key_b_qvel)) return fail(MM_EARG, "mm_walk_reset: random reset needs the second key");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.walk = 1; r.walk_random = random; r.ka_qpos = key_a_qpos; r.ka_qvel = key_a_qvel; r.kb_qpos = key_b_qpos; r.kb_qvel = key_b_qvel;
   hipLaunchKernelGGL(k_reset, dim3((s->nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, r);
@@ -1234,7 +1304,7 @@ extern "C" int mm_reorient_reset(const mm_model* m, const mm_state* s, const uin
   if (!m || !s || !init_qpos || !size_table || ntab <= 0 || !geom_size_env || !axis_half || !des_rot || !(tar_length > 0.f))
     return fail(MM_EARG, "mm_reorient_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.qpos_bcast = init_qpos;
   r.reor = 1; r.reor_ntab = ntab; r.reor_tab = size_table; r.reor_gsize = geom_size_env; r.reor_axis_half = axis_half;
@@ -1252,7 +1322,7 @@ extern "C" int mm_reorient_reset_typed(const mm_model* m, const mm_state* s, con
       !(tar_length > 0.f))
     return fail(MM_EARG, "mm_reorient_reset_typed: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.qpos_bcast = init_qpos;
   r.reor = 1; r.reor_ntab = ntab; r.reor_tab = size_tables; r.reor_gsize = geom_size_env; r.reor_axis_half = axis_half;
@@ -1268,7 +1338,7 @@ extern "C" int mm_pen_reset(const mm_model* m, const mm_state* s, const uint8_t*
   if (!m || !s || !init_qpos || !des_rot || !(tar_length > 0.f) || !(axis_half > 0.f))
     return fail(MM_EARG, "mm_pen_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.qpos_bcast = init_qpos;
   r.reor = 1; r.pen = 1; r.pen_axis_half = axis_half; r.pen_lo0 = lo0; r.pen_hi0 = hi0; r.pen_lo1 = lo1; r.pen_hi1 = hi1;
@@ -1283,7 +1353,7 @@ extern "C" int mm_objhold_reset(const mm_model* m, const mm_state* s, const uint
                                 float* geom_size_env, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
   if (!m || !s || !init_qpos || !goal_center || !goal) return fail(MM_EARG, "mm_objhold_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
-  r.blob = m->d_blob; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
+  r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;
   r.qpos_bcast = init_qpos;
   r.hold = 1; r.hold_center = goal_center; r.hold_half = goal_half; r.hold_slo = size_lo; r.hold_shi = size_hi;

@@ -35,7 +35,8 @@ RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_
  INFO_BODY_CHAINS, INFO_FOLDED_RESET) = range(16)
 
 
-MM_ABI_VERSION = 5   # include/myosim.h
+MM_ABI_VERSION = 6   # include/myosim.h
+MM_PREC_F32, MM_PREC_F64, MM_PREC_F64_STATE = 0, 1, 2   # mm_model_set_option("precision", ...)
 
 
 class EngineError(RuntimeError):
@@ -68,7 +69,10 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               # reorient <64,32,GEN>: VGPR spills 74 -> 18 (model-in-LDS variant 47 -> 0), kernel 0.705 -> 0.686 ms (+3 %), and 4x
               # less scratch traffic for a kernel whose time followed the box's memory clock.  The same flag on the 24-wide and
               # implicitfast general-row units (inst_I, inst_J) loses 1 %: not set there.
-              "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"]}
+              "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
+              # precision-mode (fp64) kernels: IEEE divide / sqrt and no reassociation -- these exist to track the fp64 reference;
+              # fma contraction stays on (it only removes roundings)
+              "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"]}
 
 
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
@@ -76,7 +80,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     spread over several translation units (myosim_inst_*.hip) that are compiled in parallel and linked into one .so."""
     import concurrent.futures
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + \
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + \
            [os.path.join(_HERE, "..", "include", h) for h in ("myosim.h", "myosim_model.h")]
     deps = srcs + hdrs
     bdir = os.path.join(CSRC, "_build")
@@ -254,8 +258,11 @@ def _stream(device=None):
 class HipModel:
     """Device-resident compiled model (mm_model)."""
 
-    def __init__(self, compiled, lanes_per_env: int = 0, device: Optional[torch.device] = None):
+    def __init__(self, compiled, lanes_per_env: int = 0, device: Optional[torch.device] = None, precision: int = MM_PREC_F32):
+        """precision: MM_PREC_F32 (default), MM_PREC_F64 (fp64 arithmetic, fp32 buffers) or MM_PREC_F64_STATE (fp64 state rows
+        too: BatchState then allocates float64 qpos / qvel / act / qacc_warmstart); include/myosim.h"""
         self.cm = compiled
+        self.precision = MM_PREC_F32
         if not torch.cuda.is_available():
             raise EngineError("no HIP device visible: the physics step only runs on the GPU (no CPU fallback)")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -264,6 +271,9 @@ class HipModel:
         with torch.cuda.device(self.device):
             _chk(lib().mm_model_create(blob.ctypes.data, int(blob.size), C.byref(h)), "mm_model_create")
         self.h = h
+        if precision != MM_PREC_F32:
+            self.set_option("precision", precision)
+            self.precision = int(precision)
         if lanes_per_env:
             _chk(lib().mm_model_set_lanes(self.h, lanes_per_env), "mm_model_set_lanes")
 
@@ -297,10 +307,12 @@ class BatchState:
         self.model = model
         self.nenv = nenv
         f = dict(dtype=torch.float32, device=dev)
-        self.qpos = torch.from_numpy(np.tile(cm.qpos0.astype(np.float32), (nenv, 1))).to(dev).contiguous()
-        self.qvel = torch.zeros(nenv, cm.nv, **f)
-        self.act = torch.zeros(nenv, max(cm.na, 1), **f)[:, :cm.na].contiguous() if cm.na == 0 else torch.zeros(nenv, cm.na, **f)
-        self.qacc_warmstart = torch.zeros(nenv, cm.nv, **f)
+        # the four state rows are float64 under MM_PREC_F64_STATE (qpos0 is an fp32 model table in every mode)
+        fs = dict(dtype=torch.float64 if model.precision == MM_PREC_F64_STATE else torch.float32, device=dev)
+        self.qpos = torch.from_numpy(np.tile(cm.qpos0.astype(np.float32), (nenv, 1))).to(dev).to(fs["dtype"]).contiguous()
+        self.qvel = torch.zeros(nenv, cm.nv, **fs)
+        self.act = torch.zeros(nenv, max(cm.na, 1), **fs)[:, :cm.na].contiguous() if cm.na == 0 else torch.zeros(nenv, cm.na, **fs)
+        self.qacc_warmstart = torch.zeros(nenv, cm.nv, **fs)
         self.time = torch.zeros(nenv, **f)
         self.status = torch.zeros(nenv, dtype=torch.int32, device=dev)
         self.geom_size_env = None

@@ -78,10 +78,13 @@ class BaseV0:
     # ------------------------------------------------------------------ setup
     def _setup(self, obs_keys, weighted_reward_keys, frame_skip=10, normalize_act=True, muscle_condition="",
                fatigue_reset_vec=None, fatigue_reset_random=False, reward_mode="dense", obs_range=(-10, 10),
-               sites=None, **kwargs):
+               sites=None, precision="f32", **kwargs):
+        """precision: "f32" (default) | "f64" | "f64_state" (or the MM_PREC_* value) -- the kernel family that steps the batch
+        (include/myosim.h: fp64 arithmetic, optionally fp64 state rows; limit-rows-only models on Euler)"""
         self.muscle_condition = muscle_condition
         self.cm = _compiled_model(self.model_name, muscle_condition)
-        self.hm = E.HipModel(self.cm, lanes_per_env=self._lanes, device=self._device)
+        self.precision = {"f32": E.MM_PREC_F32, "f64": E.MM_PREC_F64, "f64_state": E.MM_PREC_F64_STATE}.get(precision, precision)
+        self.hm = E.HipModel(self.cm, lanes_per_env=self._lanes, device=self._device, precision=self.precision)
         self.device = self.hm.device
         cm = self.cm
         if cm.na > 0 and "act" not in obs_keys:       # base_v0.py:33-37

@@ -186,35 +186,40 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
 NORTH_STAR_ENVS = 64
 
 
-def north_star_run(name, lanes, nsub=10, nenv=NORTH_STAR_ENVS, nsteps=100):
+def north_star_run(name, lanes, nsub=10, nenv=NORTH_STAR_ENVS, nsteps=100, precisions=(E.MM_PREC_F32,)):
     """100 env-steps x 10 substeps, random actions through the muscle ctrl map, free running from the Pose task's random reset:
-    per-env-step relative qpos error [step, env] of (i) the GPU and (ii) the fp64 oracle whose STATE is rounded to fp32 after
-    every substep (the floor of any engine that stores fp32 state), both against the plain fp64 oracle."""
+    per-env-step relative qpos error [step, env] of (i) the GPU -- one batch per requested precision mode, all driven by the
+    same controls -- and (ii) the fp64 oracle whose STATE is rounded to fp32 after every substep (the floor of any engine that
+    stores fp32 state), both against the plain fp64 oracle.  Returns ({precision: rel}, rel_twin, {precision: max status})."""
     cm = synth.get_model(name); om = O.OracleModel(cm)
-    hm = E.HipModel(cm, lanes_per_env=lanes)
-    assert hm.launch_lanes(nenv) == lanes
     lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
     q0 = np.stack([(lo + (hi - lo) * EO.pose_reset_draws(cm.nq, e, 0, 0)[0]).astype(np.float32) for e in range(nenv)])
-    st = E.BatchState(hm, nenv); st.qpos.copy_(torch.from_numpy(q0))
+    hms, sts = {}, {}
+    for p in precisions:
+        hms[p] = E.HipModel(cm, lanes_per_env=lanes, precision=p)
+        assert hms[p].launch_lanes(nenv) == lanes
+        sts[p] = E.BatchState(hms[p], nenv); sts[p].qpos.copy_(torch.from_numpy(q0))
     ds, tw = [], []
     for e in range(nenv):
         d = O.OracleData(om); d.qpos[:] = q0[e]; ds.append(d)
         t = O.OracleData(om); t.qpos[:] = q0[e]; t.round_state_f32(True); tw.append(t)
     a = torch.empty(nenv, cm.nu, device="cuda")
-    rel = np.zeros((nsteps, nenv)); rel_tw = np.zeros((nsteps, nenv))
+    rel = {p: np.zeros((nsteps, nenv)) for p in precisions}; rel_tw = np.zeros((nsteps, nenv))
     for s in range(nsteps):
         E.uniform(a, 0, s)
         ctrl = (1.0 / (1.0 + torch.exp(-5.0 * (a - 0.5)))).contiguous()
-        E.step(hm, st, ctrl, nsub)
+        for p in precisions:
+            E.step(hms[p], sts[p], ctrl, nsub)
         c = ctrl.cpu().numpy()
         for e in range(nenv):
             ds[e].ctrl[:] = c[e]; ds[e].step(nsub)
             tw[e].ctrl[:] = c[e]; tw[e].step(nsub)
-        oq = np.stack([d.qpos for d in ds]); gq = st.qpos.cpu().numpy(); tq = np.stack([d.qpos for d in tw])
+        oq = np.stack([d.qpos for d in ds]); tq = np.stack([d.qpos for d in tw])
         scale = max(1.0, np.abs(oq).max())
-        rel[s] = np.abs(gq - oq).max(axis=1) / scale
+        for p in precisions:
+            rel[p][s] = np.abs(sts[p].qpos.cpu().numpy().astype(np.float64) - oq).max(axis=1) / scale
         rel_tw[s] = np.abs(tq - oq).max(axis=1) / scale
-    return rel, rel_tw, int(st.status.max())
+    return rel, rel_tw, {p: int(sts[p].status.max()) for p in precisions}
 
 
 @pytest.mark.parametrize("name,lanes,nsub", [("elbow", 8, 10), ("hand", 32, 10), ("hand", 64, 10)],
@@ -233,6 +238,7 @@ def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
     that noise of the plain-fp32 level (>= 57 of 64, and never more than 6 behind the twin), the median within 5x of the twin's
     -- a kernel that loses a digit anywhere fails both -- and every env back under 1e-2 at the end of the run."""
     rel, rel_tw, status = north_star_run(name, lanes, nsub)
+    rel, status = rel[E.MM_PREC_F32], status[E.MM_PREC_F32]
     nenv = rel.shape[1]
     per_env, per_env_tw = rel.max(axis=0), rel_tw.max(axis=0)
     run = rel.max(axis=1)
@@ -258,12 +264,53 @@ def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
         assert rel[-1].max() < 1e-2, rel[-1].max()
 
 
-@pytest.mark.parametrize("env_id,n", [("myoElbowPose1D6MRandom-v0", 256), ("myoHandPoseRandom-v0", 96), ("myoHandPoseFixed-v0", 64)])
-def test_rollout_step_one_launch_matches_stepwise_path(env_id, n):
+@pytest.mark.parametrize("name,lanes", [("elbow", 8), ("hand", 32), ("hand", 64)], ids=["elbow-G8", "hand-G32", "hand-G64"])
+def test_north_star_precision_modes_strict_gate(oracle_lib, name, lanes):
+    """BASELINE.json: "state divergence vs CPU mj_step < 1e-4 rel over 1000 steps" -- on EVERY env, 256 envs per width.
+
+    The reference's state is float64 (MuJoCo's mjtNum); the precision-mode kernels (`precision=`, include/myosim.h) are the same
+    fused pipeline over `real = double`:
+      MM_PREC_F64_STATE  fp64 arithmetic, on-chip tables AND state rows: every one of the 256 envs below 1e-4 over the whole run
+                         (in fact below 1e-7: the two runs differ by summation order only);
+      MM_PREC_F64        fp64 arithmetic, fp32 state rows (rounded once per launch = per 10 substeps): at least as many envs
+                         below 1e-4 as the fp32-state twin of the oracle (rounded after every substep), every env of the
+                         elbow."""
+    nenv = 256
+    P64, P64S = E.MM_PREC_F64, E.MM_PREC_F64_STATE
+    rel, rel_tw, status = north_star_run(name, lanes, 10, nenv=nenv, precisions=(P64, P64S))
+    per = {p: rel[p].max(axis=0) for p in rel}
+    per_tw = rel_tw.max(axis=0)
+    below = {p: int((per[p] < 1e-4).sum()) for p in per}
+    below_tw = int((per_tw < 1e-4).sum())
+    print(f"precision modes {name} G={lanes}, {nenv} envs x 1000 substeps: fp64 state {below[P64S]}/{nenv} < 1e-4 (max {per[P64S].max():.2e}, "
+          f"median {np.median(per[P64S]):.2e}); fp64 arithmetic + fp32 state {below[P64]}/{nenv} (median {np.median(per[P64]):.2e}); "
+          f"fp32-state twin {below_tw}/{nenv} (median {np.median(per_tw):.2e})")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"parity_1000_{name}_G{lanes}_precision_modes.json"), "w") as f:
+        import json
+        json.dump({"nenv": nenv, "lanes": lanes, "substeps": 1000,
+                   "f64_state": {"envs_below_1e-4": below[P64S], "max_over_envs": float(per[P64S].max()), "median_env_max": float(np.median(per[P64S])),
+                                 "per_env_max_over_run": per[P64S].tolist()},
+                   "f64_arith_f32_state": {"envs_below_1e-4": below[P64], "max_over_envs": float(per[P64].max()), "median_env_max": float(np.median(per[P64])),
+                                           "per_env_max_over_run": per[P64].tolist()},
+                   "fp32_state_twin": {"envs_below_1e-4": below_tw, "median_env_max": float(np.median(per_tw)), "per_env_max_over_run": per_tw.tolist()}}, f)
+    assert status[P64] == 0 and status[P64S] == 0
+    assert below[P64S] == nenv and per[P64S].max() < 1e-6, (below[P64S], np.sort(per[P64S])[-4:])
+    assert below[P64] >= below_tw, (below[P64], below_tw, np.sort(per[P64])[-6:])
+    assert np.median(per[P64]) <= 1.5 * np.median(per_tw) + 1e-9
+    if name == "elbow":
+        assert below[P64] == nenv
+
+
+@pytest.mark.parametrize("env_id,n,precision", [("myoElbowPose1D6MRandom-v0", 256, "f32"), ("myoHandPoseRandom-v0", 96, "f32"),
+                                                ("myoHandPoseFixed-v0", 64, "f32"), ("myoHandPoseRandom-v0", 96, "f64_state"),
+                                                ("myoElbowPose1D6MRandom-v0", 64, "f64")])
+def test_rollout_step_one_launch_matches_stepwise_path(env_id, n, precision):
     """mm_rollout_step (action draw + env-step + episode stats + masked auto-reset in ONE launch) against the separate calls
     it replaces (mm_uniform, mm_env_step, mm_episode_stats, mm_pose_reset): bit-identical state, observations, targets,
-    counters and statistics across episode boundaries."""
-    kw = dict(num_envs=n, seed=11, max_episode_steps=7)
+    counters and statistics across episode boundaries -- in every precision mode (fp64 state rows included: the folded reset and
+    the reset kernel write the same fp32 draws into them)."""
+    kw = dict(num_envs=n, seed=11, max_episode_steps=7, precision=precision)
     fused = registry.make(env_id, **kw)
     ref = registry.make(env_id, **kw)
     stats_f = fused.rollout_setup(action_seed=23)
@@ -288,6 +335,31 @@ def test_rollout_step_one_launch_matches_stepwise_path(env_id, n):
         assert torch.equal(fused.step_count, ref.step_count)
         assert torch.equal(stats_f, stats_r)
     assert crossed >= 2 * n          # horizon 7: every env was re-armed at least twice
+
+
+def test_precision_modes_at_the_env_level_and_their_refusals():
+    """`registry.make(..., precision="f64_state")`: the gym-level env-step of the hand against the env oracle to output
+    resolution (observations are fp32 rows in every mode), state rows float64; models outside the fp64 family (general rows,
+    other integrators) are refused loudly -- MM_EUNSUPPORTED, never a silent fp32 launch."""
+    env = registry.make("myoHandPoseRandom-v0", num_envs=8, seed=3, precision="f64_state", autoreset=False)
+    assert env.state.qpos.dtype == torch.float64 and env.state.qvel.dtype == torch.float64
+    env.reset()
+    o = _env_oracle(env, 2)
+    a = torch.empty(8, env.cm.nu, device="cuda")
+    for s in range(5):
+        E.uniform(a, 5, s)
+        obs, rwd, term, trunc, info = env.step(a)
+        ob, r, done, _ = o.step(a[2].cpu().numpy())
+    err = np.abs(obs[2].cpu().numpy().astype(np.float64) - ob)
+    assert err.max() < 2e-7 * max(1.0, np.abs(ob).max()), err.max()      # fp32 rounding of the observation row, nothing else
+    assert np.abs(env.state.qpos[2].cpu().numpy() - o.d.qpos).max() < 1e-12
+    assert abs(float(rwd[2]) - r) < 1e-5 * max(1.0, abs(r))
+    for env_id, kw in (("myoHandReorient100-v0", {}), ("myoLegWalk-v0", {}), ("myoHandPoseRandom-v0", {"model": "hand_contact"})):
+        with pytest.raises(E.EngineError, match="precision"):
+            registry.make(env_id, num_envs=4, precision="f64", **kw)
+    hm = E.HipModel(synth.get_model("hand"))
+    with pytest.raises(E.EngineError):
+        hm.set_option("precision", 7)
 
 
 def test_rollout_step_other_tasks_and_sharded_streams():

@@ -66,3 +66,18 @@ def test_shipped_bench_kernels_do_not_spill_vector_registers():
     assert int(tab[legi]["vgpr_spill_count"]) <= 40, tab[legi]
     for name in no_spill[2:] + [legi]:
         assert int(tab[name]["sgpr_spill_count"]) < 260, tab[name]
+
+
+@pytest.mark.skipif(not (os.path.exists(E.LIB_PATH) and os.path.exists(READELF)), reason="needs the built library and llvm-readelf")
+def test_precision_mode_kernels_are_in_the_library_and_stay_off_scratch():
+    """The fp64 family (namespace mm64, myosim_inst_P.hip) is built for one wave per SIMD: a lane may use the 512 VGPRs + AGPRs,
+    and what does not fit the 256 architectural registers is parked in accumulation registers -- never in scratch memory."""
+    tab = _kernel_table()
+    def mangled(lanes, width, lds_model):
+        return f"_ZN4mm648k_engineILi{lanes}ELi{width}ELb{lds_model}ELb0ELi0ELb0EEEv5KArgs"
+    for lanes, width in ((4, 4), (8, 4), (16, 4), (32, 24), (64, 24)):
+        for lm in (0, 1):
+            name = mangled(lanes, width, lm)
+            assert name in tab, (name, [k for k in tab if "mm64" in k][:3])
+            assert int(tab[name]["private_segment_fixed_size"]) == 0, tab[name]
+            assert int(tab[name]["max_flat_workgroup_size"]) == 256, tab[name]

@@ -82,6 +82,14 @@ def test_ctypes_structs_match_header_field_order():
         assert [f[0] for f in cls._fields_] == c_fields(end), cls.__name__
 
 
+def test_precision_enum_and_abi_version_match_header():
+    from myosuite_amd import engine as E
+    hdr = open(os.path.join(ROOT, "include", "myosim.h")).read()
+    m = re.search(r"enum \{ MM_PREC_F32 = (\d+), MM_PREC_F64 = (\d+), MM_PREC_F64_STATE = (\d+) \}", hdr)
+    assert m and tuple(int(x) for x in m.groups()) == (E.MM_PREC_F32, E.MM_PREC_F64, E.MM_PREC_F64_STATE)
+    assert int(re.search(r"#define MM_ABI_VERSION (\d+)", hdr).group(1)) == E.MM_ABI_VERSION == E.lib().mm_abi_version()
+
+
 def test_sarcopenia_model_compiles_for_every_registered_sarc_id():
     """registry registers a myoSarc* variant for every myo* id (myobase/__init__.py:25-31): each must have a model whose
     muscle peak forces are halved and nothing else changed (base_v0.py:63-67)."""
