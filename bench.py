@@ -30,6 +30,9 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 
 # BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288, and the MuJoCo-default leg on the
 # implicitfast integrator) reported next to the headline line
+# the committed PMC session bench.py replays counters from (tools/prof_round.sh at the HEAD named in DESIGN.md section 5); pinned, not "the latest file"
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03j_pmc.json")
+REPEATS = 3                 # timed regions of --steps steps each; the line reports the median region
 EXTRA_MIN_TIMED_MS = 60.0   # an extra line times at least this much kernel work (a 1.5 ms timed region is launch-noise bound)
 EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
                  ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
@@ -215,9 +218,31 @@ def status_or(status) -> int:
     return functools.reduce(operator.or_, (int(v) for v in status.unique().tolist()), 0)
 
 
-def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=None):
-    """W untimed + K timed rollout steps of `env_id` with n envs on this rank; returns (elapsed_s max over ranks,
-    mean kernel ms, env, gathered stats)."""
+def gpu_clocks():
+    """current shader / memory clocks of the visible GPUs as rocm-smi reports them (MHz), or None: logged around the timed region
+    because the general-row kernels were 5...18 % slower on some boxes of the pool with the same binary"""
+    try:
+        txt = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout
+        js = json.loads(txt[txt.index("{"):])
+        out = {}
+        for card, rec in js.items():
+            for k, v in rec.items():
+                kl = k.lower()
+                if "sclk" in kl or "mclk" in kl or "fclk" in kl:
+                    import re
+                    m = re.search(r"(\d+)\s*mhz", str(v).lower())
+                    if m:
+                        out[f"{card}.{'sclk' if 'sclk' in kl else ('mclk' if 'mclk' in kl else 'fclk')}_mhz"] = int(m.group(1))
+        return out or None
+    except Exception:
+        return None
+
+
+def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=None, repeats=1):
+    """W untimed rollout steps, then `repeats` timed regions of exactly K steps each -- every region bracketed by barrier +
+    synchronize on both sides, max over ranks -- of `env_id` with n envs on this rank.  Returns (MEDIAN elapsed_s of the regions,
+    mean kernel ms of the median region, env, gathered stats, per-region elapsed list).  The reference protocol times its scan
+    with timeit.repeat(..., repeat=3) and reports one of them (benchmarks/mjx_benchmark.py:46)."""
     import numpy as np
     import torch
     from myosuite_amd import dist as D
@@ -228,20 +253,25 @@ def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=No
     ep_stats = env.rollout_setup(action_seed=seed)     # (episode return, length, solved) per env, accumulated in the launch
     for s in range(warmup):
         env.rollout_step(None, stream_id=s)
-    torch.cuda.synchronize()
-    D.barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(steps):
-        env.rollout_step(None, stream_id=warmup + s, events=evs[s])   # events bracket the fused env-step kernel alone
-    stats = D.gather_episode_stats(ep_stats)   # the one collective of a rollout
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    return elapsed, kern_ms, env, stats
+    regions = []
+    stats = None
+    for r in range(repeats):
+        torch.cuda.synchronize()
+        D.barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            env.rollout_step(None, stream_id=warmup + r * steps + s, events=evs[s])   # events bracket the fused env-step kernel alone
+        stats = D.gather_episode_stats(ep_stats)   # the one collective of a rollout
+        torch.cuda.synchronize()
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed = D.max_over_ranks(elapsed, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
+        regions.append((elapsed, float(np.mean([a.elapsed_time(b) for a, b in evs]))))
+    order = sorted(range(repeats), key=lambda i: regions[i][0])
+    med = regions[order[(repeats - 1) // 2]]          # the median region (lower median for an even count)
+    return med[0], med[1], env, stats, [e for e, _ in regions]
 
 
 def roofline(env, env_id, n, kern_ms, overrides=None):
@@ -250,23 +280,43 @@ def roofline(env, env_id, n, kern_ms, overrides=None):
     from myosuite_amd import engine as E
     b_alg = algorithmic_bytes(env)
     achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9
-    traffic = issue = None
-    try:   # PMC counters cannot be read in-process: the committed rocprofv3 summary of this same command is reported
-        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
+    traffic = None
+    profile = None
+    launch = None
+    try:
+        launch = env.hm.launch_info(n)
+    except Exception:      # (a library older than the binding: the line must still print)
+        pass
+    try:   # PMC counters cannot be read in-process: the COMMITTED rocprofv3 summary of this same command is replayed, and marked so
+        pmc_file = PMC_PROFILE if os.path.exists(PMC_PROFILE) else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))[-1]
         pm = json.load(open(pmc_file)).get(workload_key(env_id, n, overrides))
         if pm:
             traffic = (pm["fetch_kib"] + pm["write_kib"]) * 1024.0
-            waves_per_simd = pm["sq_waves"] / 1024.0
-            issue = {"valu_busy_frac": pm["sq_active_inst_valu"] / (pm["sq_wave_quadcycles"] / waves_per_simd),
-                     "wave_issue_frac": pm["sq_active_inst_any"] / pm["sq_wave_quadcycles"],
-                     "wave_waitcnt_frac": pm["sq_wait_any"] / pm["sq_wave_quadcycles"],
-                     "valu_insts_per_env_step": pm["sq_insts_valu"] * 64 / n / 64,
-                     "source": f"profiles/{os.path.basename(pmc_file)} (rocprofv3 PMC of this command)"}
+            # Waves that can be resident on one SIMD at a time: what the launch puts on a CU (occupancy of the kernel at its block
+            # size and LDS footprint: LDS, VGPRs) and never more than the launch has.  A SIMD issues at most one VALU instruction
+            # per quad-cycle, so SQ_ACTIVE_INST_VALU over (summed wave lifetime / resident waves) is a fraction of its issue slots.
+            waves_total = pm["sq_waves"]
+            if launch and launch["resident_blocks_per_cu"] > 0:
+                resident = min(launch["resident_blocks_per_cu"] * launch["waves_per_block"] / 4.0, max(1.0, waves_total / 1024.0))
+            else:
+                resident = min(2.0, max(1.0, waves_total / 1024.0))
+            simd_quadcycles = pm["sq_wave_quadcycles"] / resident
+            profile = {"replayed_from": f"profiles/{os.path.basename(pmc_file)}",
+                       "what": "rocprofv3 PMC means per dispatch of this command, collected in the session named by the file -- NOT measured in this run",
+                       "hbm_bytes_per_launch": traffic,
+                       "resident_waves_per_simd": resident,
+                       "valu_busy_frac": min(1.0, pm["sq_active_inst_valu"] / simd_quadcycles),
+                       "wave_issue_frac": pm["sq_active_inst_any"] / pm["sq_wave_quadcycles"],
+                       "wave_waitcnt_frac": pm["sq_wait_any"] / pm["sq_wave_quadcycles"],
+                       "lds_bank_conflict_frac": pm["sq_lds_bank_conflict"] / max(1.0, pm["sq_lds_idx_active"]),
+                       "valu_insts_per_env_step": pm["sq_insts_valu"] / n,
+                       "kernel_ms_in_that_session": pm.get("kernel_trace_avg_ns", 0.0) * 1e-6}
     except (OSError, ValueError, KeyError, IndexError):
         pass
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
-           "algorithmic_bytes_per_launch": b_alg * n, "valu_issue": issue}
+           "traffic": traffic, "traffic_source": (profile or {}).get("replayed_from"),
+           "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
+           "algorithmic_bytes_per_launch": b_alg * n, "launch": launch, "profile": profile}
     fl = algorithmic_flops(env_id, overrides)
     if fl:
         tf = fl["flops"] * n / (kern_ms * 1e-3) / 1e12
@@ -283,6 +333,7 @@ def main():
     ap.add_argument("--env", default="myoHandPoseRandom-v0")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs lines (elbow / reorient / leg-walk / self-contact hand)")
     ap.add_argument("--model", default=None, help="model override of the headline env (e.g. hand_contact): profile collection")
@@ -315,7 +366,10 @@ def main():
         head_ov["model"] = args.model
     if args.no_forward:
         head_ov["do_forward"] = False
-    elapsed, kern_ms, env, stats = measure(args.env, n, args.steps, args.warmup, rank, world, args.lanes, overrides=head_ov)
+    clocks_before = gpu_clocks() if rank == 0 else None
+    elapsed, kern_ms, env, stats, regions = measure(args.env, n, args.steps, args.warmup, rank, world, args.lanes, overrides=head_ov,
+                                                    repeats=max(1, args.repeats))
+    clocks_after = gpu_clocks() if rank == 0 else None
     cm = env.cm
 
     if rank == 0:
@@ -324,7 +378,10 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node) at %d envs/GPU" % n,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "repeats": len(regions),
+            "region_ms_per_step": [1e3 * e / args.steps for e in regions],      # every timed region; `value` is the median one
+            "gpu_clocks_mhz": {"before": clocks_before, "after": clocks_after},
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1) drawn in the kernel, frame_skip {env.frame_skip} + final "
                                    f"forward + obs/reward + episode stats + auto-reset in one launch per step "
@@ -347,13 +404,14 @@ def main():
                 tag = f"{env_id}, {ne} envs/GPU" + (f", {ov}" if ov else "")
                 try:
                     # a short probe sizes the timed region: at least EXTRA_MIN_TIMED_MS of kernel work (and >= steps // 2 steps)
-                    _, km0, ev0, _ = measure(env_id, ne, 4, 2, 0, 1, overrides=ov)
+                    _, km0, ev0, _, _ = measure(env_id, ne, 4, 2, 0, 1, overrides=ov)
                     del ev0
                     ks = int(max(8, args.steps // 2, min(2000, EXTRA_MIN_TIMED_MS / max(km0, 1e-3))))
-                    el, km, ev, st = measure(env_id, ne, ks, max(2, args.warmup // 2), 0, 1, overrides=ov)
+                    el, km, ev, st, rg = measure(env_id, ne, ks, max(2, args.warmup // 2), 0, 1, overrides=ov, repeats=max(1, args.repeats))
                     extra.append({"workload": tag, "key": workload_key(env_id, ne, ov), "value": ne * ks / el, "unit": "env-steps/s", "steps": ks,
                                   "dtype": {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64"}[int(getattr(ev, "precision", 0))],
-                                  "ms_per_step": 1e3 * el / ks, "lanes_per_env": ev.hm.launch_lanes(ne),
+                                  "ms_per_step": 1e3 * el / ks, "repeats": len(rg), "region_ms_per_step": [1e3 * e / ks for e in rg],
+                                  "lanes_per_env": ev.hm.launch_lanes(ne),
                                   "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": roofline(ev, env_id, ne, km, ov),
                                   "status_or": status_or(ev.state.status)})
                     del ev

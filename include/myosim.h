@@ -125,7 +125,7 @@ typedef struct {
  * caller built against an older, shorter struct keeps working (zero = "feature off" for every appended field), and a caller
  * built against a NEWER header is refused (MM_EARG) instead of having its tail silently ignored. */
 typedef struct {
-  uint32_t size;            /* sizeof(mm_task) in the caller's build (0 is refused) */
+  uint32_t size;            /* sizeof(mm_task) in the caller's build; refused below the ABI-4 struct (everything up to `obs_only`) */
   int   task;               /* MM_TASK_*                                       */
   int   nsubsteps;          /* frame_skip                                      */
   int   normalize_act;      /* 1: muscle ctrl = 1/(1+exp(-5(a-0.5)))  (base_v0.py:86-90) */
@@ -205,7 +205,7 @@ typedef struct {
  * step -- benchmarks/mjx_benchmark.py:29 draws actions, gym's autoreset wrapper / playground's TrainingWrapper re-arm
  * finished episodes, RecordEpisodeStatistics accumulates returns -- without extra kernel launches. */
 typedef struct {
-  uint32_t size;            /* sizeof(mm_rollout) in the caller's build (same rule as mm_task.size) */
+  uint32_t size;            /* sizeof(mm_rollout) in the caller's build (same rule as mm_task.size; minimum: everything up to `reset_seed`) */
   const float* action;      /* [nenv][nu], or NULL: draw action ~ U[0,1) in the kernel (Philox4x32-10, mm_uniform's scheme:
                                element i = (env_index_base + e) * nu + u is word i%4 of counter (i/4, action_stream), key action_seed) */
   uint64_t action_seed, action_stream;
@@ -282,6 +282,13 @@ enum { MM_PREC_F32 = 0, MM_PREC_F64 = 1, MM_PREC_F64_STATE = 2 };
 /* lanes per env a launch over `nenv` envs will use (the width is picked per launch from the batch size unless pinned
    with mm_model_set_lanes or fixed by the model's constraint tables) */
 int  mm_model_launch_lanes(const mm_model* m, int nenv);
+/* geometry and occupancy of the env-step launch over `nenv` envs, nothing is launched: out[MM_LAUNCH_*], nout >= MM_LAUNCH_COUNT.
+   WAVES_PER_BLOCK counts the helper waves of a two-wave launch; RESIDENT_BLOCKS_PER_CU is the HIP occupancy of that kernel at
+   that block size and LDS footprint (what bounds it: LDS bytes, VGPRS); a profile's per-wave counters are priced per resident
+   wave with it (bench.py). */
+enum { MM_LAUNCH_LANES = 0, MM_LAUNCH_WAVES_PER_BLOCK, MM_LAUNCH_TWO_WAVE, MM_LAUNCH_LDS_MODEL, MM_LAUNCH_LDS_BYTES, MM_LAUNCH_BLOCKS,
+       MM_LAUNCH_RESIDENT_BLOCKS_PER_CU, MM_LAUNCH_VGPRS, MM_LAUNCH_COUNT };
+int  mm_model_launch_info(const mm_model* m, int nenv, int* out, int nout);
 
 /* ---- physics -------------------------------------------------------------- */
 /* `nsub` mj_step substeps with ctrl [nenv][nu] applied as-is (engine boundary). */

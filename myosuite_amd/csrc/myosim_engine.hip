@@ -887,6 +887,22 @@ extern "C" void mm_debug_set_dump(float* dev_ptr) { g_dbg = dev_ptr; }
 static unsigned long long* g_prof = nullptr;
 extern "C" void mm_debug_set_prof(unsigned long long* dev_ptr) { g_prof = dev_ptr; }
 
+// mm_model_launch_info: when set, the launch path stops short of the launch and reports the geometry and the kernel's
+// occupancy instead (bench.py prices counters per RESIDENT wave with it)
+struct LaunchInfo { int* out; };
+static thread_local LaunchInfo* g_info = nullptr;
+static int report_kernel(const void* fn, dim3 grid, dim3 block, size_t lds, int lanes, int two_wave, int lm) {
+  int nb = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, (int)block.x, lds));
+  hipFuncAttributes fa;
+  HIPCHK(hipFuncGetAttributes(&fa, fn));
+  int* o = g_info->out;
+  o[MM_LAUNCH_LANES] = lanes; o[MM_LAUNCH_WAVES_PER_BLOCK] = (int)block.x / 64; o[MM_LAUNCH_TWO_WAVE] = two_wave;
+  o[MM_LAUNCH_LDS_MODEL] = lm; o[MM_LAUNCH_LDS_BYTES] = (int)lds; o[MM_LAUNCH_BLOCKS] = (int)grid.x;
+  o[MM_LAUNCH_RESIDENT_BLOCKS_PER_CU] = nb; o[MM_LAUNCH_VGPRS] = fa.numRegs;
+  return MM_OK;
+}
+
 template <int G, int NVP, bool GEN, int RK4>
 static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st, int lm) {
   // the dynamic-LDS limit is a per-device attribute of the function: one flag per (device, LM variant) of this instantiation
@@ -897,6 +913,7 @@ static int launch_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size_t l
     else HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[lm].fetch_or(bit, std::memory_order_release);
   }
+  if (g_info) return report_kernel(lm ? (const void*)k_engine<G, NVP, true, GEN, RK4> : (const void*)k_engine<G, NVP, false, GEN, RK4>, grid, block, lds, G, a.two_wave, lm);
   if (lm) hipLaunchKernelGGL((k_engine<G, NVP, true, GEN, RK4>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((k_engine<G, NVP, false, GEN, RK4>), grid, block, lds, st, a);
   HIPCHK(hipGetLastError());
@@ -912,6 +929,7 @@ static int launch_f64_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size
     else HIPCHK(hipFuncSetAttribute((const void*)mm64::k_engine<G, NVP, false, GEN, RK4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[lm].fetch_or(bit, std::memory_order_release);
   }
+  if (g_info) return report_kernel(lm ? (const void*)mm64::k_engine<G, NVP, true, GEN, RK4> : (const void*)mm64::k_engine<G, NVP, false, GEN, RK4>, grid, block, lds, G, a.two_wave, lm);
   if (lm) hipLaunchKernelGGL((mm64::k_engine<G, NVP, true, GEN, RK4>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((mm64::k_engine<G, NVP, false, GEN, RK4>), grid, block, lds, st, a);
   HIPCHK(hipGetLastError());
@@ -932,6 +950,7 @@ static int launch_obs_t(const mm_model* m, KArgs& a, dim3 grid, dim3 block, size
     HIPCHK(hipFuncSetAttribute((const void*)k_engine<G, NVP, false, GEN, RK4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done.fetch_or(bit, std::memory_order_release);
   }
+  if (g_info) return report_kernel((const void*)k_engine<G, NVP, false, GEN, RK4, true>, grid, block, lds, G, a.two_wave, 0);
   hipLaunchKernelGGL((k_engine<G, NVP, false, GEN, RK4, true>), grid, block, lds, st, a);
   HIPCHK(hipGetLastError());
   return MM_OK;
@@ -960,6 +979,20 @@ extern "C" int mm_model_launch_lanes(const mm_model* m, int nenv) {
 }
 
 static int launch_on_device(const mm_model* m, KArgs& a, void* stream, const int G);
+static int launch(const mm_model* m, KArgs& a, void* stream);
+static void fill_common(const mm_model* m, KArgs& a, const mm_state* s);
+// geometry and occupancy of the env-step launch over `nenv` envs (include/myosim.h: MM_LAUNCH_*); nothing is launched
+extern "C" int mm_model_launch_info(const mm_model* m, int nenv, int* out, int nout) {
+  if (!m || nenv <= 0 || !out || nout < MM_LAUNCH_COUNT) return fail(MM_EARG, "mm_model_launch_info: bad argument");
+  mm_state s; memset(&s, 0, sizeof(s)); s.nenv = nenv; s.geom_env_id = -1;
+  KArgs a; fill_common(m, a, &s);
+  a.mode = 2;
+  LaunchInfo li{out};
+  g_info = &li;
+  const int rc = launch(m, a, nullptr);
+  g_info = nullptr;
+  return rc;
+}
 static int launch(const mm_model* m, KArgs& a, void* stream) {
   const int G = pick_lanes(m, a.s.nenv);
   {   // launch on the model's device (the caller's stream must belong to it); restore the caller's current device afterwards
@@ -1078,11 +1111,13 @@ extern "C" int mm_forward(const mm_model* m, const mm_state* s, const float* ctr
 }
 
 // mm_task / mm_rollout grow by appending fields: take min(caller's size, ours) bytes, zero the rest (include/myosim.h)
+// min_size = the struct as ABI 4 introduced `size` (everything up to mm_task.obs_only / mm_rollout.reset_seed): a caller from
+// before that has no size field -- its first word is something else -- and must not slip through on a small value
 template <typename T>
-static int sized_copy(T* dst, const T* src, const char* what) {
+static int sized_copy(T* dst, const T* src, size_t min_size, const char* what) {
   if (!src) return fail(MM_EARG, what);
   const uint32_t sz = *reinterpret_cast<const uint32_t*>(src);
-  if (sz < 8 || sz > sizeof(T)) return fail(MM_EARG, "mm_task / mm_rollout: .size is unset or larger than this library's struct (caller built against a newer header)");
+  if (sz < min_size || sz > sizeof(T)) return fail(MM_EARG, "mm_task / mm_rollout: .size is unset, smaller than the ABI-4 struct, or larger than this library's struct (caller built against a newer header)");
   memset(dst, 0, sizeof(T));
   memcpy(dst, src, sz);
   dst->size = (uint32_t)sizeof(T);
@@ -1123,7 +1158,7 @@ static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
 extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* action, const mm_task* t,
                            const mm_derived* out, void* stream) {
   mm_task tt;
-  { const int rc = sized_copy(&tt, t, "mm_env_step: null task"); if (rc != MM_OK) return rc; }
+  { const int rc = sized_copy(&tt, t, offsetof(mm_task, obs_only) + sizeof(int), "mm_env_step: null task"); if (rc != MM_OK) return rc; }
   t = &tt;
   { const int rc = check_task(m, s, t); if (rc != MM_OK) return rc; }
   KArgs a; fill_common(m, a, s);
@@ -1136,8 +1171,8 @@ extern "C" int mm_env_step(const mm_model* m, const mm_state* s, const float* ac
 extern "C" int mm_rollout_step(const mm_model* m, const mm_state* s, const mm_task* t, const mm_rollout* r,
                                const mm_derived* out, void* stream) {
   mm_task tt; mm_rollout rr;
-  { const int rc = sized_copy(&tt, t, "mm_rollout_step: null task"); if (rc != MM_OK) return rc; }
-  { const int rc = sized_copy(&rr, r, "mm_rollout_step: null rollout description"); if (rc != MM_OK) return rc; }
+  { const int rc = sized_copy(&tt, t, offsetof(mm_task, obs_only) + sizeof(int), "mm_rollout_step: null task"); if (rc != MM_OK) return rc; }
+  { const int rc = sized_copy(&rr, r, offsetof(mm_rollout, reset_seed) + sizeof(uint64_t), "mm_rollout_step: null rollout description"); if (rc != MM_OK) return rc; }
   t = &tt; r = &rr;
   { const int rc = check_task(m, s, t); if (rc != MM_OK) return rc; }
   if (!r) return fail(MM_EARG, "mm_rollout_step: null rollout description");

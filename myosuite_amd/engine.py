@@ -226,6 +226,7 @@ def lib():
         L.mm_debug_set_dump.argtypes = [C.c_void_p]
         L.mm_debug_set_prof.argtypes = [C.c_void_p]
         L.mm_model_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.mm_model_launch_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         # the binding restates the header's structs: refuse a library built from another ABI or with other struct layouts
         L.mm_struct_size.argtypes = [C.c_int]
         if L.mm_abi_version() != MM_ABI_VERSION:
@@ -283,6 +284,15 @@ class HipModel:
     def launch_lanes(self, nenv: int) -> int:
         """lanes per env a launch over `nenv` envs uses (picked from the batch size unless pinned)"""
         return lib().mm_model_launch_lanes(self.h, int(nenv))
+
+    LAUNCH_KEYS = ("lanes", "waves_per_block", "two_wave", "lds_model", "lds_bytes", "blocks", "resident_blocks_per_cu", "vgprs")
+
+    def launch_info(self, nenv: int) -> dict:
+        """geometry and occupancy of the env-step launch over `nenv` envs (mm_model_launch_info; nothing is launched)"""
+        out = (C.c_int * len(self.LAUNCH_KEYS))()
+        with torch.cuda.device(self.device):
+            _chk(lib().mm_model_launch_info(self.h, int(nenv), out, len(self.LAUNCH_KEYS)), "mm_model_launch_info")
+        return dict(zip(self.LAUNCH_KEYS, (int(v) for v in out)))
 
     def set_option(self, name: str, value: int):
         _chk(lib().mm_model_set_option(self.h, name.encode(), int(value)), "mm_model_set_option")

@@ -277,7 +277,15 @@ class BaseV0:
         ro.autoreset = 0
         self._rollout_fill_reset(ro)
         self._ro = ro
+        self._ro_sig = self._rollout_signature()
         return self._ro_stats
+
+    def _rollout_signature(self):
+        """what the folded reset fields of mm_rollout were filled from: a later reset(seed=...) / seed() / assignment of
+        reset_type or fatigue_reset_vec (a NEW vector object: in-place edits of the old one are not seen) re-fills them at the
+        next rollout_step, so the folded and the separate reset path cannot drift apart"""
+        return (getattr(self, "_seed_u64", 0), getattr(self, "reset_type", None), getattr(self, "target_type", None), id(self.fatigue_reset_vec),
+                bool(self.fatigue_reset_random), bool(self.autoreset))
 
     def _rollout_fill_reset(self, ro):
         """tasks whose reset is folded into the launch fill mm_rollout's reset fields here (PoseEnvV0)"""
@@ -288,6 +296,11 @@ class BaseV0:
         one more (the task's masked reset) for the others.  Returns (obs, reward_row_view, reset_mask): obs holds the first
         observation of the new episode for re-armed envs; views are rewritten by the next call."""
         ro = self._ro
+        sig = self._rollout_signature()
+        if sig != self._ro_sig:
+            ro.autoreset = 0
+            self._rollout_fill_reset(ro)
+            self._ro_sig = sig
         if action is not None:
             assert action.shape == (self.num_envs, self.cm.nu) and action.dtype == torch.float32 and action.is_contiguous()
             ro.action = action.data_ptr()

@@ -58,7 +58,7 @@ def test_bench_n_gt_1_path_runs_oversubscribed_on_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", str(K), "--warmup", str(W),
-                          "--envs-per-gpu", str(E_), "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+                          "--envs-per-gpu", str(E_), "--no-extra", "--repeats", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -75,3 +75,49 @@ def test_bench_n_gt_1_path_runs_oversubscribed_on_one_gpu():
     torch.cuda.synchronize()
     assert abs(float(stats[:, 0].mean()) - d["stats"]["mean_episode_return"]) < 1e-4 * max(1.0, abs(float(stats[:, 0].mean())))
     assert abs(float(stats[:, 2].mean()) - d["stats"]["solved_frac"]) < 1e-6
+
+
+def _fracs(node, path=""):
+    """every (path, value) whose key ends in _frac / is `frac`, anywhere in the line"""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if isinstance(v, (int, float)) and (k == "frac" or k.endswith("_frac")):
+                yield path + "/" + k, float(v)
+            else:
+                yield from _fracs(v, path + "/" + k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            yield from _fracs(v, f"{path}[{i}]")
+
+
+@pytest.mark.gpu
+def test_bench_line_bookkeeping_repeats_fractions_and_replayed_counters():
+    """The default line (short): `repeats` timed regions with the median reported, no fraction above 1 anywhere (the valu-busy
+    fraction is priced per RESIDENT wave: mm_model_launch_info), counters that were not measured in the run sit under
+    roofline.profile and name the committed file they are replayed from, the GPU clocks are logged around the timed region."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["repeats"] >= 3 and len(d["region_ms_per_step"]) == d["repeats"]
+    assert sorted(d["region_ms_per_step"])[(d["repeats"] - 1) // 2] == pytest.approx(d["ms_per_step"], rel=1e-9)
+    assert "gpu_clocks_mhz" in d
+    fr = list(_fracs(d))
+    assert len(fr) >= 10, fr
+    for path, v in fr:
+        assert 0.0 <= v <= 1.0, (path, v)
+    lines = [d] + [x for x in d["extra_configs"] if "error" not in x]
+    assert len(lines) == 1 + len(d["extra_configs"]), [x for x in d["extra_configs"] if "error" in x]
+    for x in lines:
+        r = x["roofline"]
+        assert r["launch"]["resident_blocks_per_cu"] >= 1 and r["launch"]["vgprs"] > 0
+        if r["profile"] is not None:
+            assert r["profile"]["replayed_from"].startswith("profiles/") and os.path.exists(os.path.join(ROOT, r["profile"]["replayed_from"]))
+            assert r["traffic_source"] == r["profile"]["replayed_from"]
+        else:
+            assert r["traffic"] is None
+    keys = {x["key"] for x in d["extra_configs"]}
+    assert "myoHandReachRandom-v0@4096" in keys and "myoHandPoseRandom-v0@4096|precision=f64_state" in keys
+    prec = [x for x in d["extra_configs"] if x["key"] == "myoHandPoseRandom-v0@4096|precision=f64_state"][0]
+    assert prec["dtype"] == "f64" and prec["value"] >= 1.0e6          # BASELINE.json's throughput target holds in precision mode too

@@ -437,6 +437,11 @@ def test_folded_walk_and_reorient_reset_matches_the_separate_reset(env_id, n, kw
     dense_col = ref.rwd.shape[1] - 1
     crossed = 0
     for s in range(13):
+        if s == 6:      # a late seed() / fatigue_reset_vec assignment reaches the folded reset as it reaches the separate one
+            for e_ in (fused, ref):
+                e_._seed_u64 = 77
+                if e_.muscle_condition == "fatigue":
+                    e_.fatigue_reset_vec = np.full(e_.cm.na, 0.25, np.float32)
         obs_f, rwd_f, mask_f = fused.rollout_step(None, stream_id=s)
         E.uniform(a, 23, s)
         E.env_step(ref.hm, ref.state, a, ref._task)
