@@ -99,6 +99,10 @@ class _Ctx:
         self.inertiafromgeom = "auto"
         self.defaults: Dict[str, Dict[str, Dict[str, str]]] = {"main": {}}
         self.parent_class: Dict[str, str] = {}
+        # lenient: the file is known to be incomplete (includes skipped: `missing_include="skip"`, dry_run) -- a default class that
+        # only a missing include defines resolves to "main", and what could not be interpreted is counted in `skipped`
+        self.lenient = False
+        self.skipped: Dict[str, int] = {}
 
     def ang(self, x):
         return math.radians(x) if self.degree else x
@@ -146,7 +150,10 @@ class _Ctx:
     def resolve(self, tag: str, attrib: Dict[str, str], childclass: Optional[str]) -> Dict[str, str]:
         cls = attrib.get("class", childclass or "main")
         if cls not in self.defaults:
-            raise MjcfError(f"unknown default class {cls!r}")
+            if not self.lenient:
+                raise MjcfError(f"unknown default class {cls!r}")
+            self.skipped[f"default class {cls!r} (defined by a missing include)"] = self.skipped.get(f"default class {cls!r} (defined by a missing include)", 0) + 1
+            cls = "main"
         chain = []
         c = cls
         while c is not None:
@@ -243,6 +250,7 @@ def load(source: str, missing_include: str = "error", include_map: Optional[Dict
         raise MjcfError("root element must be <mujoco>")
     _expand_includes(root, base, missing_include, include_map)
     ctx = _Ctx()
+    ctx.lenient = missing_include == "skip"
     opt = dict(timestep=0.002, gravity=(0.0, 0.0, -9.81), integrator=0, iterations=100, tolerance=1e-8, ls_iterations=50,
                ls_tolerance=0.01, eulerdamp=True)
     for el in root.findall("compiler"):
@@ -572,7 +580,13 @@ def load(source: str, missing_include: str = "error", include_map: Optional[Dict
     if keys:
         nq = sum({C["MM_JNT_FREE"]: 7, C["MM_JNT_BALL"]: 4}.get(j.type, 1) for j in s.joints)
         nv = sum({C["MM_JNT_FREE"]: 6, C["MM_JNT_BALL"]: 3}.get(j.type, 1) for j in s.joints)
+        if ctx.lenient:      # keyframes are sized for the whole model: with includes skipped they cannot match what was read
+            ok = [(q, v) for q, v in keys if (q is None or len(q.split()) == nq) and (v is None or len(v.split()) == nv)]
+            if len(ok) != len(keys):
+                ctx.skipped["keyframes sized for the complete model"] = len(keys) - len(ok)
+            keys = ok
         s.keys = [(np.array(_floats(q, nq)) if q else None, np.array(_floats(v, nv)) if v else np.zeros(nv)) for q, v in keys]
+    s.import_skipped = dict(ctx.skipped)
     return s
 
 
@@ -651,7 +665,16 @@ def dry_run(source: str, include_map: Optional[Dict[str, str]] = None) -> dict:
         nm = el.attrib.get("name") or el.attrib.get("class") or ""
         return "/".join(p.tag + (f"[{p.attrib.get('name')}]" if p.attrib.get("name") else "") for p in parents[-2:]) + f"/{el.tag}" + (f"[{nm}]" if nm else "")
 
-    defaults_geom_type: Dict[str, str] = {}
+    ctx = _Ctx(); ctx.lenient = True
+    for dn in root.findall("default"):
+        ctx.read_defaults(dn)
+
+    def childclass_of(parents):
+        cc = None
+        for p in parents:
+            if p.tag in ("body", "worldbody", "frame") and "childclass" in p.attrib:
+                cc = p.attrib["childclass"]
+        return cc
 
     def walk(el, parents):
         counts[el.tag] = counts.get(el.tag, 0) + 1
@@ -668,13 +691,14 @@ def dry_run(source: str, include_map: Optional[Dict[str, str]] = None) -> dict:
             if a.get("solver", "Newton") != "Newton":
                 bad(f"solver {a['solver']}", w)
         if t == "geom" and "default" not in [p.tag for p in parents]:
-            gtype = a.get("type")
-            if gtype in ("mesh", "hfield", "sdf") or ("mesh" in a and gtype is None):
-                # collides unless contype == conaffinity == 0 (class defaults are not resolved here: reported as "may collide")
-                if a.get("contype", None) == "0" and a.get("conaffinity", None) == "0":
+            ra = ctx.resolve("geom", dict(a), childclass_of(parents))       # the element's attributes through its default classes
+            gtype = ra.get("type")
+            if gtype in ("mesh", "hfield", "sdf") or ("mesh" in ra and gtype is None):
+                # collides unless contype == conaffinity == 0 (MuJoCo's defaults are 1 / 1)
+                if int(float(ra.get("contype", "1"))) == 0 and int(float(ra.get("conaffinity", "1"))) == 0:
                     ignored["visual mesh geom"] = ignored.get("visual mesh geom", 0) + 1
                 else:
-                    bad(f"{gtype or 'mesh'} geom that may collide (contype/conaffinity not both 0 on the element)", w)
+                    bad(f"{gtype or 'mesh'} geom that collides (contype {ra.get('contype', '1')} / conaffinity {ra.get('conaffinity', '1')} after default classes)", w)
         if t == "joint" and "default" not in [p.tag for p in parents]:
             if a.get("type") == "ball" and (a.get("limited") == "true" or "range" in a):
                 bad("limited ball joint", w)

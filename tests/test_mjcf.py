@@ -8,6 +8,8 @@ import pytest
 from myosuite_amd.model import mjcf, synth
 from oracle import oracle as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.mark.parametrize("name", ["elbow", "hand", "leg", "contact_toy", "hand_reorient", "friction_toy", "hand_keyturn", "finger",
                                   "motorfinger", "elbow_exo", "tendon_limit_toy"])
@@ -320,3 +322,89 @@ def test_dry_run_lists_every_construct_the_importer_would_reject():
         assert len(sar["missing_includes"]) == 3 and all("simhive/myo_sim" in f for f in sar["missing_includes"]) and not sar["unsupported"]
         leg = mjcf.dry_run(os.path.join(ref, "leg", "myolegs_chasetag.xml"))
         assert any(k.startswith("hfield geom") for k in leg["unsupported"]) and len(leg["missing_includes"]) == 7
+
+
+MYO_SIM_STYLE = """<mujoco model="myo_like">
+  <compiler angle="radian" inertiafromgeom="auto" balanceinertia="true" boundmass="0.001" boundinertia="0.001" meshdir=".." texturedir=".."/>
+  <size njmax="1000" nconmax="400" nuser_jnt="1"/>
+  <option timestep="0.002"><flag multiccd="enable"/></option>
+  <visual><headlight ambient="0.5 0.5 0.5"/><global offwidth="1440"/></visual>
+  <default>
+    <default class="myo"><joint armature="0.01" damping="0.05" limited="true"/>
+      <geom margin="0.001" material="mat_bone" rgba="0.8 0.85 0.8 1" conaffinity="0" contype="0"/>
+      <site size="0.001" rgba="0.8 0.8 0.8 1"/>
+      <tendon rgba="0.95 0.3 0.3 1" width="0.001"/>
+      <default class="muscle"><general biasprm="0.75 1.05 -1 200 0.5 1.6 1.5 1.3 1.2 0" biastype="muscle" ctrllimited="true" ctrlrange="0 1" dynprm="0.01 0.04 0 0 0 0 0 0 0 0" dyntype="muscle" gainprm="0.75 1.05 -1 200 0.5 1.6 1.5 1.3 1.2 0" gaintype="muscle"/></default>
+      <default class="skin"><geom type="capsule" group="1" contype="1" conaffinity="1" condim="3" rgba="0.8 0.7 .5 1" margin="0.001" material="MatSkin"/></default>
+      <default class="wrap"><geom rgba=".5 .5 .9 1" group="3" contype="0" conaffinity="0" type="cylinder"/></default>
+    </default>
+  </default>
+  <asset><mesh name="bone1" file="meshes/bone1.stl" scale="1 1 1"/><texture name="t" type="2d" builtin="checker" width="8" height="8"/><material name="mat_bone" texture="t"/><material name="MatSkin"/></asset>
+  <contact><exclude body1="b1" body2="b2"/><pair geom1="s1" geom2="s2" condim="1"/></contact>
+  <worldbody>
+    <light pos="0 0 2"/><camera name="c" pos="0 -1 1"/>
+    <geom name="floor" type="plane" size="5 5 0.1" conaffinity="1" contype="1"/>
+    <body name="b1" pos="0 0 1" childclass="myo">
+      <inertial pos="0 0 0" mass="1" diaginertia="0.01 0.01 0.01"/>
+      <joint name="j1" type="hinge" axis="0 1 0" range="-1 1" user="3"/>
+      <geom name="bone1" type="mesh" mesh="bone1"/>
+      <geom name="s1" class="skin" size="0.02" fromto="0 0 0 0 0 -0.2"/>
+      <geom name="w1" class="wrap" size="0.02 0.05" pos="0 0 -0.1" euler="1.57 0 0"/>
+      <site name="a1" pos="0.02 0 -0.02"/><site name="side1" pos="0.05 0 -0.1"/>
+      <body name="b2" pos="0 0 -0.2">
+        <inertial pos="0 0 -0.1" mass="0.5" diaginertia="0.005 0.005 0.001"/>
+        <joint name="j2" type="hinge" axis="0 1 0" range="0 2"/>
+        <joint name="j2b" type="slide" axis="0 0 1" range="-0.01 0.01"/>
+        <geom name="s2" class="skin" size="0.02" fromto="0 0 0 0 0 -0.2"/>
+        <site name="a2" pos="0.02 0 -0.1"/>
+      </body>
+    </body>
+  </worldbody>
+  <tendon>
+    <spatial name="t1" class="myo" springlength="0.1"><site site="a1"/><geom geom="w1" sidesite="side1"/><site site="a2"/></spatial>
+    <fixed name="tf" limited="true" range="-1 1"><joint joint="j1" coef="1"/><joint joint="j2" coef="-0.5"/></fixed>
+  </tendon>
+  <equality><joint name="couple" joint1="j2b" joint2="j2" polycoef="0 0.005 0 0 0" solimp="0.9999 0.9999 0.001 0.5 2"/></equality>
+  <actuator><general name="m1" class="muscle" tendon="t1" lengthrange="0.05 0.3"/></actuator>
+  <sensor><jointpos joint="j1"/><actuatorfrc actuator="m1"/></sensor>
+  <keyframe><key name="stand" qpos="0 0.5 0.0025"/><key qpos="0.1 0.2 0.001" qvel="0 0 0" act="0.1" ctrl="0.2"/></keyframe>
+  <custom><numeric name="x" data="1"/></custom>
+</mujoco>"""
+
+
+def test_importer_takes_the_non_physical_constructs_of_a_myo_sim_style_file(oracle_lib):
+    """What a real `myo_sim` file is known to carry besides the physics the engine implements -- class-scoped defaults with
+    `childclass`, visual-only mesh geoms (contype = conaffinity = 0 through their class; the mesh FILE is never opened),
+    <size>, <flag>, <visual>, <asset> textures / materials, lights, cameras, `user` attributes, <contact><exclude> next to
+    explicit <pair>s, <tendon><fixed>, polycoef joint couplings, sensors, named keyframes with act / ctrl, <custom> -- goes
+    through `load`, compiles, and steps in the oracle; `dry_run` reports nothing unsupported."""
+    sp = mjcf.load(MYO_SIM_STYLE)
+    cm = sp.compile()
+    assert (cm.nq, cm.nv, cm.nu, cm.ntendon, cm.neq) == (3, 3, 1, 2, 1) and cm.npair >= 1 and len(sp.keys) == 2
+    r = mjcf.dry_run(MYO_SIM_STYLE)
+    assert r["unsupported"] == {} and r["ignored"]["visual mesh geom"] == 1 and r["loadable"]
+    d = O.OracleData(O.OracleModel(cm))
+    d.qpos[:] = sp.keys[1][0]
+    d.ctrl[:] = 0.3
+    d.step(50)
+    assert np.all(np.isfinite(d.qpos)) and float(np.abs(d.qpos).max()) < 10.0
+
+
+def test_committed_mjcf_inventory_of_the_reference_task_files():
+    """profiles/r04_mjcf_dry_run.json (tools/mjcf_inventory.py over <reference>/myosuite/envs/myo/assets): the importer's only
+    rejections are the documented physics gaps -- mesh / height-field COLLISION geoms and inertia from meshes -- plus one file
+    that is an include fragment, not a model.  Re-derived and compared when the reference checkout is present."""
+    import json
+    import subprocess
+    import sys
+    inv = json.load(open(os.path.join(ROOT, "profiles", "r04_mjcf_dry_run.json")))
+    assert inv["files_total"] >= 20
+    for f, why in inv["importer_rejections_with_includes_skipped"].items():
+        assert ("collision geom of type 'mesh'" in why or "collision geom of type 'hfield'" in why or "inertia from meshes" in why
+                or "root element must be <mujoco>" in why), (f, why)
+    for kind in inv["unsupported_constructs_by_number_of_files"]:
+        assert kind.startswith(("mesh geom that collides", "hfield geom that collides")), kind
+    if os.path.isdir("/root/reference/myosuite/envs/myo/assets"):
+        now = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "mjcf_inventory.py")], text=True))
+        assert now["importer_rejections_with_includes_skipped"] == inv["importer_rejections_with_includes_skipped"]
+        assert now["unsupported_constructs_by_number_of_files"] == inv["unsupported_constructs_by_number_of_files"]
