@@ -169,7 +169,9 @@ enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
   MM_SEC(EQ_DATA,          'f', 5)   /* polycoef */                              \
   MM_SEC(EQ_SOLREF,        'f', 2)                                               \
   MM_SEC(EQ_SOLIMP,        'f', 5)                                               \
-  /* static candidate contact pairs with pre-mixed parameters */                 \
+  /* static candidate contact pairs with pre-mixed parameters; type(geom1) <= type(geom2).  An entry yields at most two   \
+     contacts: a pair whose collider can return four (plane-box, plane-cylinder) takes TWO consecutive identical entries, \
+     entry k of the run keeping contacts 2k, 2k+1 of the collider's order (oracle/mmo_collision.inc) */                   \
   MM_SEC(PAIR_GEOM1,       'i', 1)                                               \
   MM_SEC(PAIR_GEOM2,       'i', 1)                                               \
   MM_SEC(PAIR_CONDIM,      'i', 1)                                               \

@@ -308,7 +308,7 @@ static void build_layout(mm_model* m) {
   D.cvel = take(6 * d.nbody); D.tenlen = take(d.ntendon); D.tenvel = take(d.ntendon); D.tenj = take(d.ntenJ);
   D.actfrc = take(d.nu); D.actdot = take(d.na); D.M = take(d.nv * d.nv); D.bias = take(d.nv); D.smooth = take(d.nv);
   D.qaccsm = take(d.nv); D.qacc = take(d.nv); D.qfrccon = take(d.nv);
-  D.efc_active = take(64); D.efc_D = take(64); D.efc_aref = take(64); D.scal = take(32);
+  D.efc_active = take(64); D.efc_D = take(64); D.efc_aref = take(64); D.scal = take(32 + 64);   // (+ 64: per-iteration Newton trace of a MM_NEWTON_TRACE tools build)
   D.total = o;
 }
 
@@ -461,10 +461,15 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     const int32_t* pc = (const int32_t*)(blob + m->sec[MM_SEC_PAIR_CONDIM]);
     for (int p = 0; p < d.npair; p++) {
       const int t1 = gt[p1[p]], t2 = gt[p2[p]];
-      const bool ok = (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
+      const bool ok = (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE || t2 == MM_GEOM_ELLIPSOID || t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX)) ||
                       (t1 == MM_GEOM_SPHERE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
                       (t1 == MM_GEOM_CAPSULE && (t2 == MM_GEOM_CAPSULE || t2 == MM_GEOM_ELLIPSOID || t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX));
-      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane/sphere/capsule, and capsule vs ellipsoid/cylinder/box (geom1 type <= geom2 type)"); }
+      if (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX)) {
+        // up to four contacts: two consecutive identical entries, two contacts each (include/myosim_model.h, PAIR_* sections)
+        const bool twin = (p > 0 && p1[p - 1] == p1[p] && p2[p - 1] == p2[p]) || (p + 1 < d.npair && p1[p + 1] == p1[p] && p2[p + 1] == p2[p]);
+        if (!twin) { delete m; return fail(MM_EBADBLOB, "a plane-box / plane-cylinder pair takes two consecutive entries of the PAIR_* sections"); }
+      }
+      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane vs sphere/capsule/ellipsoid/cylinder/box, sphere/capsule among themselves, capsule vs ellipsoid/cylinder/box (geom1 type <= geom2 type)"); }
       if (pc[p] != 1 && pc[p] != 3) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1 or 3"); }
     }
   }

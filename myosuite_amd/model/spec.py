@@ -464,18 +464,28 @@ class ModelSpec:
         A["EQ_SOLREF"] = np.array([e["solref"] for e in self.equalities], f32).reshape(neq, 2)
         A["EQ_SOLIMP"] = np.array([e["solimp"] for e in self.equalities], f32).reshape(neq, 5)
 
-        npair = len(self.pairs)
         for p in self.pairs:   # MuJoCo orders a pair so that type(geom1) <= type(geom2)
             if self.geoms[self._gname[p["g1"]]]["type"] > self.geoms[self._gname[p["g2"]]]["type"]:
                 p["g1"], p["g2"] = p["g2"], p["g1"]
-        A["PAIR_GEOM1"] = np.array([self._gname[p["g1"]] for p in self.pairs], i32)
-        A["PAIR_GEOM2"] = np.array([self._gname[p["g2"]] for p in self.pairs], i32)
-        A["PAIR_CONDIM"] = np.array([p["condim"] for p in self.pairs], i32)
-        A["PAIR_FRICTION"] = np.array([p["friction"] for p in self.pairs], f32).reshape(npair, 3)
-        A["PAIR_MARGIN"] = np.array([p["margin"] for p in self.pairs], f32)
-        A["PAIR_GAP"] = np.array([p["gap"] for p in self.pairs], f32)
-        A["PAIR_SOLREF"] = np.array([p["solref"] for p in self.pairs], f32).reshape(npair, 2)
-        A["PAIR_SOLIMP"] = np.array([p["solimp"] for p in self.pairs], f32).reshape(npair, 5)
+        # Entries of the PAIR_* sections: a pair whose collider can return up to FOUR contacts (plane-box, plane-cylinder) takes two
+        # consecutive, identical entries -- entry k of the run keeps contacts 2k, 2k+1 -- so that every entry (one lane of the HIP
+        # kernel) yields at most two (oracle/mmo_collision.inc)
+        def _ptypes(p):
+            return self.geoms[self._gname[p["g1"]]]["type"], self.geoms[self._gname[p["g2"]]]["type"]
+        entries = []
+        for p in self.pairs:
+            entries.append(p)
+            if _ptypes(p) in ((C["MM_GEOM_PLANE"], C["MM_GEOM_BOX"]), (C["MM_GEOM_PLANE"], C["MM_GEOM_CYLINDER"])):
+                entries.append(p)
+        npair = len(entries)
+        A["PAIR_GEOM1"] = np.array([self._gname[p["g1"]] for p in entries], i32)
+        A["PAIR_GEOM2"] = np.array([self._gname[p["g2"]] for p in entries], i32)
+        A["PAIR_CONDIM"] = np.array([p["condim"] for p in entries], i32)
+        A["PAIR_FRICTION"] = np.array([p["friction"] for p in entries], f32).reshape(npair, 3)
+        A["PAIR_MARGIN"] = np.array([p["margin"] for p in entries], f32)
+        A["PAIR_GAP"] = np.array([p["gap"] for p in entries], f32)
+        A["PAIR_SOLREF"] = np.array([p["solref"] for p in entries], f32).reshape(npair, 2)
+        A["PAIR_SOLIMP"] = np.array([p["solimp"] for p in entries], f32).reshape(npair, 5)
 
         # body levels (depth-sorted) for the cooperative engine
         depth = np.zeros(nbody, i32)
@@ -539,9 +549,11 @@ class ModelSpec:
         con_rows = 0
         for p in self.pairs:
             con_rows = max(con_rows, 1 if p["condim"] == 1 else 2 * (p["condim"] - 1))
-        # a plane-capsule pair can produce two contacts (one per end cap), every other supported pair one
-        ncon_bound = sum(2 if (self.geoms[self._gname[p["g1"]]]["type"] == 0
-                               and self.geoms[self._gname[p["g2"]]]["type"] == 3) else 1 for p in self.pairs)
+        # contacts an entry can produce: two for plane-capsule (one per end cap), capsule-capsule (parallel axes) and each of the
+        # two entries of a plane-box / plane-cylinder pair; one otherwise
+        two = ((C["MM_GEOM_PLANE"], C["MM_GEOM_CAPSULE"]), (C["MM_GEOM_CAPSULE"], C["MM_GEOM_CAPSULE"]),
+               (C["MM_GEOM_PLANE"], C["MM_GEOM_BOX"]), (C["MM_GEOM_PLANE"], C["MM_GEOM_CYLINDER"]))
+        ncon_bound = sum(2 if _ptypes(p) in two else 1 for p in entries)
         nconmax = self.nconmax if self.nconmax else ncon_bound
         nfric = int(np.count_nonzero(dof_floss > 0))
         njmax = neq + nfric + nlim_j + nlim_t + nconmax * con_rows

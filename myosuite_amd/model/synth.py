@@ -1009,6 +1009,34 @@ def _ground_keyframes(cm):
         cm.key_qpos[k, 2] -= low
 
 
+def make_plane_toy() -> ModelSpec:
+    """Test model for the multi-contact colliders (oracle/mmo_collision.inc): a box, a cylinder and an ellipsoid on free joints over
+    a tilted plane (up to 4 / 4 / 1 contacts), and a capsule on two slide joints that stays exactly parallel to a world-fixed
+    capsule (two contacts)."""
+    s = ModelSpec("plane_toy", timestep=0.002)
+    s.add_geom("floor", "world", "plane", (0, 0, 0), quat=(math.cos(0.03), 0.0, math.sin(0.03), 0.0))    # 3.4 deg tilt about y
+    s.add_body("box", "world", pos=(0.0, 0.0, 0.05), mass=0.8, inertia=(0.002, 0.003, 0.004))
+    s.add_joint("box_free", "box", "free")
+    s.add_geom("box_g", "box", "box", (0.08, 0.05, 0.03))
+    s.add_body("cyl", "world", pos=(0.4, 0.0, 0.08), mass=0.6, inertia=(0.002, 0.002, 0.001))
+    s.add_joint("cyl_free", "cyl", "free")
+    s.add_geom("cyl_g", "cyl", "cylinder", (0.04, 0.06))
+    s.add_body("ell", "world", pos=(-0.4, 0.0, 0.05), mass=0.5, inertia=(0.001, 0.002, 0.003))
+    s.add_joint("ell_free", "ell", "free")
+    s.add_geom("ell_g", "ell", "ellipsoid", (0.07, 0.05, 0.03))
+    QY90 = (math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0)
+    s.add_geom("rail", "world", "capsule", (0.02, 0.10), pos=(0.0, 0.5, 0.30), quat=QY90)
+    s.add_body("bar", "world", pos=(0.0, 0.5, 0.34), mass=0.3, inertia=(0.0005, 0.0005, 0.0001))
+    s.add_joint("bar_z", "bar", "slide", axis=(0, 0, 1), damping=0.2)
+    s.add_joint("bar_x", "bar", "slide", axis=(1, 0, 0), damping=0.2)
+    s.add_geom("bar_g", "bar", "capsule", (0.02, 0.06), quat=QY90)
+    s.add_contact_pair("floor", "box_g", condim=3, friction=(0.8, 0.005, 0.0001))
+    s.add_contact_pair("floor", "cyl_g", condim=3, friction=(0.6, 0.005, 0.0001))
+    s.add_contact_pair("floor", "ell_g", condim=3, friction=(0.7, 0.005, 0.0001))
+    s.add_contact_pair("rail", "bar_g", condim=3, friction=(0.9, 0.005, 0.0001))
+    return s
+
+
 _CACHE = {}
 
 
@@ -1022,7 +1050,7 @@ def builders() -> dict:
             "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True),
             "leg_implicit": lambda: make_leg(implicit=True), "torso_exo": lambda: make_torso(exosuit=True),
             "tree_star": lambda: make_tree_toy("star"), "tree_chain": lambda: make_tree_toy("chain"),
-            "tree_comb": lambda: make_tree_toy("comb"), "tree_free": lambda: make_tree_toy("free")}
+            "tree_comb": lambda: make_tree_toy("comb"), "tree_free": lambda: make_tree_toy("free"), "plane_toy": make_plane_toy}
 
 
 def compile_spec(name: str, edit=None) -> CompiledModel:

@@ -126,6 +126,7 @@ typedef struct {
   real *act_dot, *actuator_force, *qfrc_actuator, *qfrc_smooth, *qacc_smooth;
   /* constraints */
   int nefc, ncon;
+  int col_seq, col_part;   /* mmo_collide: contact number within the pair entry being collided, the entry's part (mmo_collision.inc) */
   int *efc_type, *efc_id;
   real *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_solref, *efc_solimp;
   real* efc_floss;   /* friction-loss rows: the dry-friction bound (0 on every other row) */
@@ -1584,6 +1585,7 @@ int mmo_ncon(const mmo_data* d) { return d->ncon; }
 int mmo_solver_niter(const mmo_data* d) { return d->solver_niter; }
 int mmo_warn(const mmo_data* d) { return d->warn_bad; }
 const int* mmo_efc_type(const mmo_data* d) { return d->efc_type; }
+const int* mmo_con_pair(const mmo_data* d) { return d->con_pair; }   /* PAIR_* entry of every detected contact */
 int mmo_dim(const mmo_model* m, int which) { return MI(m, OPT_I)[which]; }
 
 /* dense M (nv x nv) from the sparse layout, for tests */

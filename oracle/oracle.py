@@ -57,6 +57,8 @@ def lib():
             getattr(L, f).restype = C.c_int
         L.mmo_efc_type.restype = C.POINTER(C.c_int)
         L.mmo_efc_type.argtypes = [C.c_void_p]
+        L.mmo_con_pair.restype = C.POINTER(C.c_int)
+        L.mmo_con_pair.argtypes = [C.c_void_p]
         L.mmo_full_m.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.mmo_batch_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int, C.c_int]
@@ -138,6 +140,12 @@ class OracleData:
     @time.setter
     def time(self, t):
         lib().mmo_set_time(self.ptr, float(t))
+
+    @property
+    def con_pair(self):
+        """entry of the PAIR_* sections every detected contact belongs to"""
+        n = self.ncon
+        return np.ctypeslib.as_array(lib().mmo_con_pair(self.ptr), shape=(max(n, 1),))[:n].copy()
 
     @property
     def efc_type(self):

@@ -56,6 +56,96 @@ def test_axis_aligned_sliding_friction_is_mu_g(oracle_lib):
         assert 0.85 * mu * 9.81 < decel <= 1.02 * mu * 9.81, (mu, decel)
 
 
+def _free_geom_on_floor(gtype, size, quat=(1, 0, 0, 0), z=0.1, condim=3):
+    s = ModelSpec("obj", timestep=0.002)
+    s.add_geom("floor", "world", "plane", (0, 0, 0))
+    s.add_body("b", pos=(0, 0, z), mass=1.0, inertia=(0.004, 0.004, 0.004), quat=quat)
+    s.add_joint("root", "b", type="free")
+    s.add_geom("g", "b", gtype, size)
+    s.add_contact_pair("floor", "g", condim=condim, friction=(1.0, 0.005, 0.0001))
+    return s.compile()
+
+
+def test_contact_multiplicity_follows_mujocos_primitive_colliders(oracle_lib):
+    """mmo_collision.inc header: plane-capsule 2 contacts with frames aligned with the capsule axis, plane-box up to 4 (corner
+    order), plane-cylinder up to 4 (lowest rim point, the other cap, two triangle points), plane-ellipsoid 1 (support point),
+    capsule-capsule 1 in general and 2 when the axes are parallel."""
+    Y90 = (math.cos(math.pi / 4), 0, math.sin(math.pi / 4), 0)       # local z -> world x: a capsule / cylinder lying down
+    # capsule lying on the plane: two contacts, tangent 1 of both frames along the capsule axis (mjc_PlaneCapsule)
+    cm = _free_geom_on_floor("capsule", (0.05, 0.1), quat=Y90, z=0.0499)
+    d = O.OracleData(O.OracleModel(cm)); d.forward()
+    assert d.ncon == 2 and d.nefc == 8
+    np.testing.assert_allclose(d.con_dist[:2], [-1e-4, -1e-4], atol=2e-8)
+    np.testing.assert_allclose(d.con_pos[:2, 0], [0.1, -0.1], atol=2e-8)            # +axis end first
+    for c in range(2):
+        np.testing.assert_allclose(d.con_frame[c, :3], [0, 0, 1], atol=2e-8)
+        np.testing.assert_allclose(np.abs(d.con_frame[c, 3:6]), [1, 0, 0], atol=2e-8)   # the capsule axis, not the default (0, 1, 0)
+    # box flat on the plane: its four bottom corners, in corner order (x fastest)
+    cm = _free_geom_on_floor("box", (0.1, 0.06, 0.03), z=0.0299)
+    assert cm.npair == 2 and cm.arrays["PAIR_GEOM2"][0] == cm.arrays["PAIR_GEOM2"][1]    # a four-contact pair takes two entries
+    d = O.OracleData(O.OracleModel(cm)); d.forward()
+    assert d.ncon == 4 and d.nefc == 16
+    np.testing.assert_allclose(d.con_pos[:4, :2], [[-0.1, -0.06], [0.1, -0.06], [-0.1, 0.06], [0.1, 0.06]], atol=2e-8)
+    np.testing.assert_allclose(d.con_dist[:4], -1e-4, atol=2e-8)
+    d.step(800)                                                                         # ... and it rests on them: sum of normal forces = weight
+    assert d.ncon == 4 and abs(d.efc_force[:16].sum() - 9.81) < 1e-3 and np.abs(d.qvel).max() < 1e-6
+    # box on an edge: only the two corners of that edge
+    cm = _free_geom_on_floor("box", (0.1, 0.06, 0.03), quat=(math.cos(math.pi / 8), math.sin(math.pi / 8), 0, 0), z=0.0)
+    d = O.OracleData(O.OracleModel(cm)); d.qpos[2] = 0.0636; d.forward()
+    assert d.ncon == 2
+    # cylinder standing on its cap: the lowest rim point (cylinder x axis when the cap is parallel to the plane), nothing on the
+    # far cap, two triangle points at +-120 degrees
+    cm = _free_geom_on_floor("cylinder", (0.05, 0.1), z=0.0999)
+    d = O.OracleData(O.OracleModel(cm)); d.forward()
+    assert d.ncon == 3
+    r = np.hypot(d.con_pos[:3, 0], d.con_pos[:3, 1])
+    np.testing.assert_allclose(r, 0.05, atol=2e-8)
+    ang = np.sort(np.round(np.degrees(np.arctan2(d.con_pos[:3, 1], d.con_pos[:3, 0]))) % 360)
+    np.testing.assert_allclose(ang, [0, 120, 240], atol=1e-6)
+    # cylinder lying down: its line of contact is sampled at both caps
+    cm = _free_geom_on_floor("cylinder", (0.05, 0.1), quat=Y90, z=0.0499)
+    d = O.OracleData(O.OracleModel(cm)); d.forward()
+    assert d.ncon == 2
+    np.testing.assert_allclose(np.sort(d.con_pos[:2, 0]), [-0.1, 0.1], atol=2e-8)
+    # ellipsoid: one contact at the support point
+    cm = _free_geom_on_floor("ellipsoid", (0.1, 0.06, 0.03), z=0.0299)
+    d = O.OracleData(O.OracleModel(cm)); d.forward()
+    assert d.ncon == 1 and abs(d.con_dist[0] + 1e-4) < 2e-8 and np.abs(d.con_pos[0, :2]).max() < 2e-8
+
+    def two_capsules(quat2, pos2):
+        s = ModelSpec("caps", timestep=0.002)
+        s.add_body("a", pos=(0, 0, 0), mass=1.0, inertia=(0.004, 0.004, 0.004), quat=Y90)
+        s.add_joint("ja", "a", type="free")
+        s.add_geom("ca", "a", "capsule", (0.02, 0.1))
+        s.add_body("b", pos=pos2, mass=1.0, inertia=(0.004, 0.004, 0.004), quat=quat2)
+        s.add_joint("jb", "b", type="free")
+        s.add_geom("cb", "b", "capsule", (0.02, 0.06))
+        s.add_contact_pair("ca", "cb", condim=1)
+        d_ = O.OracleData(O.OracleModel(s.compile())); d_.forward()
+        return d_
+    # parallel, overlapping: MuJoCo tries capsule 1's end caps first (+-0.1: 4 cm beyond capsule 2's ends, out of reach), then
+    # capsule 2's end caps against segment 1: two contacts under the two ends of the SHORTER capsule
+    d = two_capsules(Y90, (0.0, 0.0, 0.0399))
+    assert d.ncon == 2
+    np.testing.assert_allclose(d.con_pos[:2, 0], [0.06, -0.06], atol=2e-8)
+    np.testing.assert_allclose(d.con_pos[:2, 2], 0.01995, atol=2e-8)
+    np.testing.assert_allclose(d.con_dist[:2], -1e-4, atol=2e-8)
+    # parallel, capsule 1 the shorter one in reach: its own end caps are the two contacts
+    d = two_capsules(Y90, (0.07, 0.0, 0.0399))          # capsule 2 spans x in [0.01, 0.13]: capsule 1's +end (0.1) is under it, its -end is not
+    assert d.ncon == 2
+    np.testing.assert_allclose(np.sort(d.con_pos[:2, 0]), [0.01, 0.1], atol=2e-8)
+    # crossed: one contact at the closest points
+    d = two_capsules((1, 0, 0, 0), (0.03, 0.0, 0.0399 + 0.06))                          # a vertical capsule standing on the lying one with its end cap
+    assert d.ncon == 1
+    np.testing.assert_allclose(d.con_pos[0], [0.03, 0.0, 0.01995], atol=2e-8)
+    d = two_capsules((1, 0, 0, 0), (0.03, 0.0, 0.0401 + 0.06))                          # ... and 0.2 mm higher: out of reach (margin 0)
+    assert d.ncon == 0
+    d = two_capsules((math.cos(math.pi / 4), math.sin(math.pi / 4), 0, 0), (0.03, 0.0, 0.0399))   # local z -> world -y: crossed at right angles
+    assert d.ncon == 1
+    np.testing.assert_allclose(d.con_pos[0], [0.03, 0.0, 0.01995], atol=2e-8)
+    np.testing.assert_allclose(d.con_dist[0], -1e-4, atol=2e-8)
+
+
 def test_leg_model_dimensions_and_names(oracle_lib):
     cm = synth.get_model("leg")
     # SURVEY 8d / walk_v0.py: nq 35, nv 34, 80 muscles; obs = 33+34+2+4+2+1+6+1+3*80+80 = 403
@@ -98,7 +188,17 @@ def test_leg_free_joint_mass_matrix_matches_numpy(oracle_lib):
 # ----------------------------------------------------------------------------------- GPU
 def _states(cm, name, n, rng):
     q = np.tile(cm.qpos0.astype(np.float64), (n, 1))
-    if name == "contact_toy":
+    if name == "plane_toy":
+        # three free bodies at random tilts near the plane (faces / edges / corners / rims down), the bar over, on and beside the rail
+        for k, (h, spread) in enumerate(((0.05, 0.03), (0.07, 0.04), (0.045, 0.03))):
+            o = 7 * k
+            q[:, o + 2] = h + rng.uniform(-spread, spread, n) - 0.06 * q[:, o]      # follow the 3.4 deg tilt (z falls with +x)
+            kind = rng.integers(0, 3, n)
+            qq = rng.standard_normal((n, 4)) * np.where(kind == 0, 0.02, np.where(kind == 1, 0.15, 1.0))[:, None] + np.array([1, 0, 0, 0])
+            q[:, o + 3:o + 7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+        q[:, 21] = rng.uniform(-0.004, 0.003, n); q[:, 22] = rng.uniform(-0.12, 0.12, n)
+        v = rng.standard_normal((n, cm.nv)) * 0.3
+    elif name == "contact_toy":
         q[:, 2] += rng.uniform(-0.04, 0.05, n)
         qq = rng.standard_normal((n, 4)) * 0.2 + np.array([1, 0, 0, 0]); q[:, 3:7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
         q[:, 7:10] += rng.uniform(-0.05, 0.05, (n, 3)); q[:, 9] -= rng.uniform(0.0, 0.2, n)
@@ -115,7 +215,7 @@ def _states(cm, name, n, rng):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["contact_toy", "leg"])
+@pytest.mark.parametrize("name", ["contact_toy", "leg", "plane_toy"])
 def test_gpu_general_rows_forward_and_rollout_match_oracle(oracle_lib, name):
     import torch
     from myosuite_amd import engine as E
@@ -140,6 +240,13 @@ def test_gpu_general_rows_forward_and_rollout_match_oracle(oracle_lib, name):
         assert np.abs(got - d.qfrc_constraint).max() < 2e-4 * max(1.0, np.abs(d.qfrc_smooth).max())
         assert int(dump[e, hm.layout("scal")]) == d.solver_niter          # same Newton path
     assert saw_contact >= n // 2 and saw_multi_iter >= 1
+    if name == "plane_toy":      # every multiplicity of the multi-contact colliders occurs in the sample
+        per_pair = np.zeros((n, cm.npair), int)
+        for e, d in enumerate(ds):
+            for c_ in range(d.ncon):
+                per_pair[e, d.con_pair[c_]] += 1
+        box, cyl, ell, cap = per_pair[:, 0] + per_pair[:, 1], per_pair[:, 2] + per_pair[:, 3], per_pair[:, 4], per_pair[:, 5]
+        assert box.max() == 4 and {1, 2} <= set(box) and cyl.max() >= 3 and ell.max() == 1 and cap.max() == 2, (set(box), set(cyl), set(cap))
     c = torch.from_numpy(ctrl).cuda()
     for _ in range(4):
         E.step(hm, st, c, 25)

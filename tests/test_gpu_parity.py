@@ -626,24 +626,32 @@ def test_hip_matches_libmujoco_fixture(path):
 @pytest.mark.gpu
 def test_task_struct_size_field_gives_append_only_compatibility():
     """mm_task.size / mm_rollout.size (include/myosim.h): the library copies min(size, its sizeof) bytes and zero-fills the rest.
-    A caller built against an OLDER, shorter mm_task (here: cut in front of the reset-observation fields, which it leaves at
-    zero anyway) gets the same result as the full struct; size = 0 (unset) and size > sizeof (a NEWER header) are refused
-    with MM_EARG instead of being misread."""
+    A caller built against the OLDER, shorter mm_rollout of ABI 4 (cut in front of the walk / reorient reset fields ABI 5
+    appended, which a Pose rollout leaves at zero anyway) gets the same result as the full struct.  Refused with MM_EARG instead
+    of being misread: size = 0 (unset), anything below the ABI-4 struct -- a caller from before the size field existed has some
+    other word there (a small task id, say) -- and size > sizeof (a NEWER header)."""
     import ctypes as C
     from myosuite_amd.envs import registry
-    envs = [registry.make("myoElbowPose1D6MRandom-v0", num_envs=32, seed=3, autoreset=False) for _ in range(2)]
-    a = torch.empty(32, envs[0].cm.nu, device="cuda")
-    E.uniform(a, 1, 0)
+    envs = [registry.make("myoElbowPose1D6MRandom-v0", num_envs=32, seed=3, max_episode_steps=4) for _ in range(2)]
     full, cut = envs
-    assert full._task.size == C.sizeof(E.mm_task)
-    cut._task.size = E.mm_task.env_mask.offset          # an "old" caller whose struct ended before env_mask / obs_only
-    for _ in range(3):
-        E.env_step(full.hm, full.state, a, full._task)
-        E.env_step(cut.hm, cut.state, a, cut._task)
-    assert torch.equal(full.obs, cut.obs) and torch.equal(full.state.qpos, cut.state.qpos)
-    for bad in (0, C.sizeof(E.mm_task) + 8):
+    for e_ in envs:
+        e_.rollout_setup(action_seed=5)
+    assert full._ro.size == C.sizeof(E.mm_rollout) and full._task.size == C.sizeof(E.mm_task)
+    cut._ro.size = E.mm_rollout.walk_ka_qpos.offset          # an ABI-4 caller: its struct ended after reset_seed
+    assert cut._ro.size == E.mm_rollout.reset_seed.offset + 8
+    for s_ in range(9):                                       # across two episode boundaries (folded Pose reset)
+        full.rollout_step(None, stream_id=s_)
+        cut.rollout_step(None, stream_id=s_)
+    assert torch.equal(full.obs, cut.obs) and torch.equal(full.state.qpos, cut.state.qpos) and torch.equal(full.episode, cut.episode)
+    a = torch.empty(32, cut.cm.nu, device="cuda")
+    E.uniform(a, 1, 0)
+    for bad in (0, 6, E.mm_task.env_mask.offset, C.sizeof(E.mm_task) + 8):
         cut._task.size = bad
         with pytest.raises(E.EngineError):
             E.env_step(cut.hm, cut.state, a, cut._task)
     cut._task.size = C.sizeof(E.mm_task)
     E.env_step(cut.hm, cut.state, a, cut._task)
+    for bad in (0, 8, E.mm_rollout.reset_seed.offset, C.sizeof(E.mm_rollout) + 8):
+        cut._ro.size = bad
+        with pytest.raises(E.EngineError):
+            E.rollout_step(cut.hm, cut.state, cut._task, cut._ro)

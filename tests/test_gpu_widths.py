@@ -390,7 +390,10 @@ def test_trailing_forward_warm_start_is_immaterial(env_id, n, kw):
     qa, qb = d_step["qacc"].double(), d_zero["qacc"].double()
     rel = float(((qa - qb).abs().amax(dim=1) / qa.abs().amax(dim=1).clamp(min=1.0)).max())
     print(f"trailing forward, stepped vs zero warm start {env_id} {kw}: max rel |dqacc| {rel:.2e}, rows up to {int(d_step['nefc'].max())}")
-    assert float(keep.abs().max()) > 0 and rel < 5e-5, rel
+    # measured on MI355X: elbow / hand / leg <= 1e-6, self-colliding hand 9e-7, reorient 6.3e-5 (its fp32 contact solve is good to
+    # 4e-5 against the oracle: test_full_batch_launch_width_vs_oracle).  This test is what found round 3's missing wave fence in
+    # jac_mul: one env of the self-colliding hand differed by 6 % between the two warm starts.
+    assert float(keep.abs().max()) > 0 and rel < (2e-4 if "Reorient" in env_id else 2e-5), rel
 
 
 def test_rollout_step_other_tasks_and_sharded_streams():
