@@ -1,13 +1,13 @@
 """PPO on the batched HIP envs: rollout collection + clipped-surrogate updates, the workload of the reference's
-benchmarks/mjx_benchmark_PPO.py:18-66 (brax PPO on 8192 MJX envs) restated in plain torch.
+benchmarks/mjx_benchmark_PPO.py:18-66 (brax PPO on 8192 MJX envs), with the whole iteration on the device
+(myosuite_amd/ppo.py: the unroll and the minibatch passes are HIP graphs, GAE is one kernel).
 
-One process per GPU (torch.distributed over RCCL when launched with torch.distributed.run): every rank owns its own env
-shard; the physics never communicates; gradients are all-reduced (one flattened buffer per minibatch) during the update;
-episode statistics
-use one all-gather per iteration (myosuite_amd/dist.py).
+One process per GPU (torch.distributed over RCCL when launched with torch.distributed.run): every rank owns its own env shard;
+the physics never communicates; gradients are all-reduced as ONE flat buffer per minibatch; episode statistics use one all-gather
+per run (myosuite_amd/dist.py).
 
     python benchmarks/ppo_rollout.py --env myoFatiLegWalk-v0 --num-envs 1024 --iters 3
-Prints one JSON line with rollout-only and end-to-end env-steps/s.
+Prints one JSON line with rollout-only and end-to-end (train) env-steps/s.
 """
 import argparse
 import json
@@ -17,26 +17,10 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import torch.nn as nn
 
 from myosuite_amd import dist as D
 from myosuite_amd.envs import registry
-
-
-class ActorCritic(nn.Module):
-    def __init__(self, obs_dim, act_dim, pi_hidden=(32, 32, 32, 32), v_hidden=(256, 256, 256, 256, 256)):   # brax PPO defaults
-        super().__init__()
-        def mlp(sizes):
-            layers = []
-            for a, b in zip(sizes[:-1], sizes[1:]):
-                layers += [nn.Linear(a, b), nn.SiLU()]
-            return nn.Sequential(*layers[:-1])
-        self.pi = mlp((obs_dim,) + tuple(pi_hidden) + (act_dim,))
-        self.v = mlp((obs_dim,) + tuple(v_hidden) + (1,))
-        self.log_std = nn.Parameter(torch.full((act_dim,), -0.5))
-
-    def dist(self, obs):
-        return torch.distributions.Normal(self.pi(obs), self.log_std.exp())
+from myosuite_amd.ppo import OnDevicePPO, PPOConfig
 
 
 def main():
@@ -50,83 +34,54 @@ def main():
     ap.add_argument("--gamma", type=float, default=0.97)
     ap.add_argument("--lam", type=float, default=0.95)
     ap.add_argument("--clip", type=float, default=0.3)
+    ap.add_argument("--eager", action="store_true", help="no HIP graphs (round 3's form): every op its own launch")
+    ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: ranks share the visible GPU(s), gloo group")
     args = ap.parse_args()
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(backend="gloo" if args.oversubscribe else None)
+    if args.oversubscribe:
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # rank r owns the global envs [r n, (r+1) n): Philox streams are keyed by the global env index (mm_state.env_index_base)
-    env = registry.make(args.env, num_envs=args.num_envs, seed=0, device=dev, env_index_base=rank * args.num_envs)
-    env.rollout_setup()                              # env.step + auto-reset + episode stats as one launch (mm_rollout_step)
-    dense_col = env.rwd.shape[1] - 1
-    n, T = args.num_envs, args.unroll
-    obs_dim, act_dim = env.obs_dim, env.cm.nu
-    torch.manual_seed(0)
-    net = ActorCritic(obs_dim, act_dim).to(dev)
-    if world > 1:                                   # identical initial weights on every rank
-        for p_ in net.parameters():
-            torch.distributed.broadcast(p_.data, src=0)
-    opt = torch.optim.Adam(net.parameters(), lr=3e-4)
-    obs, _ = env.reset(seed=rank)
-    obs = obs.clone()
-    buf = dict(obs=torch.zeros(T, n, obs_dim, device=dev), act=torch.zeros(T, n, act_dim, device=dev),
-               logp=torch.zeros(T, n, device=dev), rew=torch.zeros(T, n, device=dev), done=torch.zeros(T, n, device=dev),
-               val=torch.zeros(T + 1, n, device=dev))
-    t_roll = t_all = 0.0
-    ret_sum = torch.zeros(n, device=dev)
-    for it in range(args.iters + 1):                   # iteration 0 is the warm-up (not timed)
-        torch.cuda.synchronize(); D.barrier(); t0 = time.perf_counter()
-        with torch.no_grad():
-            for t in range(T):
-                d = net.dist(obs)
-                a = d.sample()
-                buf["obs"][t] = obs; buf["act"][t] = a; buf["logp"][t] = d.log_prob(a).sum(-1); buf["val"][t] = net.v(obs).squeeze(-1)
-                o, rw, ended = env.rollout_step(torch.sigmoid(a).contiguous())       # policy output -> [0,1] excitations
-                r = rw[:, dense_col]
-                buf["rew"][t] = r; buf["done"][t] = ended.float()
-                ret_sum += r
-                obs = o.clone()
-            buf["val"][T] = net.v(obs).squeeze(-1)
-            adv = torch.zeros(T, n, device=dev); last = torch.zeros(n, device=dev)
-            for t in reversed(range(T)):                                   # GAE
-                nd = 1.0 - buf["done"][t]
-                delta = buf["rew"][t] + args.gamma * buf["val"][t + 1] * nd - buf["val"][t]
-                last = delta + args.gamma * args.lam * nd * last
-                adv[t] = last
-            ret = adv + buf["val"][:T]
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        B = T * n
-        fo, fa, fl = buf["obs"].reshape(B, -1), buf["act"].reshape(B, -1), buf["logp"].reshape(B)
-        fadv = ((adv - adv.mean()) / (adv.std() + 1e-8)).reshape(B); fret = ret.reshape(B)
-        for _ in range(args.epochs):
-            perm = torch.randperm(B, device=dev)
-            for mb in perm.chunk(args.minibatches):
-                mean = net.pi(fo[mb])
-                dist = torch.distributions.Normal(mean, net.log_std.exp())
-                ratio = (dist.log_prob(fa[mb]).sum(-1) - fl[mb]).exp()
-                pg = -torch.min(ratio * fadv[mb], ratio.clamp(1 - args.clip, 1 + args.clip) * fadv[mb]).mean()
-                vl = 0.5 * ((net.v(fo[mb]).squeeze(-1) - fret[mb]) ** 2).mean()
-                loss = pg + 0.5 * vl - 1e-2 * dist.entropy().sum(-1).mean()
-                opt.zero_grad(set_to_none=True)
-                loss.backward()
-                if world > 1:                      # data-parallel PPO: one flattened gradient all-reduce per minibatch (RCCL)
-                    flat = torch.cat([p_.grad.reshape(-1) for p_ in net.parameters()])
-                    torch.distributed.all_reduce(flat); flat /= world
-                    o_ = 0
-                    for p_ in net.parameters():
-                        n_ = p_.numel(); p_.grad.copy_(flat[o_:o_ + n_].view_as(p_.grad)); o_ += n_
-                opt.step()
-        torch.cuda.synchronize(); D.barrier(); t2 = time.perf_counter()
-        if it > 0:
-            t_roll += t1 - t0; t_all += t2 - t0
-    stats = D.gather_episode_stats(torch.stack([ret_sum, torch.ones_like(ret_sum), torch.zeros_like(ret_sum)], dim=1))
-    t_roll = D.max_over_ranks(t_roll, device="cuda" if world > 1 else None)
-    t_all = D.max_over_ranks(t_all, device="cuda" if world > 1 else None)
+    env = registry.make(args.env, num_envs=args.num_envs, seed=rank, device=dev, env_index_base=rank * args.num_envs)
+    cfg = PPOConfig(unroll_length=args.unroll, num_minibatches=args.minibatches, num_updates_per_batch=args.epochs,
+                    discounting=args.gamma, gae_lambda=args.lam, clipping_epsilon=args.clip, entropy_cost=1e-2, value_cost=0.25,
+                    policy_hidden=(32, 32, 32, 32), value_hidden=(256, 256, 256, 256, 256),        # brax PPO network defaults
+                    squash="sigmoid", normalize_observations=True)
+    ppo = OnDevicePPO(env, cfg, seed=0, world=world, use_graphs=not args.eager)
+    ppo.iterate()                                   # warm-up + graph capture (not timed)
+    torch.cuda.synchronize(); D.barrier()
+    # rollout alone (the graph of the unroll), then full iterations
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        if ppo._g_roll is not None:
+            ppo._g_roll.replay()
+        else:
+            ppo._rollout()
+    torch.cuda.synchronize(); D.barrier(); t_roll = time.perf_counter() - t0
+    r0 = float(ppo.mean_reward)
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        ppo.iterate()
+    torch.cuda.synchronize(); D.barrier(); t_all = time.perf_counter() - t0
+    stats = D.gather_episode_stats(ppo.ep_stats)
+    # data-parallel ranks must hold the same parameters after every update (one all-reduce of the flat gradient per minibatch)
+    in_sync = True
+    if world > 1:
+        ck = torch.stack([ppo.flat_p.double().sum(), ppo.flat_p.double().abs().sum(), ppo.flat_p[::97].double().sum()]).cpu()
+        parts = [torch.zeros_like(ck) for _ in range(world)]
+        torch.distributed.all_gather(parts, ck if D.backend() == "gloo" else ck.to(dev))
+        in_sync = all(bool(torch.allclose(parts[0].cpu(), q.cpu(), rtol=1e-6, atol=0)) for q in parts)
+    t_roll = D.max_over_ranks(t_roll, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
+    t_all = D.max_over_ranks(t_all, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
     if rank == 0:
-        steps = args.iters * T * n * world
-        print(json.dumps({"env": args.env, "n_gpus": world, "envs_per_gpu": n, "unroll": T, "iters": args.iters,
+        steps = args.iters * ppo.steps_per_iteration
+        print(json.dumps({"env": args.env, "n_gpus": world, "envs_per_gpu": args.num_envs, "unroll": args.unroll, "iters": args.iters,
+                          "graphs": ppo._g_roll is not None, "update_graph": ppo._g_upd is not None,
                           "rollout_env_steps_per_s": steps / t_roll, "train_env_steps_per_s": steps / t_all,
-                          "mean_return_per_env": float(stats[:, 0].mean())}))
+                          "mean_reward_per_step_first_last": [r0, float(ppo.mean_reward)],
+                          "params_in_sync_across_ranks": in_sync, "mean_return_per_env": float(stats[:, 0].mean())}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

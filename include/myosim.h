@@ -368,6 +368,12 @@ int  mm_fatigue_reset(float* MA, float* MR, float* MF, const uint8_t* mask, cons
  * reset_mask[e] = done[e] | truncated[e].  stats is [nenv][3] float32, rwd has row stride rwd_cols. */
 int  mm_episode_stats(float* stats, uint8_t* reset_mask, const float* rwd, int rwd_cols, int dense_col, int solved_col,
                       const uint8_t* done, const uint8_t* truncated, int nenv, void* stream);
+/* Generalised advantage estimation of a T-step unroll, one launch (the learner side of benchmarks/mjx_benchmark_PPO.py:50-60;
+ * brax compute_gae with truncation): delta_t = r_t + gamma (1 - terminated_t) V_{t+1} - V_t,
+ * adv_t = delta_t + gamma lambda (1 - terminated_t)(1 - truncated_t) adv_{t+1}, returns = adv + V.  reward / terminated /
+ * truncated (may be NULL) / advantage / returns are [T][nenv] float32, value is [T+1][nenv]. */
+int  mm_gae(const float* reward, const float* terminated, const float* truncated, const float* value, float* advantage,
+            float* returns, int T, int nenv, float gamma, float lam, void* stream);
 /* out[i] = U[0,1) float32 from Philox4x32-10, counter = (i, stream_id), key = seed */
 int  mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
 /* the same stream from element `first_index` on: out[i] = element first_index + i (a shard of envs draws ITS slice of the

@@ -1250,6 +1250,33 @@ extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
   return mm_uniform_at(out, n, seed, stream_id, 0, stream);
 }
 
+// Generalised advantage estimation over an unroll of T steps, one thread per env (brax compute_gae with truncation; the
+// learner of benchmarks/mjx_benchmark_PPO.py:50-60): adv_t = delta_t + gamma lambda (1 - term_t)(1 - trunc_t) adv_{t+1},
+// delta_t = r_t + gamma (1 - term_t) V_{t+1} - V_t; ret = adv + V.  Arrays are [T][n] (value [T+1][n]): coalesced over envs.
+__global__ void k_gae(const float* rew, const float* term, const float* trunc, const float* val, float* adv, float* ret, int T, int n,
+                      float gamma, float lam) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float last = 0.f;
+  float vnext = val[(size_t)T * n + e];
+  for (int t = T - 1; t >= 0; t--) {
+    const size_t k = (size_t)t * n + e;
+    const float nt = 1.f - term[k], v = val[k];
+    const float delta = rew[k] + gamma * nt * vnext - v;
+    last = delta + gamma * lam * nt * (1.f - (trunc ? trunc[k] : 0.f)) * last;
+    adv[k] = last; ret[k] = last + v;
+    vnext = v;
+  }
+}
+extern "C" int mm_gae(const float* reward, const float* terminated, const float* truncated, const float* value, float* advantage,
+                      float* returns, int T, int nenv, float gamma, float lam, void* stream) {
+  if (!reward || !terminated || !value || !advantage || !returns || T <= 0 || nenv <= 0) return fail(MM_EARG, "mm_gae: bad argument");
+  hipLaunchKernelGGL(k_gae, dim3((nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, reward, terminated, truncated, value, advantage,
+                     returns, T, nenv, gamma, lam);
+  HIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
 __global__ void k_episode_stats(float* stats, uint8_t* mask, const float* rwd, int cols, int dense_col, int solved_col,
                                 const uint8_t* done, const uint8_t* trunc, int nenv) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -203,6 +203,7 @@ def lib():
         L.mm_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]
         L.mm_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p]
+        L.mm_gae.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.mm_fatigue_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.mm_env_draw.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_uint64, C.c_uint32, C.c_int, C.c_void_p]
@@ -521,6 +522,17 @@ def episode_stats(stats: torch.Tensor, reset_mask: torch.Tensor, rwd: torch.Tens
     assert stats.shape == (rwd.shape[0], 3) and stats.dtype == torch.float32 and reset_mask.dtype == torch.uint8
     _chk(lib().mm_episode_stats(_ptr(stats), _ptr(reset_mask), _ptr(rwd), int(rwd.shape[1]), int(dense_col), int(solved_col),
                                 _ptr(done), _ptr(truncated), int(rwd.shape[0]), _stream(stats.device)), "mm_episode_stats")
+
+
+def gae(reward: torch.Tensor, terminated: torch.Tensor, truncated: Optional[torch.Tensor], value: torch.Tensor, advantage: torch.Tensor,
+        returns: torch.Tensor, gamma: float, lam: float):
+    """GAE of a [T, n] unroll in one launch (mm_gae): value is [T + 1, n]; advantage / returns are written."""
+    T, n = reward.shape
+    assert value.shape == (T + 1, n) and advantage.shape == (T, n) and returns.shape == (T, n)
+    for t in (reward, terminated, value, advantage, returns) + ((truncated,) if truncated is not None else ()):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+    _chk(lib().mm_gae(_ptr(reward), _ptr(terminated), _ptr(truncated), _ptr(value), _ptr(advantage), _ptr(returns), int(T), int(n),
+                      C.c_float(gamma), C.c_float(lam), _stream(reward.device)), "mm_gae")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int, first_index: int = 0):

@@ -220,6 +220,31 @@ class TrainingWrapper:
         self.num_envs = env.num_envs
         self.observation_size, self.action_size = env.observation_size, env.action_size
 
+    # ---- the rollout facade the on-device learner drives (myosuite_amd/ppo.py): env-step + auto-reset + episode statistics as ONE
+    # launch where the task's reset is folded into it (Pose), the launch + the masked reset + the reset observation otherwise
+    @property
+    def _inner(self):
+        return self.env._env
+
+    device = property(lambda self: self._inner.device)
+    obs_dim = property(lambda self: self._inner.obs_dim)
+    cm = property(lambda self: self._inner.cm)
+    obs = property(lambda self: self._inner.obs)
+    rwd = property(lambda self: self._inner.rwd)
+    truncated = property(lambda self: self._inner.truncated)
+
+    def rollout_setup(self, **kw):
+        self._inner.autoreset = True
+        self._inner._task.obs_layout = 1
+        return self._inner.rollout_setup(**kw)
+
+    def rollout_step(self, action):
+        inner = self._inner
+        obs, rw, mask = inner.rollout_step(action)
+        if not inner._ro.autoreset:        # the separate reset wrote the env's default layout: first observation in the MJX layout
+            E.reset_observation(inner.hm, inner.state, inner._task, mask)
+        return inner.obs, rw, mask
+
     def reset(self, rng: int) -> State:
         return self.env.reset(rng)
 

@@ -501,6 +501,48 @@ def test_ppo_benchmark_port_runs_and_writes_the_reference_result_file(tmp_path):
     assert len(rew) >= 2 and rew[-1] > rew[0] + 1.0, rew
 
 
+@pytest.mark.gpu
+def test_gae_kernel_matches_the_torch_recursion():
+    """mm_gae (one launch) against the recursion the eager learner ran (brax compute_gae with truncation)."""
+    torch.manual_seed(0)
+    T, n, g, lam = 10, 777, 0.97, 0.95
+    rew = torch.randn(T, n, device="cuda"); val = torch.randn(T + 1, n, device="cuda")
+    term = (torch.rand(T, n, device="cuda") < 0.1).float(); trunc = ((torch.rand(T, n, device="cuda") < 0.1).float() * (1 - term))
+    adv = torch.zeros(T, n, device="cuda"); ret = torch.zeros(T, n, device="cuda")
+    E.gae(rew, term, trunc, val, adv, ret, g, lam)
+    ref = torch.zeros(T, n, device="cuda"); last = torch.zeros(n, device="cuda")
+    for t in reversed(range(T)):
+        delta = rew[t] + g * (1.0 - term[t]) * val[t + 1] - val[t]
+        last = delta + g * lam * (1.0 - term[t]) * (1.0 - trunc[t]) * last
+        ref[t] = last
+    assert float((adv - ref).abs().max()) < 1e-5 and float((ret - (ref + val[:T])).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_on_device_ppo_graphs_learn_and_the_two_rank_path_keeps_parameters_in_sync():
+    """benchmarks/ppo_rollout.py on the learner of myosuite_amd/ppo.py: (i) one GPU -- the unroll and the minibatch passes replay as
+    HIP graphs and the reward improves on the elbow pose task; (ii) two ranks oversubscribing the one GPU (gloo group: the N > 1 code
+    path -- sharded Philox streams, ONE all-reduce of the flat gradient per minibatch, stats gather) end with identical parameters."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "benchmarks", "ppo_rollout.py"), "--env", "myoElbowPose1D6MRandom-v0", "--num-envs", "1024",
+                          "--iters", "40"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["graphs"] and d["update_graph"] and d["train_env_steps_per_s"] > 0
+    r0, r1 = d["mean_reward_per_step_first_last"]
+    assert r1 > r0 + 0.04, (r0, r1)          # measured: 0.571 -> 0.664 mean reward per step over 40 iterations (410 k env-steps)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29731", os.path.join(root, "benchmarks", "ppo_rollout.py"), "--env", "myoElbowPose1D6MRandom-v0",
+                          "--num-envs", "256", "--iters", "3", "--oversubscribe"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["params_in_sync_across_ranks"] is True and d["graphs"] and not d["update_graph"]
+
+
 def test_mjx_make_registry_names():
     from myosuite_amd import mjx_api
     for name, obs in (("MjxElbowPoseRandom-v0", 1 + 1 + 6 + 1), ("MjxFingerPoseFixed-v0", 4 + 4 + 5 + 4), ("MjxHandReachRandom-v0", 23 + 23 + 39 + 30)):
