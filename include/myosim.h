@@ -58,7 +58,8 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
        MM_INFO_KERNEL_FAMILY,   /* 0 limit rows only, dense Cholesky (nv <= 4); 1 limit rows only, tree-sparse L'DL; 2 general rows */
        MM_INFO_MODEL_WORDS,     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */
        MM_INFO_BODY_CHAINS,     /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */
-       MM_INFO_FOLDED_RESET };  /* 1: mm_rollout.autoreset is available for the WALK / REORIENT tasks on this model (64 lanes per env, a kernel of MM_KERNELS_OBS) */
+       MM_INFO_FOLDED_RESET,    /* 1: mm_rollout.autoreset is available for the WALK / REORIENT tasks on this model (64 lanes per env, a kernel of MM_KERNELS_OBS) */
+       MM_INFO_FWD_CARRY };     /* 1: mm_task.fwd_carry is implemented for this model (see mm_task) */
 
 /* ABI version of this header: bumped whenever a struct below gains / loses / reorders a field, an entry point changes its
  * signature or a status / enum value is renumbered.  A caller compares MM_ABI_VERSION (what it was built against) with
@@ -67,8 +68,9 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
   * bits renumbered, the mm_rollout struct -- round 2, shipped under the version STRING of round 1; 3 = this constant + mm_abi_version /
  * mm_struct_size; 4 = mm_task.size / mm_rollout.size (append-only growth of the two structs that gain fields per task); 5 = mm_rollout gains the
  * walk / reorient reset fields (appended: an ABI-4 caller's shorter struct is still accepted); 6 = the "precision" option: under
- * MM_PREC_F64_STATE four mm_state pointers address fp64 rows (no struct changed: an ABI-5 caller that never sets the option is unaffected). */
-#define MM_ABI_VERSION 6
+ * MM_PREC_F64_STATE four mm_state pointers address fp64 rows (no struct changed: an ABI-5 caller that never sets the option is unaffected);
+ * 7 = mm_task.fwd_carry appended, mm_gae, mm_model_launch_info, MM_INFO_FWD_CARRY. */
+#define MM_ABI_VERSION 7
 enum { MM_STRUCT_STATE = 0, MM_STRUCT_DERIVED, MM_STRUCT_TASK, MM_STRUCT_ROLLOUT };
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
@@ -199,6 +201,15 @@ typedef struct {
   const uint8_t* env_mask;  /* optional [nenv]: envs with 0 are left untouched  */
   int   obs_only;           /* 1: no substeps, no ctrl map, no counters, no reward write: forward + obs of the CURRENT state
                                (the observation returned by reset(): env_base.py:560-575) */
+  /* --- appended in ABI 7: forward-pass carry, optional [nenv][2 nv + 1] float32, zero-initialised by the caller and otherwise
+     owned by the engine.  The trailing mj_forward of env.step k (robot.py:595-607) evaluates exactly the state the first
+     mj_step of env.step k + 1 evaluates again (robot.py:856-861) -- the new action only enters act_dot when every actuator has
+     activation dynamics -- so the trailing pass leaves (qacc, the Euler step's damped acceleration) here under a hash of the
+     state rows and per-env model deltas, and the next launch's first substep starts from them when the hash matches what it
+     loaded: one pipeline pass in frame_skip + 1 saved, results bit-identical.  Any change of the state from outside (reset,
+     set_state, a tensor write) changes the hash and the row is simply ignored.  MM_INFO_FWD_CARRY says whether the model's
+     kernel family implements it (limit-rows-only models, Euler, fp32, no stateless actuators); MM_EUNSUPPORTED otherwise. */
+  float* fwd_carry;
 } mm_task;
 
 /* Rollout bookkeeping folded into the env-step launch (mm_rollout_step): what a rollout harness around env.step does per

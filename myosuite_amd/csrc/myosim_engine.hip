@@ -208,7 +208,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 extern "C" const char* mm_last_error(void) { return g_err.c_str(); }
-extern "C" const char* mm_version(void) { return "myosim-hip 0.4 (gfx950, lane=item engine, ABI 6)"; }
+extern "C" const char* mm_version(void) { return "myosim-hip 0.4 (gfx950, lane=item engine, ABI 7)"; }
 extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
 extern "C" int mm_struct_size(int which) {
   switch (which) {
@@ -860,6 +860,14 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
 }
 
 static bool have_obs_kernel(int G, int nvp, int gen, int rk4);
+// mm_task.fwd_carry: the limit-rows-only fp32 Euler kernels (Engine::CARRY), and only where the action reaches nothing but act_dot
+// -- every actuator has activation dynamics
+static bool fwd_carry_ok(const mm_model* m) {
+  if (m->d.gen || m->d.integrator != MM_INT_EULER || m->precision != MM_PREC_F32 || m->d.nu == 0 || m->nvp < 8) return false;
+  const int32_t* dt = (const int32_t*)(m->h_blob.data() + m->sec[MM_SEC_ACT_DYNTYPE]);
+  for (int u = 0; u < m->d.nu; u++) if (dt[u] == MM_DYN_NONE) return false;
+  return true;
+}
 extern "C" int mm_model_info(const mm_model* m, int which) {
   if (!m) return MM_EARG;
   switch (which) {
@@ -872,6 +880,7 @@ extern "C" int mm_model_info(const mm_model* m, int which) {
     case MM_INFO_MODEL_WORDS: return m->blob_words;
     case MM_INFO_BODY_CHAINS: return m->d.bchain_nlevel;
     case MM_INFO_FOLDED_RESET: return (MM_FOLD_RESET && m->lanes == 64 && !m->lanes_auto && have_obs_kernel(64, m->nvp, m->d.gen, integ_kernel(m->d.integrator))) ? 1 : 0;
+    case MM_INFO_FWD_CARRY: return fwd_carry_ok(m) ? 1 : 0;
     case MM_INFO_KERNEL_FAMILY: return m->d.gen ? 2 : ((MM_SPARSE_LDL && m->nvp >= 8 && m->d.integrator != MM_INT_IMPLICITFAST) ? 1 : 0);
   }
   return MM_EARG;
@@ -1132,6 +1141,7 @@ static int sized_copy(T* dst, const T* src, size_t min_size, const char* what) {
 static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
   if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
+  if (t->fwd_carry && !fwd_carry_ok(m)) return fail(MM_EUNSUPPORTED, "mm_task.fwd_carry: limit-rows-only models on Euler, fp32, every actuator with activation dynamics (MM_INFO_FWD_CARRY)");
   if (t->task == MM_TASK_REACH && (!t->tip_sites || !t->target_pos || t->ntip <= 0)) return fail(MM_EARG, "reach task needs tip_sites/target_pos");
   if (t->task == MM_TASK_WALK) {
     if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "walk task needs do_forward");

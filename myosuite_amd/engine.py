@@ -32,10 +32,10 @@ RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "spar
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
  INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK, INFO_KERNEL_FAMILY, INFO_MODEL_WORDS,
- INFO_BODY_CHAINS, INFO_FOLDED_RESET) = range(16)
+ INFO_BODY_CHAINS, INFO_FOLDED_RESET, INFO_FWD_CARRY) = range(17)
 
 
-MM_ABI_VERSION = 6   # include/myosim.h
+MM_ABI_VERSION = 7   # include/myosim.h
 MM_PREC_F32, MM_PREC_F64, MM_PREC_F64_STATE = 0, 1, 2   # mm_model_set_option("precision", ...)
 
 
@@ -156,7 +156,7 @@ class mm_task(C.Structure):
                 ("reor_axis_half", C.c_void_p), ("reor_des_rot", C.c_void_p), ("reor_w", C.c_float * 5),
                 ("reor_obs_muscle", C.c_int),
                 ("key_goal_th", C.c_float), ("key_w", C.c_float * 6),
-                ("env_mask", C.c_void_p), ("obs_only", C.c_int)]
+                ("env_mask", C.c_void_p), ("obs_only", C.c_int), ("fwd_carry", C.c_void_p)]
 
 
 class mm_rollout(C.Structure):

@@ -78,7 +78,7 @@ class BaseV0:
     # ------------------------------------------------------------------ setup
     def _setup(self, obs_keys, weighted_reward_keys, frame_skip=10, normalize_act=True, muscle_condition="",
                fatigue_reset_vec=None, fatigue_reset_random=False, reward_mode="dense", obs_range=(-10, 10),
-               sites=None, precision="f32", **kwargs):
+               sites=None, precision="f32", fwd_carry=True, **kwargs):
         """precision: "f32" (default) | "f64" | "f64_state" (or the MM_PREC_* value) -- the kernel family that steps the batch
         (include/myosim.h: fp64 arithmetic, optionally fp64 state rows; limit-rows-only models on Euler)"""
         self.muscle_condition = muscle_condition
@@ -86,6 +86,10 @@ class BaseV0:
         self.precision = {"f32": E.MM_PREC_F32, "f64": E.MM_PREC_F64, "f64_state": E.MM_PREC_F64_STATE}.get(precision, precision)
         self.hm = E.HipModel(self.cm, lanes_per_env=self._lanes, device=self._device, precision=self.precision)
         self.device = self.hm.device
+        # forward-pass carry (mm_task.fwd_carry): the trailing forward of env.step k hands its accelerations to the first substep
+        # of env.step k + 1 (bit-identical, one pipeline pass in frame_skip + 1 saved) where the kernel family implements it
+        self._fwd_carry = (torch.zeros(self.num_envs, 2 * self.cm.nv + 1, dtype=torch.float32, device=self.device)
+                           if (fwd_carry and self.hm.info(E.INFO_FWD_CARRY) == 1) else None)
         cm = self.cm
         if cm.na > 0 and "act" not in obs_keys:       # base_v0.py:33-37
             obs_keys = list(obs_keys) + ["act"]
@@ -231,6 +235,7 @@ class BaseV0:
         t.obs = self.obs.data_ptr(); t.obs_dim = self.obs_dim; t.rwd = self.rwd.data_ptr()
         t.done = self.done.data_ptr(); t.truncated = self.truncated.data_ptr()
         t.step_count = self.step_count.data_ptr(); t.ctrl_out = self.last_ctrl.data_ptr()
+        t.fwd_carry = self._fwd_carry.data_ptr() if self._fwd_carry is not None else None
         t.reaf_src, t.reaf_dst = self.reaf
         t.obs_dt = self.dt
         return t

@@ -396,6 +396,42 @@ def test_trailing_forward_warm_start_is_immaterial(env_id, n, kw):
     assert float(keep.abs().max()) > 0 and rel < (2e-4 if "Reorient" in env_id else 2e-5), rel
 
 
+@pytest.mark.parametrize("env_id,n,lanes", [("myoHandPoseRandom-v0", 96, 32), ("myoHandPoseRandom-v0", 64, 64), ("myoHandPoseRandom-v0", 2048, 32),
+                                            ("myoHandReachRandom-v0", 64, 32), ("myoFatiHandPoseRandom-v0", 64, 32)],
+                         ids=["hand-G32-two-wave", "hand-G64", "hand-2048-one-wave", "hand-reach", "fati-hand"])
+def test_forward_carry_is_bit_identical(env_id, n, lanes):
+    """mm_task.fwd_carry: the trailing forward of env.step k hands (qacc, Euler's damped acceleration) to the first substep of
+    env.step k + 1 under a hash of the state.  Against the same rollout without the carry: states, observations, rewards and
+    statistics bit-identical -- across folded and separate resets (rows voided), a state row rewritten from outside between two
+    steps (hash mismatch: the row is ignored), and an interleaved gym-level step."""
+    kw = dict(num_envs=n, seed=3, max_episode_steps=6, lanes_per_env=lanes)
+    a = registry.make(env_id, **kw)
+    b = registry.make(env_id, fwd_carry=False, **kw)
+    assert a._fwd_carry is not None and b._fwd_carry is None and a.hm.info(E.INFO_FWD_CARRY) == 1
+    sa, sb = a.rollout_setup(action_seed=4), b.rollout_setup(action_seed=4)
+    act = torch.empty(n, a.cm.nu, device="cuda")
+    for s in range(22):
+        if s == 9:            # an outside write to the state: the stamped rows no longer match and must not be used
+            for e_ in (a, b):
+                e_.state.qpos[5:9] += 0.01
+                e_.state.qvel[7] = 0.25
+        if s in (13, 14):     # gym-level steps with explicit actions in between
+            E.uniform(act, 77, s)
+            oa = a.step(act * 2 - 1); ob = b.step(act * 2 - 1)
+            assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1])
+        else:
+            oa = a.rollout_step(None, stream_id=s); ob = b.rollout_step(None, stream_id=s)
+            assert torch.equal(oa[0], ob[0]) and torch.equal(oa[1], ob[1]) and torch.equal(oa[2], ob[2]), s
+        for k in ("qpos", "qvel", "act", "qacc_warmstart", "time", "status"):
+            assert torch.equal(getattr(a.state, k), getattr(b.state, k)), (k, s)
+        if s == 3:
+            stamped = a._fwd_carry[:, 0].view(torch.int32) != 0
+            assert int(stamped.sum()) >= n - n // 16, int(stamped.sum())          # every env that did not end its episode carries a row
+    assert torch.equal(sa, sb) and int(a.state.status.max()) == 0
+    for tiny in ("myoElbowPose1D6MRandom-v0", "myoFingerPoseRandom-v0", "myoHandReorient100-v0"):      # 4-wide / general-row kernels: not offered
+        assert registry.make(tiny, num_envs=4)._fwd_carry is None
+
+
 def test_rollout_step_other_tasks_and_sharded_streams():
     """Tasks without a folded reset: the launch writes the reset mask and the task's reset re-arms; env_index_base shifts every
     Philox stream so that a shard reproduces its slice of the unsharded rollout."""
