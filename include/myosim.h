@@ -208,7 +208,7 @@ typedef struct {
      state rows and per-env model deltas, and the next launch's first substep starts from them when the hash matches what it
      loaded: one pipeline pass in frame_skip + 1 saved, results bit-identical.  Any change of the state from outside (reset,
      set_state, a tensor write) changes the hash and the row is simply ignored.  MM_INFO_FWD_CARRY says whether the model's
-     kernel family implements it (limit-rows-only models, Euler, fp32, no stateless actuators); MM_EUNSUPPORTED otherwise. */
+     kernel family implements it (Euler, fp32, more than 4 dofs, no stateless actuators); MM_EUNSUPPORTED otherwise. */
   float* fwd_carry;
 } mm_task;
 

@@ -69,7 +69,9 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               # reorient <64,32,GEN>: VGPR spills 74 -> 18 (model-in-LDS variant 47 -> 0), kernel 0.705 -> 0.686 ms (+3 %), and 4x
               # less scratch traffic for a kernel whose time followed the box's memory clock.  The same flag on the 24-wide and
               # implicitfast general-row units (inst_I, inst_J) loses 1 %: not set there.
-              "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
+              # + the reset-observation pass of a folded reset also writes a forward-carry row: reorient 3.95 -> 4.11 M in one session
+              # (the leg unit, inst_H, loses 1 % with it: off there)
+              "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-DMM_REFOLD_CARRY=1"],
               # precision-mode (fp64) kernels: IEEE divide / sqrt and no reassociation -- these exist to track the fp64 reference;
               # fma contraction stays on (it only removes roundings)
               "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"]}

@@ -397,14 +397,19 @@ def test_trailing_forward_warm_start_is_immaterial(env_id, n, kw):
 
 
 @pytest.mark.parametrize("env_id,n,lanes", [("myoHandPoseRandom-v0", 96, 32), ("myoHandPoseRandom-v0", 64, 64), ("myoHandPoseRandom-v0", 2048, 32),
-                                            ("myoHandReachRandom-v0", 64, 32), ("myoFatiHandPoseRandom-v0", 64, 32)],
-                         ids=["hand-G32-two-wave", "hand-G64", "hand-2048-one-wave", "hand-reach", "fati-hand"])
+                                            ("myoHandReachRandom-v0", 64, 32), ("myoFatiHandPoseRandom-v0", 64, 32),
+                                            ("myoHandReorient100-v0", 96, 0), ("myoFatiLegWalk-v0", 80, 0), ("myoHandPoseRandom-v0:hand_contact", 64, 0),
+                                            ("myoHandKeyTurnRandom-v0", 48, 0), ("myoHandReorient100-v0", 1536, 0)],
+                         ids=["hand-G32-two-wave", "hand-G64", "hand-2048-one-wave", "hand-reach", "fati-hand", "reorient-folded-reset", "fati-leg-folded-reset",
+                              "hand-contact", "key-turn-separate-reset", "reorient-1536-one-wave"])
 def test_forward_carry_is_bit_identical(env_id, n, lanes):
     """mm_task.fwd_carry: the trailing forward of env.step k hands (qacc, Euler's damped acceleration) to the first substep of
     env.step k + 1 under a hash of the state.  Against the same rollout without the carry: states, observations, rewards and
     statistics bit-identical -- across folded and separate resets (rows voided), a state row rewritten from outside between two
     steps (hash mismatch: the row is ignored), and an interleaved gym-level step."""
     kw = dict(num_envs=n, seed=3, max_episode_steps=6, lanes_per_env=lanes)
+    if ":" in env_id:
+        env_id, kw["model"] = env_id.split(":")
     a = registry.make(env_id, **kw)
     b = registry.make(env_id, fwd_carry=False, **kw)
     assert a._fwd_carry is not None and b._fwd_carry is None and a.hm.info(E.INFO_FWD_CARRY) == 1
@@ -428,7 +433,7 @@ def test_forward_carry_is_bit_identical(env_id, n, lanes):
             stamped = a._fwd_carry[:, 0].view(torch.int32) != 0
             assert int(stamped.sum()) >= n - n // 16, int(stamped.sum())          # every env that did not end its episode carries a row
     assert torch.equal(sa, sb) and int(a.state.status.max()) == 0
-    for tiny in ("myoElbowPose1D6MRandom-v0", "myoFingerPoseRandom-v0", "myoHandReorient100-v0"):      # 4-wide / general-row kernels: not offered
+    for tiny in ("myoElbowPose1D6MRandom-v0", "myoFingerPoseRandom-v0", "motorFingerPoseRandom-v0"):      # 4-wide kernels / stateless actuators: not offered
         assert registry.make(tiny, num_envs=4)._fwd_carry is None
 
 

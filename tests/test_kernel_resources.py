@@ -55,16 +55,20 @@ def test_shipped_bench_kernels_do_not_spill_vector_registers():
     no_spill = [mangled(32, 24, 1, 0, 0),     # hand pose, 4096 envs (headline)
                 mangled(8, 4, 1, 0, 0),       # elbow, 4096 envs
                 mangled(64, 36, 1, 1, 0),     # leg walk, 1024 envs
-                mangled(64, 32, 0, 1, 0),     # reorient, 2048 envs (model through L2)
                 mangled(64, 24, 1, 1, 0)]     # self-contact hand, 4096 envs
-    for name in no_spill:
+    reorient = mangled(64, 32, 0, 1, 0)       # reorient, 2048 envs (model through L2)
+    for name in no_spill + [reorient]:
         assert name in tab, (name, sorted(tab)[:4])
-        assert int(tab[name]["vgpr_spill_count"]) == 0, tab[name]
         assert int(tab[name]["vgpr_count"]) <= 256
+    for name in no_spill:
+        assert int(tab[name]["vgpr_spill_count"]) == 0, tab[name]
+    # round 4: the forward carry's trailing damped solve is a second inlined factor + solve; in the 32-wide unit it costs 10...17
+    # spilled VGPRs (28...40 B of scratch) and buys +16 % (3.42 -> 3.97...4.11 M env-steps/s): kept, ratcheted
+    assert int(tab[reorient]["vgpr_spill_count"]) <= 20 and int(tab[reorient]["private_segment_fixed_size"]) <= 48, tab[reorient]
     # ratchets: the implicitfast leg still spills (26), SGPR spills of the general-row kernels stay below 260
     legi = mangled(64, 36, 1, 1, 2)
     assert int(tab[legi]["vgpr_spill_count"]) <= 40, tab[legi]
-    for name in no_spill[2:] + [legi]:
+    for name in no_spill[2:] + [reorient, legi]:
         assert int(tab[name]["sgpr_spill_count"]) < 260, tab[name]
 
 
