@@ -31,7 +31,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 # BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288, and the MuJoCo-default leg on the
 # implicitfast integrator) reported next to the headline line
 # the committed PMC session bench.py replays counters from (tools/prof_round.sh at the HEAD named in DESIGN.md section 5); pinned, not "the latest file"
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03j_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04a_pmc.json")
 REPEATS = 3                 # timed regions of --steps steps each; the line reports the median region
 EXTRA_MIN_TIMED_MS = 60.0   # an extra line times at least this much kernel work (a 1.5 ms timed region is launch-noise bound)
 EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
@@ -52,7 +52,8 @@ def algorithmic_bytes(env) -> int:
     """fp32, state read + written once per env-step (substeps are fused on chip), constant model excluded:
     B_alg = 4*[(nq+nv+na) + nu + n_task_in + n_aux + (nq+nv+na) + n_aux + obs_dim + 4], n_aux = the fatigue state (3 na) and,
     for models with a constraint solve that is warm started across steps (contacts / equalities), qacc_warmstart (nv).
-    144 B (elbow pose), 1 376 B (hand pose), 2 012 B (reorient), 5 336 B (leg walk + fatigue)."""
+    144 B (elbow pose), 1 376 B (hand pose), 2 012 B (reorient), 5 336 B (leg walk + fatigue) -- SURVEY's table -- plus, since round 4,
+    the forward-carry row where it is on (8 nv + 4 bytes read and written: hand 1 752 B, reorient 2 484 B, leg 5 888 B)."""
     cm = env.cm
     # per-step task inputs: pose targets [nq] | reach targets [3 ntip] | reorient geom type 1 + size 3 + axis_half 1 + des_rot 3 |
     # walk step counter 1
@@ -62,6 +63,8 @@ def algorithmic_bytes(env) -> int:
         n_aux += 3 * cm.na          # MA / MR / MF
     if cm.npair > 0 or cm.neq > 0:
         n_aux += cm.nv              # qacc_warmstart
+    if getattr(env, "_fwd_carry", None) is not None:
+        n_aux += 2 * cm.nv + 1      # forward-carry row (mm_task.fwd_carry): hash + qacc + Euler's damped acceleration, read and written
     sw = 8 if getattr(env, "precision", 0) == 2 else 4      # MM_PREC_F64_STATE: the state rows are fp64
     return sw * 2 * (cm.nq + cm.nv + cm.na) + 4 * (cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
 
@@ -338,6 +341,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs lines (elbow / reorient / leg-walk / self-contact hand)")
     ap.add_argument("--model", default=None, help="model override of the headline env (e.g. hand_contact): profile collection")
     ap.add_argument("--no-forward", action="store_true", help="do_forward=False override of the headline env: profile collection")
+    ap.add_argument("--precision", default=None, help="precision override of the headline env (f64 | f64_state): profile collection")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: rank r runs on cuda:(r %% visible devices) and the process group is gloo, so that the N > 1 code "
                          "path (launcher respawn, barrier, max over ranks, stats gather, sharded Philox streams) can be exercised on a "
@@ -366,6 +370,8 @@ def main():
         head_ov["model"] = args.model
     if args.no_forward:
         head_ov["do_forward"] = False
+    if args.precision:
+        head_ov["precision"] = args.precision
     clocks_before = gpu_clocks() if rank == 0 else None
     elapsed, kern_ms, env, stats, regions = measure(args.env, n, args.steps, args.warmup, rank, world, args.lanes, overrides=head_ov,
                                                     repeats=max(1, args.repeats))
@@ -382,7 +388,7 @@ def main():
             "region_ms_per_step": [1e3 * e / args.steps for e in regions],      # every timed region; `value` is the median one
             "gpu_clocks_mhz": {"before": clocks_before, "after": clocks_after},
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64"}[int(getattr(env, "precision", 0))], "data": "synthetic",
             "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1) drawn in the kernel, frame_skip {env.frame_skip} + final "
                                    f"forward + obs/reward + episode stats + auto-reset in one launch per step "
                                    f"(synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
