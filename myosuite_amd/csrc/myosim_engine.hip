@@ -863,7 +863,7 @@ static bool have_obs_kernel(int G, int nvp, int gen, int rk4);
 // mm_task.fwd_carry: the fp32 Euler kernels of 8 dofs and more (Engine::CARRY), and only where the action reaches nothing but act_dot
 // -- every actuator has activation dynamics
 static bool fwd_carry_ok(const mm_model* m) {
-  if (m->d.integrator != MM_INT_EULER || m->precision != MM_PREC_F32 || m->d.nu == 0 || m->nvp < 8) return false;
+  if (m->d.integrator == MM_INT_RK4 || m->precision != MM_PREC_F32 || m->d.nu == 0 || m->nvp < 8) return false;
   const int32_t* dt = (const int32_t*)(m->h_blob.data() + m->sec[MM_SEC_ACT_DYNTYPE]);
   for (int u = 0; u < m->d.nu; u++) if (dt[u] == MM_DYN_NONE) return false;
   return true;
@@ -1141,7 +1141,7 @@ static int sized_copy(T* dst, const T* src, size_t min_size, const char* what) {
 static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
   if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
-  if (t->fwd_carry && !fwd_carry_ok(m)) return fail(MM_EUNSUPPORTED, "mm_task.fwd_carry: Euler, fp32, nv >= 5, every actuator with activation dynamics (MM_INFO_FWD_CARRY)");
+  if (t->fwd_carry && !fwd_carry_ok(m)) return fail(MM_EUNSUPPORTED, "mm_task.fwd_carry: Euler / implicitfast, fp32, nv >= 5, every actuator with activation dynamics (MM_INFO_FWD_CARRY)");
   if (t->task == MM_TASK_REACH && (!t->tip_sites || !t->target_pos || t->ntip <= 0)) return fail(MM_EARG, "reach task needs tip_sites/target_pos");
   if (t->task == MM_TASK_WALK) {
     if (!t->do_forward && !t->obs_only) return fail(MM_EARG, "walk task needs do_forward");

@@ -399,9 +399,10 @@ def test_trailing_forward_warm_start_is_immaterial(env_id, n, kw):
 @pytest.mark.parametrize("env_id,n,lanes", [("myoHandPoseRandom-v0", 96, 32), ("myoHandPoseRandom-v0", 64, 64), ("myoHandPoseRandom-v0", 2048, 32),
                                             ("myoHandReachRandom-v0", 64, 32), ("myoFatiHandPoseRandom-v0", 64, 32),
                                             ("myoHandReorient100-v0", 96, 0), ("myoFatiLegWalk-v0", 80, 0), ("myoHandPoseRandom-v0:hand_contact", 64, 0),
-                                            ("myoHandKeyTurnRandom-v0", 48, 0), ("myoHandReorient100-v0", 1536, 0)],
+                                            ("myoHandKeyTurnRandom-v0", 48, 0), ("myoHandReorient100-v0", 1536, 0),
+                                            ("myoFatiLegWalk-v0:leg_implicit", 80, 0), ("myoLegWalk-v0:leg_implicit", 1280, 0)],
                          ids=["hand-G32-two-wave", "hand-G64", "hand-2048-one-wave", "hand-reach", "fati-hand", "reorient-folded-reset", "fati-leg-folded-reset",
-                              "hand-contact", "key-turn-separate-reset", "reorient-1536-one-wave"])
+                              "hand-contact", "key-turn-separate-reset", "reorient-1536-one-wave", "implicitfast-leg-two-wave", "implicitfast-leg-1280-one-wave"])
 def test_forward_carry_is_bit_identical(env_id, n, lanes):
     """mm_task.fwd_carry: the trailing forward of env.step k hands (qacc, Euler's damped acceleration) to the first substep of
     env.step k + 1 under a hash of the state.  Against the same rollout without the carry: states, observations, rewards and

@@ -67,7 +67,9 @@ def test_shipped_bench_kernels_do_not_spill_vector_registers():
     assert int(tab[reorient]["vgpr_spill_count"]) <= 20 and int(tab[reorient]["private_segment_fixed_size"]) <= 48, tab[reorient]
     # ratchets: the implicitfast leg still spills (26), SGPR spills of the general-row kernels stay below 260
     legi = mangled(64, 36, 1, 1, 2)
-    assert int(tab[legi]["vgpr_spill_count"]) <= 40, tab[legi]
+    # (round 4: the implicitfast unit carries the forward pass too -- a second inlined (M + h W) factor + solve: 21 -> 52 spilled VGPRs,
+    # kernel still +6 %: 1.46 -> 1.55 M env-steps/s)
+    assert int(tab[legi]["vgpr_spill_count"]) <= 64, tab[legi]
     for name in no_spill[2:] + [reorient, legi]:
         assert int(tab[name]["sgpr_spill_count"]) < 260, tab[name]
 
