@@ -183,19 +183,12 @@ def test_full_batch_launch_width_vs_oracle(oracle_lib, env_id, nenv, lanes, stag
         pass
 
 
-@pytest.mark.parametrize("env_id,nenv,overrides", [("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoHandReorient100-v0", 2048, {}),
-                                                   ("myoFatiLegWalk-v0", 1024, {}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
-                                                   ("myoHandKeyTurnRandom-v0", 1024, {})],
-                         ids=["hand-contact-4096", "reorient-2048", "fati-leg-1024", "leg-implicit-1024", "key-turn-1024"])
-def test_every_env_of_the_contact_batches_solves_like_the_oracle(oracle_lib, env_id, nenv, overrides):
-    """EVERY env of the general-row bench batches, not a sample of 32: after a short random-action rollout one forward pass of the
-    whole batch, constrained acceleration of each env against the oracle's on the same state.  A rare solver failure (round 3's
-    missing fence in jac_mul put ~1 % of the self-colliding hand's envs percent off while every sampled test passed) shows up as
-    an outlier here.  Envs whose row count differs from the oracle's (a contact within fp32 rounding of its threshold) are
-    counted, bounded, and excluded from the error statistics."""
+def _all_env_solve_scan(env_id, nenv, overrides, steps=7):
+    """one forward pass of a whole batch after a short random-action rollout, every env against the oracle on the same state
+    (per-env model deltas of the batch applied to the oracle): relative qacc error per env, row counts, row-count mismatches"""
     env = registry.make(env_id, num_envs=nenv, seed=23, **overrides)
     env.rollout_setup(action_seed=3)
-    for s in range(7):
+    for s in range(steps):
         env.rollout_step(None, stream_id=s)
     cm, hm, st = env.cm, env.hm, env.state
     d_ = E.Derived(hm, nenv, ["qacc", "nefc"])
@@ -203,25 +196,54 @@ def test_every_env_of_the_contact_batches_solves_like_the_oracle(oracle_lib, env
     E.forward(hm, st, ctrl, d_)
     torch.cuda.synchronize()
     qpos, qvel = st.qpos.cpu().numpy().astype(np.float64), st.qvel.cpu().numpy().astype(np.float64)
-    act = st.act.cpu().numpy().astype(np.float64); warm = st.qacc_warmstart.cpu().numpy().astype(np.float64)
+    act = st.act.cpu().numpy().astype(np.float64) if cm.na else np.zeros((nenv, 0)); warm = st.qacc_warmstart.cpu().numpy().astype(np.float64)
     c = ctrl.cpu().numpy().astype(np.float64)
     ga, gn = d_["qacc"].cpu().numpy().astype(np.float64), d_["nefc"].cpu().numpy()
-    is_reor = "Reorient" in env_id
-    gs = env.geom_size.cpu().numpy().astype(np.float64) if is_reor else None
-    gt = env.geom_type.cpu().numpy() if is_reor else None
-    bp = env.body_pos.cpu().numpy().astype(np.float64) if getattr(env, "body_pos", None) is not None else None     # key turn: per-env key position
+    # per-env model deltas as the batch carries them (mm_state)
+    gs = st.geom_size_env.cpu().numpy().astype(np.float64) if st.geom_size_env is not None else None
+    gt = st.geom_type_env.cpu().numpy() if st.geom_type_env is not None else None
+    bm = st.body_mass_env.cpu().numpy().astype(np.float64) if st.body_mass_env is not None else None
+    bp = st.body_pos_env.cpu().numpy().astype(np.float64) if st.body_pos_env is not None else None
     om = O.OracleModel(cm); d = O.OracleData(om)
     rel = np.zeros(nenv); mism = np.zeros(nenv, bool); rows = np.zeros(nenv, int)
     for e in range(nenv):
-        if is_reor:
-            d.set_geom_size(cm.names["geom"]["obj"], gs[e], int(gt[e]))
+        if gs is not None:
+            d.set_geom_size(int(st._c.geom_env_id), gs[e], int(gt[e]) if gt is not None else -1)
+        if bm is not None:
+            d.set_body_mass(int(st._c.body_mass_env_id), float(bm[e]))
         if bp is not None:
-            d.set_body_pos(env.key_body, bp[e])
-        d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.act[:] = act[e]; d.ctrl[:] = c[e]; d.qacc_warmstart[:] = warm[e]
+            d.set_body_pos(int(st._c.body_pos_env_id), bp[e])
+        d.qpos[:] = qpos[e]; d.qvel[:] = qvel[e]; d.ctrl[:] = c[e]; d.qacc_warmstart[:] = warm[e]
+        if cm.na:
+            d.act[:] = act[e]
         d.forward()
         rows[e] = d.nefc
         mism[e] = d.nefc != gn[e]
         rel[e] = np.abs(ga[e] - d.qacc).max() / max(1.0, np.abs(d.qacc).max())
+    return rel, mism, rows, int(st.status.max())
+
+
+ALL_ENV_SCANS = [("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
+                 ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}), ("myoHandKeyTurnRandom-v0", 1024, {}),
+                 # ... and the rest of the task families at 512 envs: limit rows only (sparse and dense kernels), condim-1 contacts, cylinder / box /
+                 # ellipsoid objects, the 210-tendon torso, the exo elbow's carried weight, RK4-free variants of the muscle conditions
+                 ("myoHandPoseRandom-v0", 512, {}), ("myoHandReachRandom-v0", 512, {}), ("myoElbowPose1D6MRandom-v0", 512, {}),
+                 ("myoElbowPose1D6MExoRandom-v0", 512, {}), ("myoFingerPoseRandom-v0", 512, {}), ("motorFingerReachRandom-v0", 512, {}),
+                 ("myoHandObjHoldRandom-v0", 512, {}), ("myoHandPenTwirlRandom-v0", 512, {}), ("myoHandReorientOOD-v0", 512, {}),
+                 ("myoTorsoPoseFixed-v0", 512, {}), ("myoTorsoExoPoseFixed-v0", 512, {}), ("myoLegStandRandom-v0", 512, {}),
+                 ("myoSarcHandPoseRandom-v0", 512, {}), ("myoReafHandPoseRandom-v0", 512, {}), ("myoLegWalk-v0", 512, {"reset_type": "random"})]
+
+
+@pytest.mark.parametrize("env_id,nenv,overrides", ALL_ENV_SCANS, ids=[f"{c[0]}@{c[1]}" + "".join(f"-{v}" for v in c[2].values()) for c in ALL_ENV_SCANS])
+def test_every_env_of_the_contact_batches_solves_like_the_oracle(oracle_lib, env_id, nenv, overrides):
+    """EVERY env of a batch, not a sample of 32: after a short random-action rollout one forward pass of the whole batch,
+    constrained acceleration of each env against the oracle's on the same state -- the general-row bench batches at full size and
+    every other task family at 512 envs.  A rare failure shows up as an outlier here: round 3's missing fence in jac_mul put ~1 %
+    of the self-colliding hand's envs percent off while every sampled test passed, and the first run of this scan found 7 of 1024
+    key-turn envs with contact rows 15 % off (an unconverged closest-point iteration on the flat key head).  Envs whose row count
+    differs from the oracle's (a contact / limit within fp32 rounding of its threshold) are counted, bounded, and excluded from the
+    error statistics."""
+    rel, mism, rows, status = _all_env_solve_scan(env_id, nenv, overrides)
     ok = ~mism
     q = np.quantile(rel[ok], [0.5, 0.99, 1.0])
     print(f"all-env solve check {env_id} {overrides}: {nenv} envs, rows median {int(np.median(rows))} max {rows.max()}, row-count mismatches {int(mism.sum())}, "
@@ -230,13 +252,12 @@ def test_every_env_of_the_contact_batches_solves_like_the_oracle(oracle_lib, env
     import json
     fn = os.path.join("gpurun_out", "all_env_solve_check.json")
     rec = json.load(open(fn)) if os.path.exists(fn) else {}
-    rec[env_id + "".join(f"|{k}={v}" for k, v in overrides.items())] = {"envs": nenv, "rows_median": int(np.median(rows)), "rows_max": int(rows.max()),
+    rec[env_id + f"@{nenv}" + "".join(f"|{k}={v}" for k, v in overrides.items())] = {"envs": nenv, "rows_median": int(np.median(rows)), "rows_max": int(rows.max()),
         "row_count_mismatches": int(mism.sum()), "rel_qacc_err_median": float(q[0]), "rel_qacc_err_p99": float(q[1]), "rel_qacc_err_max": float(q[2]),
         "envs_with_rows": int((rows > 0).sum())}
     json.dump(rec, open(fn, "w"), indent=1)
-    assert int(st.status.max()) & ~1 == 0
+    assert status & ~1 == 0
     assert mism.sum() <= max(2, nenv // 100), int(mism.sum())
-    assert (rows > 0).sum() >= nenv // 2                      # the batch really is in contact / at its limits
     assert q[2] < 2e-3 and q[1] < 3e-4, q
 
 
