@@ -35,6 +35,11 @@ def main():
     ap.add_argument("--lam", type=float, default=0.95)
     ap.add_argument("--clip", type=float, default=0.3)
     ap.add_argument("--eager", action="store_true", help="no HIP graphs (round 3's form): every op its own launch")
+    ap.add_argument("--nets", choices=["reference", "brax"], default="reference",
+                    help="reference: policy / value MLPs of (64, 64, 64), the reference's ppo_config (myosuite/envs/myo/mjx/__init__.py:43-67); "
+                         "brax: brax PPO's own defaults, policy (32,)*4 and value (256,)*5 -- wider than the fused learner kernels take, "
+                         "runs on the torch-autograd learner")
+    ap.add_argument("--torch-learner", action="store_true", help="torch autograd + torch Adam instead of the fused learner kernels")
     ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: ranks share the visible GPU(s), gloo group")
     args = ap.parse_args()
 
@@ -47,9 +52,10 @@ def main():
     env = registry.make(args.env, num_envs=args.num_envs, seed=rank, device=dev, env_index_base=rank * args.num_envs)
     cfg = PPOConfig(unroll_length=args.unroll, num_minibatches=args.minibatches, num_updates_per_batch=args.epochs,
                     discounting=args.gamma, gae_lambda=args.lam, clipping_epsilon=args.clip, entropy_cost=1e-2, value_cost=0.25,
-                    policy_hidden=(32, 32, 32, 32), value_hidden=(256, 256, 256, 256, 256),        # brax PPO network defaults
+                    policy_hidden=(64, 64, 64) if args.nets == "reference" else (32, 32, 32, 32),
+                    value_hidden=(64, 64, 64) if args.nets == "reference" else (256, 256, 256, 256, 256),
                     squash="sigmoid", normalize_observations=True)
-    ppo = OnDevicePPO(env, cfg, seed=0, world=world, use_graphs=not args.eager)
+    ppo = OnDevicePPO(env, cfg, seed=0, world=world, use_graphs=not args.eager, fused=False if args.torch_learner else None)
     ppo.iterate()                                   # warm-up + graph capture (not timed)
     torch.cuda.synchronize(); D.barrier()
     # rollout alone (the graph of the unroll), then full iterations
@@ -78,7 +84,8 @@ def main():
     if rank == 0:
         steps = args.iters * ppo.steps_per_iteration
         print(json.dumps({"env": args.env, "n_gpus": world, "envs_per_gpu": args.num_envs, "unroll": args.unroll, "iters": args.iters,
-                          "graphs": ppo._g_roll is not None, "update_graph": ppo._g_upd is not None,
+                          "graphs": ppo._g_roll is not None, "update_graph": ppo._g_upd is not None, "nets": args.nets,
+                          "fused_learner_kernels": ppo.kern is not None, "epochs": args.epochs, "minibatches": args.minibatches,
                           "rollout_env_steps_per_s": steps / t_roll, "train_env_steps_per_s": steps / t_all,
                           "mean_reward_per_step_first_last": [r0, float(ppo.mean_reward)],
                           "params_in_sync_across_ranks": in_sync, "mean_return_per_env": float(stats[:, 0].mean())}))

@@ -74,7 +74,9 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-DMM_REFOLD_CARRY=1"],
               # precision-mode (fp64) kernels: IEEE divide / sqrt and no reassociation -- these exist to track the fp64 reference;
               # fma contraction stays on (it only removes roundings)
-              "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"]}
+              "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"],
+              # the PPO learner kernels are checked against torch autograd: IEEE exp / log / divide
+              "myosim_ppo.hip": ["-fno-fast-math", "-ffp-contract=fast"]}
 
 
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
@@ -84,7 +86,8 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + \
            [os.path.join(_HERE, "..", "include", h) for h in ("myosim.h", "myosim_model.h")]
-    deps = srcs + hdrs
+    ppo_hdr = os.path.join(_HERE, "..", "include", "myosim_ppo.h")         # seen by myosim_ppo.hip only
+    deps = srcs + hdrs + [ppo_hdr]
     bdir = os.path.join(CSRC, "_build")
     # the compiler flags are part of the build's identity: a library built with other flags is rebuilt from scratch
     stamp, flags_now = os.path.join(bdir, "flags.txt"), " ".join(EXTRA_FLAGS) + " | " + repr(sorted(SCHED_STRATEGY.items())) + repr(sorted(FILE_FLAGS.items()))
@@ -98,7 +101,8 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
 
     def compile_one(src):
         obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+        own_hdr = os.path.getmtime(ppo_hdr) if os.path.basename(src) == "myosim_ppo.hip" else 0.0
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr, own_hdr):
             return obj
         sched = SCHED_STRATEGY.get(os.path.basename(src), SCHED_STRATEGY["default"])
         cmd = (["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS + FILE_FLAGS.get(os.path.basename(src), []) +
@@ -117,6 +121,18 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     with open(stamp, "w") as f:
         f.write(flags_now)
     return LIB_PATH
+
+
+MM_PPO_MAX_LAYERS, MM_PPO_MAX_WIDTH, MM_PPO_MAX_OBS, MM_PPO_MAX_OUT = 8, 128, 512, 256        # include/myosim_ppo.h
+MM_PPO_SQUASH_TANH, MM_PPO_SQUASH_SIGMOID = 0, 1
+
+
+class mm_ppo_config(C.Structure):
+    _fields_ = [("size", C.c_int), ("obs_dim", C.c_int), ("act_dim", C.c_int), ("pi_layers", C.c_int), ("vf_layers", C.c_int),
+                ("pi_widths", C.c_int * MM_PPO_MAX_LAYERS), ("vf_widths", C.c_int * MM_PPO_MAX_LAYERS), ("squash", C.c_int),
+                ("max_minibatch", C.c_int), ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("adam_eps", C.c_float), ("clipping_epsilon", C.c_float), ("entropy_cost", C.c_float), ("value_cost", C.c_float),
+                ("max_grad_norm", C.c_float)]
 
 
 class mm_state(C.Structure):
@@ -230,6 +246,19 @@ def lib():
         L.mm_debug_set_prof.argtypes = [C.c_void_p]
         L.mm_model_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.mm_model_launch_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        # fused PPO learner kernels (include/myosim_ppo.h)
+        L.mm_ppo_create.argtypes = [C.POINTER(mm_ppo_config), C.c_int, C.POINTER(C.c_void_p)]
+        L.mm_ppo_destroy.argtypes = [C.c_void_p]
+        L.mm_ppo_destroy.restype = None
+        L.mm_ppo_last_error.restype = C.c_char_p
+        L.mm_ppo_param_count.argtypes = [C.c_void_p]
+        L.mm_ppo_value_offset.argtypes = [C.c_void_p]
+        L.mm_ppo_reset_optimizer.argtypes = [C.c_void_p, C.c_void_p]
+        L.mm_ppo_act.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 6
+        L.mm_ppo_store.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+        L.mm_ppo_grad.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 6
+        L.mm_ppo_adam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
         # the binding restates the header's structs: refuse a library built from another ABI or with other struct layouts
         L.mm_struct_size.argtypes = [C.c_int]
         if L.mm_abi_version() != MM_ABI_VERSION:
@@ -535,6 +564,100 @@ def gae(reward: torch.Tensor, terminated: torch.Tensor, truncated: Optional[torc
         assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
     _chk(lib().mm_gae(_ptr(reward), _ptr(terminated), _ptr(truncated), _ptr(value), _ptr(advantage), _ptr(returns), int(T), int(n),
                       C.c_float(gamma), C.c_float(lam), _stream(reward.device)), "mm_gae")
+
+
+class FusedPPO:
+    """Handle of the fused PPO learner kernels (include/myosim_ppo.h): policy / value MLPs over ONE flat parameter vector (policy
+    first; per layer weight [out][in], bias [out] -- the parameter order of torch nn.Sequential(Linear, SiLU, ...)).
+
+    act():   one launch per rollout step (normalise, policy forward, sample, log-prob, squash, value forward)
+    grad():  two launches per minibatch (gather + forward + losses + backward into per-workgroup partials; ordered reduction)
+    adam():  one launch (global-norm clip + Adam), two after a data-parallel all-reduce (norm recomputed)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, policy_hidden, value_hidden, squash: str, max_minibatch: int, learning_rate: float,
+                 clipping_epsilon: float, entropy_cost: float, value_cost: float, max_grad_norm: Optional[float],
+                 device: Optional[torch.device] = None, betas=(0.9, 0.999), adam_eps: float = 1e-8):
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible: the fused PPO kernels only run on the GPU")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        c = mm_ppo_config()
+        c.size = C.sizeof(mm_ppo_config)
+        c.obs_dim, c.act_dim = int(obs_dim), int(act_dim)
+        pw, vw = list(policy_hidden) + [2 * act_dim], list(value_hidden) + [1]
+        if len(pw) > MM_PPO_MAX_LAYERS or len(vw) > MM_PPO_MAX_LAYERS:
+            raise EngineError(f"fused PPO kernels take at most {MM_PPO_MAX_LAYERS} linear layers per network")
+        c.pi_layers, c.vf_layers = len(pw), len(vw)
+        for i, w in enumerate(pw):
+            c.pi_widths[i] = int(w)
+        for i, w in enumerate(vw):
+            c.vf_widths[i] = int(w)
+        c.squash = {"tanh": MM_PPO_SQUASH_TANH, "sigmoid": MM_PPO_SQUASH_SIGMOID}[squash]
+        c.max_minibatch = int(max_minibatch)
+        c.learning_rate, c.beta1, c.beta2, c.adam_eps = float(learning_rate), float(betas[0]), float(betas[1]), float(adam_eps)
+        c.clipping_epsilon, c.entropy_cost, c.value_cost = float(clipping_epsilon), float(entropy_cost), float(value_cost)
+        c.max_grad_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        self.cfg = c
+        h = C.c_void_p()
+        self._chk(lib().mm_ppo_create(C.byref(c), self.device.index or 0, C.byref(h)), "mm_ppo_create")
+        self.h = h
+        self.param_count = lib().mm_ppo_param_count(h)
+        self.value_offset = lib().mm_ppo_value_offset(h)
+        self.obs_dim, self.act_dim = int(obs_dim), int(act_dim)
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed (rc={rc}): {lib().mm_ppo_last_error().decode()}")
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.mm_ppo_destroy(h)
+
+    def _f32(self, t, shape=None):
+        assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous() and (shape is None or tuple(t.shape) == tuple(shape)), (t.dtype, t.shape, shape)
+        return t.data_ptr()
+
+    def act(self, params, obs, obs_mean, obs_std, noise, obs_out, raw_out, logp_out, value_out, action_out):
+        """action_out None: value network only (bootstrap value)"""
+        n = obs.shape[0]
+        self._f32(params, (self.param_count,)); self._f32(obs, (n, self.obs_dim)); self._f32(value_out, (n,))
+        if action_out is not None:
+            for t in (noise, raw_out, action_out):
+                self._f32(t, (n, self.act_dim))
+            self._f32(logp_out, (n,))
+            if obs_out is not None:
+                self._f32(obs_out, (n, self.obs_dim))
+        self._chk(lib().mm_ppo_act(self.h, _ptr(params), _ptr(obs), _ptr(obs_mean), _ptr(obs_std), _ptr(noise) if action_out is not None else None,
+                                   int(n), _ptr(obs_out) if action_out is not None else None, _ptr(raw_out) if action_out is not None else None,
+                                   _ptr(logp_out) if action_out is not None else None, _ptr(value_out), _ptr(action_out), _stream(obs.device)),
+                  "mm_ppo_act")
+
+    def store(self, rwd, rwd_col, reward_scale, ended, truncated, reward_out, trunc_out, term_out):
+        n = rwd.shape[0]
+        assert ended.dtype == torch.uint8 and (truncated is None or truncated.dtype == torch.uint8)
+        self._f32(rwd); self._f32(reward_out, (n,)); self._f32(trunc_out, (n,)); self._f32(term_out, (n,))
+        self._chk(lib().mm_ppo_store(_ptr(rwd), int(rwd.shape[1]), int(rwd_col), C.c_float(reward_scale), _ptr(ended), _ptr(truncated), int(n),
+                                     _ptr(reward_out), _ptr(trunc_out), _ptr(term_out), _stream(rwd.device)), "mm_ppo_store")
+
+    def grad(self, params, obs, obs_mean, obs_std, idx, raw, logp_old, adv, ret, grad_out):
+        """obs [B, obs_dim], raw [B, act_dim], logp_old / adv / ret [B] (the flattened unroll buffers); idx int64 [mb]"""
+        B = obs.shape[0]
+        assert idx.dtype == torch.int64 and idx.is_cuda and idx.is_contiguous()
+        self._f32(params, (self.param_count,)); self._f32(obs, (B, self.obs_dim)); self._f32(raw, (B, self.act_dim))
+        for t in (logp_old, adv, ret):
+            self._f32(t, (B,))
+        self._f32(grad_out, (self.param_count,))
+        self._chk(lib().mm_ppo_grad(self.h, _ptr(params), _ptr(obs), _ptr(obs_mean), _ptr(obs_std), idx.data_ptr(), int(idx.numel()), _ptr(raw),
+                                    _ptr(logp_old), _ptr(adv), _ptr(ret), _ptr(grad_out), _stream(obs.device)), "mm_ppo_grad")
+
+    def adam(self, params, grad, grad_scale: float = 1.0, recompute_norm: bool = False):
+        self._f32(params, (self.param_count,)); self._f32(grad, (self.param_count,))
+        self._chk(lib().mm_ppo_adam(self.h, _ptr(params), _ptr(grad), C.c_float(grad_scale), int(bool(recompute_norm)), _stream(params.device)),
+                  "mm_ppo_adam")
+
+    def reset_optimizer(self):
+        self._chk(lib().mm_ppo_reset_optimizer(self.h, _stream(self.device)), "mm_ppo_reset_optimizer")
 
 
 def uniform(out: torch.Tensor, seed: int, stream_id: int, first_index: int = 0):

@@ -81,7 +81,10 @@ class OnDevicePPO:
     """PPO learner + rollout over an env of ``myosuite_amd.envs`` (anything with ``rollout_setup / rollout_step / obs / rwd /
     truncated``), captured into HIP graphs.  ``world`` > 1: data-parallel ranks with one flat-gradient all-reduce per minibatch."""
 
-    def __init__(self, env, cfg: PPOConfig, seed: int = 0, world: int = 1, use_graphs: bool = True):
+    def __init__(self, env, cfg: PPOConfig, seed: int = 0, world: int = 1, use_graphs: bool = True, fused: Optional[bool] = None):
+        """fused: None = the fused HIP learner kernels (include/myosim_ppo.h: one launch per rollout step for policy + sampling +
+        value, three per minibatch update) whenever the networks fit them (hidden widths <= 128), else the torch-autograd form;
+        True = require them; False = torch autograd (the checker of the fused kernels, and the only form for wider networks)."""
         self.env, self.cfg, self.world = env, cfg, world
         dev = env.device
         self.dev = dev
@@ -103,7 +106,21 @@ class OnDevicePPO:
             o += k
         if world > 1:
             torch.distributed.broadcast(self.flat_p, src=0)
-        self.opt = torch.optim.Adam(self.params, lr=cfg.learning_rate, capturable=True, foreach=True)
+        self.kern = None
+        if fused is not False and torch.cuda.is_available():
+            try:
+                self.kern = E.FusedPPO(od, ad, cfg.policy_hidden, cfg.value_hidden, cfg.squash, max_minibatch=max(1, (T * n) // cfg.num_minibatches),
+                                       learning_rate=cfg.learning_rate, clipping_epsilon=cfg.clipping_epsilon, entropy_cost=cfg.entropy_cost,
+                                       value_cost=cfg.value_cost, max_grad_norm=cfg.max_grad_norm, device=dev)
+                assert self.kern.param_count == self.flat_p.numel()
+            except E.EngineError:
+                if fused:
+                    raise
+                self.kern = None
+        elif fused:
+            raise E.EngineError("fused PPO kernels need a HIP device")
+        self.opt = None if self.kern else torch.optim.Adam(self.params, lr=cfg.learning_rate, capturable=True, foreach=True)
+        self.noise = torch.zeros(T, n, ad, dtype=torch.float32, device=dev) if self.kern else None
         self.norm = _Norm(od, dev) if cfg.normalize_observations else None
         f = dict(dtype=torch.float32, device=dev)
         self.obs_b = torch.zeros(T, n, od, **f); self.act_b = torch.zeros(T, n, ad, **f); self.logp_b = torch.zeros(T, n, **f)
@@ -141,7 +158,16 @@ class OnDevicePPO:
     def _rollout(self):
         env, cfg = self.env, self.cfg
         with torch.no_grad():
-            for t in range(self.T):
+            if self.kern:                          # fused: ONE launch per step next to the env-step launch (+ one for the buffer rows)
+                K = self.kern
+                mean, std = (self.norm.mean, self.norm.std) if self.norm else (None, None)
+                self.noise.normal_()
+                for t in range(self.T):
+                    K.act(self.flat_p, env.obs, mean, std, self.noise[t], self.obs_b[t], self.act_b[t], self.logp_b[t], self.val_b[t], self.action)
+                    _, rw, ended = env.rollout_step(self.action)
+                    K.store(rw, self.dense_col, cfg.reward_scaling, ended, env.truncated, self.rew_b[t], self.trunc_b[t], self.term_b[t])
+                K.act(self.flat_p, env.obs, mean, std, None, None, None, None, self.val_b[self.T], None)
+            for t in range(0 if self.kern else self.T):
                 obs = env.obs
                 self.obs_b[t].copy_(obs)
                 mean, std = self._dist(obs)
@@ -156,7 +182,8 @@ class OnDevicePPO:
                 en = ended.to(torch.float32)
                 self.trunc_b[t].copy_(tr * en)
                 self.term_b[t].copy_(en * (1.0 - tr))             # ended without a time-limit: a true termination
-            self.val_b[self.T].copy_(self._value(env.obs))
+            if not self.kern:
+                self.val_b[self.T].copy_(self._value(env.obs))
             E.gae(self.rew_b, self.term_b, self.trunc_b, self.val_b, self.adv_b, self.ret_b, cfg.discounting, cfg.gae_lambda)
             self.nadv_b.copy_((self.adv_b - self.adv_b.mean()) / (self.adv_b.std() + 1e-8))
             if self.norm:
@@ -192,6 +219,13 @@ class OnDevicePPO:
         (pg - cfg.entropy_cost * ent).backward()
         cur.wait_stream(self._side)
 
+    def _minibatch_fused(self, idx):
+        """the same gradient from the fused kernels: two launches (forward + losses + backward into partials; ordered reduction)"""
+        B = self.T * self.n
+        mean, std = (self.norm.mean, self.norm.std) if self.norm else (None, None)
+        self.kern.grad(self.flat_p, self.obs_b.view(B, -1), mean, std, idx, self.act_b.view(B, -1), self.logp_b.view(B), self.nadv_b.view(B),
+                       self.ret_b.view(B), self.flat_g)
+
     def _step_opt(self):
         if self.cfg.max_grad_norm:
             torch.nn.utils.clip_grad_norm_(self.params, self.cfg.max_grad_norm, foreach=True)
@@ -202,14 +236,23 @@ class OnDevicePPO:
         perm = torch.argsort(torch.rand(B, device=self.dev))          # device-side permutation (graph safe)
         mb = B // self.cfg.num_minibatches
         for k in range(self.cfg.num_minibatches):
-            self._minibatch_backward(perm[k * mb:(k + 1) * mb])
+            if self.kern:
+                self._minibatch_fused(perm[k * mb:(k + 1) * mb])
+            else:
+                self._minibatch_backward(perm[k * mb:(k + 1) * mb])
             if self.world > 1:                 # ONE collective per minibatch on the flat gradient buffer
                 if self.flat_g.is_cuda and torch.distributed.get_backend() == "gloo":
                     h = self.flat_g.cpu(); torch.distributed.all_reduce(h); self.flat_g.copy_(h)
                 else:
                     torch.distributed.all_reduce(self.flat_g)
+                if self.kern:
+                    self.kern.adam(self.flat_p, self.flat_g, 1.0 / self.world, recompute_norm=True)
+                    continue
                 self.flat_g.div_(self.world)
-            self._step_opt()
+            if self.kern:
+                self.kern.adam(self.flat_p, self.flat_g)
+            else:
+                self._step_opt()
 
     # ------------------------------------------------------------------ graphs
     def _capture(self):
