@@ -48,9 +48,18 @@ struct NetD {
   int nl, in, npar, pad_;
   int w[MM_PPO_MAX_LAYERS], woff[MM_PPO_MAX_LAYERS], boff[MM_PPO_MAX_LAYERS];
   int ldx, ldh, ldo, total;
-  int ldz[MM_PPO_MAX_LAYERS], oZ[MM_PPO_MAX_LAYERS];
-  int oX, oOUT, oH, oD0, oD1, pad2_;
+  int ldz[MM_PPO_MAX_LAYERS], oZ[MM_PPO_MAX_LAYERS], oA[MM_PPO_MAX_LAYERS];   // hidden layer l: pre-activations Z, activations A = swish(Z)
+  int oX, oOUT, oD0, oD1, oAUX, pad2_;          // oAUX: S x act_dim raw actions of the policy's loss stage
 };
+
+#ifndef MM_PPO_PROF
+#define MM_PPO_PROF 0        /* 1 (tools/build_variant.py ppoprof -DMM_PPO_PROF=1): k_ppo_grad stamps clock64() per stage into mm_ppo_debug_set_prof's buffer */
+#endif
+__device__ unsigned long long* g_ppo_prof = nullptr;
+#define PPROF(i)                                                                                                       \
+  do {                                                                                                                 \
+    if (MM_PPO_PROF && threadIdx.x == 0 && g_ppo_prof) g_ppo_prof[(size_t)blockIdx.x * 64 + (i)] = clock64();         \
+  } while (0)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float silu_(float z) { return z * sigmoidf_(z); }
@@ -66,6 +75,7 @@ __device__ __forceinline__ void gemm_F(const float* A, int lda, int K, const flo
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
   const int K16 = (K + 15) & ~15, NT = (N + 15) >> 4;
   const bool vec = (K & 3) == 0;
+  constexpr int PF = 8;
   for (int nt = wv; nt < NT; nt += 4) {
     f4 acc[RT];
 #pragma unroll
@@ -73,21 +83,31 @@ __device__ __forceinline__ void gemm_F(const float* A, int lda, int K, const flo
     const int n = 16 * nt + lr;
     const bool nok = n < N;
     const float* wr = Wg + (size_t)(nok ? n : 0) * K;
-
-    for (int c = 0; c < K16; c += 16) {
-      const int k0 = c + 4 * lk;
-      f4 b;
-      if (vec) {
-        b = (nok && k0 < K) ? (f4)(*(const f4u*)(wr + k0)) : f4{0.f, 0.f, 0.f, 0.f};
-      } else {
+    // the weight operand of PF k chunks is requested before the first MFMA of the batch: one L2 round trip per batch, not per chunk
+    // (a wave has its SIMD to itself here -- nothing else hides the latency)
+    for (int c0 = 0; c0 < K16; c0 += 16 * PF) {
+      f4 b[PF];
 #pragma unroll
-        for (int m = 0; m < 4; m++) b[m] = (nok && k0 + m < K) ? wr[k0 + m] : 0.f;
+      for (int u = 0; u < PF; u++) {
+        const int k0 = c0 + 16 * u + 4 * lk;
+        if (vec) {
+          b[u] = (nok && k0 < K) ? (f4)(*(const f4u*)(wr + k0)) : f4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; m++) b[u][m] = (nok && k0 + m < K) ? wr[k0 + m] : 0.f;
+        }
       }
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        const f4 av = *(const f4*)(A + (16 * rt + lr) * lda + k0);
+      for (int u = 0; u < PF; u++) {
+        if (c0 + 16 * u < K16) {
+          const int k0 = c0 + 16 * u + 4 * lk;
 #pragma unroll
-        for (int m = 0; m < 4; m++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], b[m], acc[rt], 0, 0, 0);
+          for (int rt = 0; rt < RT; rt++) {
+            const f4 av = *(const f4*)(A + (16 * rt + lr) * lda + k0);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], b[u][m], acc[rt], 0, 0, 0);
+          }
+        }
       }
     }
     const float bias = nok ? bg[n] : 0.f;
@@ -103,23 +123,33 @@ template <int RT, class Epi>
 __device__ __forceinline__ void gemm_B(const float* dZ, int ldz, int N, const float* __restrict__ Wg, int K, Epi epi) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
   const int N16 = (N + 15) & ~15, KT = (K + 15) >> 4;
+  constexpr int PF = 4;
   for (int kt = wv; kt < KT; kt += 4) {
     f4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) acc[rt] = f4{0.f, 0.f, 0.f, 0.f};
     const int kc = 16 * kt + lr;
     const bool kok = kc < K;
-
-    for (int c = 0; c < N16; c += 16) {
-      const int n0 = c + 4 * lk;
-      float b[4];
+    for (int c0 = 0; c0 < N16; c0 += 16 * PF) {
+      float b[PF][4];
 #pragma unroll
-      for (int m = 0; m < 4; m++) b[m] = (kok && n0 + m < N) ? Wg[(size_t)(n0 + m) * K + kc] : 0.f;
+      for (int u = 0; u < PF; u++)
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++) {
-        const f4 av = *(const f4*)(dZ + (16 * rt + lr) * ldz + n0);
+        for (int m = 0; m < 4; m++) {
+          const int n = c0 + 16 * u + 4 * lk + m;
+          b[u][m] = (kok && n < N) ? Wg[(size_t)n * K + kc] : 0.f;
+        }
 #pragma unroll
-        for (int m = 0; m < 4; m++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], b[m], acc[rt], 0, 0, 0);
+      for (int u = 0; u < PF; u++) {
+        if (c0 + 16 * u < N16) {
+          const int n0 = c0 + 16 * u + 4 * lk;
+#pragma unroll
+          for (int rt = 0; rt < RT; rt++) {
+            const f4 av = *(const f4*)(dZ + (16 * rt + lr) * ldz + n0);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], b[u][m], acc[rt], 0, 0, 0);
+          }
+        }
       }
     }
 #pragma unroll
@@ -135,8 +165,8 @@ template <int RT>
 __device__ __forceinline__ void gemm_G(const float* dZ, int ldz, int N, const float* A, int lda, int K, float* __restrict__ dWg, float* __restrict__ dbg) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, lr = lane & 15, lk = lane >> 4;
   const int NT = (N + 15) >> 4, KT = (K + 15) >> 4;
+  int nt = wv / KT, kt = wv - nt * KT;
   for (int t = wv; t < NT * KT; t += 4) {
-    const int nt = t / KT, kt = t - nt * KT;
     f4 acc = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 16 * RT; c += 16) {
@@ -150,40 +180,55 @@ __device__ __forceinline__ void gemm_G(const float* dZ, int ldz, int N, const fl
       const int n = 16 * nt + 4 * lk + v, k = 16 * kt + lr;
       if (n < N && k < K) dWg[(size_t)n * K + k] = acc[v];
     }
+    kt += 4;
+    while (kt >= KT) { kt -= KT; nt++; }
   }
-  for (int n = threadIdx.x; n < N; n += NTHREADS) {
-    float s = 0.f;
-    for (int r = 0; r < 16 * RT; r++) s += dZ[r * ldz + n];
-    dbg[n] = s;
+  // bias gradient: column sums of dZ; 16 RT rows split over the lanes of a 4-lane group
+  for (int i = threadIdx.x; i < 4 * ((N + 3) & ~3); i += NTHREADS) {
+    const int n = i >> 2, q = i & 3;
+    float sum = 0.f;
+    if (n < N)
+#pragma unroll
+      for (int r = 0; r < 4 * RT; r++) sum += dZ[(4 * RT * q + r) * ldz + n];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (q == 0 && n < N) dbg[n] = sum;
   }
 }
 
-// normalised observation rows of the workgroup's samples into LDS (rows >= cnt and columns >= in are zero)
+// normalised observation rows of the workgroup's samples into LDS (rows >= cnt and columns >= in are zero).  The row indices go
+// through LDS first and the element loop requests XU rows' worth of loads before it uses any: a gathered row is an HBM round trip,
+// and the loop is 14 (hand) ... 50 (leg) elements per thread.
 template <int RT, class RowF>
 __device__ __forceinline__ void load_x(const NetD* d, float* L, const float* __restrict__ obs, int od, const float* __restrict__ mean,
-                                       const float* __restrict__ sd, int cnt, RowF rowf, float* __restrict__ obs_copy) {
+                                       const float* __restrict__ sd, int cnt, RowF rowf, float* __restrict__ obs_copy, long long* rows) {
   const int in = d->in, in16 = (in + 15) & ~15, ldx = d->ldx;
   float* X = L + d->oX;
-  for (int i = threadIdx.x; i < 16 * RT * in16; i += NTHREADS) {
-    const int s = i / in16, c = i - s * in16;
-    float x = 0.f;
-    if (s < cnt && c < in) {
-      const size_t row = (size_t)rowf(s);
-      x = obs[row * od + c];
-      if (obs_copy) obs_copy[row * od + c] = x;
-      if (mean) x = fminf(fmaxf((x - mean[c]) / sd[c], -5.f), 5.f);
+  if ((int)threadIdx.x < 16 * RT) rows[threadIdx.x] = (int)threadIdx.x < cnt ? (long long)rowf(threadIdx.x) : 0;
+  __syncthreads();
+  // a thread owns columns c = tid, tid + 256, ... of every row: no index arithmetic beyond adds, and the 16 RT row loads of a
+  // column are requested together
+  const bool nrm = mean != nullptr;
+  for (int c = threadIdx.x; c < in16; c += NTHREADS) {
+    const bool cok = c < in;
+    const float m = (cok && nrm) ? mean[c] : 0.f, q = (cok && nrm) ? 1.f / sd[c] : 1.f;
+    float x[16 * RT];
+#pragma unroll
+    for (int r = 0; r < 16 * RT; r++) x[r] = (cok && r < cnt) ? obs[(size_t)rows[r] * od + c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16 * RT; r++) {
+      if (cok && r < cnt && obs_copy) obs_copy[(size_t)rows[r] * od + c] = x[r];
+      X[r * ldx + c] = nrm ? fminf(fmaxf((x[r] - m) * q, -5.f), 5.f) : x[r];
     }
-    X[s * ldx + c] = x;
   }
   __syncthreads();
 }
 
-// forward pass of one network over the workgroup's samples: hidden pre-activations kept in Z[l], output layer in OUT
+// forward pass of one network over the workgroup's samples: every hidden layer's pre-activations Z[l] AND activations A[l] stay in
+// LDS (the backward pass wants both: recomputing A costs a stage -- a barrier and a pass of exponentials -- per layer)
 template <int RT>
 __device__ __forceinline__ void forward(const NetD* d, float* L, const float* __restrict__ Pn) {
-  const int nl = d->nl, ldh = d->ldh, ldo = d->ldo;
-  float* Hn = L + d->oH;
-  float* Ho = L + d->oD0;
+  const int nl = d->nl, ldo = d->ldo;
   const float* Ain = L + d->oX;
   int lda = d->ldx, K = d->in;
   for (int l = 0; l < nl; l++) {
@@ -192,14 +237,15 @@ __device__ __forceinline__ void forward(const NetD* d, float* L, const float* __
     const float* bg = Pn + d->boff[l];
     if (l < nl - 1) {
       float* Z = L + d->oZ[l];
+      float* A = L + d->oA[l];
       const int ldz = d->ldz[l];
       gemm_F<RT>(Ain, lda, K, Wg, bg, N, [&](int s, int n, bool ok, float z) {
         Z[s * ldz + n] = ok ? z : 0.f;
-        Hn[s * ldh + n] = ok ? silu_(z) : 0.f;
+        A[s * ldz + n] = ok ? silu_(z) : 0.f;
       });
       __syncthreads();
-      Ain = Hn; lda = ldh; K = N;
-      float* t = Hn; Hn = Ho; Ho = t;
+      PPROF(20 + l);
+      Ain = A; lda = ldz; K = N;
     } else {
       float* O = L + d->oOUT;
       gemm_F<RT>(Ain, lda, K, Wg, bg, N, [&](int s, int n, bool ok, float z) { O[s * ldo + n] = ok ? z : 0.f; });
@@ -208,37 +254,29 @@ __device__ __forceinline__ void forward(const NetD* d, float* L, const float* __
   }
 }
 
-// backward pass: OUT holds d loss / d output; partial gradients of every layer go to `part` (the network's parameter layout)
+// backward pass: OUT holds d loss / d output; partial gradients of every layer go to `part` (the network's parameter layout).
+// Per layer ONE stage: the weight-gradient tiles (LDS x LDS -> global) and the input-gradient tiles (LDS x weights -> LDS) have no
+// dependence on each other.
 template <int RT>
 __device__ __forceinline__ void backward(const NetD* d, float* L, const float* __restrict__ Pn, float* __restrict__ part) {
   const int nl = d->nl, ldh = d->ldh;
   const float* dZ = L + d->oOUT;
   int ldd = d->ldo;
-  float* H = L + d->oH;
   float* Dn = L + d->oD0;
   float* Do = L + d->oD1;
   for (int l = nl - 1; l >= 0; l--) {
     const int N = d->w[l], K = l ? d->w[l - 1] : d->in;
-    const float* Ain; int lda;
-    if (l) {           // input of layer l: swish of the previous layer's pre-activations, recomputed
-      const float* Z = L + d->oZ[l - 1];
-      const int ldz = d->ldz[l - 1], K16 = (K + 15) & ~15;
-      for (int i = threadIdx.x; i < 16 * RT * K16; i += NTHREADS) {
-        const int s = i / K16, c = i - s * K16;
-        H[s * ldh + c] = silu_(Z[s * ldz + c]);
-      }
-      __syncthreads();
-      Ain = H; lda = ldh;
-    } else {
-      Ain = L + d->oX; lda = d->ldx;
-    }
+    const float* Ain = l ? L + d->oA[l - 1] : L + d->oX;
+    const int lda = l ? d->ldz[l - 1] : d->ldx;
     gemm_G<RT>(dZ, ldd, N, Ain, lda, K, part + d->woff[l], part + d->boff[l]);
+    PPROF(31 + 3 * l);
     if (l) {
       const float* Z = L + d->oZ[l - 1];
       const int ldz = d->ldz[l - 1];
       float* D = Dn;
       gemm_B<RT>(dZ, ldd, N, Pn + d->woff[l], K, [&](int s, int k, bool ok, float v) { D[s * ldh + k] = ok ? v * dsilu_(Z[s * ldz + k]) : 0.f; });
       __syncthreads();
+      PPROF(32 + 3 * l);
       dZ = D; ldd = ldh;
       float* t = Dn; Dn = Do; Do = t;
     }
@@ -260,23 +298,52 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_grad(GradArgs a) {
   constexpr int S = 16 * RT, LPS = NTHREADS / S;         // lanes per sample in the loss stage
   const bool is_pi = (int)blockIdx.x < a.nb_pi;
   const int b = is_pi ? blockIdx.x : blockIdx.x - a.nb_pi;
-  const NetD* d = is_pi ? a.dpi : a.dvf;
+  // the network descriptor goes through LDS: every layer reads a handful of its fields, and from global memory each read is an L2
+  // round trip in front of the layer's first weight load
+  __shared__ NetD sdesc;
+  __shared__ long long rows[32];
+  __shared__ float s_old[32], s_adv[32];
+  PPROF(0);
+  {
+    const int* src = (const int*)(is_pi ? a.dpi : a.dvf);
+    for (int i = threadIdx.x; i < (int)(sizeof(NetD) / sizeof(int)); i += NTHREADS) ((int*)&sdesc)[i] = src[i];
+    __syncthreads();
+  }
+  PPROF(1);
+  const NetD* d = &sdesc;
+  float* s_raw = L + d->oAUX;
   const float* Pn = a.P + (is_pi ? 0 : a.voff);
   const int cnt = min(S, a.mb - b * S);
   const long long* idx = a.idx + (size_t)b * S;
-  load_x<RT>(d, L, a.obs, a.od, a.mean, a.sd, cnt, [&](int s) { return idx[s]; }, nullptr);
+  load_x<RT>(d, L, a.obs, a.od, a.mean, a.sd, cnt, [&](int s) { return idx[s]; }, nullptr, rows);
+  PPROF(2);
+  // the per-sample operands of the loss are requested now and used after the forward pass
+  if (is_pi) {
+    const int ad = a.ad;
+    for (int q = threadIdx.x; q < ad; q += NTHREADS) {         // act_dim <= 128 columns: the 16 RT row loads of a column together
+      float r[16 * RT];
+#pragma unroll
+      for (int u = 0; u < 16 * RT; u++) r[u] = u < cnt ? a.raw[(size_t)rows[u] * ad + q] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16 * RT; u++) s_raw[u * ad + q] = r[u];
+    }
+    if ((int)threadIdx.x < cnt) { s_old[threadIdx.x] = a.lold[rows[threadIdx.x]]; s_adv[threadIdx.x] = a.adv[rows[threadIdx.x]]; }
+  } else if ((int)threadIdx.x < cnt) {
+    s_old[threadIdx.x] = a.ret[rows[threadIdx.x]];
+  }
+  PPROF(3);
   forward<RT>(d, L, Pn);
+  PPROF(4);
   float* O = L + d->oOUT;
   const int ldo = d->ldo;
   const float inv_mb = 1.f / (float)a.mb;
   if (is_pi) {
     const int s = threadIdx.x / LPS, j = threadIdx.x - s * LPS, ad = a.ad;
     const bool valid = s < cnt;
-    const size_t row = valid ? (size_t)idx[s] : 0;
     float lp = 0.f;
     if (valid)
       for (int q = j; q < ad; q += LPS) {
-        const float m = O[s * ldo + q], sd = softplus_(O[s * ldo + ad + q]) + 1e-3f, r = a.raw[row * ad + q];
+        const float m = O[s * ldo + q], sd = softplus_(O[s * ldo + ad + q]) + 1e-3f, r = s_raw[s * ad + q];
         const float z = (r - m) / sd;
         lp += -0.5f * z * z - logf(sd) - HALF_LOG_2PI;
         lp -= a.squash == MM_PPO_SQUASH_TANH ? 2.f * (0.69314718055994530942f - r - softplus_(-2.f * r)) : (-softplus_(-r) - softplus_(r));
@@ -285,14 +352,14 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_grad(GradArgs a) {
     for (int o = LPS >> 1; o; o >>= 1) lp += __shfl_xor(lp, o);
     float glp = 0.f;
     if (valid) {
-      const float ratio = expf(lp - a.lold[row]), A = a.adv[row];
+      const float ratio = expf(lp - s_old[s]), A = s_adv[s];
       const float cl = fminf(fmaxf(ratio, 1.f - a.eps), 1.f + a.eps);
       glp = (ratio * A <= cl * A) ? -A * inv_mb * ratio : 0.f;       // d loss / d logp through min(r A, clip(r) A)
     }
     for (int q = j; q < ad; q += LPS) {
       float dm = 0.f, dro = 0.f;
       if (valid) {
-        const float m = O[s * ldo + q], o = O[s * ldo + ad + q], sd = softplus_(o) + 1e-3f, r = a.raw[row * ad + q];
+        const float m = O[s * ldo + q], o = O[s * ldo + ad + q], sd = softplus_(o) + 1e-3f, r = s_raw[s * ad + q];
         const float isd = 1.f / sd, z = (r - m) * isd;
         dm = glp * z * isd;
         dro = (glp * (z * z * isd - isd) - a.entc * inv_mb * isd) * dsoftplus_(o);
@@ -303,10 +370,11 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_grad(GradArgs a) {
   } else {
     if ((int)threadIdx.x < S) {
       const int s = threadIdx.x;
-      O[s * ldo] = s < cnt ? 2.f * a.vc * inv_mb * (O[s * ldo] - a.ret[(size_t)idx[s]]) : 0.f;
+      O[s * ldo] = s < cnt ? 2.f * a.vc * inv_mb * (O[s * ldo] - s_old[s]) : 0.f;
     }
   }
   __syncthreads();
+  PPROF(5);
   backward<RT>(d, L, Pn, (is_pi ? a.part_pi : a.part_vf) + (size_t)b * d->npar);
 }
 
@@ -321,35 +389,50 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return t;
 }
 
-// grad[p] = sum over the workgroups' partials in index order; sum of squares of this block's slice -> blocksq[block]
+// grad[p] = sum over the workgroups' partials in a fixed order (deterministic): a workgroup owns 64 consecutive parameters, its four
+// waves each add every fourth partial (four independent accumulators: 16 loads in flight per lane), the four sums meet in LDS.
+// Sum of squares of the workgroup's slice -> blocksq[block].  64 parameters never straddle the two networks' partial arrays only if
+// np_pi is a multiple of 64 -- it is not in general, so every lane picks its own source.
+constexpr int RED_P = 64;
 __global__ __launch_bounds__(NTHREADS) void k_ppo_reduce(const float* __restrict__ part_pi, int nb_pi, int np_pi, const float* __restrict__ part_vf,
                                                          int nb_vf, int np_vf, float* __restrict__ grad, float* __restrict__ blocksq) {
-  __shared__ float sh[4];
-  const int p = blockIdx.x * NTHREADS + threadIdx.x;
+  __shared__ float sh[4][RED_P];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * RED_P + lane;
   float g = 0.f;
   if (p < np_pi + np_vf) {
     const bool pi = p < np_pi;
     const float* src = pi ? part_pi + p : part_vf + (p - np_pi);
-    const int nb = pi ? nb_pi : nb_vf, st = pi ? np_pi : np_vf;
+    const int nb = pi ? nb_pi : nb_vf;
+    const size_t st = pi ? np_pi : np_vf;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= nb; b += 4) {
-      g0 += src[(size_t)b * st]; g1 += src[(size_t)(b + 1) * st]; g2 += src[(size_t)(b + 2) * st]; g3 += src[(size_t)(b + 3) * st];
+    int b = grp;
+    for (; b + 12 < nb; b += 16) {
+      g0 += src[(size_t)b * st]; g1 += src[(size_t)(b + 4) * st]; g2 += src[(size_t)(b + 8) * st]; g3 += src[(size_t)(b + 12) * st];
     }
-    for (; b < nb; b++) g0 += src[(size_t)b * st];
+    for (; b < nb; b += 4) g0 += src[(size_t)b * st];
     g = (g0 + g1) + (g2 + g3);
-    grad[p] = g;
   }
-  const float t = block_sum(g * g, sh);
-  if (threadIdx.x == 0) blocksq[blockIdx.x] = t;
+  sh[grp][lane] = g;
+  __syncthreads();
+  float q = 0.f;
+  if (grp == 0) {
+    g = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    if (p < np_pi + np_vf) grad[p] = g;
+    q = g * g;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) blocksq[blockIdx.x] = q;
+  }
 }
 
-__global__ __launch_bounds__(NTHREADS) void k_ppo_sumsq(const float* __restrict__ grad, int np, float* __restrict__ blocksq) {
-  __shared__ float sh[4];
-  const int p = blockIdx.x * NTHREADS + threadIdx.x;
+__global__ __launch_bounds__(RED_P) void k_ppo_sumsq(const float* __restrict__ grad, int np, float* __restrict__ blocksq) {
+  const int p = blockIdx.x * RED_P + threadIdx.x;
   const float g = p < np ? grad[p] : 0.f;
-  const float t = block_sum(g * g, sh);
-  if (threadIdx.x == 0) blocksq[blockIdx.x] = t;
+  float q = g * g;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+  if (threadIdx.x == 0) blocksq[blockIdx.x] = q;
 }
 
 // torch.nn.utils.clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6))) + torch.optim.Adam (bias-corrected, eps outside the root)
@@ -387,10 +470,17 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_act(ActArgs a) {
   constexpr int S = 16 * RT, LPS = NTHREADS / S;
   const bool is_pi = (int)blockIdx.x < a.nb_pi;
   const int b = is_pi ? blockIdx.x : blockIdx.x - a.nb_pi;
-  const NetD* d = is_pi ? a.dpi : a.dvf;
+  __shared__ NetD sdesc;
+  __shared__ long long rows[32];
+  {
+    const int* src = (const int*)(is_pi ? a.dpi : a.dvf);
+    for (int i = threadIdx.x; i < (int)(sizeof(NetD) / sizeof(int)); i += NTHREADS) ((int*)&sdesc)[i] = src[i];
+    __syncthreads();
+  }
+  const NetD* d = &sdesc;
   const float* Pn = a.P + (is_pi ? 0 : a.voff);
   const int cnt = min(S, a.n - b * S), base = b * S;
-  load_x<RT>(d, L, a.obs, a.od, a.mean, a.sd, cnt, [&](int s) { return base + s; }, is_pi ? a.obs_out : nullptr);
+  load_x<RT>(d, L, a.obs, a.od, a.mean, a.sd, cnt, [&](int s) { return base + s; }, is_pi ? a.obs_out : nullptr, rows);
   forward<RT>(d, L, Pn);
   const float* O = L + d->oOUT;
   const int ldo = d->ldo;
@@ -429,18 +519,18 @@ __global__ void k_ppo_store(const float* __restrict__ rwd, int cols, int col, fl
 int r16(int x) { return (x + 15) & ~15; }
 
 // LDS plan of a workgroup of S samples
-void plan(NetD& d, int S) {
+void plan(NetD& d, int S, int aux_cols) {
   int maxh = 16;
   for (int l = 0; l + 1 < d.nl; l++) maxh = std::max(maxh, r16(d.w[l]));
   d.ldx = r16(d.in) + 4; d.ldh = maxh + 4; d.ldo = r16(d.w[d.nl - 1]) + 4;
   int o = 0;
   d.oX = o; o += S * d.ldx;
-  for (int l = 0; l < MM_PPO_MAX_LAYERS; l++) { d.ldz[l] = 0; d.oZ[l] = 0; }
-  for (int l = 0; l + 1 < d.nl; l++) { d.ldz[l] = r16(d.w[l]) + 4; d.oZ[l] = o; o += S * d.ldz[l]; }
+  for (int l = 0; l < MM_PPO_MAX_LAYERS; l++) { d.ldz[l] = 0; d.oZ[l] = 0; d.oA[l] = 0; }
+  for (int l = 0; l + 1 < d.nl; l++) { d.ldz[l] = r16(d.w[l]) + 4; d.oZ[l] = o; o += S * d.ldz[l]; d.oA[l] = o; o += S * d.ldz[l]; }
   d.oOUT = o; o += S * d.ldo;
-  d.oH = o; o += S * d.ldh;
   d.oD0 = o; o += S * d.ldh;
   d.oD1 = o; o += S * d.ldh;
+  d.oAUX = o; o += S * aux_cols;
   d.total = o;
 }
 
@@ -496,11 +586,11 @@ extern "C" int mm_ppo_create(const mm_ppo_config* c, int device, mm_ppo** out) {
   int rc;
   for (int r = 0; r < 2; r++) {
     if ((rc = fill_net(h->net[0][r], c->obs_dim, c->pi_layers, c->pi_widths, "policy")) || (rc = fill_net(h->net[1][r], c->obs_dim, c->vf_layers, c->vf_widths, "value"))) { delete h; return rc; }
-    plan(h->net[0][r], 16 * (r + 1)); plan(h->net[1][r], 16 * (r + 1));
+    plan(h->net[0][r], 16 * (r + 1), c->act_dim); plan(h->net[1][r], 16 * (r + 1), 0);
     h->lds[r] = sizeof(float) * (size_t)std::max(h->net[0][r].total, h->net[1][r].total);
   }
   h->np_pi = h->net[0][0].npar; h->np_vf = h->net[1][0].npar; h->np = h->np_pi + h->np_vf;
-  const size_t lds_limit = 152 * 1024;
+  const size_t lds_limit = 150 * 1024;       // 160 KB per CU minus the kernels' static arrays (descriptor, row indices, per-sample scalars) and a margin
   if (h->lds[0] > lds_limit) { const size_t need = h->lds[0]; delete h; return pfail(MM_ELDS, "mm_ppo_create: a 16-sample workgroup needs " + std::to_string(need) + " B of LDS"); }
   h->max_rt = h->lds[1] <= lds_limit ? 2 : 1;
   if (const char* e = getenv("MYOSIM_PPO_SAMPLES")) h->force_rt = atoi(e) == 32 ? 2 : atoi(e) == 16 ? 1 : 0;
@@ -512,7 +602,7 @@ extern "C" int mm_ppo_create(const mm_ppo_config* c, int device, mm_ppo** out) {
   CREATE_CHK(hipMemcpy(h->dnet, &h->net[0][0], 4 * sizeof(NetD), hipMemcpyHostToDevice));
   h->nb_max = (c->max_minibatch + 15) / 16;
   CREATE_CHK(hipMalloc(&h->part, sizeof(float) * (size_t)h->nb_max * h->np));
-  h->nbq = (h->np + NTHREADS - 1) / NTHREADS;
+  h->nbq = (h->np + RED_P - 1) / RED_P;          // workgroups of k_ppo_reduce / k_ppo_sumsq = entries of blocksq
   CREATE_CHK(hipMalloc(&h->m1, sizeof(float) * h->np)); CREATE_CHK(hipMalloc(&h->m2, sizeof(float) * h->np));
   CREATE_CHK(hipMalloc(&h->blocksq, sizeof(float) * h->nbq)); CREATE_CHK(hipMalloc(&h->step, 2 * sizeof(float)));
   CREATE_CHK(hipMemset(h->m1, 0, sizeof(float) * h->np)); CREATE_CHK(hipMemset(h->m2, 0, sizeof(float) * h->np));
@@ -530,6 +620,12 @@ extern "C" int mm_ppo_create(const mm_ppo_config* c, int device, mm_ppo** out) {
   return MM_OK;
 }
 
+// tools builds only (-DMM_PPO_PROF=1): buf = [workgroups][64] uint64 stage stamps of the next mm_ppo_grad launches; NULL switches it off
+extern "C" int mm_ppo_debug_set_prof(void* buf) {
+  PHIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ppo_prof), &buf, sizeof(buf)));
+  return MM_OK;
+}
+
 extern "C" int mm_ppo_param_count(const mm_ppo* h) { return h ? h->np : 0; }
 extern "C" int mm_ppo_value_offset(const mm_ppo* h) { return h ? h->np_pi : 0; }
 
@@ -541,11 +637,12 @@ extern "C" int mm_ppo_reset_optimizer(mm_ppo* h, void* stream) {
   return MM_OK;
 }
 
-// samples per workgroup: 32 when that still gives every network >= 128 workgroups (and fits in LDS), else 16 -- measured: 1 280 rows
-// (fati-leg at 1024 envs) 40 workgroups of 32 per network 0.94 M train env-steps/s, 80 of 16 1.04 M; 5 120 rows (hand at 4096) the same
+// samples per workgroup: 16.  A workgroup is one dependent chain of ~20 stages (one wave per SIMD: nothing inside it hides a
+// stage's latencies), so the launch takes as long as the chain as long as every workgroup is resident -- and the chain of 16 samples
+// is the shorter one (three 16-sample workgroups fit a CU's LDS for the hand networks).  MYOSIM_PPO_SAMPLES=32 for A/B.
 static int pick_rt(const mm_ppo* h, int rows) {
-  if (h->force_rt) return std::min(h->force_rt, h->max_rt);
-  return (h->max_rt == 2 && (rows + 31) / 32 >= 128) ? 2 : 1;
+  (void)rows;
+  return h->force_rt ? std::min(h->force_rt, h->max_rt) : 1;
 }
 
 extern "C" int mm_ppo_act(mm_ppo* h, const float* params, const float* obs, const float* obs_mean, const float* obs_std, const float* noise,
@@ -593,11 +690,11 @@ extern "C" int mm_ppo_grad(mm_ppo* h, const float* params, const float* obs, con
 extern "C" int mm_ppo_adam(mm_ppo* h, float* params, const float* grad, float grad_scale, int recompute_norm, void* stream) {
   if (!h || !params || !grad) return pfail(MM_EARG, "mm_ppo_adam: null argument");
   if (recompute_norm) {
-    hipLaunchKernelGGL(k_ppo_sumsq, dim3(h->nbq), dim3(NTHREADS), 0, (hipStream_t)stream, grad, h->np, h->blocksq);
+    hipLaunchKernelGGL(k_ppo_sumsq, dim3(h->nbq), dim3(RED_P), 0, (hipStream_t)stream, grad, h->np, h->blocksq);
     PHIPCHK(hipGetLastError());
   }
   const mm_ppo_config& c = h->cfg;
-  hipLaunchKernelGGL(k_ppo_adam, dim3(h->nbq), dim3(NTHREADS), 0, (hipStream_t)stream, params, grad, h->m1, h->m2, h->blocksq, h->nbq, h->step,
+  hipLaunchKernelGGL(k_ppo_adam, dim3((h->np + NTHREADS - 1) / NTHREADS), dim3(NTHREADS), 0, (hipStream_t)stream, params, grad, h->m1, h->m2, h->blocksq, h->nbq, h->step,
                      (unsigned*)(h->step + 1), h->np, grad_scale, c.learning_rate, c.beta1, c.beta2, c.adam_eps, c.max_grad_norm);
   PHIPCHK(hipGetLastError());
   return MM_OK;
