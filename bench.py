@@ -328,6 +328,48 @@ def roofline(env, env_id, n, kern_ms, overrides=None):
     return out
 
 
+def ppo_training_lines():
+    """The consumer of the env-step on the reference's training path (benchmarks/mjx_benchmark_PPO.py:50-60, ppo_config of
+    myosuite/envs/myo/mjx/__init__.py:43-67 -- (64, 64, 64) networks, 10-step unroll; here 8 minibatches x 4 passes per batch of
+    10 x E steps, the setting of benchmarks/ppo_rollout.py; the reference's own 8192-env protocol is benchmarks/mjx_benchmark_PPO.py):
+    whole PPO iterations on the device (myosuite_amd/ppo.py: rollout and update are two HIP graphs, the learner is the fused
+    kernels of include/myosim_ppo.h).  Train env-steps/s end to end, and of the rollout graph alone; NOT the headline metric."""
+    import time
+    from myosuite_amd.envs import registry
+    from myosuite_amd.ppo import OnDevicePPO, PPOConfig
+    lines = []
+    for env_id, ne, iters in (("myoHandPoseRandom-v0", 4096, 12), ("myoFatiLegWalk-v0", 1024, 12)):
+        try:
+            env = registry.make(env_id, num_envs=ne, seed=0)
+            cfg = PPOConfig(unroll_length=10, num_minibatches=8, num_updates_per_batch=4, entropy_cost=1e-2, policy_hidden=(64, 64, 64),
+                            value_hidden=(64, 64, 64), squash="sigmoid", normalize_observations=True)
+            ppo = OnDevicePPO(env, cfg, seed=0)
+            ppo.iterate()                                  # warm-up + graph capture
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                ppo._g_roll.replay()
+            torch.cuda.synchronize()
+            t_roll = time.perf_counter() - t0
+            r0 = float(ppo.mean_reward)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                ppo.iterate()
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            steps = iters * ppo.steps_per_iteration
+            lines.append({"workload": f"PPO on {env_id}, {ne} envs/GPU: ppo_config of the reference (64,64,64) MLPs, unroll 10, 8 minibatches x 4 passes",
+                          "key": f"ppo|{env_id}@{ne}", "train_env_steps_per_s": steps / t_all, "rollout_env_steps_per_s": steps / t_roll,
+                          "iterations": iters, "env_steps_per_iteration": ppo.steps_per_iteration, "minibatch_updates_per_iteration": 32,
+                          "learner": "fused HIP kernels (include/myosim_ppo.h)" if ppo.kern is not None else "torch autograd",
+                          "hip_graphs": ppo._g_roll is not None and ppo._g_upd is not None,
+                          "mean_reward_per_step_first_last": [r0, float(ppo.mean_reward)]})
+            del ppo, env
+        except Exception as exc:          # never takes the headline line down
+            lines.append({"key": f"ppo|{env_id}@{ne}", "error": repr(exc)})
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,6 +380,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the ppo_training lines (whole PPO iterations on the device)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs lines (elbow / reorient / leg-walk / self-contact hand)")
     ap.add_argument("--model", default=None, help="model override of the headline env (e.g. hand_contact): profile collection")
     ap.add_argument("--no-forward", action="store_true", help="do_forward=False override of the headline env: profile collection")
@@ -424,6 +467,8 @@ def main():
                 except Exception as exc:      # an extra line must never take the headline line down
                     extra.append({"workload": tag, "error": repr(exc)})
             out["extra_configs"] = extra
+        if world == 1 and not args.no_extra and not args.no_ppo:
+            out["ppo_training"] = ppo_training_lines()
         if not args.no_cpu_baseline:
             # ~12 s of wall time on rank 0's host cores, after the timed region (the other ranks wait in destroy_process_group)
             out["cpu_baseline"] = cpu_baseline(args.env)

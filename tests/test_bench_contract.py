@@ -119,5 +119,10 @@ def test_bench_line_bookkeeping_repeats_fractions_and_replayed_counters():
             assert r["traffic"] is None
     keys = {x["key"] for x in d["extra_configs"]}
     assert "myoHandReachRandom-v0@4096" in keys and "myoHandPoseRandom-v0@4096|precision=f64_state" in keys
+    ppo = {x["key"]: x for x in d["ppo_training"]}
+    assert not [x for x in d["ppo_training"] if "error" in x], d["ppo_training"]
+    hand, leg = ppo["ppo|myoHandPoseRandom-v0@4096"], ppo["ppo|myoFatiLegWalk-v0@1024"]
+    assert hand["hip_graphs"] and hand["learner"].startswith("fused") and hand["train_env_steps_per_s"] >= 1.5e6 and leg["train_env_steps_per_s"] >= 0.4e6
+    assert hand["rollout_env_steps_per_s"] >= hand["train_env_steps_per_s"]
     prec = [x for x in d["extra_configs"] if x["key"] == "myoHandPoseRandom-v0@4096|precision=f64_state"][0]
     assert prec["dtype"] == "f64" and prec["value"] >= 1.0e6          # BASELINE.json's throughput target holds in precision mode too
