@@ -230,7 +230,7 @@ static bool have_kernel(int G, int nvp, int gen, int rk4 = 0) {
   return false;
 }
 
-// ... and of the precision-mode family (mm64::k_engine: limit-rows-only models, Euler)
+// ... and of the precision-mode family (mm64::k_engine; myosim_inst_list.hpp: MM_KERNELS_F64)
 static bool have_kernel_f64(int G, int nvp, int gen, int rk4) {
 #define X(G_, N_, GN_, RK_) if (G == G_ && nvp == N_ && gen == GN_ && rk4 == RK_) return true;
   MM_KERNELS_F64(X)
@@ -841,7 +841,7 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
     if (value != MM_PREC_F32) {
       bool any = false;
       for (int c : {4, 8, 16, 32, 64}) any = any || (check_lanes(m, c) && have_kernel_f64(c, m->nvp, m->d.gen, integ_kernel(m->d.integrator)));
-      if (!any) return fail(MM_EUNSUPPORTED, "precision: the fp64 kernels cover limit-rows-only models (no contacts / equalities / friction loss) on the Euler integrator, nv <= 24");
+      if (!any) return fail(MM_EUNSUPPORTED, "precision: no fp64 kernel for this model (compiled: limit-rows-only models with nv <= 24 on Euler; general-row models with nv <= 36 at 64 lanes per env on Euler, 36-wide also implicitfast; no RK4)");
     }
     const int old = m->precision;
     m->precision = value;

@@ -2,5 +2,5 @@
 #include "myosim_engine_kernel_f64.hpp"
 #include "myosim_inst_list.hpp"
 namespace mm64 {
-MM_KERNELS_F64(MM_INSTANTIATE)
+MM_KERNELS_F64_P(MM_INSTANTIATE)
 }

@@ -16,8 +16,13 @@
    folded into the env-step launch -- reorient, leg-walk (Euler and implicitfast) */
 #define MM_KERNELS_OBS(X) X(64, 32, 1, 0) X(64, 36, 1, 0) X(64, 36, 1, 2)
 /* precision mode (real = double, namespace mm64; myosim_engine_kernel_f64.hpp): the limit-rows-only Euler kernels of the elbow-
-   and hand-sized models -- BASELINE.json's accuracy target is stated on configs 2-3 */
-#define MM_KERNELS_F64(X) X(4, 4, 0, 0) X(8, 4, 0, 0) X(16, 4, 0, 0) X(32, 24, 0, 0) X(64, 24, 0, 0)
+   and hand-sized models -- BASELINE.json's accuracy target is stated on configs 2-3 (group P) -- and the general-row kernels of the
+   contact / equality models, one env per wave: self-colliding hand / key turn / torso (24), reorient family (32), legs (36; Euler
+   and implicitfast) (group Q) */
+#define MM_KERNELS_F64_P(X) X(4, 4, 0, 0) X(8, 4, 0, 0) X(16, 4, 0, 0) X(32, 24, 0, 0) X(64, 24, 0, 0)
+#define MM_KERNELS_F64_Q(X) X(64, 24, 1, 0) X(64, 32, 1, 0)
+#define MM_KERNELS_F64_R(X) X(64, 36, 1, 0) X(64, 36, 1, 2)
+#define MM_KERNELS_F64(X) MM_KERNELS_F64_P(X) MM_KERNELS_F64_Q(X) MM_KERNELS_F64_R(X)
 #define MM_KERNEL_LIST(X) MM_KERNELS_J(X) MM_KERNELS_A(X) MM_KERNELS_B(X) MM_KERNELS_C(X) MM_KERNELS_D(X) MM_KERNELS_E(X) MM_KERNELS_F(X) MM_KERNELS_G(X) MM_KERNELS_H(X) MM_KERNELS_I(X)
 #define MM_INSTANTIATE(G_, N_, GN_, RK_)                                        \
   template __global__ void k_engine<G_, N_, true, GN_ != 0, RK_>(KArgs);   \

@@ -74,7 +74,9 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-DMM_REFOLD_CARRY=1"],
               # precision-mode (fp64) kernels: IEEE divide / sqrt and no reassociation -- these exist to track the fp64 reference;
               # fma contraction stays on (it only removes roundings)
-              "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"]}
+              "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"],
+              "myosim_inst_Q.hip": ["-fno-fast-math", "-ffp-contract=fast"],
+              "myosim_inst_R.hip": ["-fno-fast-math", "-ffp-contract=fast"]}
 # (myosim_ppo.hip, the PPO learner kernels, takes the default flags: with IEEE exp / log / divide its loss stage alone was 16 k of a
 #  workgroup's 131 k cycles; the gradient test against torch autograd holds its 2e-4 either way)
 

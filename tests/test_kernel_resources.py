@@ -76,14 +76,16 @@ def test_shipped_bench_kernels_do_not_spill_vector_registers():
 
 @pytest.mark.skipif(not (os.path.exists(E.LIB_PATH) and os.path.exists(READELF)), reason="needs the built library and llvm-readelf")
 def test_precision_mode_kernels_are_in_the_library_and_stay_off_scratch():
-    """The fp64 family (namespace mm64, myosim_inst_P.hip) is built for one wave per SIMD: a lane may use the 512 VGPRs + AGPRs,
+    """The fp64 family (namespace mm64, myosim_inst_P / Q / R.hip) is built for one wave per SIMD: a lane may use the 512 VGPRs + AGPRs,
     and what does not fit the 256 architectural registers is parked in accumulation registers -- never in scratch memory."""
     tab = _kernel_table()
-    def mangled(lanes, width, lds_model):
-        return f"_ZN4mm648k_engineILi{lanes}ELi{width}ELb{lds_model}ELb0ELi0ELb0EEEv5KArgs"
-    for lanes, width in ((4, 4), (8, 4), (16, 4), (32, 24), (64, 24)):
+    def mangled(lanes, width, lds_model, gen=0, integ=0):
+        return f"_ZN4mm648k_engineILi{lanes}ELi{width}ELb{lds_model}ELb{gen}ELi{integ}ELb0EEEv5KArgs"
+    # limit-rows-only kernels (myosim_inst_P.hip), then the general-row ones (inst_Q / inst_R: 24- / 32- / 36-wide, Euler; 36-wide implicitfast)
+    for lanes, width, gen, integ in ((4, 4, 0, 0), (8, 4, 0, 0), (16, 4, 0, 0), (32, 24, 0, 0), (64, 24, 0, 0),
+                                     (64, 24, 1, 0), (64, 32, 1, 0), (64, 36, 1, 0), (64, 36, 1, 2)):
         for lm in (0, 1):
-            name = mangled(lanes, width, lm)
+            name = mangled(lanes, width, lm, gen, integ)
             assert name in tab, (name, [k for k in tab if "mm64" in k][:3])
             assert int(tab[name]["private_segment_fixed_size"]) == 0, tab[name]
             assert int(tab[name]["max_flat_workgroup_size"]) == 256, tab[name]
