@@ -334,7 +334,7 @@ def ppo_training_lines():
     10 x E steps, the setting of benchmarks/ppo_rollout.py; the reference's own 8192-env protocol is benchmarks/mjx_benchmark_PPO.py):
     whole PPO iterations on the device (myosuite_amd/ppo.py: rollout and update are two HIP graphs, the learner is the fused
     kernels of include/myosim_ppo.h).  Train env-steps/s end to end, and of the rollout graph alone; NOT the headline metric."""
-    import time
+    import torch
     from myosuite_amd.envs import registry
     from myosuite_amd.ppo import OnDevicePPO, PPOConfig
     lines = []
