@@ -72,6 +72,10 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               # + the reset-observation pass of a folded reset also writes a forward-carry row: reorient 3.95 -> 4.11 M in one session
               # (the leg unit, inst_H, loses 1 % with it: off there)
               "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-DMM_REFOLD_CARRY=1"],
+              # implicitfast units: with the forward carry in (a second inlined implicit solve in the trailing pass) the 36-wide leg kernel
+              # spilled 52 / 60 VGPRs (148 / 188 B of scratch per lane, 13.5 MB of scratch writes per launch); with the flag 0 / 0 and
+              # +0.9 % (1.690 -> 1.705 M in one session).  Round 3 had measured -1 % for it on this unit, at 26 spills and no carry.
+              "myosim_inst_J.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
               # precision-mode (fp64) kernels: IEEE divide / sqrt and no reassociation -- these exist to track the fp64 reference;
               # fma contraction stays on (it only removes roundings)
               "myosim_inst_P.hip": ["-fno-fast-math", "-ffp-contract=fast"],
