@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 session L: the bench bookkeeping test, the default bench line (incl. ppo_training), the reference's PPO protocol at HEAD
+# the bench bookkeeping test, the default bench line (incl. ppo_training), the reference's PPO protocol at HEAD
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out/ppo
 timeout 900 python -m pytest tests/test_bench_contract.py -m gpu -q -rf --no-header -p no:cacheprovider 2>&1 < /dev/null | grep -v amdgpu.ids | tail -8

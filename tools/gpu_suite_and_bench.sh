@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 session B: whole gpu suite (no -x), default bench line.
+# whole gpu suite (no -x), then the default bench line:  gpurun --timeout 2400 -- bash tools/gpu_suite_and_bench.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 timeout 1800 python -m pytest tests -m gpu -q -rf --no-header -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -40 | tee gpurun_out/pytest_gpu.log
