@@ -64,7 +64,10 @@ SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative
                   "myosim_inst_J.hip": "iterative-ilp"}   # (inst_H, the Euler leg: iterative-ilp until the stage fences went in; since then maxocc +2 %)
 # Extra per-file flags.  -sink-insts-to-avoid-spills: hand pose <32,24> 5.55 -> 5.67 M; within +-1 % (mostly -) on the others.
 FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-mllvm", "-amdgpu-set-wave-priority=1"],   # wave priority: hand +0.6 %
-              "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # leg <64,36,GEN>: +0.8 %
+              # leg <64,36,GEN>: +0.8 %.  (Incremental Newton, -DMM_NEWTON_INCR=2 -- rank-one factor modifications when <= 2 rows changed set --
+              # measured +2.4 % in the upright phase / +0.9 % in the steady mix of the episode, kernel 568 -> 559 us, for 52 spilled VGPRs and
+              # 3x the HBM write traffic (4.0 -> 12.2 MB of scratch per launch): off.)
+              "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
               "myosim_inst_I.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # self-contact hand <64,24,GEN>: VGPR spills 14 -> 0 (end of round 3)
               # reorient <64,32,GEN>: VGPR spills 74 -> 18 (model-in-LDS variant 47 -> 0), kernel 0.705 -> 0.686 ms (+3 %), and 4x
               # less scratch traffic for a kernel whose time followed the box's memory clock.  The same flag on the 24-wide and
@@ -75,6 +78,7 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               # implicitfast units: with the forward carry in (a second inlined implicit solve in the trailing pass) the 36-wide leg kernel
               # spilled 52 / 60 VGPRs (148 / 188 B of scratch per lane, 13.5 MB of scratch writes per launch); with the flag 0 / 0 and
               # +0.9 % (1.690 -> 1.705 M in one session).  Round 3 had measured -1 % for it on this unit, at 26 spills and no carry.
+              # (incremental Newton measured +2.3 % here -- and 45 spilled VGPRs: off, this unit stays at zero)
               "myosim_inst_J.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
               # precision-mode (fp64) kernels: IEEE divide / sqrt and no reassociation -- these exist to track the fp64 reference;
               # fma contraction stays on (it only removes roundings)
