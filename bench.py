@@ -34,26 +34,36 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r04b_pmc.json")
 REPEATS = 3                 # timed regions of --steps steps each; the line reports the median region
 EXTRA_MIN_TIMED_MS = 60.0   # an extra line times at least this much kernel work (a 1.5 ms timed region is launch-noise bound)
-EXTRA_CONFIGS = [("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
-                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
-                 # the step of the reference's own GPU path: mjx_env.step = n_substeps x mjx.step, observation straight from the
+# Order matters: the driver's record keeps the TAIL of the printed line, so the BASELINE.json configs 2 / 4 / 5 (elbow, reorient,
+# fati-leg) come last, and a compact `baseline_configs` digest of every line closes the JSON.
+EXTRA_CONFIGS = [# the step of the reference's own GPU path: mjx_env.step = n_substeps x mjx.step, observation straight from the
                  # stepped data (envs/myo/mjx/mjx_base_env.py:74-91) -- no trailing mj_forward as in the CPU path
                  # (robot.py:595-607), whose outputs the Pose observation / reward do not read.  NOT the headline protocol.
                  ("myoHandPoseRandom-v0", 4096, {"do_forward": False}),
-                 # precision mode (include/myosim.h MM_PREC_F64_STATE): the same launch over real = double with fp64 state rows --
-                 # the kernels that meet "state divergence < 1e-4 rel over 1000 steps" on every env (tests/test_gpu_widths.py)
-                 ("myoHandPoseRandom-v0", 4096, {"precision": "f64_state"}),
+                 # precision modes (include/myosim.h): MM_PREC_F64_STATE = the same launch over real = double with fp64 state rows --
+                 # the kernels that meet "state divergence < 1e-4 rel over 1000 steps" on every env (tests/test_gpu_widths.py);
+                 # MM_PREC_MIXED = fp64 state rows + fp64 kinematics / tendons / solver / integration, fp32 CRB / RNE / muscles
                  ("myoElbowPose1D6MRandom-v0", 4096, {"precision": "f64_state"}),
+                 ("myoHandPoseRandom-v0", 4096, {"precision": "f64_state"}),
                  # the one workload the reference publishes GPU numbers for (MjxHandReachRandom-v0)
-                 ("myoHandReachRandom-v0", 4096, {})]
+                 ("myoHandReachRandom-v0", 4096, {}),
+                 ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
+                 ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}),
+                 ("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {})]
 
 
-def algorithmic_bytes(env) -> int:
+BASELINE_PRESETS = {2: ("myoElbowPose1D6MRandom-v0", 4096), 3: ("myoHandPoseRandom-v0", 4096), 4: ("myoHandReorient100-v0", 2048),
+                    5: ("myoFatiLegWalk-v0", 1024)}      # --config N (config 5: 8192 envs over 8 GPUs = 1024 per GPU)
+
+
+def algorithmic_bytes(env, include_carry: bool = False) -> int:
     """fp32, state read + written once per env-step (substeps are fused on chip), constant model excluded:
     B_alg = 4*[(nq+nv+na) + nu + n_task_in + n_aux + (nq+nv+na) + n_aux + obs_dim + 4], n_aux = the fatigue state (3 na) and,
     for models with a constraint solve that is warm started across steps (contacts / equalities), qacc_warmstart (nv).
-    144 B (elbow pose), 1 376 B (hand pose), 2 012 B (reorient), 5 336 B (leg walk + fatigue) -- SURVEY's table -- plus, since round 4,
-    the forward-carry row where it is on (8 nv + 4 bytes read and written: hand 1 752 B, reorient 2 484 B, leg 5 888 B)."""
+    144 B (elbow pose), 1 376 B (hand pose), 2 012 B (reorient), 5 336 B (leg walk + fatigue) -- SURVEY's table; this is the figure
+    `roofline.achieved / frac` are priced with.  `include_carry=True` adds the traffic this engine ADDED in round 4, the forward-carry
+    row where it is on (8 nv + 4 bytes read and written: hand 1 752 B, reorient 2 484 B, leg 5 888 B): reported next to it as
+    `*_incl_carry`, never as the contract figure."""
     cm = env.cm
     # per-step task inputs: pose targets [nq] | reach targets [3 ntip] | reorient geom type 1 + size 3 + axis_half 1 + des_rot 3 |
     # walk step counter 1
@@ -63,9 +73,9 @@ def algorithmic_bytes(env) -> int:
         n_aux += 3 * cm.na          # MA / MR / MF
     if cm.npair > 0 or cm.neq > 0:
         n_aux += cm.nv              # qacc_warmstart
-    if getattr(env, "_fwd_carry", None) is not None:
+    if include_carry and getattr(env, "_fwd_carry", None) is not None:
         n_aux += 2 * cm.nv + 1      # forward-carry row (mm_task.fwd_carry): hash + qacc + Euler's damped acceleration, read and written
-    sw = 8 if getattr(env, "precision", 0) == 2 else 4      # MM_PREC_F64_STATE: the state rows are fp64
+    sw = 8 if getattr(env, "precision", 0) in (2, 3) else 4      # MM_PREC_F64_STATE / MM_PREC_MIXED: the state rows are fp64
     return sw * 2 * (cm.nq + cm.nv + cm.na) + 4 * (cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
 
 
@@ -188,11 +198,16 @@ def cpu_baseline(env_id: str):
     """The fp64 oracle on the host cores, two points: ONE thread -- the reference's own CPU protocol is one env on one core
     (benchmarks/mjx_benchmark_baseline.py:8-25) -- and one thread per PHYSICAL core (`value`, `cores`).  Bounded sample: ~4 s
     + ~8 s of wall time."""
+    from oracle import oracle as O
+    O.use_variant("fast")       # oracle/Makefile: the same sources -O3 -march=native + fma contraction, built on THIS host (never the checker)
+    O.build(variant="fast")
     topo = host_topology()
     one = cpu_rollout_rate(env_id, 1, target_s=4.0)
     cores = topo["physical_cores"]
     allc = cpu_rollout_rate(env_id, cores, target_s=8.0, per_thread_rate=one["value"]) if cores > 1 else one
     return {"value": allc["value"], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "build": "oracle/liboracle_fast.so: gcc -O3 -march=native -ffp-contract=fast, built on this host (the checker build "
+                     "liboracle.so is -O2 without contraction and is not what is timed)",
             "sample": f"{allc['envs']} envs x {allc['env_steps_each']} env-steps of {env_id} (fp64 C oracle, one thread per physical "
                       f"core = {cores} threads, {allc['seconds']:.1f} s)",
             "single_thread": {"value": one["value"], "unit": "env-steps/s", "cores": 1,
@@ -269,20 +284,61 @@ def measure(env_id, n, steps, warmup, rank, world, lanes=0, seed=0, overrides=No
         stats = D.gather_episode_stats(ep_stats)   # the one collective of a rollout
         torch.cuda.synchronize()
         D.barrier()
-        elapsed = time.perf_counter() - t0
-        elapsed = D.max_over_ranks(elapsed, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
-        regions.append((elapsed, float(np.mean([a.elapsed_time(b) for a, b in evs]))))
+        own = time.perf_counter() - t0
+        elapsed = D.max_over_ranks(own, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
+        regions.append((elapsed, float(np.mean([a.elapsed_time(b) for a, b in evs])), own))
     order = sorted(range(repeats), key=lambda i: regions[i][0])
     med = regions[order[(repeats - 1) // 2]]          # the median region (lower median for an even count)
-    return med[0], med[1], env, stats, [e for e, _ in regions]
+    measure.ep_stats = ep_stats
+    measure.own_elapsed_of_median_region = med[2]     # this rank's own clock around the region `value` is quoted on (N > 1 line: per-rank values)
+    return med[0], med[1], env, stats, [e for e, _, _ in regions]
+
+
+def collective_report(ep_stats, stats, n, world, own_elapsed, steps):
+    """What the N > 1 line says about its one collective, so that an 8-GPU record is self-evidencing: backend, world
+    size, RCCL version, the gathered row count (asserted = world x E), the all-gather's own latency (median of 20, synchronised),
+    and every rank's OWN env-steps/s (its clock around the same timed region; `value` uses the slowest rank's)."""
+    import torch
+    import torch.distributed as dist
+    from myosuite_amd import dist as D
+    assert stats.shape[0] == world * n, f"gathered {stats.shape[0]} rows, expected world x E = {world * n}"
+    ts = []
+    for _ in range(20):
+        torch.cuda.synchronize(); D.barrier()
+        t0 = time.perf_counter()
+        D.gather_episode_stats(ep_stats)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    own = torch.tensor([n * steps / own_elapsed], dtype=torch.float64)
+    if world > 1:
+        parts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        if D.backend() == "nccl":
+            dev = [p.cuda() for p in parts]
+            dist.all_gather(dev, own.cuda())
+            parts = [p.cpu() for p in dev]
+        else:
+            dist.all_gather(parts, own)
+    else:
+        parts = [own]
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())       # RCCL's version on ROCm
+    except Exception:
+        ver = None
+    return {"backend": D.backend() or "none", "is_rccl": D.backend() == "nccl", "world_size": world, "rccl_version": ver,
+            "what": "one all-gather of [E, 3] episode statistics per rollout; no collective on the step path",
+            "gathered_rows": int(stats.shape[0]), "expected_rows": world * n, "bytes_per_rank": int(ep_stats.numel() * ep_stats.element_size()),
+            "allgather_us": 1e6 * ts[len(ts) // 2], "per_rank_env_steps_per_s": [float(p.item()) for p in parts]}
 
 
 def roofline(env, env_id, n, kern_ms, overrides=None):
     """HBM roofline of the fused kernel (the contract's definition) + the views that actually bound it: fp32 vector issue
     (PMC counters of the committed profile of this command) and algorithmic flops against the fp32 vector peak."""
     from myosuite_amd import engine as E
-    b_alg = algorithmic_bytes(env)
+    b_alg = algorithmic_bytes(env)                              # SURVEY 8(d): the contract figure
+    b_carry = algorithmic_bytes(env, include_carry=True)        # + the forward-carry row this engine added (equal when it is off)
     achieved = (b_alg * n / (kern_ms * 1e-3)) / 1e9
+    achieved_c = (b_carry * n / (kern_ms * 1e-3)) / 1e9
     traffic = None
     profile = None
     launch = None
@@ -317,14 +373,26 @@ def roofline(env, env_id, n, kern_ms, overrides=None):
     except (OSError, ValueError, KeyError, IndexError):
         pass
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "bytes_definition": "SURVEY.md 8(d) B_alg x envs per launch (achieved / frac); *_incl_carry adds the forward-carry row this engine reads and writes per env-step",
+           "achieved_incl_carry": achieved_c, "frac_incl_carry": achieved_c / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": (profile or {}).get("replayed_from"),
+           "traffic_over_algorithmic": (traffic / (b_alg * n)) if traffic else None,
            "kernel": "k_engine (fused env-step)", "kernel_ms": kern_ms,
-           "algorithmic_bytes_per_launch": b_alg * n, "launch": launch, "profile": profile}
+           "algorithmic_bytes_per_launch": b_alg * n, "algorithmic_bytes_per_launch_incl_carry": b_carry * n,
+           "launch": launch, "profile": profile}
     fl = algorithmic_flops(env_id, overrides)
     if fl:
         tf = fl["flops"] * n / (kern_ms * 1e-3) / 1e12
         out["flops"] = {"algorithmic_flops_per_env_step": fl["flops"], "achieved_tflops": tf, "peak_tflops": FP32_PEAK_TFLOPS,
                         "frac": tf / FP32_PEAK_TFLOPS, "source": fl.get("source", "instrumented oracle")}
+        # arithmetic intensity against the ridge point of the two roofs: far right of it the binding roof is fp32 issue, not HBM
+        intensity = fl["flops"] / float(b_alg)
+        ridge = FP32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        out["bound_by"] = "fp32-issue" if intensity > ridge else "hbm"
+        out["bound_by_detail"] = {"flop_per_byte": intensity, "ridge_flop_per_byte": ridge, "x_ridge": intensity / ridge,
+                                  "fp32_vector_peak_frac": tf / FP32_PEAK_TFLOPS,
+                                  "note": "the HBM fraction above is the contract's definition; with the substeps fused on chip the kernel is "
+                                          "bounded by dependent fp32 issue (valu_busy_frac / wave_waitcnt_frac in `profile`), not by bytes"}
     return out
 
 
@@ -378,6 +446,9 @@ def main():
     ap.add_argument("--env", default="myoHandPoseRandom-v0")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
+                    help="preset = BASELINE.json config number: 2 elbow@4096, 3 hand@4096 (the default headline), 4 reorient@2048, "
+                         "5 myoFatiLegWalk-v0@1024 per GPU (8192 over 8: `--gpus 8 --config 5`); overrides --env / --envs-per-gpu")
     ap.add_argument("--repeats", type=int, default=REPEATS, help="timed regions of --steps steps each (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true", help="skip the ppo_training lines (whole PPO iterations on the device)")
@@ -390,6 +461,8 @@ def main():
                          "path (launcher respawn, barrier, max over ranks, stats gather, sharded Philox streams) can be exercised on a "
                          "one-GPU box.  The printed line is marked oversubscribed and is NOT a scaling measurement.")
     args = ap.parse_args()
+    if args.config:
+        args.env, args.envs_per_gpu = BASELINE_PRESETS[args.config]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_launcher(args))
@@ -420,10 +493,13 @@ def main():
                                                     repeats=max(1, args.repeats))
     clocks_after = gpu_clocks() if rank == 0 else None
     cm = env.cm
+    # every rank takes part (one small all-gather + the per-rank values); only rank 0 prints
+    coll = collective_report(measure.ep_stats, stats, n, world, measure.own_elapsed_of_median_region, args.steps) if world > 1 else None
 
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
+        prec_name = {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64", 3: "mixed f64/f32 (fp64 state rows)"}
         out = {
             "metric": "env-steps/sec (whole node) at %d envs/GPU" % n,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -431,7 +507,7 @@ def main():
             "region_ms_per_step": [1e3 * e / args.steps for e in regions],      # every timed region; `value` is the median one
             "gpu_clocks_mhz": {"before": clocks_before, "after": clocks_after},
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64"}[int(getattr(env, "precision", 0))], "data": "synthetic",
+            "vs_baseline": None, "dtype": prec_name[int(getattr(env, "precision", 0))], "data": "synthetic",
             "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1) drawn in the kernel, frame_skip {env.frame_skip} + final "
                                    f"forward + obs/reward + episode stats + auto-reset in one launch per step "
                                    f"(synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
@@ -441,11 +517,26 @@ def main():
             "stats": {"mean_episode_return": float(stats[:, 0].mean()), "solved_frac": float(stats[:, 2].mean()),
                       "envs_in_stats": int(stats.shape[0]), "status_or": status_or(env.state.status)},
         }
+        if coll is not None:
+            out["collective"] = coll
+        if args.config:
+            out["config"]["baseline_config"] = args.config
         if head_ov:
             out["config"]["overrides"] = {k: str(v) for k, v in head_ov.items()}
         if args.oversubscribe:
             out["config"]["oversubscribed"] = f"{world} ranks on {torch.cuda.device_count()} device(s), gloo group: a test of the N > 1 path, not a scaling point"
+        digest = {workload_key(args.env, n, head_ov) + " [headline]": {
+            "env_steps_per_s": value, "kernel_ms": kern_ms, "hbm_frac_8d": out["roofline"]["frac"],
+            "fp32_peak_frac": (out["roofline"].get("flops") or {}).get("frac"), "traffic_over_algorithmic": out["roofline"]["traffic_over_algorithmic"]}}
         del env
+        if not args.no_cpu_baseline:
+            # ~12 s of wall time on rank 0's host cores, after the timed region (the other ranks wait in destroy_process_group)
+            out["cpu_baseline"] = cpu_baseline(args.env)
+        if world == 1 and not args.no_extra and not args.no_ppo:
+            out["ppo_training"] = ppo_training_lines()
+        for line in out.get("ppo_training", []):
+            digest[line["key"]] = ({"train_env_steps_per_s": line["train_env_steps_per_s"], "rollout_env_steps_per_s": line["rollout_env_steps_per_s"]}
+                                   if "error" not in line else {"error": line["error"][:120]})
         if world == 1 and not args.no_extra:
             # driver-visible numbers for the other BASELINE.json configs (same timed loop, shorter): not the headline value
             extra = []
@@ -457,21 +548,23 @@ def main():
                     del ev0
                     ks = int(max(8, args.steps // 2, min(2000, EXTRA_MIN_TIMED_MS / max(km0, 1e-3))))
                     el, km, ev, st, rg = measure(env_id, ne, ks, max(2, args.warmup // 2), 0, 1, overrides=ov, repeats=max(1, args.repeats))
+                    rf = roofline(ev, env_id, ne, km, ov)
                     extra.append({"workload": tag, "key": workload_key(env_id, ne, ov), "value": ne * ks / el, "unit": "env-steps/s", "steps": ks,
-                                  "dtype": {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64"}[int(getattr(ev, "precision", 0))],
+                                  "dtype": prec_name[int(getattr(ev, "precision", 0))],
                                   "ms_per_step": 1e3 * el / ks, "repeats": len(rg), "region_ms_per_step": [1e3 * e / ks for e in rg],
                                   "lanes_per_env": ev.hm.launch_lanes(ne),
-                                  "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": roofline(ev, env_id, ne, km, ov),
+                                  "launches_per_step": 1 if ev._ro.autoreset else "1 + the task's masked reset", "roofline": rf,
                                   "status_or": status_or(ev.state.status)})
+                    digest[workload_key(env_id, ne, ov)] = {
+                        "env_steps_per_s": ne * ks / el, "kernel_ms": km, "hbm_frac_8d": rf["frac"],
+                        "fp32_peak_frac": (rf.get("flops") or {}).get("frac"), "traffic_over_algorithmic": rf["traffic_over_algorithmic"]}
                     del ev
                 except Exception as exc:      # an extra line must never take the headline line down
                     extra.append({"workload": tag, "error": repr(exc)})
+                    digest[workload_key(env_id, ne, ov)] = {"error": repr(exc)[:120]}
             out["extra_configs"] = extra
-        if world == 1 and not args.no_extra and not args.no_ppo:
-            out["ppo_training"] = ppo_training_lines()
-        if not args.no_cpu_baseline:
-            # ~12 s of wall time on rank 0's host cores, after the timed region (the other ranks wait in destroy_process_group)
-            out["cpu_baseline"] = cpu_baseline(args.env)
+        # LAST key of the line (the driver's record keeps the tail): one compact row per measured workload, BASELINE configs 2 / 4 / 5 at the end
+        out["baseline_configs"] = digest
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -73,12 +73,21 @@ def main():
     torch.cuda.synchronize(); D.barrier(); t_all = time.perf_counter() - t0
     stats = D.gather_episode_stats(ppo.ep_stats)
     # data-parallel ranks must hold the same parameters after every update (one all-reduce of the flat gradient per minibatch)
-    in_sync = True
+    in_sync, norm_in_sync, noise_differs = True, True, True
     if world > 1:
-        ck = torch.stack([ppo.flat_p.double().sum(), ppo.flat_p.double().abs().sum(), ppo.flat_p[::97].double().sum()]).cpu()
-        parts = [torch.zeros_like(ck) for _ in range(world)]
-        torch.distributed.all_gather(parts, ck if D.backend() == "gloo" else ck.to(dev))
-        in_sync = all(bool(torch.allclose(parts[0].cpu(), q.cpu(), rtol=1e-6, atol=0)) for q in parts)
+        def gathered(vec):
+            vec = vec.cpu() if D.backend() == "gloo" else vec.to(dev)
+            parts = [torch.zeros_like(vec) for _ in range(world)]
+            torch.distributed.all_gather(parts, vec)
+            return [q.cpu() for q in parts]
+        parts = gathered(torch.stack([ppo.flat_p.double().sum(), ppo.flat_p.double().abs().sum(), ppo.flat_p[::97].double().sum()]))
+        in_sync = all(bool(torch.allclose(parts[0], q, rtol=1e-6, atol=0)) for q in parts)
+        if ppo.norm is not None:       # the observation normaliser is part of the policy / value function: merged over all ranks' rows
+            parts = gathered(torch.cat([ppo.norm.mean.double(), ppo.norm.std.double(), ppo.norm.n.double().reshape(1)]))
+            norm_in_sync = all(bool(torch.equal(parts[0], q)) for q in parts)
+        if ppo.noise is not None:      # ... while the exploration noise must NOT be the same draw on every rank
+            parts = gathered(ppo.noise[0, 0, :4].double())
+            noise_differs = not any(bool(torch.equal(parts[0], q)) for q in parts[1:])
     t_roll = D.max_over_ranks(t_roll, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
     t_all = D.max_over_ranks(t_all, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
     if rank == 0:
@@ -88,7 +97,8 @@ def main():
                           "fused_learner_kernels": ppo.kern is not None, "epochs": args.epochs, "minibatches": args.minibatches,
                           "rollout_env_steps_per_s": steps / t_roll, "train_env_steps_per_s": steps / t_all,
                           "mean_reward_per_step_first_last": [r0, float(ppo.mean_reward)],
-                          "params_in_sync_across_ranks": in_sync, "mean_return_per_env": float(stats[:, 0].mean())}))
+                          "params_in_sync_across_ranks": in_sync, "normaliser_in_sync_across_ranks": norm_in_sync,
+                          "action_noise_differs_across_ranks": noise_differs, "mean_return_per_env": float(stats[:, 0].mean())}))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -379,9 +379,11 @@ int  mm_fatigue_reset(float* MA, float* MR, float* MF, const uint8_t* mask, cons
  * reset_mask[e] = done[e] | truncated[e].  stats is [nenv][3] float32, rwd has row stride rwd_cols. */
 int  mm_episode_stats(float* stats, uint8_t* reset_mask, const float* rwd, int rwd_cols, int dense_col, int solved_col,
                       const uint8_t* done, const uint8_t* truncated, int nenv, void* stream);
-/* Generalised advantage estimation of a T-step unroll, one launch (the learner side of benchmarks/mjx_benchmark_PPO.py:50-60;
- * brax compute_gae with truncation): delta_t = r_t + gamma (1 - terminated_t) V_{t+1} - V_t,
- * adv_t = delta_t + gamma lambda (1 - terminated_t)(1 - truncated_t) adv_{t+1}, returns = adv + V.  reward / terminated /
+/* Generalised advantage estimation of a T-step unroll, one launch (the learner side of benchmarks/mjx_benchmark_PPO.py:50-60):
+ * brax's compute_gae term by term -- delta_t = (r_t + gamma (1 - terminated_t) V_{t+1} - V_t)(1 - truncated_t);
+ * acc_t = delta_t + gamma lambda (1 - terminated_t)(1 - truncated_t) acc_{t+1}; returns_t = vs_t = acc_t + V_t;
+ * advantage_t = (r_t + gamma (1 - terminated_t) vs_{t+1} - V_t)(1 - truncated_t), vs_T = V_T.  A truncated step neither bootstraps
+ * from V_{t+1} (after an auto-reset that is the next episode's first observation) nor carries an advantage.  reward / terminated /
  * truncated (may be NULL) / advantage / returns are [T][nenv] float32, value is [T+1][nenv]. */
 int  mm_gae(const float* reward, const float* terminated, const float* truncated, const float* value, float* advantage,
             float* returns, int T, int nenv, float gamma, float lam, void* stream);

@@ -1260,22 +1260,29 @@ extern "C" int mm_uniform(float* out, size_t n, uint64_t seed, uint64_t stream_i
   return mm_uniform_at(out, n, seed, stream_id, 0, stream);
 }
 
-// Generalised advantage estimation over an unroll of T steps, one thread per env (brax compute_gae with truncation; the
-// learner of benchmarks/mjx_benchmark_PPO.py:50-60): adv_t = delta_t + gamma lambda (1 - term_t)(1 - trunc_t) adv_{t+1},
-// delta_t = r_t + gamma (1 - term_t) V_{t+1} - V_t; ret = adv + V.  Arrays are [T][n] (value [T+1][n]): coalesced over envs.
+// Generalised advantage estimation over an unroll of T steps, one thread per env: brax.training.agents.ppo.losses.compute_gae (the
+// learner of benchmarks/mjx_benchmark_PPO.py:50-60), term by term --
+//   delta_t = (r_t + gamma (1 - term_t) V_{t+1} - V_t) (1 - trunc_t)          a truncated step does NOT bootstrap from V_{t+1} (under
+//                                                                              auto-reset that is the value of the NEXT episode's first observation)
+//   acc_t   = delta_t + gamma (1 - term_t)(1 - trunc_t) lambda acc_{t+1}
+//   vs_t    = acc_t + V_t                                                      -> returns (the value target)
+//   adv_t   = (r_t + gamma (1 - term_t) vs_{t+1} - V_t)(1 - trunc_t),  vs_T = V_T (the bootstrap value)
+// Arrays are [T][n] (value [T+1][n]): coalesced over envs.
 __global__ void k_gae(const float* rew, const float* term, const float* trunc, const float* val, float* adv, float* ret, int T, int n,
                       float gamma, float lam) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  float last = 0.f;
-  float vnext = val[(size_t)T * n + e];
+  float acc = 0.f;
+  float vnext = val[(size_t)T * n + e], vs_next = vnext;
   for (int t = T - 1; t >= 0; t--) {
     const size_t k = (size_t)t * n + e;
-    const float nt = 1.f - term[k], v = val[k];
-    const float delta = rew[k] + gamma * nt * vnext - v;
-    last = delta + gamma * lam * nt * (1.f - (trunc ? trunc[k] : 0.f)) * last;
-    adv[k] = last; ret[k] = last + v;
-    vnext = v;
+    const float nt = 1.f - term[k], tm = 1.f - (trunc ? trunc[k] : 0.f), v = val[k], r = rew[k];
+    const float delta = (r + gamma * nt * vnext - v) * tm;
+    acc = delta + gamma * nt * tm * lam * acc;
+    const float vs = acc + v;
+    adv[k] = (r + gamma * nt * vs_next - v) * tm;
+    ret[k] = vs;
+    vs_next = vs; vnext = v;
   }
 }
 extern "C" int mm_gae(const float* reward, const float* terminated, const float* truncated, const float* value, float* advantage,

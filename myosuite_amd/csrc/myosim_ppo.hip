@@ -218,7 +218,7 @@ __device__ __forceinline__ void load_x(const NetD* d, float* L, const float* __r
 #pragma unroll
     for (int r = 0; r < 16 * RT; r++) {
       if (cok && r < cnt && obs_copy) obs_copy[(size_t)rows[r] * od + c] = x[r];
-      X[r * ldx + c] = nrm ? fminf(fmaxf((x[r] - m) * q, -5.f), 5.f) : x[r];
+      X[r * ldx + c] = (nrm && r < cnt) ? fminf(fmaxf((x[r] - m) * q, -5.f), 5.f) : x[r];      // rows >= cnt stay zero with the normaliser on too
     }
   }
   __syncthreads();
@@ -553,6 +553,13 @@ struct mm_ppo {
 
 extern "C" const char* mm_ppo_last_error(void) { return g_perr.c_str(); }
 
+// the launches of a handle go to ITS device (workspace, descriptors), whatever device is current in the calling thread
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 extern "C" void mm_ppo_destroy(mm_ppo* h) {
   if (!h) return;
   for (void* p : {(void*)h->dnet, (void*)h->part, (void*)h->m1, (void*)h->m2, (void*)h->blocksq, (void*)h->step}) (void)hipFree(p);
@@ -607,12 +614,12 @@ extern "C" int mm_ppo_create(const mm_ppo_config* c, int device, mm_ppo** out) {
   CREATE_CHK(hipMalloc(&h->blocksq, sizeof(float) * h->nbq)); CREATE_CHK(hipMalloc(&h->step, 2 * sizeof(float)));
   CREATE_CHK(hipMemset(h->m1, 0, sizeof(float) * h->np)); CREATE_CHK(hipMemset(h->m2, 0, sizeof(float) * h->np));
   CREATE_CHK(hipMemset(h->blocksq, 0, sizeof(float) * h->nbq)); CREATE_CHK(hipMemset(h->step, 0, 2 * sizeof(float)));
-  CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_grad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds[0]));
-  CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_act<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds[0]));
-  if (h->max_rt == 2) {
-    CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_grad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds[1]));
-    CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_act<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds[1]));
-  }
+  // The dynamic-LDS ceiling is per-KERNEL state of the process, not of this handle: set it to the fixed upper bound every handle is
+  // checked against (lds_limit), so that creating a second handle with smaller networks never lowers it under a live one's launches.
+  CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_grad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+  CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_act<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+  CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_grad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+  CREATE_CHK(hipFuncSetAttribute((const void*)k_ppo_act<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
   CREATE_CHK(hipDeviceSynchronize());
   (void)hipSetDevice(cur);
 #undef CREATE_CHK
@@ -649,6 +656,7 @@ extern "C" int mm_ppo_act(mm_ppo* h, const float* params, const float* obs, cons
                           int nenv, float* obs_out, float* raw_out, float* logp_out, float* value_out, float* action_out, void* stream) {
   if (!h || !params || !obs || !value_out || nenv <= 0 || (obs_mean && !obs_std)) return pfail(MM_EARG, "mm_ppo_act: bad argument");
   if (action_out && (!noise || !raw_out || !logp_out)) return pfail(MM_EARG, "mm_ppo_act: noise / raw_out / logp_out are required with action_out");
+  DeviceGuard guard(h->device);
   const int rt = pick_rt(h, nenv), S = 16 * rt, nb = (nenv + S - 1) / S;
   ActArgs a{params, obs, obs_mean, obs_std, noise, obs_out, raw_out, logp_out, value_out, action_out,
             h->dnet + (rt - 1), h->dnet + 2 + (rt - 1), nenv, h->cfg.obs_dim, h->cfg.act_dim, action_out ? nb : 0, h->np_pi, h->cfg.squash};
@@ -672,6 +680,7 @@ extern "C" int mm_ppo_grad(mm_ppo* h, const float* params, const float* obs, con
                            int mb, const float* raw, const float* logp_old, const float* adv, const float* ret, float* grad_out, void* stream) {
   if (!h || !params || !obs || !idx || !raw || !logp_old || !adv || !ret || !grad_out || (obs_mean && !obs_std)) return pfail(MM_EARG, "mm_ppo_grad: null argument");
   if (mb < 1 || mb > h->cfg.max_minibatch) return pfail(MM_EARG, "mm_ppo_grad: minibatch of " + std::to_string(mb) + " rows, workspace sized for " + std::to_string(h->cfg.max_minibatch));
+  DeviceGuard guard(h->device);
   const int rt = pick_rt(h, mb), S = 16 * rt, nb = (mb + S - 1) / S;
   float* part_pi = h->part;
   float* part_vf = h->part + (size_t)h->nb_max * h->np_pi;
@@ -689,6 +698,7 @@ extern "C" int mm_ppo_grad(mm_ppo* h, const float* params, const float* obs, con
 
 extern "C" int mm_ppo_adam(mm_ppo* h, float* params, const float* grad, float grad_scale, int recompute_norm, void* stream) {
   if (!h || !params || !grad) return pfail(MM_EARG, "mm_ppo_adam: null argument");
+  DeviceGuard guard(h->device);
   if (recompute_norm) {
     hipLaunchKernelGGL(k_ppo_sumsq, dim3(h->nbq), dim3(RED_P), 0, (hipStream_t)stream, grad, h->np, h->blocksq);
     PHIPCHK(hipGetLastError());

@@ -306,6 +306,7 @@ class HipModel:
         too: BatchState then allocates float64 qpos / qvel / act / qacc_warmstart); include/myosim.h"""
         self.cm = compiled
         self.precision = MM_PREC_F32
+        self._n_states = 0          # BatchStates allocated for this model (their row width is fixed by the precision mode at that time)
         if not torch.cuda.is_available():
             raise EngineError("no HIP device visible: the physics step only runs on the GPU (no CPU fallback)")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -316,7 +317,6 @@ class HipModel:
         self.h = h
         if precision != MM_PREC_F32:
             self.set_option("precision", precision)
-            self.precision = int(precision)
         if lanes_per_env:
             _chk(lib().mm_model_set_lanes(self.h, lanes_per_env), "mm_model_set_lanes")
 
@@ -337,7 +337,17 @@ class HipModel:
         return dict(zip(self.LAUNCH_KEYS, (int(v) for v in out)))
 
     def set_option(self, name: str, value: int):
+        """mm_model_set_option.  "precision" also decides the element type of the state rows a BatchState allocates (fp64 under
+        MM_PREC_F64_STATE): the mode is tracked here, and a change of the state-row width is refused once a BatchState of this
+        model exists -- its buffers would be read and written at the wrong width."""
+        if name == "precision":
+            wide = lambda p: int(p) == MM_PREC_F64_STATE
+            if self._n_states and wide(value) != wide(self.precision):
+                raise EngineError("precision: the state-row width cannot change after a BatchState was created for this model "
+                                  "(create the model with precision=... instead)")
         _chk(lib().mm_model_set_option(self.h, name.encode(), int(value)), "mm_model_set_option")
+        if name == "precision":
+            self.precision = int(value)
 
     def layout(self, name: str) -> int:
         return lib().mm_debug_layout(self.h, name.encode())
@@ -358,6 +368,7 @@ class BatchState:
         dev = model.device
         self.model = model
         self.nenv = nenv
+        model._n_states += 1
         f = dict(dtype=torch.float32, device=dev)
         # the four state rows are float64 under MM_PREC_F64_STATE (qpos0 is an fp32 model table in every mode)
         fs = dict(dtype=torch.float64 if model.precision == MM_PREC_F64_STATE else torch.float32, device=dev)

@@ -11,7 +11,15 @@ a 6.4 M env-steps/s hand).  Here one training iteration is TWO HIP graphs:
 * ``update``: one pass over the batch -- a device-side permutation, then for every minibatch gather, forward, clipped-surrogate /
   value / entropy losses, backward, global-norm clipping and a capturable Adam step.
 
-Data parallel (one process per GPU): parameters and gradients live in ONE flat buffer each, so the exchange is a single
+Deviations from brax's PPO, stated: (i) the entropy bonus is the entropy of the PRE-squash normal (`sum(0.5 + 0.5 log 2 pi + log std)`);
+brax's NormalTanhDistribution.entropy adds the squashing log-det-Jacobian of a fresh sample, which also feeds gradient into the mean --
+at entropy_cost 1e-2..1e-3 a small shaping term, left out in both learners (torch and fused) so that they stay each other's checker;
+(ii) advantages are normalised per rank over the whole batch once per iteration (brax: per minibatch, per device); (iii) GAE, the
+clipped surrogate, the value loss 0.5 * 0.5 * mse, global-norm clipping and Adam follow brax term by term (mm_gae: compute_gae with
+its truncation masks).
+
+Data parallel (one process per GPU): the running observation statistics are merged over ALL ranks' rows (one small all-reduce per
+iteration: `_Norm.update(world=...)`), so the normaliser -- part of the policy and value function -- is identical on every rank; parameters and gradients live in ONE flat buffer each, so the exchange is a single
 all-reduce of the flat gradient per minibatch (RCCL over xGMI; < 100 KB) with no flatten / copy-back; the update then runs eagerly
 between the collectives (a gloo group cannot be captured).
 """
@@ -62,15 +70,35 @@ class _Norm:
         self.n = torch.zeros((), device=device); self.mean = torch.zeros(dim, device=device); self.m2 = torch.zeros(dim, device=device)
         self.std = torch.ones(dim, device=device)
 
-    def update(self, x):
+    def update(self, x, world: int = 1):
+        """Chan / Welford merge of one batch into the running statistics.  world > 1 (data-parallel ranks): the batch is the UNION of
+        every rank's rows -- count, sum and sum of squares about the (rank-identical) current mean go through ONE all-reduce, so the
+        normaliser, which is part of the policy and the value function, stays bit-identical on every rank (brax pmean-reduces
+        running_statistics the same way).  The world > 1 form runs outside the captured graph (a gloo group cannot be captured)."""
         x = x.reshape(-1, x.shape[-1])
-        b = float(x.shape[0])
-        tot = self.n + b
-        bm = x.mean(0)
-        d = bm - self.mean
-        self.m2.add_(((x - bm) ** 2).sum(0) + d * d * self.n * b / tot)
-        self.mean.add_(d * b / tot)
-        self.n.copy_(tot)
+        if world > 1:
+            c = x - self.mean
+            pack = torch.cat([c.sum(0), (c * c).sum(0), torch.full((1,), float(x.shape[0]), device=x.device)]).double()
+            if pack.is_cuda and torch.distributed.get_backend() == "gloo":
+                h = pack.cpu(); torch.distributed.all_reduce(h); pack = h.to(x.device)
+            else:
+                torch.distributed.all_reduce(pack)
+            dim = x.shape[1]
+            b = pack[2 * dim]
+            d = pack[:dim] / b                                    # batch mean - running mean
+            bm2 = pack[dim:2 * dim] - b * d * d                   # sum of squares about the batch mean
+            tot = self.n.double() + b
+            self.m2.add_((bm2 + d * d * self.n.double() * b / tot).float())
+            self.mean.add_((d * b / tot).float())
+            self.n.copy_(tot.float())
+        else:
+            b = float(x.shape[0])
+            tot = self.n + b
+            bm = x.mean(0)
+            d = bm - self.mean
+            self.m2.add_(((x - bm) ** 2).sum(0) + d * d * self.n * b / tot)
+            self.mean.add_(d * b / tot)
+            self.n.copy_(tot)
         self.std.copy_(torch.sqrt(self.m2 / torch.clamp(self.n, min=1.0)).clamp(1e-6, 1e6))
 
     def __call__(self, x):
@@ -106,6 +134,9 @@ class OnDevicePPO:
             o += k
         if world > 1:
             torch.distributed.broadcast(self.flat_p, src=0)
+            # parameters are rank 0's; everything drawn from here on (action noise, minibatch permutations) must DIFFER per rank, or the
+            # data-parallel ranks explore with identical noise (brax folds the process index into its keys)
+            torch.manual_seed(int(seed) + 1000003 * (1 + torch.distributed.get_rank()))
         self.kern = None
         if fused is not False and torch.cuda.is_available():
             try:
@@ -186,8 +217,8 @@ class OnDevicePPO:
                 self.val_b[self.T].copy_(self._value(env.obs))
             E.gae(self.rew_b, self.term_b, self.trunc_b, self.val_b, self.adv_b, self.ret_b, cfg.discounting, cfg.gae_lambda)
             self.nadv_b.copy_((self.adv_b - self.adv_b.mean()) / (self.adv_b.std() + 1e-8))
-            if self.norm:
-                self.norm.update(self.obs_b)
+            if self.norm and self.world == 1:
+                self.norm.update(self.obs_b)       # (world > 1: iterate() merges every rank's batch, outside the graph)
             self.mean_reward.copy_(self.rew_b.mean())
 
     def _minibatch_backward(self, idx):
@@ -281,6 +312,9 @@ class OnDevicePPO:
             self._g_roll.replay()
         else:
             self._rollout()
+        if self.norm and self.world > 1:
+            with torch.no_grad():
+                self.norm.update(self.obs_b, world=self.world)
         for _ in range(self.cfg.num_updates_per_batch):
             if self._g_upd is not None:
                 self._g_upd.replay()

@@ -13,17 +13,62 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# Which build of the SAME sources this process binds (oracle/Makefile): "" = the checker (-O2, no contraction: every parity test),
+# "fast" = -O3 -march=native (bench.py's cpu_baseline leg only), "asan" = AddressSanitizer + UBSan (tests/test_oracle_sanitizers.py,
+# in a child process with libasan preloaded).  Chosen once per process: $MYOSIM_ORACLE_VARIANT or use_variant() before the first call.
+_VARIANTS = {"": "liboracle.so", "fast": "liboracle_fast.so", "asan": "liboracle_asan.so"}
+_variant = os.environ.get("MYOSIM_ORACLE_VARIANT", "")
+_LIB_PATH = os.path.join(_HERE, _VARIANTS[_variant])
 _lib = None
 
 
-def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("mmo_engine.c", "mmo_collision.inc", "mmo_batch.c")]
+def variant() -> str:
+    return _variant
+
+
+def use_variant(name: str) -> None:
+    """Select the build this process binds; only before the first oracle call (one process, one library)."""
+    global _variant, _LIB_PATH
+    if name not in _VARIANTS:
+        raise ValueError(f"unknown oracle variant {name!r}")
+    if _lib is not None and name != _variant:
+        raise RuntimeError(f"oracle library {_VARIANTS[_variant]} is already loaded in this process")
+    _variant, _LIB_PATH = name, os.path.join(_HERE, _VARIANTS[name])
+
+
+def _host_cpu() -> str:
+    """identity of the CPU a -march=native build is valid for"""
+    model, flags = "", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = str(hash(line.split(":", 1)[1].strip()) & 0xffffffff)
+            if model and flags:
+                break
+    except OSError:
+        pass
+    return f"{model}|{flags}"
+
+
+def build(force: bool = False, variant: str = None) -> str:
+    """make the selected variant (default: the one this process binds) when a source is newer than it; the -march=native variant is
+    also rebuilt when it was built on another CPU (built .so files travel to the GPU box with the snapshot)."""
+    v = _variant if variant is None else variant
+    path = os.path.join(_HERE, _VARIANTS[v])
+    srcs = [os.path.join(_HERE, f) for f in ("mmo_engine.c", "mmo_collision.inc", "mmo_batch.c", "Makefile")]
     srcs.append(os.path.join(_HERE, "..", "include", "myosim_model.h"))
-    if force or not os.path.exists(_LIB_PATH) or any(
-            os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s)):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
-    return _LIB_PATH
+    stamp = path + ".host"
+    if v == "fast" and os.path.exists(path) and not (os.path.exists(stamp) and open(stamp).read() == _host_cpu()):
+        force = True
+    if force or not os.path.exists(path) or any(
+            os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", _VARIANTS[v]], stdout=subprocess.DEVNULL)
+        if v == "fast":
+            with open(stamp, "w") as f:
+                f.write(_host_cpu())
+    return path
 
 
 def lib():

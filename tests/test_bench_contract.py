@@ -67,6 +67,14 @@ def test_bench_n_gt_1_path_runs_oversubscribed_on_one_gpu():
     assert d["stats"]["envs_in_stats"] == 2 * E_                      # the gather returned both shards
     assert abs(d["ms_per_step"] - 1e3 * 2 * E_ / d["value"]) < 1e-6 * d["ms_per_step"] + 1e-9
     assert d["cpu_baseline"]["single_thread"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "-O3 -march=native" in d["cpu_baseline"]["build"]         # the timed CPU build is the optimised one, and says so
+    # the N > 1 line is self-evidencing about its one collective
+    c = d["collective"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["is_rccl"] is False          # (RCCL refuses two ranks on one device)
+    assert c["gathered_rows"] == c["expected_rows"] == 2 * E_ and c["bytes_per_rank"] == E_ * 3 * 4
+    assert c["allgather_us"] > 0 and len(c["per_rank_env_steps_per_s"]) == 2
+    assert min(c["per_rank_env_steps_per_s"]) * 2 >= d["value"] * 0.999      # `value` is priced on the slowest rank's clock
+    assert "rccl_version" in c
     # the same rollout unsharded, in this process
     full = registry.make("myoHandPoseRandom-v0", num_envs=2 * E_, seed=0)
     stats = full.rollout_setup(action_seed=0)
@@ -117,6 +125,16 @@ def test_bench_line_bookkeeping_repeats_fractions_and_replayed_counters():
             assert r["traffic_source"] == r["profile"]["replayed_from"]
         else:
             assert r["traffic"] is None
+    # both byte figures, SURVEY 8(d)'s as the contract one
+    r = d["roofline"]
+    assert r["algorithmic_bytes_per_launch"] == 1376 * 4096 and r["algorithmic_bytes_per_launch_incl_carry"] == 1752 * 4096
+    assert r["frac"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"], rel=1e-9)
+    assert r["frac_incl_carry"] > r["frac"] and r["bound_by"] == "fp32-issue" and r["bound_by_detail"]["x_ridge"] > 10
+    # the line ENDS with the compact digest, BASELINE.json configs 2 / 4 / 5 last (the driver's record keeps the tail)
+    assert list(d.keys())[-1] == "baseline_configs"
+    assert list(d["baseline_configs"].keys())[-3:] == ["myoElbowPose1D6MRandom-v0@4096", "myoHandReorient100-v0@2048", "myoFatiLegWalk-v0@1024"]
+    assert [x["key"] for x in d["extra_configs"]][-3:] == ["myoElbowPose1D6MRandom-v0@4096", "myoHandReorient100-v0@2048", "myoFatiLegWalk-v0@1024"]
+    assert len(json.dumps(d["baseline_configs"])) < 4000
     keys = {x["key"] for x in d["extra_configs"]}
     assert "myoHandReachRandom-v0@4096" in keys and "myoHandPoseRandom-v0@4096|precision=f64_state" in keys
     ppo = {x["key"]: x for x in d["ppo_training"]}

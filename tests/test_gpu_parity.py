@@ -502,20 +502,31 @@ def test_ppo_benchmark_port_runs_and_writes_the_reference_result_file(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gae_kernel_matches_the_torch_recursion():
-    """mm_gae (one launch) against the recursion the eager learner ran (brax compute_gae with truncation)."""
+def test_gae_kernel_matches_brax_compute_gae():
+    """mm_gae (one launch) against a literal, array-level restatement of brax.training.agents.ppo.losses.compute_gae: deltas masked
+    by truncation, the lambda accumulator cut at terminations and truncations, vs = acc + V, advantages from vs_{t+1} and masked by
+    truncation (the round-4 kernel kept the bootstrap from V_{t+1} on truncated steps and returned the accumulator)."""
     torch.manual_seed(0)
     T, n, g, lam = 10, 777, 0.97, 0.95
     rew = torch.randn(T, n, device="cuda"); val = torch.randn(T + 1, n, device="cuda")
     term = (torch.rand(T, n, device="cuda") < 0.1).float(); trunc = ((torch.rand(T, n, device="cuda") < 0.1).float() * (1 - term))
     adv = torch.zeros(T, n, device="cuda"); ret = torch.zeros(T, n, device="cuda")
     E.gae(rew, term, trunc, val, adv, ret, g, lam)
-    ref = torch.zeros(T, n, device="cuda"); last = torch.zeros(n, device="cuda")
+    # --- brax compute_gae(truncation, termination, rewards, values, bootstrap_value, lambda_, discount), float64 on the host
+    R, V, TE, TR = (x.double().cpu().numpy() for x in (rew, val[:T], term, trunc))
+    boot = val[T].double().cpu().numpy()
+    truncation_mask = 1 - TR
+    values_t_plus_1 = np.concatenate([V[1:], boot[None]], axis=0)
+    deltas = (R + g * (1 - TE) * values_t_plus_1 - V) * truncation_mask
+    acc = np.zeros_like(boot); vs_minus_v = np.zeros_like(V)
     for t in reversed(range(T)):
-        delta = rew[t] + g * (1.0 - term[t]) * val[t + 1] - val[t]
-        last = delta + g * lam * (1.0 - term[t]) * (1.0 - trunc[t]) * last
-        ref[t] = last
-    assert float((adv - ref).abs().max()) < 1e-5 and float((ret - (ref + val[:T])).abs().max()) < 1e-5
+        acc = deltas[t] + g * (1 - TE[t]) * truncation_mask[t] * lam * acc
+        vs_minus_v[t] = acc
+    vs = vs_minus_v + V
+    vs_t_plus_1 = np.concatenate([vs[1:], boot[None]], axis=0)
+    advantages = (R + g * (1 - TE) * vs_t_plus_1 - V) * truncation_mask
+    assert np.abs(ret.cpu().numpy() - vs).max() < 1e-5 and np.abs(adv.cpu().numpy() - advantages).max() < 1e-5
+    assert float(adv[trunc > 0].abs().max()) == 0.0          # a truncated step carries no advantage
 
 
 @pytest.mark.gpu
@@ -541,6 +552,8 @@ def test_on_device_ppo_graphs_learn_and_the_two_rank_path_keeps_parameters_in_sy
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["params_in_sync_across_ranks"] is True and d["graphs"] and not d["update_graph"]
+    # the observation normaliser is merged over both ranks' rows (bit-identical on every rank), the exploration noise is not shared
+    assert d["normaliser_in_sync_across_ranks"] is True and d["action_noise_differs_across_ranks"] is True
 
 
 def test_mjx_make_registry_names():
