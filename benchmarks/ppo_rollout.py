@@ -41,6 +41,14 @@ def main():
                          "runs on the torch-autograd learner")
     ap.add_argument("--torch-learner", action="store_true", help="torch autograd + torch Adam instead of the fused learner kernels")
     ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: ranks share the visible GPU(s), gloo group")
+    ap.add_argument("--curve", default=None, help="write the learning curve (JSON: per iteration mean reward per step, terminations, truncations; "
+                                                  "per window of --window iterations their means) to this file; reads three scalars back per "
+                                                  "iteration, so the throughput of such a run is NOT the benchmark figure")
+    ap.add_argument("--window", type=int, default=10, help="iterations per curve window (hand pose: 10 iterations = one 100-step episode)")
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--entropy", type=float, default=1e-2)
+    ap.add_argument("--reward-scaling", type=float, default=1.0)
+    ap.add_argument("--skip-rollout-only", action="store_true", help="no rollout-only timing pass before training (curve runs)")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env(backend="gloo" if args.oversubscribe else None)
@@ -51,7 +59,8 @@ def main():
     # rank r owns the global envs [r n, (r+1) n): Philox streams are keyed by the global env index (mm_state.env_index_base)
     env = registry.make(args.env, num_envs=args.num_envs, seed=rank, device=dev, env_index_base=rank * args.num_envs)
     cfg = PPOConfig(unroll_length=args.unroll, num_minibatches=args.minibatches, num_updates_per_batch=args.epochs,
-                    discounting=args.gamma, gae_lambda=args.lam, clipping_epsilon=args.clip, entropy_cost=1e-2, value_cost=0.25,
+                    discounting=args.gamma, gae_lambda=args.lam, clipping_epsilon=args.clip, entropy_cost=args.entropy, value_cost=0.25,
+                    learning_rate=args.lr, reward_scaling=args.reward_scaling,
                     policy_hidden=(64, 64, 64) if args.nets == "reference" else (32, 32, 32, 32),
                     value_hidden=(64, 64, 64) if args.nets == "reference" else (256, 256, 256, 256, 256),
                     squash="sigmoid", normalize_observations=True)
@@ -60,16 +69,19 @@ def main():
     torch.cuda.synchronize(); D.barrier()
     # rollout alone (the graph of the unroll), then full iterations
     t0 = time.perf_counter()
-    for _ in range(args.iters):
+    for _ in range(0 if args.skip_rollout_only else args.iters):
         if ppo._g_roll is not None:
             ppo._g_roll.replay()
         else:
             ppo._rollout()
-    torch.cuda.synchronize(); D.barrier(); t_roll = time.perf_counter() - t0
+    torch.cuda.synchronize(); D.barrier(); t_roll = max(time.perf_counter() - t0, 1e-9)
     r0 = float(ppo.mean_reward)
+    curve = []
     t0 = time.perf_counter()
     for _ in range(args.iters):
         ppo.iterate()
+        if args.curve:
+            curve.append((float(ppo.mean_reward) / cfg.reward_scaling, float(ppo.term_b.sum()), float(ppo.trunc_b.sum())))
     torch.cuda.synchronize(); D.barrier(); t_all = time.perf_counter() - t0
     stats = D.gather_episode_stats(ppo.ep_stats)
     # data-parallel ranks must hold the same parameters after every update (one all-reduce of the flat gradient per minibatch)
@@ -90,6 +102,20 @@ def main():
             noise_differs = not any(bool(torch.equal(parts[0], q)) for q in parts[1:])
     t_roll = D.max_over_ranks(t_roll, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
     t_all = D.max_over_ranks(t_all, device="cuda" if (world > 1 and D.backend() == "nccl") else None)
+    if rank == 0 and args.curve:
+        W = max(1, args.window)
+        wins = []
+        for k in range(0, len(curve) - W + 1, W):
+            c = curve[k:k + W]
+            ended = sum(x[1] + x[2] for x in c)
+            wins.append({"iterations": [k, k + W], "env_steps_so_far": (k + W) * ppo.steps_per_iteration,
+                         "mean_reward_per_step": sum(x[0] for x in c) / W,
+                         "mean_episode_length": (W * ppo.T * ppo.n / ended) if ended else None,
+                         "terminated_frac_of_ended": (sum(x[1] for x in c) / ended) if ended else None})
+        json.dump({"env": args.env, "envs": args.num_envs, "unroll": args.unroll, "epochs": args.epochs, "minibatches": args.minibatches,
+                   "lr": args.lr, "entropy_cost": args.entropy, "gamma": args.gamma, "lam": args.lam, "reward_scaling": args.reward_scaling,
+                   "learner": "fused HIP kernels" if ppo.kern is not None else "torch autograd", "window_iterations": W,
+                   "windows": wins, "per_iteration_mean_reward_per_step": [x[0] for x in curve]}, open(args.curve, "w"))
     if rank == 0:
         steps = args.iters * ppo.steps_per_iteration
         print(json.dumps({"env": args.env, "n_gpus": world, "envs_per_gpu": args.num_envs, "unroll": args.unroll, "iters": args.iters,
