@@ -336,7 +336,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.nq = oi[MM_OI_NQ]; d.nv = oi[MM_OI_NV]; d.nu = oi[MM_OI_NU]; d.na = oi[MM_OI_NA]; d.nbody = oi[MM_OI_NBODY];
   d.njnt = oi[MM_OI_NJNT]; d.ngeom = oi[MM_OI_NGEOM]; d.nsite = oi[MM_OI_NSITE]; d.ntendon = oi[MM_OI_NTENDON];
   d.nwrap = oi[MM_OI_NWRAP]; d.neq = oi[MM_OI_NEQ]; d.npair = oi[MM_OI_NPAIR]; d.nM = oi[MM_OI_NM];
-  d.nlevel = oi[MM_OI_NLEVEL]; d.njmax = oi[MM_OI_NJMAX]; d.ntenJ = oi[MM_OI_NTENJ];
+  d.nlevel = oi[MM_OI_NLEVEL]; d.njmax = oi[MM_OI_NJMAX]; d.nconmax = oi[MM_OI_NCONMAX]; d.ntenJ = oi[MM_OI_NTENJ];
   d.iterations = oi[MM_OI_ITERATIONS]; d.ls_iterations = oi[MM_OI_LS_ITERATIONS]; d.eulerdamp = oi[MM_OI_EULERDAMP];
   d.timestep = of[MM_OF_TIMESTEP]; d.gx = of[MM_OF_GRAV_X]; d.gy = of[MM_OF_GRAV_Y]; d.gz = of[MM_OF_GRAV_Z];
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];

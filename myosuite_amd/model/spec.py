@@ -549,14 +549,17 @@ class ModelSpec:
         con_rows = 0
         for p in self.pairs:
             con_rows = max(con_rows, 1 if p["condim"] == 1 else 2 * (p["condim"] - 1))
-        # contacts an entry can produce: two for plane-capsule (one per end cap), capsule-capsule (parallel axes) and each of the
-        # two entries of a plane-box / plane-cylinder pair; one otherwise
+        # contacts an entry can produce: two for plane-capsule (one per end cap), capsule-capsule (parallel axes), capsule-box (the
+        # second sphere of mjc_CapsuleBox along a face) and each of the two entries of a plane-box / plane-cylinder pair; one otherwise
         two = ((C["MM_GEOM_PLANE"], C["MM_GEOM_CAPSULE"]), (C["MM_GEOM_CAPSULE"], C["MM_GEOM_CAPSULE"]),
-               (C["MM_GEOM_PLANE"], C["MM_GEOM_BOX"]), (C["MM_GEOM_PLANE"], C["MM_GEOM_CYLINDER"]))
+               (C["MM_GEOM_PLANE"], C["MM_GEOM_BOX"]), (C["MM_GEOM_PLANE"], C["MM_GEOM_CYLINDER"]),
+               (C["MM_GEOM_CAPSULE"], C["MM_GEOM_BOX"]), (C["MM_GEOM_BOX"], C["MM_GEOM_CAPSULE"]))
         ncon_bound = sum(2 if _ptypes(p) in two else 1 for p in entries)
         nconmax = self.nconmax if self.nconmax else ncon_bound
         nfric = int(np.count_nonzero(dof_floss > 0))
         njmax = neq + nfric + nlim_j + nlim_t + nconmax * con_rows
+        if getattr(self, "njmax", 0):      # explicit row bound (mjModel.njmax is independent of nconmax): rows beyond it are dropped and flagged
+            njmax = int(self.njmax)
 
         oi = np.zeros(C["MM_OI_COUNT"], i32)
         oi[C["MM_OI_NQ"]] = nq; oi[C["MM_OI_NV"]] = nv; oi[C["MM_OI_NU"]] = nu; oi[C["MM_OI_NA"]] = na

@@ -793,6 +793,12 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
                         ("OBJRx", "hinge", (1, 0, 0)), ("OBJRy", "hinge", (0, 1, 0)), ("OBJRz", "hinge", (0, 0, 1))):
         s.add_joint(nm, "Object", typ, axis=ax, armature=0.0)
     if kind == "reorient":
+        # a box object makes up to two contacts per finger capsule (mjc_CapsuleBox): the eight-contact bound of the other objects is hit
+        # by ~1 box env in 20 under random actions.  Twelve contacts, and the ROW bound stays where it was (23 limit rows + 8 x 4 = 55,
+        # rounded to 56): the efc_J table of an env is efc_rows x 36 words of LDS, and 64 rows cost this kernel its second resident
+        # wave per SIMD (measured: 4.10 -> 2.46 M env-steps/s).  MuJoCo's njmax / nconmax are independent bounds in the same way.
+        s.nconmax = 12
+        s.njmax = 56
         s.add_geom("obj", "Object", "capsule", REORIENT_CAPS_100[0][:2])
         s.add_geom("top", "Object", "sphere", (0.002,), pos=(0, 0, -0.035))     # xml:36-37 (names as in the reference)
         s.add_geom("bot", "Object", "sphere", (0.002,), pos=(0, 0, 0.035))
@@ -1011,8 +1017,8 @@ def _ground_keyframes(cm):
 
 def make_plane_toy() -> ModelSpec:
     """Test model for the multi-contact colliders (oracle/mmo_collision.inc): a box, a cylinder and an ellipsoid on free joints over
-    a tilted plane (up to 4 / 4 / 1 contacts), and a capsule on two slide joints that stays exactly parallel to a world-fixed
-    capsule (two contacts)."""
+    a tilted plane (up to 4 / 4 / 1 contacts), a capsule on two slide joints that stays exactly parallel to a world-fixed
+    capsule (two contacts), and a free capsule ("rod") over a world-fixed box ("anvil"): mjc_CapsuleBox's one or two contacts."""
     s = ModelSpec("plane_toy", timestep=0.002)
     s.add_geom("floor", "world", "plane", (0, 0, 0), quat=(math.cos(0.03), 0.0, math.sin(0.03), 0.0))    # 3.4 deg tilt about y
     s.add_body("box", "world", pos=(0.0, 0.0, 0.05), mass=0.8, inertia=(0.002, 0.003, 0.004))
@@ -1034,6 +1040,11 @@ def make_plane_toy() -> ModelSpec:
     s.add_contact_pair("floor", "cyl_g", condim=3, friction=(0.6, 0.005, 0.0001))
     s.add_contact_pair("floor", "ell_g", condim=3, friction=(0.7, 0.005, 0.0001))
     s.add_contact_pair("rail", "bar_g", condim=3, friction=(0.9, 0.005, 0.0001))
+    s.add_geom("anvil", "world", "box", (0.06, 0.04, 0.02), pos=(0.0, -0.5, 0.10))            # top face at z = 0.12
+    s.add_body("rod", "world", pos=(0.0, -0.5, 0.135), mass=0.2, inertia=(0.0002, 0.0002, 0.00003), quat=QY90)
+    s.add_joint("rod_free", "rod", "free")
+    s.add_geom("rod_g", "rod", "capsule", (0.015, 0.05))
+    s.add_contact_pair("rod_g", "anvil", condim=3, friction=(0.8, 0.005, 0.0001))
     return s
 
 
