@@ -312,9 +312,11 @@ def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
     the same algorithm sits at 62 of 64 / 2.4e-6 (CPU emulation, profiles/r03_precision_study.json; reaching the twin takes fp64
     in kinematics + tendons + solver + integration).  Measured on MI355X (profiles/r03_north_star_ab.json): 61 (G = 32) and 60
     (G = 64) of 64, median 3.6e-6; seven arithmetic variants of the kernel (sin/cos form, solver polish, IEEE divide, no
-    fast-math) spread over 57..61, i.e. the count carries +-2 of sampling noise at this sample size.  Gated: the count within
-    that noise of the plain-fp32 level (>= 57 of 64, and never more than 6 behind the twin), the median within 5x of the twin's
-    -- a kernel that loses a digit anywhere fails both -- and every env back under 1e-2 at the end of the run."""
+    fast-math) spread over 57..61, i.e. the count carries +-2 of sampling noise at this sample size.  Gated (tightened in round 5,
+    VERDICT r04 #2): the count at the plain-fp32 emulation's level minus 2 (>= 60 of 64; it was >= 57), never more than 3 behind the
+    twin, the median within 5x of the twin's -- a kernel that loses a digit anywhere fails both -- and every env back under 1e-2
+    at the end of the run.  What closes the rest is NOT more fp32 care but fp64 state rows and fp64 in every stage except CRB and
+    the velocity / RNE stage (profiles/r05_precision_mixed_study.json): that is precision mode."""
     rel, rel_tw, status = north_star_run(name, lanes, nsub)
     rel, status = rel[E.MM_PREC_F32], status[E.MM_PREC_F32]
     nenv = rel.shape[1]
@@ -337,7 +339,7 @@ def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
         assert run.max() < 1e-4, run.max()
     else:
         below, below_tw = int((per_env < 1e-4).sum()), int((per_env_tw < 1e-4).sum())
-        assert below >= 57 and below >= below_tw - 6, (below, below_tw, np.sort(per_env)[-8:])
+        assert below >= 60 and below >= below_tw - 3, (below, below_tw, np.sort(per_env)[-8:])
         assert np.median(per_env) < 5.0 * max(np.median(per_env_tw), 5e-7), (np.median(per_env), np.median(per_env_tw))
         assert rel[-1].max() < 1e-2, rel[-1].max()
 
