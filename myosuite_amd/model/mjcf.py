@@ -290,14 +290,18 @@ def load(source: str, missing_include: str = "error", include_map: Optional[Dict
                 opt["eulerdamp"] = False
     for el in root.findall("default"):
         ctx.read_defaults(el)
-    nconmax = 0
+    nconmax = njmax = 0
     for el in root.findall("size"):
         if int(el.attrib.get("nconmax", "-1")) > 0:
             nconmax = int(el.attrib["nconmax"])
+        if int(el.attrib.get("njmax", "-1")) > 0:          # the row bound is independent of the contact bound (mjModel.njmax)
+            njmax = int(el.attrib["njmax"])
 
     s = ModelSpec(root.attrib.get("model", "mjcf"), timestep=opt["timestep"], gravity=opt["gravity"],
                   tolerance=opt["tolerance"], iterations=opt["iterations"], ls_iterations=opt["ls_iterations"],
                   ls_tolerance=opt["ls_tolerance"], integrator=opt["integrator"], eulerdamp=opt["eulerdamp"], nconmax=nconmax)
+    if njmax:
+        s.njmax = njmax
     geom_info: List[dict] = []       # contact attributes of every geom (for the generated pairs)
     auto = [0]
 
@@ -738,8 +742,9 @@ def dump(spec: ModelSpec) -> str:
                       ls_tolerance=repr(float(spec.ls_tolerance)), cone="pyramidal", solver="Newton")
     if not spec.eulerdamp:
         ET.SubElement(o, "flag", eulerdamp="disable")
-    if spec.nconmax:
-        ET.SubElement(root, "size", nconmax=str(spec.nconmax))
+    if spec.nconmax or getattr(spec, "njmax", 0):
+        ET.SubElement(root, "size", **({"nconmax": str(spec.nconmax)} if spec.nconmax else {}),
+                      **({"njmax": str(spec.njmax)} if getattr(spec, "njmax", 0) else {}))
     wb = ET.SubElement(root, "worldbody")
     nodes = {0: wb}
     jt = {C["MM_JNT_FREE"]: "free", C["MM_JNT_BALL"]: "ball", C["MM_JNT_SLIDE"]: "slide", C["MM_JNT_HINGE"]: "hinge"}

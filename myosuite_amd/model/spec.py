@@ -163,6 +163,7 @@ class ModelSpec:
         self.integrator = integrator
         self.eulerdamp = eulerdamp
         self.nconmax = nconmax
+        self.njmax = 0          # 0: derived from the row kinds (limits + nconmax contacts); > 0: explicit row bound (mjModel.njmax)
         self.bodies: List[_Body] = [_Body("world", -1, np.zeros(3), np.array([1., 0, 0, 0]), 0.0,
                                           np.zeros(3), np.array([1., 0, 0, 0]), np.zeros(3))]
         self.joints: List[_Joint] = []
@@ -558,7 +559,7 @@ class ModelSpec:
         nconmax = self.nconmax if self.nconmax else ncon_bound
         nfric = int(np.count_nonzero(dof_floss > 0))
         njmax = neq + nfric + nlim_j + nlim_t + nconmax * con_rows
-        if getattr(self, "njmax", 0):      # explicit row bound (mjModel.njmax is independent of nconmax): rows beyond it are dropped and flagged
+        if self.njmax:      # explicit row bound (mjModel.njmax is independent of nconmax): rows beyond it are dropped and flagged
             njmax = int(self.njmax)
 
         oi = np.zeros(C["MM_OI_COUNT"], i32)

@@ -479,7 +479,7 @@ static void mmo_jacp(const mmo_model* m, const mmo_data* d, real* jacp, const re
 }
 
 /* full 6-D Jacobian rows: jacp (3 x nv) and jacr (3 x nv) */
-static void mmo_jac(const mmo_model* m, const mmo_data* d, real* jacp, real* jacr, const real* pnt, int body) {
+__attribute__((unused)) static void mmo_jac(const mmo_model* m, const mmo_data* d, real* jacp, real* jacr, const real* pnt, int body) {
   int nv = m->nv;
   mmo_jacp(m, d, jacp, pnt, body);
   memset(jacr, 0, sizeof(real) * 3 * nv);
