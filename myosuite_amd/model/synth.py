@@ -743,7 +743,13 @@ def _hand_palm_up_with_capsules(name: str):
     the carpal row.  Returns (spec, capsule geom names)."""
     s = make_hand()
     s.name = name
-    s.nconmax = 8
+    # Contact and row bounds (mjModel.nconmax / njmax, independent as in MuJoCo; both are honoured by oracle and kernel, surplus is
+    # dropped and flagged): twelve contacts -- a box object makes up to two per finger capsule (mjc_CapsuleBox), and under random
+    # actions the pen / box envs do reach 9...11 -- within the row bound the models always had (23 limit rows + 8 x 4 = 55, rounded to
+    # 56): an env's efc_J table is efc_rows x 36 words of LDS, and 64 rows cost the 32-wide kernel its second resident wave per SIMD
+    # (measured on reorient: 4.10 -> 2.46 M env-steps/s).
+    s.nconmax = 12
+    s.njmax = 56
     phi = -(math.pi - 1.5)                         # base roll: pro_sup = -1.5 then sums to -pi, palm (local -z) up
     s.bodies[s._bname["ulna"]].quat = np.array([math.cos(phi / 2), math.sin(phi / 2), 0.0, 0.0])
     return s, _add_hand_capsules(s)
@@ -793,12 +799,6 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
                         ("OBJRx", "hinge", (1, 0, 0)), ("OBJRy", "hinge", (0, 1, 0)), ("OBJRz", "hinge", (0, 0, 1))):
         s.add_joint(nm, "Object", typ, axis=ax, armature=0.0)
     if kind == "reorient":
-        # a box object makes up to two contacts per finger capsule (mjc_CapsuleBox): the eight-contact bound of the other objects is hit
-        # by ~1 box env in 20 under random actions.  Twelve contacts, and the ROW bound stays where it was (23 limit rows + 8 x 4 = 55,
-        # rounded to 56): the efc_J table of an env is efc_rows x 36 words of LDS, and 64 rows cost this kernel its second resident
-        # wave per SIMD (measured: 4.10 -> 2.46 M env-steps/s).  MuJoCo's njmax / nconmax are independent bounds in the same way.
-        s.nconmax = 12
-        s.njmax = 56
         s.add_geom("obj", "Object", "capsule", REORIENT_CAPS_100[0][:2])
         s.add_geom("top", "Object", "sphere", (0.002,), pos=(0, 0, -0.035))     # xml:36-37 (names as in the reference)
         s.add_geom("bot", "Object", "sphere", (0.002,), pos=(0, 0, 0.035))
