@@ -743,13 +743,7 @@ def _hand_palm_up_with_capsules(name: str):
     the carpal row.  Returns (spec, capsule geom names)."""
     s = make_hand()
     s.name = name
-    # Contact and row bounds (mjModel.nconmax / njmax, independent as in MuJoCo; both are honoured by oracle and kernel, surplus is
-    # dropped and flagged): twelve contacts -- a box object makes up to two per finger capsule (mjc_CapsuleBox), and under random
-    # actions the pen / box envs do reach 9...11 -- within the row bound the models always had (23 limit rows + 8 x 4 = 55, rounded to
-    # 56): an env's efc_J table is efc_rows x 36 words of LDS, and 64 rows cost the 32-wide kernel its second resident wave per SIMD
-    # (measured on reorient: 4.10 -> 2.46 M env-steps/s).
-    s.nconmax = 12
-    s.njmax = 56
+    s.nconmax = 8
     phi = -(math.pi - 1.5)                         # base roll: pro_sup = -1.5 then sums to -pi, palm (local -z) up
     s.bodies[s._bname["ulna"]].quat = np.array([math.cos(phi / 2), math.sin(phi / 2), 0.0, 0.0])
     return s, _add_hand_capsules(s)
@@ -788,6 +782,13 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
     phalanges and the carpal row catch the object.  Object geom: compiled as a capsule; type (capsule / ellipsoid /
     cylinder / box) and size are per-env model deltas re-drawn every episode from the reference's tables."""
     s, caps = _hand_palm_up_with_capsules("myohand_sar" if kind == "reorient" else "myohand_pen")
+    # Contact and row bounds (mjModel.nconmax / njmax, independent as in MuJoCo; both are honoured by oracle and kernel, surplus is
+    # dropped and flagged): twelve contacts -- a box object makes up to two per finger capsule (mjc_CapsuleBox), and under random
+    # actions the pen / box envs do reach 9...11 -- within the row bound the models always had (23 limit rows + 8 x 4 = 55, rounded to
+    # 56): an env's efc_J table is efc_rows x 36 words of LDS, and 64 rows cost the 32-wide kernel its second resident wave per SIMD
+    # (measured on reorient: 4.10 -> 2.46 M env-steps/s).
+    s.nconmax = 12
+    s.njmax = 56
     # object above the palm centre (world frame at init: local (x, y, z) -> (x, -y, 1 - z) for the rolled forearm)
     OX, OZ = 0.325, 1.0 + 0.009 + 0.022
     eul = 1.27                                                              # myohand_sar.xml:26  euler="0 1.27 0"
