@@ -161,8 +161,8 @@ def _capsule_over_box(quat, pos, margin=0.0, half=0.08, box=(0.05, 0.03, 0.02), 
 def test_capsule_box_second_contact_and_convex_collider_contract(oracle_lib):
     """a4.3.  (i) mjc_CapsuleBox's result contract (mmo_collision.inc capsule_box_second): a capsule lying on a box
     face makes TWO contacts, one under each end -- clipped to the face when the capsule overhangs it --, a tilted capsule pressed
-    into the face keeps the second one while its far sphere is within the margin, a capsule across a box edge, on a corner or
-    standing on its end cap makes ONE.  (ii) the general convex collider's contract for capsule vs ellipsoid / cylinder: one
+    into the face keeps the second one while its far sphere is within the margin, so does a capsule lying ALONG an edge; a capsule
+    across a box edge, on a corner or standing on its end cap makes ONE.  (ii) the general convex collider's contract for capsule vs ellipsoid / cylinder: one
     contact, and the reported (distance, normal) satisfy the support-mapping optimality GJK terminates on -- the shape's support
     point along +n and the capsule's along -n are the witnesses, their gap along n is the distance -- to 1e-6."""
     Y90 = (math.cos(math.pi / 4), 0, math.sin(math.pi / 4), 0)       # capsule axis (local z) -> world x
@@ -206,6 +206,16 @@ def test_capsule_box_second_contact_and_convex_collider_contract(oracle_lib):
     d = _capsule_over_box((math.cos(3 * math.pi / 8), 0, math.sin(3 * math.pi / 8), 0), tuple(c), half=0.03)
     assert d.ncon == 1 and abs(d.con_dist[0] + 1e-4) < 1e-8
     np.testing.assert_allclose(np.abs(d.con_frame[0, :3]), [math.sin(math.pi / 4), 0, math.cos(math.pi / 4)], atol=1e-7)
+    # lying ALONG the top edge y = +0.03 (axis -> x), outside it on the diagonal: the stretch beside the edge, two contacts on the edge line
+    e45 = np.array([0.0, math.sin(math.pi / 4), math.cos(math.pi / 4)])
+    d = _capsule_over_box(Y90, tuple(np.array([0.0, 0.03, top]) + (r - 1e-4) * e45), half=0.03)
+    assert d.ncon == 2
+    np.testing.assert_allclose(np.sort(d.con_pos[:2, 0]), [-0.03, 0.03], atol=1e-9)
+    np.testing.assert_allclose(d.con_dist[:2], -1e-4, atol=1e-8)
+    np.testing.assert_allclose(np.abs(d.con_frame[:2, :3]), [np.abs(e45)] * 2, atol=1e-7)
+    d = _capsule_over_box(Y90, tuple(np.array([0.0, 0.03, top]) + (r - 1e-4) * e45), half=0.08)       # longer than the edge: clipped to it
+    assert d.ncon == 2
+    np.testing.assert_allclose(np.sort(d.con_pos[:2, 0]), [-0.05, 0.05], atol=1e-9)
     # lying ALONG the edge direction but over the face interior, crossing the y edges (axis -> y, half 0.08 > 0.03): clipped to the face in y
     d = _capsule_over_box(X90, (0.0, 0.0, top + r - 1e-4), half=0.08)
     assert d.ncon == 2
@@ -330,6 +340,11 @@ def _states(cm, name, n, rng):
                            w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2]
         q[:, 23] = rng.uniform(-0.05, 0.05, n); q[:, 24] = -0.5 + rng.uniform(-0.03, 0.03, n)
         q[:, 25] = 0.135 + np.where(kind == 3, 0.01, rng.uniform(-4e-4, -5e-5, n)) + 0.05 * np.abs(np.sin(tilt)) * (kind == 2)
+        # every other "flat" env lies ALONG the anvil's top edge y = -0.46 instead (no yaw, pressed in 1e-4 on the edge's diagonal):
+        # mjc_CapsuleBox's two contacts beside an edge
+        along = np.nonzero(kind == 0)[0][1::2]
+        q[along, 26:30] = [math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0]
+        q[along, 24] = -0.46 + (0.015 - 1e-4) * math.sin(math.pi / 4); q[along, 25] = 0.12 + (0.015 - 1e-4) * math.cos(math.pi / 4)
         v = rng.standard_normal((n, cm.nv)) * 0.3
     elif name == "contact_toy":
         q[:, 2] += rng.uniform(-0.04, 0.05, n)
