@@ -411,6 +411,88 @@ def test_gpu_general_rows_forward_and_rollout_match_oracle(oracle_lib, name):
     assert np.median(err) < 2e-5 and err.max() < 1e-3, (np.median(err), err.max(), worst, np.round(by_dof, 6).tolist(), q[worst].tolist())
 
 
+@pytest.mark.gpu
+def test_gpu_capsule_box_narrow_phase_matches_oracle_on_adversarial_poses(oracle_lib):
+    """2048 rod poses over the anvil of `plane_toy`, biased to the places where the capsule-box rule branches: exactly flat / tilted
+    by micro- to milliradians on the face, overhanging an edge and tipping over it, lying along an edge, crossing edges and corners,
+    penetrating by 1e-6...1e-3, clear by as little -- one forward pass of the whole batch, and for EVERY env the number of
+    constraint rows (4 per rod contact; the other bodies are parked in the air) and the constrained acceleration against the oracle
+    on the same state.  Envs whose row count differs must be rare (a sphere within fp32 rounding of its margin) and are excluded
+    from the error statistics."""
+    import torch
+    from myosuite_amd import engine as E
+    cm = synth.get_model("plane_toy"); hm = E.HipModel(cm); om = O.OracleModel(cm)
+    rng = np.random.default_rng(11)
+    n = 2048
+    q = np.tile(cm.qpos0.astype(np.float64), (n, 1))
+    for k in range(3):
+        q[:, 7 * k + 2] += 1.0                               # box / cylinder / ellipsoid: a metre above the plane
+    q[:, 21] = 0.2                                           # the bar: well above the rail
+    kind = rng.integers(0, 6, n)
+    r, top, hx, hy, hl = 0.015, 0.12, 0.06, 0.04, 0.05       # rod radius, anvil top, anvil half sizes, rod half length
+    pen = -np.exp(rng.uniform(np.log(1e-6), np.log(1e-3), n)) * np.where(rng.random(n) < 0.25, -1.0, 1.0)     # signed gap of the closest sphere
+    tilt = np.where(kind == 0, 0.0, np.where(kind == 1, np.exp(rng.uniform(np.log(1e-6), np.log(2e-2), n)) * rng.choice([-1, 1], n),
+                    np.where(kind == 5, rng.uniform(-0.8, 0.8, n), rng.uniform(-3e-3, 3e-3, n))))
+    yaw = np.where(kind == 3, 0.0, np.where(kind == 4, rng.uniform(0.3, 1.2, n), rng.uniform(-0.5, 0.5, n)))
+    x = np.where(kind == 2, rng.uniform(0.02, 0.09, n), rng.uniform(-0.03, 0.03, n))        # kind 2: one end overhangs the +x edge
+    y = rng.uniform(-0.02, 0.02, n)
+    z = top + r + pen + hl * np.abs(np.sin(tilt))            # the lower end's sphere sits `pen` from the face (face poses)
+    diag = math.sqrt(0.5)
+    along = kind == 3                                        # along the +y top edge, on its diagonal
+    y = np.where(along, hy + (r + pen) * diag, y); z = np.where(along, top + (r + pen) * diag, z)
+    tilt = np.where(along, 0.0, tilt)
+    for e in range(n):
+        cy, sy = math.cos(math.pi / 4 + tilt[e] / 2), math.sin(math.pi / 4 + tilt[e] / 2)
+        w1, z1 = math.cos(yaw[e] / 2), math.sin(yaw[e] / 2)
+        q[e, 26:30] = [w1 * cy, -z1 * sy, w1 * sy, z1 * cy]                                  # yaw about world z after the lying-down rotation
+    # kind 4: ACROSS the +y top edge (tangent to it at an angle), every third one at the (+x, +y) corner instead: the rod lies in the
+    # plane at distance r + pen from a supporting plane of the box through the edge / corner point, so that point is its closest one
+    def quat_from_z(u):
+        c = float(u[2]); ax = np.array([-u[1], u[0], 0.0]); sn = np.linalg.norm(ax)
+        if sn < 1e-12:
+            return np.array([1.0, 0, 0, 0]) if c > 0 else np.array([0.0, 1, 0, 0])
+        half = 0.5 * math.atan2(sn, c)
+        return np.concatenate([[math.cos(half)], math.sin(half) * ax / sn])
+    for e in np.nonzero(kind == 4)[0]:
+        corner = e % 3 == 0
+        if corner:
+            nrm = rng.uniform(0.25, 1.0, 3); cp = np.array([hx, hy, top])
+        else:
+            th = rng.uniform(0.3, 1.25); nrm = np.array([0.0, math.sin(th), math.cos(th)]); cp = np.array([rng.uniform(-0.03, 0.03), hy, top])
+        nrm /= np.linalg.norm(nrm)
+        t1_ = np.cross(nrm, [1.0, 0.0, 0.0] if not corner else rng.standard_normal(3)); t1_ /= np.linalg.norm(t1_)
+        t2_ = np.cross(nrm, t1_)
+        psi = rng.uniform(0.3, 1.2) if not corner else rng.uniform(0, 2 * math.pi)
+        u_ = math.cos(psi) * t2_ + math.sin(psi) * t1_            # (edge: t2_ = +-x, so psi is the crossing angle)
+        c_ = cp + (r + pen[e]) * nrm + rng.uniform(-0.6, 0.6) * hl * u_
+        x[e], y[e], z[e] = c_
+        q[e, 26:30] = quat_from_z(u_)
+    q[:, 23] = x; q[:, 24] = -0.5 + y; q[:, 25] = z
+    q32 = q.astype(np.float32)
+    v = (rng.standard_normal((n, cm.nv)) * 0.2).astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q32)); st.qvel.copy_(torch.from_numpy(v))
+    dv = E.Derived(hm, n, ["qacc", "nefc"])
+    ctrl = torch.zeros(n, max(cm.nu, 1), device="cuda")[:, :cm.nu].contiguous()
+    E.forward(hm, st, ctrl, dv)
+    torch.cuda.synchronize()
+    gn, ga = dv["nefc"].cpu().numpy(), dv["qacc"].cpu().numpy().astype(np.float64)
+    d = O.OracleData(om)
+    on = np.zeros(n, int); rel = np.zeros(n)
+    for e in range(n):
+        d.qpos[:] = q32[e]; d.qvel[:] = v[e]; d.qacc_warmstart[:] = 0; d.forward()
+        on[e] = d.nefc
+        rel[e] = np.abs(ga[e] - d.qacc).max() / max(1.0, np.abs(d.qacc).max())
+    mism = on != gn
+    hist = {int(k_): int((on == k_).sum()) for k_ in np.unique(on)}
+    print(f"capsule-box sweep: oracle row counts {hist}; row-count mismatches {int(mism.sum())} of {n} (by kind {[int(mism[kind == k_].sum()) for k_ in range(6)]}); "
+          f"rel |dqacc| median {np.median(rel[~mism]):.1e} max {rel[~mism].max():.1e}")
+    assert set(hist) == {0, 4, 8} and min(hist.values()) >= n // 20, hist                    # none / one / two rod contacts all well represented
+    assert mism.sum() <= n // 200, (int(mism.sum()), np.nonzero(mism)[0][:10], on[mism][:10], gn[mism][:10])
+    assert rel[~mism].max() < 2e-3 and np.quantile(rel[~mism], 0.99) < 3e-4, (rel[~mism].max(), np.quantile(rel[~mism], 0.99))
+    assert int(st.status.cpu().max()) & ~1 == 0
+
+
 def test_friction_loss_rows_oracle(oracle_lib):
     """Dry joint friction (MuJoCo `frictionloss`): the row force saturates at +-frictionloss, holds a load below the bound
     (up to the soft-constraint creep) and dissipates energy."""
