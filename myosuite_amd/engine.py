@@ -69,11 +69,11 @@ FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "
               # 3x the HBM write traffic (4.0 -> 12.2 MB of scratch per launch): off.)
               "myosim_inst_H.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],
               "myosim_inst_I.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1"],   # self-contact hand <64,24,GEN>: VGPR spills 14 -> 0 (end of round 3)
-              # reorient <64,32,GEN>: VGPR spills 74 -> 18 (model-in-LDS variant 47 -> 0), kernel 0.705 -> 0.686 ms (+3 %), and 4x
-              # less scratch traffic for a kernel whose time followed the box's memory clock.  The same flag on the 24-wide and
-              # implicitfast general-row units (inst_I, inst_J) loses 1 %: not set there.
-              # + the reset-observation pass of a folded reset also writes a forward-carry row: reorient 3.95 -> 4.11 M in one session
-              # (the leg unit, inst_H, loses 1 % with it: off there)
+              # reorient <64,32,GEN>: -sink-insts-to-avoid-spills took its VGPR spills from 74 to 18 in round 3 (kernel 0.705 -> 0.686 ms);
+              # the 10...17 that the forward carry brought back in round 4 were three live 64-bit carry-row pointers, gone in round 5
+              # (Engine::carry_row re-derives the address): 0 spilled VGPRs, 0 B of scratch, HBM traffic 10.5 -> 6.4 MB per launch.
+              # MM_REFOLD_CARRY: the reset-observation pass of a folded reset also writes a forward-carry row: reorient 3.95 -> 4.11 M in
+              # one session (the leg unit, inst_H, loses 1 % with it: off there)
               "myosim_inst_D.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-DMM_REFOLD_CARRY=1"],
               # implicitfast units: with the forward carry in (a second inlined implicit solve in the trailing pass) the 36-wide leg kernel
               # spilled 52 / 60 VGPRs (148 / 188 B of scratch per lane, 13.5 MB of scratch writes per launch); with the flag 0 / 0 and
