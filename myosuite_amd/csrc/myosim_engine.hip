@@ -462,14 +462,14 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     for (int p = 0; p < d.npair; p++) {
       const int t1 = gt[p1[p]], t2 = gt[p2[p]];
       const bool ok = (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE || t2 == MM_GEOM_ELLIPSOID || t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX)) ||
-                      (t1 == MM_GEOM_SPHERE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE)) ||
+                      (t1 == MM_GEOM_SPHERE && (t2 == MM_GEOM_SPHERE || t2 == MM_GEOM_CAPSULE || t2 == MM_GEOM_ELLIPSOID || t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX)) ||
                       (t1 == MM_GEOM_CAPSULE && (t2 == MM_GEOM_CAPSULE || t2 == MM_GEOM_ELLIPSOID || t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX));
       if (t1 == MM_GEOM_PLANE && (t2 == MM_GEOM_CYLINDER || t2 == MM_GEOM_BOX)) {
         // up to four contacts: two consecutive identical entries, two contacts each (include/myosim_model.h, PAIR_* sections)
         const bool twin = (p > 0 && p1[p - 1] == p1[p] && p2[p - 1] == p2[p]) || (p + 1 < d.npair && p1[p + 1] == p1[p] && p2[p + 1] == p2[p]);
         if (!twin) { delete m; return fail(MM_EBADBLOB, "a plane-box / plane-cylinder pair takes two consecutive entries of the PAIR_* sections"); }
       }
-      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane vs sphere/capsule/ellipsoid/cylinder/box, sphere/capsule among themselves, capsule vs ellipsoid/cylinder/box (geom1 type <= geom2 type)"); }
+      if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane vs sphere/capsule/ellipsoid/cylinder/box, sphere/capsule among themselves, sphere/capsule vs ellipsoid/cylinder/box (geom1 type <= geom2 type)"); }
       if (pc[p] != 1 && pc[p] != 3) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1 or 3"); }
     }
   }

@@ -228,6 +228,19 @@ def test_capsule_box_second_contact_and_convex_collider_contract(oracle_lib):
     d = _capsule_over_box(Y90, tuple(np.array([0.05, 0.03, top]) + (r - 1e-4) * cdir + np.array([0.03, 0, 0])), half=0.03)
     assert d.ncon == 1 and abs(d.con_dist[0] + 1e-4) < 1e-8
 
+    # a sphere against the three convex primitives = the capsule of zero length: one contact at the closest point
+    for gname, size, zc in (("box", (0.05, 0.03, 0.02), 0.02), ("cylinder", (0.03, 0.02), 0.02), ("ellipsoid", (0.05, 0.03, 0.02), 0.02)):
+        s_ = ModelSpec("sphcvx", timestep=0.002)
+        s_.add_geom("shape", "world", gname, size)
+        off = (0.0, 0.0) if gname == "ellipsoid" else (0.004, -0.003)
+        s_.add_body("b", pos=(off[0], off[1], zc + 0.01 - 1e-4), mass=0.1, inertia=(1e-5, 1e-5, 1e-5)); s_.add_joint("jb", "b", type="free")
+        s_.add_geom("ball", "b", "sphere", (0.01,))
+        s_.add_contact_pair("ball", "shape", condim=1)
+        cm_ = s_.compile()
+        d = O.OracleData(O.OracleModel(cm_)); d.forward()
+        assert d.ncon == 1 and d.warn == 0, gname
+        assert abs(d.con_dist[0] + 1e-4) < 1e-8
+        np.testing.assert_allclose(d.con_frame[0, :3], [0, 0, -1], atol=1e-7)
     # ---- (ii) capsule vs ellipsoid / cylinder: the convex collider's result contract
     def support_shape(gtype, size, R, x, n):
         nl = R.T @ n
@@ -491,6 +504,61 @@ def test_gpu_capsule_box_narrow_phase_matches_oracle_on_adversarial_poses(oracle
     assert mism.sum() <= n // 200, (int(mism.sum()), np.nonzero(mism)[0][:10], on[mism][:10], gn[mism][:10])
     assert rel[~mism].max() < 2e-3 and np.quantile(rel[~mism], 0.99) < 3e-4, (rel[~mism].max(), np.quantile(rel[~mism], 0.99))
     assert int(st.status.cpu().max()) & ~1 == 0
+
+
+@pytest.mark.gpu
+def test_gpu_sphere_vs_convex_primitives_matches_oracle(oracle_lib):
+    """sphere vs box / cylinder / ellipsoid (the zero-length capsule of the capsule-convex collider): 256 random ball positions around
+    each of three world-fixed shapes -- faces, edges, corners, caps, rims; touching, penetrating, just clear -- one forward pass,
+    row counts and constrained acceleration of every env against the oracle."""
+    import torch
+    from myosuite_amd import engine as E
+    s = ModelSpec("sphere_convex_toy", timestep=0.002)
+    shapes = (("box", (0.05, 0.03, 0.02)), ("cylinder", (0.03, 0.025)), ("ellipsoid", (0.05, 0.03, 0.02)))
+    for k, (gname, size) in enumerate(shapes):
+        s.add_geom(f"shape{k}", "world", gname, size, pos=(0.3 * k, 0.0, 0.0), quat=(0.9, 0.1 * k, -0.2, 0.3))
+    for k in range(3):
+        s.add_body(f"b{k}", pos=(0.3 * k, 0.0, 0.08), mass=0.1, inertia=(1e-5, 1e-5, 1e-5)); s.add_joint(f"j{k}", f"b{k}", type="free")
+        s.add_geom(f"ball{k}", f"b{k}", "sphere", (0.012,))
+        s.add_contact_pair(f"ball{k}", f"shape{k}", condim=3, margin=0.001)
+    cm = s.compile(); hm = E.HipModel(cm); om = O.OracleModel(cm)
+    rng = np.random.default_rng(4)
+    n = 256
+    q = np.tile(cm.qpos0.astype(np.float64), (n, 1))
+    for k, (gname, size) in enumerate(shapes):
+        # a point on / near the shape's surface in its own frame, pushed out along a random direction by r + gap
+        dirs = rng.standard_normal((n, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        ext = np.array(size if len(size) == 3 else (size[0], size[0], size[1]))
+        surf = dirs * ext * rng.uniform(0.9, 1.4, (n, 1))
+        gap = np.where(rng.random(n) < 0.6, 1.0, -1.0) * np.exp(rng.uniform(np.log(1e-5), np.log(1e-2), n))
+        d0 = O.OracleData(om); d0.forward()
+        R = d0.geom_xmat[cm.names["geom"][f"shape{k}"]].reshape(3, 3); xs = d0.geom_xpos[cm.names["geom"][f"shape{k}"]]
+        # project to the surface by the oracle's own signed distance (test hook), then offset
+        gt = {"box": 6, "cylinder": 5, "ellipsoid": 4}[gname]
+        for e in range(n):
+            p = surf[e].copy()
+            for _ in range(3):
+                sd, _, g = O.seg_shape(gt, ext if gt != 5 else np.array([size[0], size[1], 0.0]), p, np.array([0.0, 0.0, 1.0]), 0.0)
+                p = p - sd * g
+            sd, _, g = O.seg_shape(gt, ext if gt != 5 else np.array([size[0], size[1], 0.0]), p, np.array([0.0, 0.0, 1.0]), 0.0)
+            c = p + (0.012 + gap[e]) * g
+            q[e, 7 * k:7 * k + 3] = xs + R @ c
+    q32 = q.astype(np.float32); v = (0.2 * rng.standard_normal((n, cm.nv))).astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q32)); st.qvel.copy_(torch.from_numpy(v))
+    dv = E.Derived(hm, n, ["qacc", "nefc"])
+    E.forward(hm, st, None, dv)
+    torch.cuda.synchronize()
+    gn, ga = dv["nefc"].cpu().numpy(), dv["qacc"].cpu().numpy().astype(np.float64)
+    d = O.OracleData(om); on = np.zeros(n, int); rel = np.zeros(n)
+    for e in range(n):
+        d.qpos[:] = q32[e]; d.qvel[:] = v[e]; d.qacc_warmstart[:] = 0; d.forward()
+        on[e] = d.nefc; rel[e] = np.abs(ga[e] - d.qacc).max() / max(1.0, np.abs(d.qacc).max())
+        assert d.warn == 0
+    mism = on != gn
+    print(f"sphere-convex sweep: oracle row counts {({int(k_): int((on == k_).sum()) for k_ in np.unique(on)})}, mismatches {int(mism.sum())}, rel |dqacc| max {rel[~mism].max():.1e}")
+    assert {4, 8, 12} <= set(on.tolist()) and (on < 12).sum() >= n // 4 and mism.sum() <= 2 and rel[~mism].max() < 2e-3
+    assert int(st.status.cpu().max()) == 0
 
 
 def test_friction_loss_rows_oracle(oracle_lib):
