@@ -436,8 +436,8 @@ def ppo_training_lines():
                           # committed curves (benchmarks/ppo_rollout.py --curve, 1000 iterations) and asserted on the hand by
                           # tests/test_gpu_parity.py::test_ppo_learns_on_the_baseline_hand_workload
                           "mean_reward_per_step_first_last_of_this_sample": [r0, float(ppo.mean_reward)],
-                          "learning_curve": {"myoHandPoseRandom-v0": "profiles/r05_ppo_curve_hand4096.json: mean reward per step -3.65 -> -3.31 (200 it.) -> -2.94 (1000 it., 41 M env-steps)",
-                                             "myoFatiLegWalk-v0": "profiles/r05_ppo_curve_fatileg1024.json: 2.27 -> 7.85 reward per step, mean episode length 38 -> 62 steps (1000 it., 10 M env-steps)"}[env_id]})
+                          "learning_curve": {"myoHandPoseRandom-v0": "profiles/r05_ppo_curve_hand4096.json: mean reward per step -3.65 -> -3.39 (200 it.) -> -2.97 (1000 it., 41 M env-steps)",
+                                             "myoFatiLegWalk-v0": "profiles/r05_ppo_curve_fatileg1024.json: 2.27 -> 9.13 reward per step, mean episode length 38 -> 128 steps (1000 it., 10 M env-steps)"}[env_id]})
             del ppo, env
         except Exception as exc:          # never takes the headline line down
             lines.append({"key": f"ppo|{env_id}@{ne}", "error": repr(exc)})

@@ -86,10 +86,16 @@ int mm_ppo_store(const float* rwd, int rwd_cols, int rwd_col, float reward_scale
 
 /* Gradient of one minibatch: rows idx[0..mb) (int64) of the flattened unroll buffers obs [B][obs_dim], raw [B][act_dim],
  * logp_old / adv / ret [B].  loss = -mean(min(r A, clip(r, 1 -+ eps) A)) - entropy_cost mean(H) + value_cost mean((V - ret)^2),
- * r = exp(logp - logp_old).  grad_out [param_count] is overwritten; the sum of its squares is left in the workspace for
+ * r = exp(logp - logp_old); H = the pre-squash normal's entropy (+ the squash term when mm_ppo_set_entropy_noise gave draws).  grad_out [param_count] is overwritten; the sum of its squares is left in the workspace for
  * mm_ppo_adam.  Two launches (partials, ordered reduction). */
 int mm_ppo_grad(mm_ppo* h, const float* params, const float* obs, const float* obs_mean, const float* obs_std, const int64_t* idx,
                 int mb, const float* raw, const float* logp_old, const float* adv, const float* ret, float* grad_out, void* stream);
+
+/* brax's NormalTanhDistribution.entropy = entropy of the pre-squash normal + log|d squash / d x| at a reparametrised sample
+ * x = mean + std e.  `noise` = standard-normal draws e, [B][act_dim], row-indexed like `raw` (the caller refreshes them as it likes;
+ * they must not depend on the parameters); NULL (the default) = pre-squash entropy only.  The pointer is kept in the handle and
+ * read by every following mm_ppo_grad. */
+int mm_ppo_set_entropy_noise(mm_ppo* h, const float* noise);
 
 /* params -= Adam(clip_by_global_norm(grad * grad_scale)).  recompute_norm != 0: the gradient was modified after mm_ppo_grad
  * (data-parallel all-reduce; grad_scale = 1 / world), its norm is recomputed first (one more launch). */

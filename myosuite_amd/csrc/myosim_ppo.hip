@@ -49,7 +49,7 @@ struct NetD {
   int w[MM_PPO_MAX_LAYERS], woff[MM_PPO_MAX_LAYERS], boff[MM_PPO_MAX_LAYERS];
   int ldx, ldh, ldo, total;
   int ldz[MM_PPO_MAX_LAYERS], oZ[MM_PPO_MAX_LAYERS], oA[MM_PPO_MAX_LAYERS];   // hidden layer l: pre-activations Z, activations A = swish(Z)
-  int oX, oOUT, oD0, oD1, oAUX, pad2_;          // oAUX: S x act_dim raw actions of the policy's loss stage
+  int oX, oOUT, oD0, oD1, oAUX, pad2_;          // oAUX: S x act_dim raw actions + S x act_dim entropy-sample noise of the policy's loss stage
 };
 
 #ifndef MM_PPO_PROF
@@ -286,6 +286,7 @@ __device__ __forceinline__ void backward(const NetD* d, float* L, const float* _
 struct GradArgs {
   const float* P; const float* obs; const float* mean; const float* sd; const long long* idx;
   const float* raw; const float* lold; const float* adv; const float* ret;
+  const float* enoise;      // [B][act_dim] standard-normal draws for the entropy's log-det-Jacobian sample, or null (pre-squash entropy only)
   float* part_pi; float* part_vf;
   const NetD* dpi; const NetD* dvf;
   int mb, od, ad, nb_pi, voff, squash;
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_grad(GradArgs a) {
   PPROF(1);
   const NetD* d = &sdesc;
   float* s_raw = L + d->oAUX;
+  float* s_eps = s_raw + S * a.ad;      // noise rows of the entropy's log-det-Jacobian sample (a.enoise)
   const float* Pn = a.P + (is_pi ? 0 : a.voff);
   const int cnt = min(S, a.mb - b * S);
   const long long* idx = a.idx + (size_t)b * S;
@@ -326,6 +328,12 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_grad(GradArgs a) {
       for (int u = 0; u < 16 * RT; u++) r[u] = u < cnt ? a.raw[(size_t)rows[u] * ad + q] : 0.f;
 #pragma unroll
       for (int u = 0; u < 16 * RT; u++) s_raw[u * ad + q] = r[u];
+      if (a.enoise) {
+#pragma unroll
+        for (int u = 0; u < 16 * RT; u++) r[u] = u < cnt ? a.enoise[(size_t)rows[u] * ad + q] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16 * RT; u++) s_eps[u * ad + q] = r[u];
+      }
     }
     if ((int)threadIdx.x < cnt) { s_old[threadIdx.x] = a.lold[rows[threadIdx.x]]; s_adv[threadIdx.x] = a.adv[rows[threadIdx.x]]; }
   } else if ((int)threadIdx.x < cnt) {
@@ -362,7 +370,16 @@ __global__ __launch_bounds__(NTHREADS) void k_ppo_grad(GradArgs a) {
         const float m = O[s * ldo + q], o = O[s * ldo + ad + q], sd = softplus_(o) + 1e-3f, r = s_raw[s * ad + q];
         const float isd = 1.f / sd, z = (r - m) * isd;
         dm = glp * z * isd;
-        dro = (glp * (z * z * isd - isd) - a.entc * inv_mb * isd) * dsoftplus_(o);
+        float dsd = glp * (z * z * isd - isd) - a.entc * inv_mb * isd;
+        if (a.enoise) {
+          // brax NormalTanhDistribution.entropy: + log|d squash / d x| at a reparametrised sample x = m + sd e; d/dx = -2 tanh(x)
+          // (tanh) or 1 - 2 sigma(x) (sigmoid squashing)
+          const float e = s_eps[s * ad + q], x = m + sd * e;
+          const float dl = a.squash == MM_PPO_SQUASH_TANH ? -2.f * tanhf(x) : 1.f - 2.f / (1.f + expf(-x));
+          dm -= a.entc * inv_mb * dl;
+          dsd -= a.entc * inv_mb * dl * e;
+        }
+        dro = dsd * dsoftplus_(o);
       }
       O[s * ldo + q] = dm;
       O[s * ldo + ad + q] = dro;
@@ -549,6 +566,7 @@ struct mm_ppo {
   int nb_max = 0;
   float *m1 = nullptr, *m2 = nullptr, *blocksq = nullptr, *step = nullptr;   // step: [0] update counter, [1] the finished-workgroup counter of k_ppo_adam
   int nbq = 0;
+  const float* ent_noise = nullptr;   // mm_ppo_set_entropy_noise: [B][act_dim] draws for the entropy's squash log-det-Jacobian sample, or null
 };
 
 extern "C" const char* mm_ppo_last_error(void) { return g_perr.c_str(); }
@@ -593,7 +611,7 @@ extern "C" int mm_ppo_create(const mm_ppo_config* c, int device, mm_ppo** out) {
   int rc;
   for (int r = 0; r < 2; r++) {
     if ((rc = fill_net(h->net[0][r], c->obs_dim, c->pi_layers, c->pi_widths, "policy")) || (rc = fill_net(h->net[1][r], c->obs_dim, c->vf_layers, c->vf_widths, "value"))) { delete h; return rc; }
-    plan(h->net[0][r], 16 * (r + 1), c->act_dim); plan(h->net[1][r], 16 * (r + 1), 0);
+    plan(h->net[0][r], 16 * (r + 1), 2 * c->act_dim); plan(h->net[1][r], 16 * (r + 1), 0);      // raw actions + the entropy sample's noise rows
     h->lds[r] = sizeof(float) * (size_t)std::max(h->net[0][r].total, h->net[1][r].total);
   }
   h->np_pi = h->net[0][0].npar; h->np_vf = h->net[1][0].npar; h->np = h->np_pi + h->np_vf;
@@ -684,7 +702,7 @@ extern "C" int mm_ppo_grad(mm_ppo* h, const float* params, const float* obs, con
   const int rt = pick_rt(h, mb), S = 16 * rt, nb = (mb + S - 1) / S;
   float* part_pi = h->part;
   float* part_vf = h->part + (size_t)h->nb_max * h->np_pi;
-  GradArgs a{params, obs, obs_mean, obs_std, (const long long*)idx, raw, logp_old, adv, ret, part_pi, part_vf,
+  GradArgs a{params, obs, obs_mean, obs_std, (const long long*)idx, raw, logp_old, adv, ret, h->ent_noise, part_pi, part_vf,
              h->dnet + (rt - 1), h->dnet + 2 + (rt - 1), mb, h->cfg.obs_dim, h->cfg.act_dim, nb, h->np_pi, h->cfg.squash,
              h->cfg.clipping_epsilon, h->cfg.entropy_cost, h->cfg.value_cost};
   if (rt == 2) hipLaunchKernelGGL(k_ppo_grad<2>, dim3(2 * nb), dim3(NTHREADS), h->lds[1], (hipStream_t)stream, a);
@@ -693,6 +711,12 @@ extern "C" int mm_ppo_grad(mm_ppo* h, const float* params, const float* obs, con
   hipLaunchKernelGGL(k_ppo_reduce, dim3(h->nbq), dim3(NTHREADS), 0, (hipStream_t)stream, part_pi, nb, h->np_pi, part_vf, nb, h->np_vf, grad_out,
                      h->blocksq);
   PHIPCHK(hipGetLastError());
+  return MM_OK;
+}
+
+extern "C" int mm_ppo_set_entropy_noise(mm_ppo* h, const float* noise) {
+  if (!h) return pfail(MM_EARG, "mm_ppo_set_entropy_noise: null handle");
+  h->ent_noise = noise;
   return MM_OK;
 }
 

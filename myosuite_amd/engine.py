@@ -269,6 +269,7 @@ def lib():
                                    C.c_void_p, C.c_void_p]
         L.mm_ppo_grad.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 6
         L.mm_ppo_adam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.mm_ppo_set_entropy_noise.argtypes = [C.c_void_p, C.c_void_p]
         # the binding restates the header's structs: refuse a library built from another ABI or with other struct layouts
         L.mm_struct_size.argtypes = [C.c_int]
         if L.mm_abi_version() != MM_ABI_VERSION:
@@ -671,6 +672,14 @@ class FusedPPO:
         self._f32(grad_out, (self.param_count,))
         self._chk(lib().mm_ppo_grad(self.h, _ptr(params), _ptr(obs), _ptr(obs_mean), _ptr(obs_std), idx.data_ptr(), int(idx.numel()), _ptr(raw),
                                     _ptr(logp_old), _ptr(adv), _ptr(ret), _ptr(grad_out), _stream(obs.device)), "mm_ppo_grad")
+
+    def set_entropy_noise(self, noise: Optional[torch.Tensor]):
+        """[B, act_dim] standard-normal draws for the entropy's squash log-det-Jacobian sample (brax NormalTanhDistribution.entropy),
+        row-indexed like `raw`; None = pre-squash entropy only.  The tensor must stay alive while gradients are taken."""
+        if noise is not None:
+            self._f32(noise); assert noise.shape[-1] == self.act_dim
+        self._ent_noise = noise
+        self._chk(lib().mm_ppo_set_entropy_noise(self.h, _ptr(noise)), "mm_ppo_set_entropy_noise")
 
     def adam(self, params, grad, grad_scale: float = 1.0, recompute_norm: bool = False):
         self._f32(params, (self.param_count,)); self._f32(grad, (self.param_count,))

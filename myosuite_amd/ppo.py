@@ -11,12 +11,12 @@ a 6.4 M env-steps/s hand).  Here one training iteration is TWO HIP graphs:
 * ``update``: one pass over the batch -- a device-side permutation, then for every minibatch gather, forward, clipped-surrogate /
   value / entropy losses, backward, global-norm clipping and a capturable Adam step.
 
-Deviations from brax's PPO, stated: (i) the entropy bonus is the entropy of the PRE-squash normal (`sum(0.5 + 0.5 log 2 pi + log std)`);
-brax's NormalTanhDistribution.entropy adds the squashing log-det-Jacobian of a fresh sample, which also feeds gradient into the mean --
-at entropy_cost 1e-2..1e-3 a small shaping term, left out in both learners (torch and fused) so that they stay each other's checker;
-(ii) advantages are normalised per rank over the whole batch once per iteration (brax: per minibatch, per device); (iii) GAE, the
-clipped surrogate, the value loss 0.5 * 0.5 * mse, global-norm clipping and Adam follow brax term by term (mm_gae: compute_gae with
-its truncation masks).
+What follows brax's PPO term by term: GAE (mm_gae = compute_gae with its truncation masks), the clipped surrogate, the value loss
+0.5 * 0.5 * mse, global-norm clipping, Adam, and -- since the end of round 5 -- the entropy bonus of NormalTanhDistribution: the
+pre-squash normal's entropy PLUS the squashing log-det-Jacobian at a reparametrised sample x = mean + std e, which also feeds
+gradient into the mean (`PPOConfig.entropy_squash_term`; e is drawn once per iteration per sample, brax draws per loss call; both
+learners, torch and fused, implement it and check each other).  Deviation, stated: advantages are normalised per rank over the
+whole batch once per iteration (brax: per minibatch, per device).
 
 Data parallel (one process per GPU): the running observation statistics are merged over ALL ranks' rows (one small all-reduce per
 iteration: `_Norm.update(world=...)`), so the normaliser -- part of the policy and value function -- is identical on every rank; parameters and gradients live in ONE flat buffer each, so the exchange is a single
@@ -54,6 +54,7 @@ class PPOConfig:
     value_hidden: Tuple[int, ...] = (64, 64, 64)
     squash: str = "tanh"                          # "tanh": brax NormalTanhDistribution, actions in [-1, 1]; "sigmoid": excitations in [0, 1]
     unrolls: int = 1                              # unrolls of `unroll_length` per iteration (brax: batch_size * num_minibatches // num_envs)
+    entropy_squash_term: bool = True              # brax NormalTanhDistribution.entropy: + log|d squash / d x| at a reparametrised sample
 
 
 def _mlp(sizes):
@@ -152,6 +153,10 @@ class OnDevicePPO:
             raise E.EngineError("fused PPO kernels need a HIP device")
         self.opt = None if self.kern else torch.optim.Adam(self.params, lr=cfg.learning_rate, capturable=True, foreach=True)
         self.noise = torch.zeros(T, n, ad, dtype=torch.float32, device=dev) if self.kern else None
+        # draws of the entropy term's reparametrised sample (refreshed once per iteration inside the rollout graph)
+        self.ent_noise = torch.zeros(T, n, ad, dtype=torch.float32, device=dev) if cfg.entropy_squash_term else None
+        if self.kern and self.ent_noise is not None:
+            self.kern.set_entropy_noise(self.ent_noise.view(T * n, ad))
         self.norm = _Norm(od, dev) if cfg.normalize_observations else None
         f = dict(dtype=torch.float32, device=dev)
         self.obs_b = torch.zeros(T, n, od, **f); self.act_b = torch.zeros(T, n, ad, **f); self.logp_b = torch.zeros(T, n, **f)
@@ -220,6 +225,8 @@ class OnDevicePPO:
             if self.norm and self.world == 1:
                 self.norm.update(self.obs_b)       # (world > 1: iterate() merges every rank's batch, outside the graph)
             self.mean_reward.copy_(self.rew_b.mean())
+            if self.ent_noise is not None:
+                self.ent_noise.normal_()
 
     def _minibatch_backward(self, idx):
         """gradients of one minibatch into the flat gradient buffer.  The policy and the value network share nothing but the
@@ -246,7 +253,12 @@ class OnDevicePPO:
         ratio = (self._logp(mean, std, raw) - old).exp()
         eps = cfg.clipping_epsilon
         pg = -torch.min(ratio * adv, ratio.clamp(1 - eps, 1 + eps) * adv).mean()
-        ent = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)).sum(-1).mean()     # entropy of the pre-squash normal
+        ent = (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)).sum(-1)            # entropy of the pre-squash normal ...
+        if self.ent_noise is not None:      # ... + log|d squash / d x| at x = mean + std e (brax NormalTanhDistribution.entropy)
+            x = mean + std * self.ent_noise.reshape(B, -1).index_select(0, idx)
+            ldj = 2.0 * (math.log(2.0) - x - F.softplus(-2.0 * x)) if cfg.squash == "tanh" else (-F.softplus(-x) - F.softplus(x))
+            ent = ent + ldj.sum(-1)
+        ent = ent.mean()
         (pg - cfg.entropy_cost * ent).backward()
         cur.wait_stream(self._side)
 

@@ -561,8 +561,8 @@ def test_ppo_learns_on_the_baseline_hand_workload(tmp_path):
     """learning shown on a BASELINE workload, not only the elbow -- benchmarks/ppo_rollout.py on myoHandPoseRandom-v0 at
     4096 envs, 200 iterations (8.2 M env-steps, the reference's ppo_config networks, fused learner kernels): the mean reward per step
     of the last 10-iteration window (10 iterations x 10-step unroll = one whole 100-step episode, so windows are free of episode
-    phase) beats the first window's.  Measured (profiles/r05_ppo_curve_hand4096.json): -3.65 -> -3.31 after 200 iterations,
-    -2.94 after 1000; fati-leg@1024 2.27 -> 7.85 with the mean episode length 38 -> 62 steps (profiles/r05_ppo_curve_fatileg1024.json)."""
+    phase) beats the first window's.  Measured (profiles/r05_ppo_curve_hand4096.json): -3.65 -> -3.39 after 200 iterations,
+    -2.97 after 1000; fati-leg@1024 2.27 -> 9.13 with the mean episode length 38 -> 128 steps (profiles/r05_ppo_curve_fatileg1024.json)."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     curve = tmp_path / "curve.json"

@@ -39,10 +39,11 @@ CONFIGS = [  # env id, envs, policy hidden, value hidden, squash, normalise, min
     ("myoElbowPose1D6MRandom-v0", 50, (32, 48), (16,), "sigmoid", False, 3, "16"),              # odd widths, ragged last workgroup, no normalisation
     ("myoElbowPose1D6MRandom-v0", 50, (32, 32, 32, 32), (128, 128), "sigmoid", True, 2, "32"),  # four hidden layers; the widest hidden the kernels take
     ("myoFatiLegWalk-v0", 40, (64, 64, 64), (64, 64, 64), "tanh", True, 2, None),               # obs 403 (not a multiple of 4: scalar weight loads), 160 outputs
+    ("myoElbowPose1D6MRandom-v0", 50, (32, 48), (16,), "tanh", True, 2, "16", False),           # entropy of the pre-squash normal only (no squash log-det term)
 ]
 
 
-def _make(env_id, n, ph, vh, squash, norm, nmb, samples, fused=None):
+def _make(env_id, n, ph, vh, squash, norm, nmb, samples, ent_squash=True, fused=None):
     from myosuite_amd.envs import registry
     from myosuite_amd.ppo import OnDevicePPO, PPOConfig
     if samples:
@@ -52,7 +53,7 @@ def _make(env_id, n, ph, vh, squash, norm, nmb, samples, fused=None):
     try:
         env = registry.make(env_id, num_envs=n, seed=5)
         cfg = PPOConfig(unroll_length=10, num_minibatches=nmb, num_updates_per_batch=2, policy_hidden=ph, value_hidden=vh, squash=squash,
-                        normalize_observations=norm, entropy_cost=1e-2, clipping_epsilon=0.2, max_grad_norm=0.5)
+                        normalize_observations=norm, entropy_cost=1e-2, clipping_epsilon=0.2, max_grad_norm=0.5, entropy_squash_term=ent_squash)
         return OnDevicePPO(env, cfg, seed=3, use_graphs=False, fused=fused)
     finally:
         os.environ.pop("MYOSIM_PPO_SAMPLES", None)
@@ -63,9 +64,12 @@ def _make(env_id, n, ph, vh, squash, norm, nmb, samples, fused=None):
 def test_fused_minibatch_gradient_matches_torch_autograd(cfg):
     """mm_ppo_grad (gather + normalise + policy / value forward + clipped surrogate / entropy / value losses + backward, MFMA tiles
     over LDS-resident activations) against loss.backward() of the torch restatement on the same minibatch of a real unroll, with the
-    parameters perturbed after the unroll so that ratios leave the clipping range on both sides."""
+    parameters perturbed after the unroll so that ratios leave the clipping range on both sides.  The entropy is brax's
+    NormalTanhDistribution.entropy (pre-squash normal + squash log-det-Jacobian at a reparametrised sample, both squashings) in all
+    configurations but the last, which keeps the pre-squash form."""
     ppo = _make(*cfg)
-    assert ppo.kern is not None
+    assert ppo.kern is not None and (ppo.ent_noise is not None) == (len(cfg) < 9 or cfg[8])
+
     ppo._rollout()                                                     # fills the unroll buffers through mm_ppo_act / mm_ppo_store
     torch.manual_seed(1)
     ppo.flat_p.add_(0.03 * torch.randn_like(ppo.flat_p))               # "after a few updates": ratios spread around 1
@@ -164,7 +168,7 @@ def test_fused_adam_matches_torch_clip_and_adam():
     b = _make(*cfg, fused=False)
     b.flat_p.copy_(a.flat_p)
     a._rollout()
-    for name in ("obs_b", "act_b", "logp_b", "nadv_b", "ret_b"):
+    for name in ("obs_b", "act_b", "logp_b", "nadv_b", "ret_b", "ent_noise"):
         getattr(b, name).copy_(getattr(a, name))
     B = a.T * a.n
     torch.manual_seed(2)
