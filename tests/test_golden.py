@@ -184,9 +184,22 @@ def test_oracle_matches_libmujoco_fixture(oracle_lib, path):
                 continue
             assert got.size == ref.size and np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), k
     assert d.nefc == int(g["f_nefc"])
+
+    def check_contacts(tag):
+        """the colliders against libmujoco's contact list (fixtures written since round 5): multiplicity, order, distance, position, normal"""
+        if f"k{tag}_ncon" not in g.files:
+            return
+        n = int(g[f"k{tag}_ncon"])
+        assert d.ncon == n and d.nefc == int(g[f"k{tag}_nefc"]), (tag, d.ncon, n)
+        if n:
+            np.testing.assert_allclose(d.con_dist[:n], g[f"k{tag}_dist"], atol=2e-6)          # (the convex collider's own tolerance is 1e-6)
+            np.testing.assert_allclose(d.con_pos[:n], g[f"k{tag}_pos"], atol=2e-6)
+            np.testing.assert_allclose(d.con_frame[:n, :3], g[f"k{tag}_normal"], atol=1e-5)
+    check_contacts(0)
     for s in range(g["ctrl"].shape[0]):
         d.ctrl[:] = g["ctrl"][s]; d.step()
         assert np.abs(d.qpos - g["t_qpos"][s]).max() < 1e-6 * max(1.0, np.abs(g["t_qpos"][s]).max()), s
+        check_contacts(s + 1)
 
 
 def test_libmujoco_validation_tool_round_trips_through_a_fake_mujoco(oracle_lib, tmp_path, monkeypatch, capsys):
@@ -210,8 +223,8 @@ def test_libmujoco_validation_tool_round_trips_through_a_fake_mujoco(oracle_lib,
         real_savez = np.savez_compressed
         monkeypatch.setattr(np, "savez_compressed", lambda path, **kw: (written.append(str(tmp_path / os.path.basename(path))),
                                                                            real_savez(str(tmp_path / os.path.basename(path)), **kw))[1])
-        for model in ("hand", "contact_toy"):
-            monkeypatch.setattr(sys, "argv", ["validate_against_mujoco.py", "--model", model, "--steps", "12", "--write-fixture"])
+        for model, nsteps in (("hand", 12), ("contact_toy", 12), ("plane_toy", 90)):      # plane_toy: every primitive collider, bodies fall into contact
+            monkeypatch.setattr(sys, "argv", ["validate_against_mujoco.py", "--model", model, "--steps", str(nsteps), "--write-fixture"])
             assert tool.main() == 0
             out = capsys.readouterr().out
             rep = json.loads(out[out.index("{"):out.rindex("}") + 1])
@@ -219,7 +232,10 @@ def test_libmujoco_validation_tool_round_trips_through_a_fake_mujoco(oracle_lib,
             assert max(rep["compile_constants_maxabs_diff"].values()) < 1e-6, rep["compile_constants_maxabs_diff"]
             assert all(v < 1e-9 for k, v in rep["forward_rel_diff"].items() if k != "nefc") and rep["forward_rel_diff"]["nefc"][0] == rep["forward_rel_diff"]["nefc"][1]
             assert rep["qpos_divergence"]["oracle_vs_mujoco"]["max"] < 1e-9
-        assert len(written) == 2 and all(os.path.exists(w) for w in written)
+        assert len(written) == 3 and all(os.path.exists(w) for w in written)
+        gp = np.load(written[2])          # the contact lists travel with the fixture (start / middle / end of the trajectory)
+        assert {"k0_ncon", "k45_ncon", "k90_ncon", "k90_dist", "k90_pos", "k90_normal", "k90_nefc"} <= set(gp.files)
+        assert int(gp["k90_ncon"]) >= 3 and gp["k90_pos"].shape == (int(gp["k90_ncon"]), 3)
         g = np.load(written[0])
         assert str(g["mujoco_version"]) == "fake-oracle" and g["t_qpos"].shape[0] == 12
         assert {"q0", "v0", "a0", "ctrl", "t_qpos", "model_hash", "f_qacc", "f_nefc", "c_meaninertia"} <= set(g.files)

@@ -43,8 +43,12 @@ class MjData:
         object.__setattr__(self, "_d", O.OracleData(model._om))
 
     def __getattr__(self, name):
-        if name == "nefc":
-            return self._d.nefc
+        if name in ("nefc", "ncon"):
+            return getattr(self._d, name)
+        if name == "contact":           # mjData.contact[i].dist / .pos / .frame (normal first), in detection order
+            d = self._d
+            return [types.SimpleNamespace(dist=float(d.con_dist[i]), pos=np.array(d.con_pos[i]), frame=np.array(d.con_frame[i]))
+                    for i in range(d.ncon)]
         return getattr(self._d, name)
 
 

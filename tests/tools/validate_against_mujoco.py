@@ -1,7 +1,7 @@
 """Pin the engine against libmujoco where it is available (NOT runnable in the authoring container or on
 the GPU boxes of this project: `mujoco` is not installed and there is no network).
 
-    python tests/tools/validate_against_mujoco.py [--write-fixture] [--model hand|elbow|leg|contact_toy|hand_reorient|hand_keyturn|friction_toy|tendon_limit_toy|finger|torso|... | --xml path.xml] [--steps 200] [--gpu]
+    python tests/tools/validate_against_mujoco.py [--write-fixture] [--model <any name of model/synth.py builders(): hand|elbow|leg|plane_toy|hand_reorient|hand_contact|...> | --xml path.xml] [--steps 200] [--gpu]
 
 1. writes the model as MJCF (`myosuite_amd.model.mjcf.dump`) or takes an MJCF file (e.g. the real myo_sim models) and imports it
    with `mjcf.load`;
@@ -12,7 +12,9 @@ the GPU boxes of this project: `mujoco` is not installed and there is no network
    mj_step calls: mujoco (fp64) vs oracle (fp64) vs, with --gpu, the HIP engine (fp32).
 The report is what would turn "PARITY UNPINNED"  into pinned parity.
 4. --write-fixture stores what libmujoco computed -- compile-time constants, every per-stage field of one mj_forward, a
-   `--steps`-step (qpos, qvel, act) trajectory and the ctrl stream -- as tests/golden/mujoco_<model>.npz.  Committed, that file
+   `--steps`-step (qpos, qvel, act) trajectory, the ctrl stream and (round 5) libmujoco's CONTACT LIST (count, distance, position,
+   normal, in detection order) at the start, the middle and the end of the trajectory: `--model plane_toy` pins every primitive
+   collider incl. mjc_CapsuleBox's one-or-two contacts -- as tests/golden/mujoco_<model>.npz.  Committed, that file
    makes tests/test_golden.py::test_oracle_matches_libmujoco_fixture (CPU) and
    tests/test_gpu_parity.py::test_hip_matches_libmujoco_fixture (GPU) run against libmujoco's numbers on hosts WITHOUT mujoco:
    one run by anyone who has `pip install mujoco` flips the engine rows of the scope table from "unpinned" to pinned.
@@ -52,11 +54,7 @@ def main():
         path = args.xml
         spec = mjcf.load(path)
     else:
-        spec = {"elbow": synth.make_elbow, "hand": synth.make_hand, "leg": synth.make_leg, "contact_toy": synth.make_contact_toy,
-                "hand_reorient": synth.make_hand_reorient, "hand_pen": synth.make_hand_pen, "hand_hold": synth.make_hand_hold,
-                "hand_keyturn": synth.make_hand_keyturn, "friction_toy": synth.make_friction_toy,
-                "tendon_limit_toy": synth.make_tendon_limit_toy, "finger": synth.make_finger, "torso": synth.make_torso,
-                "elbow_exo": synth.make_elbow_exo}[args.model]()
+        spec = synth.builders()[args.model]()        # every synthetic model: incl. plane_toy (all primitive colliders, mjc_CapsuleBox), hand_contact, leg_implicit
         path = os.path.join(tempfile.mkdtemp(), f"{args.model}.xml")
         open(path, "w").write(mjcf.dump(spec))
         # everything below uses the model AS IMPORTED FROM THE XML libmujoco reads: MuJoCo numbers sites / geoms / tendons in
@@ -96,6 +94,17 @@ def main():
         for f in FORWARD_FIELDS:
             fix["f_" + f] = np.array(getattr(mjd, f)).copy()
         fix["f_nefc"] = np.array(int(mjd.nefc))
+
+    def contacts(tag):
+        """the contact list libmujoco holds right now (detection order): pins the colliders -- multiplicity, distance, position, normal"""
+        n = int(mjd.ncon)
+        fix[f"k{tag}_ncon"] = np.array(n)
+        fix[f"k{tag}_dist"] = np.array([mjd.contact[i].dist for i in range(n)], float)
+        fix[f"k{tag}_pos"] = np.array([np.array(mjd.contact[i].pos) for i in range(n)], float).reshape(n, 3)
+        fix[f"k{tag}_normal"] = np.array([np.array(mjd.contact[i].frame)[:3] for i in range(n)], float).reshape(n, 3)
+        fix[f"k{tag}_nefc"] = np.array(int(mjd.nefc))
+    if fix is not None:
+        contacts(0)
     fw = {}
     for ours, theirs in (("xpos", "xpos"), ("ten_length", "ten_length"), ("actuator_force", "actuator_force"),
                          ("qfrc_bias", "qfrc_bias"), ("qacc_smooth", "qacc_smooth"), ("qacc", "qacc")):
@@ -117,6 +126,9 @@ def main():
         mjd.ctrl[:] = ctrl[s]; d.ctrl[:] = ctrl[s]
         mujoco.mj_step(mjm, mjd); d.step()
         traj["qpos"].append(np.array(mjd.qpos)); traj["qvel"].append(np.array(mjd.qvel)); traj["act"].append(np.array(mjd.act))
+        if fix is not None and s + 1 in (args.steps // 2, args.steps):
+            # (mj_step leaves the contacts of the state it STARTED from: the readers compare after the same call)
+            contacts(s + 1)
         div["oracle_vs_mujoco"].append(float(np.abs(d.qpos - mjd.qpos).max()))
         if hip:
             hm, st, E, torch = hip
