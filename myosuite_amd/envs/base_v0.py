@@ -94,6 +94,12 @@ class BaseV0:
         if cm.na > 0 and "act" not in obs_keys:       # base_v0.py:33-37
             obs_keys = list(obs_keys) + ["act"]
         self.obs_keys = list(obs_keys)
+        # the fused launch writes the task's DEFAULT key order (ObsVecDict.obsdict2obsvec over the class's DEFAULT_OBS_KEYS + "act",
+        # obs_vec_dict.py:76-88); a caller's own `obs_keys` (a subset / another order / "time": env_base.py:208-218 takes any key
+        # of obs_dict) is served by step() / reset() as the concatenation of the obs_dict entries it names (_obs_out)
+        self._kernel_obs_keys = list(type(self).DEFAULT_OBS_KEYS) + (["act"] if cm.na > 0 and "act" not in type(self).DEFAULT_OBS_KEYS else [])
+        self._custom_obs = self.obs_keys != self._kernel_obs_keys
+        self._custom_obs_ready = False
         self.rwd_keys_wt = dict(weighted_reward_keys)
         self.rwd_mode = reward_mode
         self.frame_skip = int(frame_skip)
@@ -241,6 +247,22 @@ class BaseV0:
         return t
 
     # ------------------------------------------------------------------ step (env_base.py:377-407, base_v0.py:82-118)
+    def _obs_out(self) -> torch.Tensor:
+        """the observation vector step() / reset() hand out: the kernel's buffer for the task's default keys, else the caller's
+        `obs_keys` gathered from obs_dict (as the reference's obsdict2obsvec does over ITS obs_keys)"""
+        if not self._custom_obs:
+            return self.obs
+        n = self.num_envs
+        missing = [k for k in self.obs_keys if k not in self.obs_dict]
+        if missing:
+            raise KeyError(f"obs_keys {missing} are not keys of this task's obs_dict {list(self.obs_dict)}")
+        out = torch.cat([self.obs_dict[k].reshape(n, -1).to(torch.float32) for k in self.obs_keys], dim=1)
+        if not self._custom_obs_ready:
+            self.kernel_obs_dim, self.obs_dim = self.obs_dim, int(out.shape[1])
+            self.observation_space = Box(self._obs_range[0] * np.ones(self.obs_dim), self._obs_range[1] * np.ones(self.obs_dim), dtype=np.float32)
+            self._custom_obs_ready = True
+        return out
+
     def step(self, a, **kwargs):
         """One fused kernel launch: ctrl map / fatigue, frame_skip x mj_step, final forward, task obs + reward; then the
         masked auto-reset (always enqueued, no host sync; a no-op for envs that continue).  Subclasses provide
@@ -256,14 +278,14 @@ class BaseV0:
         terminated = self.done.bool()
         truncated = self.truncated.bool() & ~terminated
         info = self.get_env_infos()
-        obs = self.obs
+        obs = self._obs_out()
         if self.autoreset:
             # info describes the step that just ended (its obs_dict views would otherwise show the post-reset observation of
             # finished envs): snapshot before the masked reset rewrites self.obs
             info["final_obs"] = obs.clone()
             info["obs_dict"] = collections.OrderedDict((k, v.clone()) for k, v in self.obs_dict.items())
             self.reset(mask=(self.done | self.truncated))
-            obs = self.obs
+            obs = self._obs_out()
         return obs, reward, terminated, truncated, info
 
     # ------------------------------------------------------------------ rollout step (one launch)
@@ -300,6 +322,9 @@ class BaseV0:
         launch for the Pose family (action ~ U[0,1) drawn in the kernel when `action` is None, benchmarks/mjx_benchmark.py:29),
         one more (the task's masked reset) for the others.  Returns (obs, reward_row_view, reset_mask): obs holds the first
         observation of the new episode for re-armed envs; views are rewritten by the next call."""
+        if self._custom_obs:
+            raise NotImplementedError("rollout_step / the on-device PPO read the kernel's observation buffer (the task's default obs_keys); "
+                                      "custom obs_keys are served by step() / reset()")
         ro = self._ro
         sig = self._rollout_signature()
         if sig != self._ro_sig:

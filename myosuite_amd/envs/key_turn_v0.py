@@ -103,4 +103,4 @@ class KeyTurnEnvV0(BaseV0):
             self.step_count.masked_fill_(m, 0)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

@@ -85,4 +85,4 @@ class ObjHoldEnvV0(BaseV0):
                         (0.020, 0.030) if self.randomize else None, self.goal, self.episode, self.step_count, self._seed_u64)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

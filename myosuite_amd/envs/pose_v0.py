@@ -143,7 +143,7 @@ class PoseEnvV0(BaseV0):
     def get_obs(self):
         """Observation vector of the current state without stepping (mm_forward-free: Pose needs none)."""
         d = self.get_obs_dict()
-        return torch.cat([d[k].reshape(self.num_envs, -1) for k in self.obs_keys], dim=1).to(torch.float32)
+        return torch.cat([d[k].reshape(self.num_envs, -1) for k in self._kernel_obs_keys], dim=1).to(torch.float32)
 
     # ------------------------------------------------------------------ reset (pose_v0.py:174-257)
     def reset(self, seed=None, mask: Optional[torch.Tensor] = None, reset_qpos=None, reset_qvel=None, **kwargs):
@@ -200,4 +200,4 @@ class PoseEnvV0(BaseV0):
             self.obs.copy_(self.get_obs()) if mask is None else self.obs.copy_(
                 torch.where(mask.bool()[:, None], self.get_obs(), self.obs))
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

@@ -96,4 +96,4 @@ class ReachEnvV0(BaseV0):
         E.reach_reset(self.hm, self.state, mask, self._tlo, self._thi, self.target_pos, self._tip0, self.ntip,
                       self.episode, self.step_count, self._seed_u64, obs=self.obs)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

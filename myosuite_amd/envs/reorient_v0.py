@@ -114,7 +114,7 @@ class ReorientEnvV0(BaseV0):
                                self.des_rot, self.tar_length, self.episode, self.step_count, self._seed_u64)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}
 
 
 class PenTwirlEnvV0(ReorientEnvV0):
@@ -169,4 +169,4 @@ class PenTwirlEnvV0(ReorientEnvV0):
                     self.episode, self.step_count, self._seed_u64)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

@@ -112,4 +112,4 @@ class StandEnvV0(BaseV0):
             self.episode += m.to(torch.int32); self.step_count.masked_fill_(m, 0)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

@@ -124,4 +124,4 @@ class WalkEnvV0(BaseV0):
                          self.step_count, self._seed_u64)
         E.reset_observation(self.hm, self.state, self._task, mask)
         self._refresh_dicts()
-        return self.obs, {}
+        return self._obs_out(), {}

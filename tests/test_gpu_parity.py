@@ -576,6 +576,31 @@ def test_ppo_learns_on_the_baseline_hand_workload(tmp_path):
     assert sum(b["mean_reward_per_step"] > a["mean_reward_per_step"] for a, b in zip(w[:-1], w[1:])) >= 14      # a trend, not one lucky window
 
 
+@pytest.mark.gpu
+def test_custom_obs_keys_are_served_from_obs_dict_like_obsdict2obsvec():
+    """`obs_keys=` is a kwarg of every reference task (env_base.py:208-218 builds the vector from whatever keys it names,
+    obs_vec_dict.py:76-88).  The fused launch writes the task's DEFAULT order; a caller's own subset / order / "time" comes back
+    from step() and reset() as the concatenation of the named obs_dict entries ("act" appended as BaseV0 does, base_v0.py:33-37),
+    observation_space follows, and the paths that read the kernel's buffer directly refuse instead of returning another layout."""
+    n = 16
+    ref = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=2, autoreset=False)
+    env = registry.make("myoHandPoseRandom-v0", num_envs=n, seed=2, autoreset=False, obs_keys=["pose_err", "time", "qvel"])
+    assert env.obs_keys == ["pose_err", "time", "qvel", "act"] and ref.obs_keys == ["qpos", "qvel", "pose_err", "act"]
+    o_ref, _ = ref.reset(seed=2); o, _ = env.reset(seed=2)
+    nq, nv, na = ref.cm.nq, ref.cm.nv, ref.cm.na
+    assert o.shape == (n, nq + 1 + nv + na) and env.obs_dim == nq + 1 + nv + na and env.observation_space.shape == (env.obs_dim,)
+    a = torch.rand(n, ref.cm.nu, device="cuda")
+    for _ in range(3):
+        o_ref, r_ref, *_ = ref.step(a); o, r, *_ = env.step(a)
+    assert torch.equal(r, r_ref)                                               # same physics, same reward
+    want = torch.cat([o_ref[:, nq + nv:2 * nq + nv], ref.state.time[:, None], o_ref[:, nq:nq + nv], o_ref[:, 2 * nq + nv:]], 1)
+    assert torch.equal(o, want) and float(o[:, nq].min()) > 0                  # pose_err | time | qvel dt | act
+    with pytest.raises(NotImplementedError):
+        env.rollout_setup(); env.rollout_step(None)
+    with pytest.raises(KeyError):
+        registry.make("myoHandPoseRandom-v0", num_envs=2, obs_keys=["qpos", "no_such_key"])
+
+
 def test_mjx_make_registry_names():
     from myosuite_amd import mjx_api
     for name, obs in (("MjxElbowPoseRandom-v0", 1 + 1 + 6 + 1), ("MjxFingerPoseFixed-v0", 4 + 4 + 5 + 4), ("MjxHandReachRandom-v0", 23 + 23 + 39 + 30)):
