@@ -247,6 +247,13 @@ class BaseV0:
         return t
 
     # ------------------------------------------------------------------ step (env_base.py:377-407, base_v0.py:82-118)
+    def _check_reward_keys(self, supported):
+        """weighted_reward_keys may re-weight or drop the task's reward terms; a key the fused launch does not sum (the reference
+        would add ANY key of rwd_dict, env_base.py:440-446) is refused instead of being silently left out of `dense`"""
+        unknown = [k for k, wt in self.rwd_keys_wt.items() if k not in supported and float(wt) != 0.0]
+        if unknown:
+            raise NotImplementedError(f"weighted_reward_keys {unknown}: the launch sums {list(supported)} for this task")
+
     def _obs_out(self) -> torch.Tensor:
         """the observation vector step() / reset() hand out: the kernel's buffer for the task's default keys, else the caller's
         `obs_keys` gathered from obs_dict (as the reference's obsdict2obsvec does over ITS obs_keys)"""

@@ -62,6 +62,7 @@ class KeyTurnEnvV0(BaseV0):
         t = self._new_task(E.MM_TASK_KEYTURN)
         t.tip_sites = self._sites.data_ptr(); t.ntip = 3
         t.key_goal_th = self.goal_th
+        self._check_reward_keys(("key_turn", "IFtip_approach", "THtip_approach", "act_reg", "bonus", "penalty"))
         for i, k in enumerate(("key_turn", "IFtip_approach", "THtip_approach", "act_reg", "bonus", "penalty")):
             t.key_w[i] = float(w.get(k, 0.0))
         self._task = t

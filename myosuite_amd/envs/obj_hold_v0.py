@@ -55,6 +55,7 @@ class ObjHoldEnvV0(BaseV0):
                                      dtype=np.float32)
         w = self.rwd_keys_wt
         t = self._new_task(E.MM_TASK_OBJHOLD)
+        self._check_reward_keys(("goal_dist", "bonus", "act_reg", "penalty"))
         t.w_pose = float(w.get("goal_dist", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
         t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
         t.tip_sites = self._obj_site.data_ptr(); t.ntip = 1; t.target_pos = self.goal.data_ptr()

@@ -75,6 +75,7 @@ class PoseEnvV0(BaseV0):
         w = self.rwd_keys_wt
         t = self._new_task(E.MM_TASK_POSE, do_forward)
         t.pose_thd = self.pose_thd; t.far_th = self.FAR_TH
+        self._check_reward_keys(("pose", "bonus", "act_reg", "penalty"))
         t.w_pose = float(w.get("pose", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
         t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
         t.target_jnt_value = self.target_jnt_value.data_ptr()

@@ -60,6 +60,7 @@ class ReorientEnvV0(BaseV0):
         t = self._new_task(E.MM_TASK_REORIENT)
         t.reor_obj_body = cm.body_id("Object"); t.reor_eps_site = cm.site_id("eps_ball"); t.reor_pen_length = self.pen_length
         t.reor_axis_half = self.axis_half.data_ptr(); t.reor_des_rot = self.des_rot.data_ptr()
+        self._check_reward_keys(("pos_align", "rot_align", "act_reg", "drop", "bonus"))
         for i, k in enumerate(("pos_align", "rot_align", "act_reg", "drop", "bonus")):
             t.reor_w[i] = float(w.get(k, 0.0))
         t.reor_obs_muscle = 1
@@ -147,6 +148,7 @@ class PenTwirlEnvV0(ReorientEnvV0):
         t = self._new_task(E.MM_TASK_REORIENT)
         t.reor_obj_body = cm.body_id("Object"); t.reor_eps_site = cm.site_id("eps_ball"); t.reor_pen_length = self.pen_length
         t.reor_axis_half = self.axis_half.data_ptr(); t.reor_des_rot = self.des_rot.data_ptr()
+        self._check_reward_keys(("pos_align", "rot_align", "act_reg", "drop", "bonus"))
         for i, k in enumerate(("pos_align", "rot_align", "act_reg", "drop", "bonus")):
             t.reor_w[i] = float(w.get(k, 0.0))
         t.reor_obs_muscle = 0

@@ -60,6 +60,7 @@ class StandEnvV0(BaseV0):
                                      dtype=np.float32)
         w = self.rwd_keys_wt
         t = self._new_task(E.MM_TASK_REACH)
+        self._check_reward_keys(("reach", "bonus", "act_reg", "penalty"))
         t.w_pose = float(w.get("reach", 0.0)); t.w_bonus = float(w.get("bonus", 0.0))
         t.w_act_reg = float(w.get("act_reg", 0.0)); t.w_penalty = float(w.get("penalty", 0.0))
         t.tip_sites = self._tip_sites.data_ptr(); t.ntip = self.ntip; t.target_pos = self.target_pos.data_ptr()

@@ -64,6 +64,7 @@ class WalkEnvV0(BaseV0):
         rot = self.target_rot if self.target_rot is not None else self.init_qpos[3:7]
         for i in range(4):
             t.walk_target_rot[i] = float(rot[i])
+        self._check_reward_keys(("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew"))
         for i, k in enumerate(("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew")):
             t.walk_w[i] = float(w.get(k, 0.0))
         self._task = t

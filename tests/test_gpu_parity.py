@@ -599,6 +599,13 @@ def test_custom_obs_keys_are_served_from_obs_dict_like_obsdict2obsvec():
         env.rollout_setup(); env.rollout_step(None)
     with pytest.raises(KeyError):
         registry.make("myoHandPoseRandom-v0", num_envs=2, obs_keys=["qpos", "no_such_key"])
+    # reward weights: re-weighting / dropping the task's terms goes into the launch; a key it does not sum is refused, not ignored
+    w = registry.make("myoHandPoseRandom-v0", num_envs=4, seed=2, autoreset=False, weighted_reward_keys={"pose": 2.0, "act_reg": 0.5})
+    w.reset(seed=2); ref2 = registry.make("myoHandPoseRandom-v0", num_envs=4, seed=2, autoreset=False); ref2.reset(seed=2)
+    w.step(a[:4]); ref2.step(a[:4])
+    assert torch.allclose(w.rwd_dict["dense"], 2.0 * ref2.rwd_dict["pose"] + 0.5 * ref2.rwd_dict["act_reg"], rtol=1e-6, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        registry.make("myoHandPoseRandom-v0", num_envs=2, weighted_reward_keys={"pose": 1.0, "sparse": 1.0})
 
 
 def test_mjx_make_registry_names():
