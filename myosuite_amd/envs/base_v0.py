@@ -14,6 +14,7 @@ bookkeeping.  API differences from the single-env reference: every returned arra
 from __future__ import annotations
 
 import collections
+import collections.abc
 from typing import Dict, Optional
 
 import numpy as np
@@ -58,6 +59,29 @@ def _compiled_model(name: str, muscle_condition: str):
     return _MODEL_CACHE[key]
 
 
+class _LazyEnvState(collections.abc.Mapping):
+    """info["state"] (env_base.py:614: get_env_state() of the step that just ended): materialised on first access -- five batched
+    clones per env.step are not paid by callers that never look at it.  Read it before the next step() (as the reference's dict,
+    it describes the state at the time it is taken; here that is the first access)."""
+
+    def __init__(self, env):
+        self._env, self._d = env, None
+
+    def _get(self):
+        if self._d is None:
+            self._d = self._env.get_env_state()
+        return self._d
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+
 class BaseV0:
     MYO_CREDIT = "MyoSuite: A contact-rich simulation suite for musculoskeletal motor control"
 
@@ -78,9 +102,13 @@ class BaseV0:
     # ------------------------------------------------------------------ setup
     def _setup(self, obs_keys, weighted_reward_keys, frame_skip=10, normalize_act=True, muscle_condition="",
                fatigue_reset_vec=None, fatigue_reset_random=False, reward_mode="dense", obs_range=(-10, 10),
-               sites=None, precision="f32", fwd_carry=True, **kwargs):
+               sites=None, precision="f32", fwd_carry=True, proprio_keys=None, visual_keys=None, **kwargs):
         """precision: "f32" (default) | "f64" | "f64_state" (or the MM_PREC_* value) -- the kernel family that steps the batch
         (include/myosim.h: fp64 arithmetic, optionally fp64 state rows; limit-rows-only models on Euler)"""
+        if visual_keys:
+            raise NotImplementedError("visual_keys need the renderer / visual encoders (env_base.py:222-300): out of this engine's scope")
+        self.proprio_keys = None if proprio_keys is None else list(proprio_keys)       # env_base.py:112,557-576
+        self.proprio_dict = {}
         self.muscle_condition = muscle_condition
         self.cm = _compiled_model(self.model_name, muscle_condition)
         self.precision = {"f32": E.MM_PREC_F32, "f64": E.MM_PREC_F64, "f64_state": E.MM_PREC_F64_STATE}.get(precision, precision)
@@ -221,12 +249,27 @@ class BaseV0:
         if "step_count" in state_dict:
             self.step_count.copy_(state_dict["step_count"])
 
+    def get_proprioception(self, obs_dict=None):
+        """env_base.py:557-576: (time, proprio vector, proprio dict) over `proprio_keys`, or (None, None, None) when none are configured"""
+        if self.proprio_keys is None:
+            return None, None, None
+        od = self.obs_dict if obs_dict is None else obs_dict
+        n = self.num_envs
+        pd = collections.OrderedDict(time=od["time"])
+        for k in self.proprio_keys:
+            pd[k] = od[k]
+        vec = torch.cat([od[k].reshape(n, -1).to(torch.float32) for k in self.proprio_keys], dim=1) if self.proprio_keys else \
+            torch.zeros(n, 0, device=self.device)
+        return pd["time"], vec, pd
+
     # ------------------------------------------------------------------ info dict (env_base.py:585-616)
     def get_env_infos(self) -> dict:
+        if self.proprio_keys is not None:
+            self.proprio_dict = self.get_proprioception()[2]
         return collections.OrderedDict(
             time=self.obs_dict["time"], rwd_dense=self.rwd_dict["dense"], rwd_sparse=self.rwd_dict["sparse"],
             solved=self.rwd_dict["solved"], done=self.rwd_dict["done"], obs_dict=self.obs_dict, visual_dict={},
-            proprio_dict={}, rwd_dict=self.rwd_dict, state=None)
+            proprio_dict=self.proprio_dict, rwd_dict=self.rwd_dict, state=_LazyEnvState(self))
 
     def _new_task(self, task_id: int, do_forward: bool = True) -> "E.mm_task":
         """mm_task with the fields every task shares (frame_skip, ctrl map, fatigue state, output buffers, counters).

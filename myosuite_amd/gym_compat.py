@@ -82,7 +82,7 @@ class SingleEnv(_EnvBase):
         obs, rwd, term, trunc, info = self._env.step(np.asarray(a, np.float32)[None])
         flat = {"time": float(info["time"][0]), "rwd_dense": float(info["rwd_dense"][0]), "rwd_sparse": float(info["rwd_sparse"][0]),
                 "solved": bool(info["solved"][0]), "done": bool(info["done"][0]), "obs_dict": info["obs_dict"],
-                "rwd_dict": info["rwd_dict"], "visual_dict": {}, "proprio_dict": {}, "state": info.get("state")}   # env_base.py:604-615
+                "rwd_dict": info["rwd_dict"], "visual_dict": {}, "proprio_dict": info.get("proprio_dict", {}), "state": info.get("state")}   # env_base.py:604-615
         return obs[0].cpu().numpy(), float(rwd[0]), bool(term[0]), False, flat
 
     def render(self):

@@ -599,6 +599,17 @@ def test_custom_obs_keys_are_served_from_obs_dict_like_obsdict2obsvec():
         env.rollout_setup(); env.rollout_step(None)
     with pytest.raises(KeyError):
         registry.make("myoHandPoseRandom-v0", num_envs=2, obs_keys=["qpos", "no_such_key"])
+    # proprio_keys (env_base.py:112,557-576) and info["state"] (env_base.py:614)
+    p = registry.make("myoHandPoseRandom-v0", num_envs=4, seed=2, autoreset=False, proprio_keys=["qpos", "qvel"])
+    p.reset(seed=2)
+    _, _, _, _, info = p.step(a[:4])
+    t_, vec, pd = p.get_proprioception()
+    assert list(pd) == ["time", "qpos", "qvel"] and vec.shape == (4, nq + nv) and torch.equal(vec[:, :nq], p.obs_dict["qpos"])
+    assert list(info["proprio_dict"]) == ["time", "qpos", "qvel"] and ref.get_proprioception() == (None, None, None)
+    st = info["state"]
+    assert set(st) >= {"time", "qpos", "qvel", "act"} and torch.equal(st["qpos"], p.state.qpos) and st["qpos"] is not p.state.qpos
+    with pytest.raises(NotImplementedError):
+        registry.make("myoHandPoseRandom-v0", num_envs=2, visual_keys=["rgb:vil_camera:224x224:2d"])
     # reward weights: re-weighting / dropping the task's terms goes into the launch; a key it does not sum is refused, not ignored
     w = registry.make("myoHandPoseRandom-v0", num_envs=4, seed=2, autoreset=False, weighted_reward_keys={"pose": 2.0, "act_reg": 0.5})
     w.reset(seed=2); ref2 = registry.make("myoHandPoseRandom-v0", num_envs=4, seed=2, autoreset=False); ref2.reset(seed=2)
