@@ -189,6 +189,47 @@ class BaseV0:
     def time(self) -> torch.Tensor:
         return self.state.time
 
+    # ------------------------------------------------------------------ what the reference's own env test touches (tests/test_envs.py:54-128)
+    @property
+    def mj_model(self):
+        """read-only view of the compiled model with mjModel's dimension names (nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon,
+        opt.timestep): `env.mj_model.nu` as in the reference's tests / tutorials.  Not a MuJoCo object: there is none."""
+        import types
+        cm = self.cm
+        return types.SimpleNamespace(nq=cm.nq, nv=cm.nv, nu=cm.nu, na=cm.na, nbody=cm.nbody, njnt=cm.njnt, ngeom=cm.ngeom, nsite=cm.nsite,
+                                     ntendon=cm.ntendon, opt=types.SimpleNamespace(timestep=float(cm.arrays["OPT_F"][0])), names=cm.names)
+
+    @property
+    def mj_data(self):
+        """view of the batched state with mjData's field names (time, qpos, qvel, act, ctrl): tensors [num_envs, ...]"""
+        import types
+        s = self.state
+        return types.SimpleNamespace(time=s.time, qpos=s.qpos, qvel=s.qvel, act=s.act, ctrl=self.last_ctrl, qacc_warmstart=s.qacc_warmstart)
+
+    def get_obs_dict(self, *sim_args, state=None):
+        """the reference's `get_obs_dict(sim)` / `get_obs_dict(mj_model, mj_data)` on the env's OWN simulation: the obs_dict of the
+        current state, which the launch computed (tasks with a torch restatement -- Pose -- also take another `state`)"""
+        if state is not None:
+            raise NotImplementedError(f"{type(self).__name__}.get_obs_dict on a foreign state: only the current obs_dict is available")
+        return self.obs_dict
+
+    def get_reward_dict(self, obs_dict):
+        if obs_dict is not self.obs_dict:
+            raise NotImplementedError(f"{type(self).__name__}.get_reward_dict on a foreign obs_dict: only the current rwd_dict is available")
+        return self.rwd_dict
+
+    def get_exteroception(self, **kwargs) -> dict:
+        """env_base.py:578-582 = get_visuals: no visual keys can be configured here (rendering is out of scope), so nothing to return"""
+        return {}
+
+    def __reduce__(self):
+        """pickle / copy as the reference's EzPickle does: by re-running the constructor with the arguments of `registry.make`"""
+        from . import registry
+        args = getattr(self, "_make_args", None)
+        if args is None:
+            raise TypeError(f"{type(self).__name__} was not built by registry.make: cannot be pickled")
+        return (registry._remake, (args,))
+
     def seed(self, seed=None):
         self.input_seed = seed
         self.np_random = np.random.default_rng(seed)

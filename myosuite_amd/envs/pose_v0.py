@@ -97,7 +97,7 @@ class PoseEnvV0(BaseV0):
         self.rwd_dict["solved"] = self.rwd_dict["solved"] > 0.5
         self.rwd_dict["done"] = self.rwd_dict["done"] > 0.5
 
-    def get_obs_dict(self, state=None):
+    def get_obs_dict(self, *sim_args, state=None):
         """pose_v0.py:100-111 on the current (or given) batched state, as torch ops."""
         s = state if state is not None else self.state
         d = collections.OrderedDict()

@@ -66,7 +66,14 @@ def make(id: str, num_envs: int = 1, device=None, seed=None, **overrides):
     kw = copy.deepcopy(s["kwargs"])
     kw.update(overrides)
     horizon = kw.pop("max_episode_steps", s["max_episode_steps"])      # gym.make(id, max_episode_steps=...) override
-    return s["entry_point"](env_id=id, num_envs=num_envs, device=device, seed=seed, max_episode_steps=horizon, **kw)
+    env = s["entry_point"](env_id=id, num_envs=num_envs, device=device, seed=seed, max_episode_steps=horizon, **kw)
+    env._make_args = dict(id=id, num_envs=num_envs, device=None if device is None else str(device), seed=seed, overrides=copy.deepcopy(overrides))
+    return env
+
+
+def _remake(args: dict):
+    """unpickling: the env is rebuilt by its constructor (the reference's gym.utils.EzPickle), not copied buffer by buffer"""
+    return make(args["id"], num_envs=args["num_envs"], device=args["device"], seed=args["seed"], **args["overrides"])
 
 
 # ------------------------------------------------------------------ registrations

@@ -51,6 +51,10 @@ except ImportError:
     _HAVE_SB3 = False
 
 
+def _rebuild_single(env_id, device, seed, kwargs):
+    return SingleEnv(env_id, device=device, seed=seed, **kwargs)
+
+
 class SingleEnv(_EnvBase):
     """`gym.make(id)`: one environment with the reference's single-env signatures (envs/env_base.py:395-407, 640-654):
     reset(seed=...) -> (obs, {}), step(a) -> (obs, reward, terminated, truncated=False, info); numpy float32 observations.
@@ -58,12 +62,18 @@ class SingleEnv(_EnvBase):
     metadata: Dict[str, Any] = {"render_modes": []}
 
     def __init__(self, env_id: str, device=None, seed=None, **kwargs):
+        self._ctor = dict(env_id=env_id, device=None if device is None else str(device), seed=seed, kwargs=dict(kwargs))
+        kwargs = dict(kwargs)
         kwargs.pop("max_episode_steps", None)
         self._env = registry.make(env_id, num_envs=1, device=device, seed=seed, autoreset=False, max_episode_steps=0, **kwargs)
         b = self._env
         self.observation_space = _box(b.observation_space.low, b.observation_space.high)
         self.action_space = _box(b.action_space.low, b.action_space.high, seed=seed)
         self.spec = None
+
+    def __reduce__(self):          # pickle.loads(pickle.dumps(env)) as the reference's EzPickle envs (tests/test_envs.py:80): rebuilt by the constructor
+        c = self._ctor
+        return (_rebuild_single, (c["env_id"], c["device"], c["seed"], c["kwargs"]))
 
     @property
     def unwrapped(self):
@@ -74,16 +84,35 @@ class SingleEnv(_EnvBase):
             raise AttributeError(name)
         return getattr(self._env, name)
 
+    @staticmethod
+    def _np0(d):
+        """env 0 of a dict of batched tensors as numpy (the single-env door speaks numpy, like the reference)"""
+        return {k: (v[0].detach().cpu().numpy() if hasattr(v, "detach") else v) for k, v in d.items()}
+
     def reset(self, *, seed=None, options=None, **kwargs):
         obs, info = self._env.reset(seed=seed, **kwargs)
         return obs[0].cpu().numpy(), info
 
     def step(self, a):
         obs, rwd, term, trunc, info = self._env.step(np.asarray(a, np.float32)[None])
+        st = info.get("state")
         flat = {"time": float(info["time"][0]), "rwd_dense": float(info["rwd_dense"][0]), "rwd_sparse": float(info["rwd_sparse"][0]),
-                "solved": bool(info["solved"][0]), "done": bool(info["done"][0]), "obs_dict": info["obs_dict"],
-                "rwd_dict": info["rwd_dict"], "visual_dict": {}, "proprio_dict": info.get("proprio_dict", {}), "state": info.get("state")}   # env_base.py:604-615
+                "solved": bool(info["solved"][0]), "done": bool(info["done"][0]), "obs_dict": self._np0(info["obs_dict"]),
+                "rwd_dict": self._np0(info["rwd_dict"]), "visual_dict": {}, "proprio_dict": self._np0(info.get("proprio_dict", {})),
+                "state": None if st is None else self._np0({k: v for k, v in st.items() if v is not None})}   # env_base.py:604-615
         return obs[0].cpu().numpy(), float(rwd[0]), bool(term[0]), False, flat
+
+    def get_proprioception(self, obs_dict=None):
+        t, vec, d = self._env.get_proprioception()
+        if d is None:
+            return None, None, None
+        return float(t[0]), vec[0].cpu().numpy(), self._np0(d)
+
+    def get_obs_dict(self, *sim_args, **kw):
+        return self._np0(self._env.get_obs_dict())
+
+    def get_reward_dict(self, obs_dict=None):
+        return self._np0(self._env.get_reward_dict(self._env.obs_dict))
 
     def render(self):
         return None

@@ -152,3 +152,67 @@ def test_sb3_style_training_loop_runs_on_make_vec_env(gym_stub):
     o, info = venv.reset5(seed=0)
     o, r, term, trunc, info = venv.step5(np.zeros((4, 39), np.float32))
     assert o.shape == (4, 108) and term.shape == (4,) and trunc.shape == (4,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoElbowPose1D6MRandom-v0", "myoHandPoseRandom-v0", "myoHandReachRandom-v0", "myoHandKeyTurnRandom-v0",
+                                    "myoHandReorient100-v0", "myoLegWalk-v0"])
+def test_single_env_passes_the_reference_check_env_protocol(env_id):
+    """The reference's own env test (tests/test_envs.py:39-128 `check_env`), line for line, against the `gym.make` door
+    (gym_compat.SingleEnv): seeded construction, get_input_seed / seed / reset, a small-control step through `env.mj_model.nu`,
+    get_proprioception / get_exteroception, get_obs_dict(mj_model, mj_data) / get_reward_dict, a pickle round trip (the reference's
+    envs are EzPickle: rebuilt by their constructor), equal spaces, and a second env that reproduces the first one's reset
+    observation, step observation, reward, done flag and info dict."""
+    import copy
+    import pickle
+    from myosuite_amd.gym_compat import SingleEnv
+
+    def close(a, b, atol=1e-5):
+        if isinstance(a, dict):
+            assert isinstance(b, dict) and a.keys() == b.keys(), (a.keys(), b.keys() if isinstance(b, dict) else b)
+            for k in a:
+                close(a[k], b[k], atol)
+        elif a is None or isinstance(a, (bool, str)):
+            assert a == b
+        else:
+            np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), atol=atol, rtol=1e-5)
+
+    input_seed = 1234
+    env1w = SingleEnv(env_id, seed=input_seed)
+    env1 = env1w.unwrapped
+    assert env1.get_input_seed() == input_seed
+    env1.seed(input_seed)
+    reset_obs1, *_ = env1.reset()
+    u = 0.01 * np.random.default_rng(0).uniform(low=0, high=1, size=env1.mj_model.nu)
+    obs1, rwd1, done1, *_, infos1 = env1.step(u.copy())
+    infos1 = copy.deepcopy(infos1)
+    proprio1_t, proprio1_vec, proprio1_dict = env1.get_proprioception()
+    extero1 = env1.get_exteroception()
+    assert len(obs1) > 0 and len(infos1) > 0
+    obs_dict1 = env1.get_obs_dict(env1.mj_model, env1.mj_data)
+    assert len(obs_dict1) > 0
+    rwd_dict1 = env1.get_reward_dict(obs_dict1)
+    assert len(rwd_dict1) > 0 and {"dense", "sparse", "solved", "done"} <= set(rwd_dict1)
+    reset_data = env1.reset()
+    assert isinstance(reset_data, tuple) and len(reset_data) == 2 and isinstance(reset_data[1], dict)
+    # serialize / deserialize
+    env2w = pickle.loads(pickle.dumps(env1w))
+    env2 = env2w.unwrapped
+    assert env2.get_input_seed() == input_seed == env1.get_input_seed()
+    for sp in ("action_space", "observation_space"):
+        a_, b_ = getattr(env1, sp), getattr(env2, sp)
+        assert a_.shape == b_.shape and np.array_equal(a_.low, b_.low) and np.array_equal(a_.high, b_.high)
+    env2.seed(input_seed)
+    reset_obs2, *_ = env2.reset()
+    close(reset_obs1, reset_obs2)
+    obs2, rwd2, done2, *_, infos2 = env2.step(u)
+    infos2 = copy.deepcopy(infos2)
+    proprio2_t, proprio2_vec, proprio2_dict = env2.get_proprioception()
+    extero2 = env2.get_exteroception()
+    close(obs1, obs2); close(rwd1, rwd2)
+    assert proprio1_vec is None and proprio2_vec is None and extero1 == extero2 == {}          # (no proprio / visual keys in these registrations)
+    assert done1 == done2 and len(infos1) == len(infos2)
+    close(infos1, infos2)
+    assert isinstance(infos1["obs_dict"]["time"], np.ndarray) or np.isscalar(infos1["obs_dict"]["time"])       # numpy, as the reference's info
+    assert set(infos1) == {"time", "rwd_dense", "rwd_sparse", "solved", "done", "obs_dict", "visual_dict", "proprio_dict", "rwd_dict", "state"}
+    env2.reset()
