@@ -154,10 +154,7 @@ def test_sb3_style_training_loop_runs_on_make_vec_env(gym_stub):
     assert o.shape == (4, 108) and term.shape == (4,) and trunc.shape == (4,)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("env_id", ["myoElbowPose1D6MRandom-v0", "myoHandPoseRandom-v0", "myoHandReachRandom-v0", "myoHandKeyTurnRandom-v0",
-                                    "myoHandReorient100-v0", "myoLegWalk-v0"])
-def test_single_env_passes_the_reference_check_env_protocol(env_id):
+def _check_env(env_id):
     """The reference's own env test (tests/test_envs.py:39-128 `check_env`), line for line, against the `gym.make` door
     (gym_compat.SingleEnv): seeded construction, get_input_seed / seed / reset, a small-control step through `env.mj_model.nu`,
     get_proprioception / get_exteroception, get_obs_dict(mj_model, mj_data) / get_reward_dict, a pickle round trip (the reference's
@@ -216,3 +213,25 @@ def test_single_env_passes_the_reference_check_env_protocol(env_id):
     assert isinstance(infos1["obs_dict"]["time"], np.ndarray) or np.isscalar(infos1["obs_dict"]["time"])       # numpy, as the reference's info
     assert set(infos1) == {"time", "rwd_dense", "rwd_sparse", "solved", "done", "obs_dict", "visual_dict", "proprio_dict", "rwd_dict", "state"}
     env2.reset()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoElbowPose1D6MRandom-v0", "myoHandPoseRandom-v0", "myoHandReachRandom-v0", "myoHandKeyTurnRandom-v0",
+                                    "myoHandReorient100-v0", "myoLegWalk-v0"])
+def test_single_env_passes_the_reference_check_env_protocol(env_id):
+    _check_env(env_id)
+
+
+@pytest.mark.gpu
+def test_whole_myobase_suite_passes_the_reference_check_envs():
+    """tests/test_myo.py::test_myosuite_envs = check_envs("MyoBase Suite", myosuite_myobase_suite): EVERY registered id -- the 33 base
+    tasks the reference registers (all but its three height-field terrain walks) with their Sarc / Fati / Reaf variants, 136 ids --
+    through the same protocol."""
+    from myosuite_amd.envs import registry
+    ids = sorted(registry._SPECS)
+    assert len(ids) >= 136
+    for env_id in ids:
+        try:
+            _check_env(env_id)
+        except Exception as exc:
+            raise AssertionError(f"check_env failed on {env_id}: {exc!r}") from exc
