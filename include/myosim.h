@@ -277,7 +277,8 @@ int  mm_model_set_lanes(mm_model* m, int lanes_per_env);
 /* tuning knobs: "lds_model" (1 = stage the model tables in LDS unless that costs resident waves the batch needs,
    0 = never, 2 = always), "waves_per_block" (0 = auto), "origin_shift" (1 = the kernel works in a frame centred on the
    model; 0 = raw world coordinates, for the fp32 error study),
-   "precision" (MM_PREC_*, below) */
+   "precision" (MM_PREC_*, below), "iterations" / "ls_iterations" (mjOption.iterations / ls_iterations of this handle; the
+   blob's values are the default -- the reference's MJX envs set both to 6 after loading, envs/myo/mjx/mjx_base_env.py:50-51) */
 int  mm_model_set_option(mm_model* m, const char* name, int value);
 /* "precision": which kernel family steps the model.
      MM_PREC_F32        the default: fp32 arithmetic, tables and state rows (the throughput kernels).

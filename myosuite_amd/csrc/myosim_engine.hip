@@ -852,6 +852,13 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
     build_layout(m);
     return upload_consts(m);
   }
+  // mjOption.iterations / ls_iterations of THIS model handle (the blob's values are the default): the reference's MJX envs overwrite
+  // them after loading the model (envs/myo/mjx/mjx_base_env.py:50-51: spec.option.iterations = 6, ls_iterations = 6)
+  if (!strcmp(name, "iterations") || !strcmp(name, "ls_iterations")) {
+    if (value < 1 || value > 1000) return fail(MM_EARG, "iterations / ls_iterations: 1 ... 1000");
+    if (name[0] == 'i') m->d.iterations = value; else m->d.ls_iterations = value;
+    return upload_consts(m);
+  }
   if (!strcmp(name, "origin_shift")) {   // 0: the kernel works in raw world coordinates (A/B of the fp32 error study)
     m->d.ox = value ? m->origin[0] : 0.f; m->d.oy = value ? m->origin[1] : 0.f; m->d.oz = value ? m->origin[2] : 0.f;
     return upload_consts(m);

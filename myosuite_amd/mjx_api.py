@@ -34,6 +34,16 @@ class State:                                     # mujoco_playground.State field
         return dataclasses.replace(self, **kw)
 
 
+MJX_ITERATIONS = MJX_LS_ITERATIONS = 6
+
+
+def _mjx_solver_options(env):
+    """MjxMyoBase.preprocess_spec (envs/myo/mjx/mjx_base_env.py:50-51) overwrites the loaded model's solver budget:
+    `spec.option.iterations = 6; spec.option.ls_iterations = 6`.  The same on this env's model handle (mm_model_set_option)."""
+    env.hm.set_option("iterations", MJX_ITERATIONS)
+    env.hm.set_option("ls_iterations", MJX_LS_ITERATIONS)
+
+
 class MjxPoseEnv:
     """Batched counterpart of ``MjxPoseEnvV0`` (defaults: myo_registry / playground config of the MJX hand-pose task)."""
 
@@ -52,6 +62,7 @@ class MjxPoseEnv:
                               frame_skip=int(round(ctrl_dt / sim_dt)),
                               weighted_reward_keys={"pose": angle_reward_weight, "act_reg": ctrl_cost_weight,
                                                     "bonus": bonus_weight, "penalty": 1.0})
+        _mjx_solver_options(self._env)
         t = self._env._task
         t.obs_layout = 1; t.act_reg_mean = 0; t.obs_dt = sim_dt; t.far_th = float(far_th)
         self.max_episode_steps = max_episode_steps
@@ -118,6 +129,7 @@ class MjxReachEnv:
                   weighted_reward_keys={"reach": reach_weight, "bonus": bonus_scale, "penalty": penalty_scale})
         self._env = ReachEnvV0(env_id="mjx-" + env_id, num_envs=num_envs, device=device, seed=seed,
                                max_episode_steps=max_episode_steps, autoreset=False, **kw)
+        _mjx_solver_options(self._env)
         t = self._env._task
         t.obs_layout = 1; t.obs_dt = sim_dt
         self.max_episode_steps = max_episode_steps

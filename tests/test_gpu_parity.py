@@ -619,6 +619,47 @@ def test_custom_obs_keys_are_served_from_obs_dict_like_obsdict2obsvec():
         registry.make("myoHandPoseRandom-v0", num_envs=2, weighted_reward_keys={"pose": 1.0, "sparse": 1.0})
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hand", "hand_contact"])
+def test_solver_budget_option_matches_a_model_compiled_with_it(name):
+    """mm_model_set_option(m, "iterations" / "ls_iterations", n): the reference's MJX envs overwrite the loaded model's solver budget
+    (mjx_base_env.py:50-51: 6 / 6) -- mjx_api applies the same to its model handles.  Here a Newton budget that BINDS (1 iteration;
+    the line search keeps its default budget -- a TRUNCATED line search is implementation-specific, oracle and kernel only agree on
+    its converged result): the HIP engine with the option set on the default model equals the oracle over a model COMPILED with that
+    budget, and differs from the default-budget solve on states with several active rows."""
+    cm = synth.get_model(name)
+    cm_cap = synth.compile_spec(name, edit=lambda s_: setattr(s_, "iterations", 1))
+    hm = E.HipModel(cm); hm.set_option("iterations", 1)
+    hm_def = E.HipModel(cm)
+    n = 32
+    rng = np.random.default_rng(3)
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    q = (lo + (hi - lo) * (0.5 + 0.6 * (rng.random((n, cm.nq)) - 0.5) * 2)).astype(np.float32)       # many joints past their limits
+    v = (2.0 * rng.standard_normal((n, cm.nv))).astype(np.float32)
+    out = {}
+    for key, h in (("cap", hm), ("def", hm_def)):
+        st = E.BatchState(h, n)
+        st.qpos.copy_(torch.from_numpy(q)); st.qvel.copy_(torch.from_numpy(v))
+        dv = E.Derived(h, n, ["qacc", "solver_niter"])
+        E.forward(h, st, torch.full((n, cm.nu), 0.3, device="cuda"), dv)
+        torch.cuda.synchronize()
+        out[key] = (dv["qacc"].cpu().numpy().astype(np.float64), dv["solver_niter"].cpu().numpy())
+    binds = name == "hand_contact"          # (limit rows alone converge in one step from a zero warm start; contact rows do not)
+    assert out["cap"][1].max() <= 1 and (out["def"][1].max() >= 2) == binds
+    om = O.OracleModel(cm_cap); d = O.OracleData(om)
+    worst = 0.0
+    for e in range(n):
+        d.qpos[:] = q[e]; d.qvel[:] = v[e]; d.act[:] = 0; d.ctrl[:] = 0.3; d.qacc_warmstart[:] = 0; d.forward()
+        assert d.solver_niter <= 1
+        worst = max(worst, float(np.abs(out["cap"][0][e] - d.qacc).max() / max(1.0, np.abs(d.qacc).max())))
+    assert worst < 5e-4, worst
+    if binds:
+        assert np.abs(out["cap"][0] - out["def"][0]).max() > 1e-3 * np.abs(out["def"][0]).max()      # the budget really bound
+    from myosuite_amd import mjx_api
+    env = mjx_api.make("MjxHandReachRandom-v0", num_envs=8)
+    assert (mjx_api.MJX_ITERATIONS, mjx_api.MJX_LS_ITERATIONS) == (6, 6)
+
+
 def test_mjx_make_registry_names():
     from myosuite_amd import mjx_api
     for name, obs in (("MjxElbowPoseRandom-v0", 1 + 1 + 6 + 1), ("MjxFingerPoseFixed-v0", 4 + 4 + 5 + 4), ("MjxHandReachRandom-v0", 23 + 23 + 39 + 30)):
