@@ -85,6 +85,25 @@ def test_bench_n_gt_1_path_runs_oversubscribed_on_one_gpu():
     assert abs(float(stats[:, 2].mean()) - d["stats"]["solved_frac"]) < 1e-6
 
 
+@pytest.mark.gpu
+def test_bench_config_5_preset_runs_the_fati_leg_share_on_two_ranks():
+    """`--config 5` = BASELINE.json config 5's per-GPU share (myoFatiLegWalk-v0, 1024 envs per GPU: 8192 over 8): the preset through the
+    N > 1 path on the one-GPU box (two oversubscribed ranks), with the collective block and both ranks' own rates in the line."""
+    import subprocess, sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--config", "5", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--repeats", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["baseline_config"] == 5 and d["config"]["envs_per_gpu"] == 1024
+    assert "myoFatiLegWalk-v0" in d["config"]["workload"] and d["metric"].endswith("1024 envs/GPU")
+    c = d["collective"]
+    assert c["gathered_rows"] == c["expected_rows"] == 2048 and len(c["per_rank_env_steps_per_s"]) == 2
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 5336 * 1024          # SURVEY 8(d): 5 336 B per env-step of the fatigue leg
+
+
 def _fracs(node, path=""):
     """every (path, value) whose key ends in _frac / is `frac`, anywhere in the line"""
     if isinstance(node, dict):
