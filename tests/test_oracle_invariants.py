@@ -333,3 +333,61 @@ def test_oracle_step_path_makes_no_heap_calls_and_threads_scale(oracle_lib):
     assert np.array_equal(q1, q4)
     c1 = min(c1, run(1)[0]); c4 = min(c4, run(4)[0])
     assert c4 < 1.5 * c1 + 0.02, (c1, c4)
+
+
+def test_impedance_and_reference_acceleration_follow_mujocos_published_formulas(oracle_lib):
+    """The constraint model of MuJoCo's "Computation" chapter, written out independently in numpy, against the oracle's rows for a
+    1-dof joint-limit constraint over a sweep of violations and solver parameters:
+      impedance   d(r) = d0 + y(|r| / width) (dwidth - d0),  y = x (power 1) | x^p / mid^(p-1) (x <= mid) | 1 - (1-x)^p / (1-mid)^(p-1)
+      regulariser R = (1 - d) / d * diagApprox,  D = 1 / R
+      reference   aref = -b v - k r:  solref = (timeconst, dampratio) > 0: b = 2 / (dwidth tc), k = d(r) / (dwidth^2 tc^2 dampratio^2)
+                  with tc >= 2 timestep ("refsafe");  solref = (-stiffness, -damping): b = damping / dwidth, k = stiffness d(r) / dwidth^2
+    (r = distance - margin < 0 inside the limit's active zone; diagApprox = dof_invweight0 for a joint limit)."""
+    O = oracle_lib
+    rng = np.random.default_rng(7)
+
+    def ref(r, v, diag, solref, solimp, h):
+        d0, dw, width, mid, p = solimp
+        x = min(abs(r) / width, 1.0)
+        if p == 1:
+            y = x
+        elif x <= mid:
+            y = x ** p / mid ** (p - 1)
+        else:
+            y = 1 - (1 - x) ** p / (1 - mid) ** (p - 1)
+        d = d0 + y * (dw - d0)
+        R = (1 - d) / d * diag
+        if solref[0] > 0:
+            tc = max(solref[0], 2 * h)
+            b, k = 2 / (dw * tc), d / (dw * dw * tc * tc * solref[1] ** 2)
+        else:
+            b, k = -solref[1] / dw, -solref[0] * d / (dw * dw)
+        return R, -b * v - k * r
+
+    cases = [((0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)),            # MuJoCo's defaults
+             ((0.02, 1.0), (0.9, 0.95, 0.01, 0.5, 1.0)),             # linear ramp
+             ((0.01, 0.7), (0.8, 0.99, 0.02, 0.3, 3.0)),             # cubic, early midpoint, under-damped
+             ((0.001, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)),           # timeconst below 2 h: refsafe clamps it
+             ((-400.0, -25.0), (0.85, 0.97, 0.005, 0.6, 2.0))]       # direct stiffness / damping
+    for solref, solimp in cases:
+        s = ModelSpec("limit_toy", timestep=0.002)
+        s.add_body("arm", "world", pos=(0, 0, 1), mass=1.3, ipos=(0.1, 0, 0), inertia=(2e-3, 3e-3, 1e-3))
+        s.add_joint("hinge", "arm", "hinge", axis=(0, 1, 0), range=(-0.5, 0.7), margin=0.01, solref=solref, solimp=solimp)
+        cm = s.compile()
+        d = O.OracleData(O.OracleModel(cm))
+        diag = float(cm.arrays["DOF_INVWEIGHT0"][0])
+        for _ in range(12):
+            side = rng.choice([-1, 1])
+            viol = rng.choice([rng.uniform(0, 0.3 * solimp[2]), rng.uniform(0.3 * solimp[2], 1.2 * solimp[2]), rng.uniform(0, 0.009)])
+            # distance to the limit = margin - viol  ->  r = dist - margin = -viol  (active: dist < margin)
+            q = (0.7 - 0.01 + viol) if side > 0 else (-0.5 + 0.01 - viol)
+            v = float(rng.standard_normal())
+            d.qpos[0] = q; d.qvel[0] = v; d.forward()
+            assert d.nefc == 1, (solref, solimp, q)
+            r = float(d.efc_pos[0] - d.efc_margin[0])
+            assert abs(r + viol) < 1e-7
+            R, aref = ref(r, float(d.efc_vel[0]), diag, solref, solimp, 0.002)
+            assert abs(float(d.efc_vel[0]) + side * v) < 1e-12                       # J = -side e_dof
+            np.testing.assert_allclose(d.efc_R[0], R, rtol=2e-6)                     # (solref / solimp travel as fp32 model tables)
+            np.testing.assert_allclose(d.efc_D[0], 1 / R, rtol=2e-6)
+            np.testing.assert_allclose(d.efc_aref[0], aref, rtol=2e-6, atol=1e-9)
