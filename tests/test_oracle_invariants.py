@@ -1,5 +1,6 @@
 """The fp64 oracle against physics invariants and an independent numpy implementation
 (SURVEY.md section 7 step 2): since MuJoCo itself is absent, these pin the restatement."""
+import math
 import os
 
 import numpy as np
@@ -391,3 +392,53 @@ def test_impedance_and_reference_acceleration_follow_mujocos_published_formulas(
             np.testing.assert_allclose(d.efc_R[0], R, rtol=2e-6)                     # (solref / solimp travel as fp32 model tables)
             np.testing.assert_allclose(d.efc_D[0], 1 / R, rtol=2e-6)
             np.testing.assert_allclose(d.efc_aref[0], aref, rtol=2e-6, atol=1e-9)
+
+
+def test_passive_spring_forces_are_the_gradient_of_their_potential(oracle_lib):
+    """Joint springs (stiffness about springref) and tendon springs with a dead band (springlength = (lo, hi): force only outside
+    it) are conservative: qfrc_passive = -dV/dq with V = sum 1/2 k (q - q_ref)^2 + sum 1/2 k_t dead(L_t)^2, where the tendon lengths
+    come from the INDEPENDENT numpy kinematics (model/kin_np.py) and the gradient from central differences -- no oracle Jacobian
+    involved.  With velocities, the dampers add -b_j v_j and -J_t' b_t (J_t v)."""
+    O = oracle_lib
+    s = ModelSpec("spring_toy", timestep=0.002)
+    s.add_body("upper", "world", pos=(0, 0, 1.0), mass=1.0, ipos=(0, 0, -0.15), inertia=(0.01, 0.01, 0.002))
+    s.add_joint("sh", "upper", "hinge", axis=(0, 1, 0), stiffness=3.0, damping=0.4, springref=0.2, range=(-2, 2))
+    s.add_body("lower", "upper", pos=(0, 0, -0.3), mass=0.7, ipos=(0, 0, -0.12), inertia=(0.006, 0.006, 0.001))
+    s.add_joint("el", "lower", "hinge", axis=(0, 1, 0), stiffness=1.5, damping=0.2, springref=-0.4, range=(-2.5, 2.5))
+    s.add_geom("wrapper", "upper", "cylinder", (0.03, 0.05), pos=(0, 0, -0.3), quat=(math.cos(math.pi / 4), math.sin(math.pi / 4), 0, 0))
+    s.add_site("o1", "world", (0.04, 0.0, 1.05)); s.add_site("m1", "upper", (0.05, 0.0, -0.2)); s.add_site("i1", "lower", (0.04, 0.0, -0.1))
+    s.add_site("side", "upper", (0.06, 0.0, -0.3))
+    s.add_site("o2", "upper", (-0.04, 0.0, -0.05)); s.add_site("i2", "lower", (-0.03, 0.0, -0.15))
+    s.add_tendon("t_wrap", [("site", "o1"), ("site", "m1"), ("cylinder", "wrapper", "side"), ("site", "i1")], stiffness=80.0, damping=2.0,
+                 springlength=(0.39, 0.46))
+    s.add_tendon("t_plain", [("site", "o2"), ("site", "i2")], stiffness=120.0, damping=0.0, springlength=(0.33, 0.33))
+    cm = s.compile()
+    km = K.KinModel(cm.arrays, cm.nq, cm.nv, cm.nbody)
+    d = O.OracleData(O.OracleModel(cm))
+    kj = cm.arrays["JNT_STIFFNESS"].astype(float); q_ref = cm.arrays["QPOS_SPRING"].astype(float)
+    kt = cm.arrays["TENDON_STIFFNESS"].astype(float); bt = cm.arrays["TENDON_DAMPING"].astype(float)
+    ls = cm.arrays["TENDON_LENGTHSPRING"].astype(float).reshape(-1, 2)
+    bj = cm.arrays["DOF_DAMPING"].astype(float)
+
+    def V(q):
+        L = km.tendon_length(q[None])[0]
+        dead = np.where(L > ls[:, 1], L - ls[:, 1], np.where(L < ls[:, 0], L - ls[:, 0], 0.0))
+        return 0.5 * np.sum(kj * (q - q_ref) ** 2) + 0.5 * np.sum(kt * dead ** 2)
+
+    rng = np.random.default_rng(3)
+    saw = set()
+    for _ in range(24):
+        q = rng.uniform([-1.2, -1.8], [1.2, 1.8])
+        d.qpos[:] = q; d.qvel[:] = 0; d.forward()
+        L = np.array(d.ten_length)
+        saw |= {("above" if L[0] > ls[0, 1] else "below" if L[0] < ls[0, 0] else "inside")}
+        if min(abs(L[0] - ls[0, 0]), abs(L[0] - ls[0, 1])) < 2e-4:
+            continue                                                     # (the dead band's kink: one-sided derivatives differ)
+        g = np.array([(V(q + e) - V(q - e)) / 2e-6 for e in np.eye(2) * 1e-6])
+        np.testing.assert_allclose(d.qfrc_passive, -g, atol=2e-5 * max(1.0, np.abs(g).max()))
+        v = rng.standard_normal(2)
+        d.qvel[:] = v; d.forward()
+        J = np.array(d.ten_J).reshape(cm.ntendon, cm.nv)
+        want = -g - bj * v - J.T @ (bt * (J @ v))
+        np.testing.assert_allclose(d.qfrc_passive, want, atol=2e-5 * max(1.0, np.abs(want).max()))
+    assert saw == {"above", "below", "inside"}, saw
