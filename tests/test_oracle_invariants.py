@@ -442,3 +442,56 @@ def test_passive_spring_forces_are_the_gradient_of_their_potential(oracle_lib):
         want = -g - bj * v - J.T @ (bt * (J @ v))
         np.testing.assert_allclose(d.qfrc_passive, want, atol=2e-5 * max(1.0, np.abs(want).max()))
     assert saw == {"above", "below", "inside"}, saw
+
+
+def test_euler_step_closed_forms(oracle_lib):
+    """mj_Euler on systems with closed-form steps: (i) a damped flywheel (no gravity torque about its axis): with eulerdamp the velocity
+    update is implicit in the damper, v' = v I / (I + h b) per step (armature counted in I); with the flag off it is the explicit
+    v' = v (1 - h b / I); (ii) a free body spinning about a fixed axis with no forces: the quaternion advances by the exponential map
+    of h w (MuJoCo's mju_quatIntegrate), i.e. after n steps it is the rotation by n h |w| about w, and the position by n h v;
+    (iii) muscle activation integrates with the first-order filter act' = act + h (ctrl - act) / tau(ctrl, act) and never leaves [0, 1]."""
+    O = oracle_lib
+    f32 = lambda x: float(np.float32(x))            # model parameters travel as float32 tables
+    h, b, I0, arm = f32(0.002), f32(0.8), f32(0.004), f32(0.001)
+    for damp_flag in (True, False):
+        s = ModelSpec("flywheel", timestep=h, eulerdamp=damp_flag, gravity=(0, 0, 0))
+        s.add_body("wheel", "world", pos=(0, 0, 1), mass=1.0, ipos=(0, 0, 0), inertia=(I0, I0, I0))
+        s.add_joint("ax", "wheel", "hinge", axis=(0, 0, 1), damping=b, armature=arm)
+        d = O.OracleData(O.OracleModel(s.compile()))
+        d.qvel[0] = 3.0
+        v, I = 3.0, I0 + arm
+        for _ in range(50):
+            d.step()
+            v = v * I / (I + h * b) if damp_flag else v * (1 - h * b / I)
+            assert abs(d.qvel[0] - v) < 1e-12 * max(1.0, abs(v)), (damp_flag, d.qvel[0], v)
+    # (ii) free body, no gravity, spherical inertia (no gyroscopic torque): constant twist
+    s = ModelSpec("spinner", timestep=h, gravity=(0, 0, 0))
+    s.add_body("b", "world", pos=(0.1, -0.2, 0.3), mass=2.0, inertia=(0.01, 0.01, 0.01))
+    s.add_joint("root", "b", type="free")
+    d = O.OracleData(O.OracleModel(s.compile()))
+    w = np.array([0.7, -1.1, 0.4]); vlin = np.array([0.3, 0.1, -0.2])
+    d.qvel[:3] = vlin; d.qvel[3:] = w
+    n = 400
+    d.step(n)
+    ang = n * h * np.linalg.norm(w); ax = w / np.linalg.norm(w)
+    qref = np.concatenate([[math.cos(ang / 2)], math.sin(ang / 2) * ax])
+    q = np.array(d.qpos[3:7])
+    assert abs(np.linalg.norm(q) - 1) < 1e-12 and min(np.abs(q - qref).max(), np.abs(q + qref).max()) < 1e-10
+    np.testing.assert_allclose(d.qpos[:3], np.array([0.1, -0.2, 0.3]) + n * h * vlin, atol=1e-12)
+    np.testing.assert_allclose(d.qvel, np.concatenate([vlin, w]), atol=1e-12)
+    # (iii) activation dynamics of the elbow's six muscles under a constant excitation, against the filter written out here
+    from myosuite_amd.model import synth
+    cm = synth.get_model("elbow")
+    d = O.OracleData(O.OracleModel(cm))
+    d.act[:] = [0.0, 0.2, 0.9, 1.0, 0.5, 0.05]
+    ctrl = np.array([1.0, 0.0, 0.1, 0.0, 0.5, 1.5])                     # (1.5: clamped to 1 by the muscle's ctrl range)
+    d.ctrl[:] = ctrl
+    act = np.array(d.act)
+    tau_a, tau_d = f32(0.01), f32(0.04)
+    for _ in range(60):
+        d.step()
+        c = np.clip(ctrl, 0, 1); a = np.clip(act, 0, 1)
+        tau = np.where(c - act > 0, tau_a * (0.5 + 1.5 * a), tau_d / (0.5 + 1.5 * a))
+        act = np.clip(act + float(cm.timestep) * (c - act) / tau, 0, 1)
+        np.testing.assert_allclose(d.act, act, atol=1e-12)
+    assert act.min() >= 0 and act.max() <= 1
