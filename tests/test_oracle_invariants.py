@@ -495,3 +495,36 @@ def test_euler_step_closed_forms(oracle_lib):
         act = np.clip(act + float(cm.timestep) * (c - act) / tau, 0, 1)
         np.testing.assert_allclose(d.act, act, atol=1e-12)
     assert act.min() >= 0 and act.max() <= 1
+
+
+def test_pyramidal_contact_rows_closed_form(oracle_lib):
+    """A sphere pressed into a plane, condim 3, friction mu: four pyramid-edge rows J = (n +- mu t_k) J_point in MuJoCo's order
+    (+t1, -t1, +t2, -t2), each with diagApprox = (1 + mu^2)(invweight0[b1] + invweight0[b2]) (translational weights), impedance
+    from solimp at r = dist - margin, and the regulariser every edge of a pyramid shares: R = 2 mu^2 (1 - d) / d diagApprox."""
+    O = oracle_lib
+    mu, pen, rad = 0.7, 2e-4, 0.05
+    s = ModelSpec("ball", timestep=0.002)
+    s.add_geom("floor", "world", "plane", (0, 0, 0))
+    s.add_body("b", pos=(0.0, 0.0, rad - pen), mass=0.5, inertia=(5e-4, 5e-4, 5e-4)); s.add_joint("root", "b", type="free")
+    s.add_geom("g", "b", "sphere", (rad,))
+    solimp = (0.9, 0.95, 0.001, 0.5, 2.0)
+    s.add_contact_pair("floor", "g", condim=3, friction=(mu, 0.005, 0.0001), solimp=solimp)
+    cm = s.compile()
+    d = O.OracleData(O.OracleModel(cm)); d.qvel[:3] = [0.3, -0.2, 0.1]; d.forward()
+    assert d.ncon == 1 and d.nefc == 4
+    n = np.array(d.con_frame[0, 0:3]); t1 = np.array(d.con_frame[0, 3:6]); t2 = np.array(d.con_frame[0, 6:9])
+    np.testing.assert_allclose(n, [0, 0, 1], atol=1e-12)
+    assert abs(t1 @ n) < 1e-12 and abs(t2 @ n) < 1e-12 and abs(np.linalg.norm(t1) - 1) < 1e-12 and np.allclose(np.cross(n, t1), t2, atol=1e-12)
+    J = np.array(d.efc_J[:4]).reshape(4, cm.nv)
+    muf = float(np.float32(mu))
+    for k, dirn in enumerate((n + muf * t1, n - muf * t1, n + muf * t2, n - muf * t2)):
+        np.testing.assert_allclose(J[k, :3], dirn, atol=1e-12)                    # translation dofs of the free joint: the point Jacobian is I
+    tran = float(cm.arrays["BODY_INVWEIGHT0"].reshape(-1, 2)[1, 0])                # the plane's body (world) has zero inverse weight
+    d0, dw, width, mid, p = (float(np.float32(x)) for x in solimp)
+    x = min(pen / width, 1.0)
+    y = x ** p / mid ** (p - 1) if x <= mid else 1 - (1 - x) ** p / (1 - mid) ** (p - 1)
+    imp = d0 + y * (dw - d0)
+    R = 2 * muf * muf * (1 - imp) / imp * (1 + muf * muf) * tran
+    np.testing.assert_allclose(d.efc_R[:4], R, rtol=5e-6)
+    np.testing.assert_allclose(d.efc_D[:4], 1 / R, rtol=5e-6)
+    np.testing.assert_allclose(d.efc_pos[:4] - d.efc_margin[:4], -pen, atol=1e-9)
