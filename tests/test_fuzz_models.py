@@ -1,0 +1,136 @@
+"""Random small models through the HIP engine and the oracle: feature INTERACTIONS the hand / leg / toy models do not combine (random
+trees of hinge and slide joints with springs, dampers, armature and reference angles; spatial tendons over several bodies with a
+sphere or cylinder wrap, tendon springs with dead bands, tendon dampers and limits; muscles next to torque motors and position
+servos; dry joint friction; a polynomial joint coupling).  Every model goes through the model compiler, the launch-width choice and
+the kernel family its structure selects (tree-sparse or general rows)."""
+import math
+
+import numpy as np
+import pytest
+
+from myosuite_amd.model.spec import ModelSpec
+
+
+def random_model(seed: int) -> ModelSpec:
+    rng = np.random.default_rng(seed)
+    s = ModelSpec(f"fuzz{seed}", timestep=0.002)
+    nlink = int(rng.integers(4, 10))
+    names, parents = [], []
+    for i in range(nlink):
+        parent = "world" if i == 0 else names[int(rng.integers(max(0, i - 3), i))]          # bushy-ish tree, bounded depth growth
+        length = float(rng.uniform(0.08, 0.2))
+        pos = (0.0, 0.0, 1.2) if parent == "world" else tuple(rng.uniform(-0.03, 0.03, 2)) + (-float(rng.uniform(0.08, 0.2)),)
+        s.add_body(f"b{i}", parent, pos=pos, mass=float(rng.uniform(0.2, 1.0)), ipos=(0.0, 0.0, -0.5 * length),
+                   inertia=tuple(rng.uniform(3e-4, 3e-3, 3)))
+        slide = rng.random() < 0.2
+        ax = rng.standard_normal(3); ax /= np.linalg.norm(ax)
+        kw = dict(axis=tuple(ax), damping=float(rng.uniform(0.01, 0.2)), armature=float(rng.uniform(5e-4, 5e-3)))
+        if rng.random() < 0.5:
+            kw.update(stiffness=float(rng.uniform(0.5, 5.0)), springref=float(rng.uniform(-0.3, 0.3)))
+        if slide:
+            s.add_joint(f"j{i}", f"b{i}", "slide", range=(-0.05, 0.06), **kw)
+        else:
+            s.add_joint(f"j{i}", f"b{i}", "hinge", range=(float(rng.uniform(-1.2, -0.3)), float(rng.uniform(0.3, 1.2))),
+                        **({**kw, "frictionloss": 0.05} if (i == 2 and seed % 2 == 0) else kw))
+        names.append(f"b{i}"); parents.append(parent)
+        for k in range(2):
+            s.add_site(f"s{i}_{k}", f"b{i}", tuple(rng.uniform(-0.03, 0.03, 2)) + (-float(rng.uniform(0.02, 0.9 * length)),))
+    s.add_site("anchor", "world", (0.02, 0.01, 1.25))
+    # tendons from the anchor (or a proximal body) down a chain of bodies; one of them wraps a sphere fixed to the first link
+    s.add_geom("wrap_sph", "b0", "sphere", (0.025,), pos=(0.0, 0.0, -0.06))
+    s.add_site("wrap_side", "b0", (0.05, 0.0, -0.06))
+    ntend = int(rng.integers(2, 5))
+    for t in range(ntend):
+        leaf = int(rng.integers(1, nlink))
+        chain = [leaf]
+        while parents[chain[-1]] != "world":
+            chain.append(names.index(parents[chain[-1]]))
+        chain = chain[::-1][:4]                                     # root-side first, at most four bodies
+        path = [("site", "anchor")] if t % 2 == 0 else []
+        for ci, b in enumerate(chain):
+            if t == 0 and ci == 1:
+                path.append(("sphere", "wrap_sph", "wrap_side"))
+            path.append(("site", f"s{b}_{t % 2}"))
+        if len([p for p in path if p[0] == "site"]) < 2:
+            path.append(("site", f"s{chain[-1]}_{(t + 1) % 2}"))
+        kw = {}
+        if t == 1:
+            kw.update(stiffness=float(rng.uniform(20, 120)), damping=float(rng.uniform(0.2, 2.0)), springlength=(0.12, 0.2))
+        if t == 2:
+            kw.update(limited=True, range=(0.05, 0.45), margin=0.002)
+        s.add_tendon(f"t{t}", path, **kw)
+        if t != 2:
+            s.add_muscle(f"mus{t}", f"t{t}", force=float(rng.uniform(20, 80)))
+    for i in range(0, nlink, 3):
+        s.add_motor(f"mot{i}", f"j{i}", gear=float(rng.uniform(0.3, 2.0)), ctrlrange=(-1.0, 1.0))
+    if nlink >= 5:
+        s.add_general("servo", joint="j4", gainprm=(1.5,), biasprm=(0.0, -1.5, -0.05), ctrlrange=(-0.5, 0.5))
+    if seed % 3 == 0 and nlink >= 6:
+        s.add_equality_joint("j5", "j1", (0.0, 0.3, 0.1))
+    return s
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_models_compile_and_the_oracle_steps_them(oracle_lib, seed):
+    """CPU half: the generator's models are valid (the oracle accepts the blob), stay finite under random excitation, and conserve
+    nothing they should not (sanity: accelerations bounded).  The GPU half below compares the engines."""
+    O = oracle_lib
+    cm = random_model(seed).compile()
+    d = O.OracleData(O.OracleModel(cm))
+    rng = np.random.default_rng(seed)
+    for _ in range(40):
+        d.ctrl[:] = rng.uniform(-1, 1, cm.nu)
+        d.step()
+    assert np.all(np.isfinite(d.qpos)) and np.all(np.isfinite(d.qvel)) and np.abs(d.qacc).max() < 1e5 and d.warn == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(32))
+def test_gpu_random_models_match_the_oracle(oracle_lib, seed):
+    """one forward pass (poses, tendon lengths, actuator forces, constrained acceleration, row counts) and 20 free-running substeps
+    of 24 random states per model, HIP engine vs oracle"""
+    import torch
+    from myosuite_amd import engine as E
+    O = oracle_lib
+    cm = random_model(seed).compile()
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    rng = np.random.default_rng(100 + seed)
+    n = 24
+    lo, hi = cm.jnt_range[:, 0].astype(float), cm.jnt_range[:, 1].astype(float)
+    q = (lo + (hi - lo) * (0.5 + 0.58 * (2 * rng.random((n, cm.nq)) - 1))).astype(np.float32)      # some joints past their limits
+    v = rng.standard_normal((n, cm.nv)).astype(np.float32)
+    act = rng.random((n, cm.na)).astype(np.float32); ctrl = rng.uniform(-0.5, 1.0, (n, cm.nu)).astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q)); st.qvel.copy_(torch.from_numpy(v))
+    if cm.na:
+        st.act.copy_(torch.from_numpy(act))
+    dv = E.Derived(hm, n, ["qacc", "nefc", "ten_length", "actuator_force", "xpos"])
+    c = torch.from_numpy(ctrl).cuda().contiguous()
+    E.forward(hm, st, c, dv)
+    torch.cuda.synchronize()
+    ga, gn = dv["qacc"].cpu().numpy().astype(np.float64), dv["nefc"].cpu().numpy()
+    ds = []
+    mism = 0
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q[e]; d.qvel[:] = v[e]; d.ctrl[:] = ctrl[e]
+        if cm.na:
+            d.act[:] = act[e]
+        d.forward(); ds.append(d)
+        np.testing.assert_allclose(dv["xpos"][e].cpu().numpy(), d.xpos, atol=2e-6)
+        # (a wrap that grazes its sphere is ill-conditioned in fp32: the arc is r acos(c) with c -> 1; seed 22 has one at 3.9e-6 m)
+        np.testing.assert_allclose(dv["ten_length"][e].cpu().numpy(), d.ten_length, atol=2e-5)
+        np.testing.assert_allclose(dv["actuator_force"][e].cpu().numpy(), d.actuator_force, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(d.actuator_force).max()))
+        if d.nefc != gn[e]:
+            mism += 1
+            continue
+        assert np.abs(ga[e] - d.qacc).max() < 1e-3 * max(1.0, np.abs(d.qacc).max()), (seed, e, np.abs(ga[e] - d.qacc).max(), np.abs(d.qacc).max())
+    assert mism <= 1, mism
+    for _ in range(2):
+        E.step(hm, st, c, 10)
+        for d in ds:
+            d.step(10)
+    err = np.abs(st.qpos.cpu().numpy() - np.array([d.qpos for d in ds])).max(axis=1)
+    assert int(st.status.cpu().max()) == 0 and max(d.warn for d in ds) == 0
+    assert np.median(err) < 2e-5 and np.quantile(err, 0.9) < 5e-4, (seed, np.median(err), err.max())
+    print(f"FUZZ seed {seed}: nv {cm.nv} ntendon {cm.ntendon} nu {cm.nu} neq {cm.neq} njmax {cm.njmax} kernel family {hm.info(E.INFO_KERNEL_FAMILY)} "
+          f"lanes {hm.launch_lanes(n)} rows max {int(gn.max())} rollout err median {np.median(err):.1e} max {err.max():.1e}")
