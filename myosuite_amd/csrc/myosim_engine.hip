@@ -183,6 +183,7 @@ struct mm_model {
   Aux x;
   int lanes = 64;
   int lanes_auto = 1;        // pick the group width per launch from the batch size
+  int lanes_user = 0;        // the width was pinned by the caller (mm_model_set_lanes), not chosen as the model's default
   int nvp = 24;
   int waves_per_block = 0;   // 0 = auto
   int lds_model = 1;
@@ -826,6 +827,7 @@ extern "C" int mm_model_set_lanes(mm_model* m, int lanes) {
     return fail(MM_EARG, "lanes_per_env must be 4/8/16/32/64, >= nbody, nv, njnt, padded nv (and constraint rows), with a compiled kernel");
   m->lanes = lanes;
   m->lanes_auto = 0;
+  m->lanes_user = 1;
   build_layout(m);
   return upload_consts(m);
 }
@@ -845,8 +847,8 @@ extern "C" int mm_model_set_option(mm_model* m, const char* name, int value) {
     }
     const int old = m->precision;
     m->precision = value;
-    if (!m->lanes_auto && !have_model_kernel(m, m->lanes)) { m->precision = old; return fail(MM_EUNSUPPORTED, "precision: no kernel of that family at the pinned lanes_per_env"); }
-    if (m->lanes_auto && !have_model_kernel(m, m->lanes)) {   // default width of the family
+    if (m->lanes_user && !have_model_kernel(m, m->lanes)) { m->precision = old; return fail(MM_EUNSUPPORTED, "precision: no kernel of that family at the pinned lanes_per_env"); }
+    if (!m->lanes_user && !have_model_kernel(m, m->lanes)) {   // default width of the family (a general-row model's default is fixed, not pinned: the fp64 general-row kernels are 64 lanes wide)
       for (int c : {64, 32, 16, 8, 4}) if (check_lanes(m, c) && have_model_kernel(m, c)) m->lanes = c;
     }
     build_layout(m);

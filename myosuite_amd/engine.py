@@ -316,10 +316,10 @@ class HipModel:
         with torch.cuda.device(self.device):
             _chk(lib().mm_model_create(blob.ctypes.data, int(blob.size), C.byref(h)), "mm_model_create")
         self.h = h
+        if lanes_per_env:       # (pinned first: the precision option then refuses a family that has no kernel at the pinned width)
+            _chk(lib().mm_model_set_lanes(self.h, lanes_per_env), "mm_model_set_lanes")
         if precision != MM_PREC_F32:
             self.set_option("precision", precision)
-        if lanes_per_env:
-            _chk(lib().mm_model_set_lanes(self.h, lanes_per_env), "mm_model_set_lanes")
 
     def info(self, which: int) -> int:
         return lib().mm_model_info(self.h, which)

@@ -11,9 +11,9 @@ import pytest
 from myosuite_amd.model.spec import ModelSpec
 
 
-def random_model(seed: int) -> ModelSpec:
+def random_model(seed: int, integrator: int = 0) -> ModelSpec:
     rng = np.random.default_rng(seed)
-    s = ModelSpec(f"fuzz{seed}", timestep=0.002)
+    s = ModelSpec(f"fuzz{seed}", timestep=0.002, integrator=integrator)
     nlink = int(rng.integers(4, 10))
     names, parents = [], []
     for i in range(nlink):
@@ -134,3 +134,82 @@ def test_gpu_random_models_match_the_oracle(oracle_lib, seed):
     assert np.median(err) < 2e-5 and np.quantile(err, 0.9) < 5e-4, (seed, np.median(err), err.max())
     print(f"FUZZ seed {seed}: nv {cm.nv} ntendon {cm.ntendon} nu {cm.nu} neq {cm.neq} njmax {cm.njmax} kernel family {hm.info(E.INFO_KERNEL_FAMILY)} "
           f"lanes {hm.launch_lanes(n)} rows max {int(gn.max())} rollout err median {np.median(err):.1e} max {err.max():.1e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,integrator", [(s_, i_) for s_ in (1, 4, 6, 13, 21) for i_ in (1, 3)], ids=lambda v: str(v))
+def test_gpu_random_models_on_rk4_and_implicitfast(oracle_lib, seed, integrator):
+    """the same generated models on the other two integrators (RK4 = 1, implicitfast = 3): kernels exist for the elbow- / hand- /
+    leg-sized widths; a model whose width has no kernel of that integrator must be REFUSED (MM_EUNSUPPORTED), never stepped by
+    another integrator"""
+    import torch
+    from myosuite_amd import engine as E
+    O = oracle_lib
+    cm = random_model(seed, integrator=integrator).compile()
+    try:
+        hm = E.HipModel(cm)
+    except E.EngineError as exc:
+        assert "unsupported" in str(exc).lower() or "kernel" in str(exc).lower() or "integrator" in str(exc).lower(), str(exc)
+        pytest.skip(f"no kernel for nv {cm.nv} on integrator {integrator}: refused loudly ({exc})")
+    om = O.OracleModel(cm)
+    rng = np.random.default_rng(200 + seed)
+    n = 16
+    lo, hi = cm.jnt_range[:, 0].astype(float), cm.jnt_range[:, 1].astype(float)
+    q = (lo + (hi - lo) * (0.5 + 0.45 * (2 * rng.random((n, cm.nq)) - 1))).astype(np.float32)
+    v = (0.5 * rng.standard_normal((n, cm.nv))).astype(np.float32)
+    act = rng.random((n, cm.na)).astype(np.float32); ctrl = rng.uniform(-0.5, 1.0, (n, cm.nu)).astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q)); st.qvel.copy_(torch.from_numpy(v))
+    if cm.na:
+        st.act.copy_(torch.from_numpy(act))
+    c = torch.from_numpy(ctrl).cuda().contiguous()
+    ds = []
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q[e]; d.qvel[:] = v[e]; d.ctrl[:] = ctrl[e]
+        if cm.na:
+            d.act[:] = act[e]
+        ds.append(d)
+    E.step(hm, st, c, 20)
+    for d in ds:
+        d.step(20)
+    err = np.abs(st.qpos.cpu().numpy() - np.array([d.qpos for d in ds])).max(axis=1)
+    assert int(st.status.cpu().max()) == 0
+    assert np.median(err) < 2e-5 and np.quantile(err, 0.9) < 5e-4, (seed, integrator, np.median(err), err.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 5, 12, 23])
+def test_gpu_random_models_in_precision_mode_track_the_oracle_to_fp64_resolution(oracle_lib, seed):
+    """MM_PREC_F64_STATE on generated models (tree-sparse, dense limit-row and general-row families): two independent fp64
+    implementations of the pipeline agree to summation order over 20 free-running substeps -- or the model is refused loudly."""
+    import torch
+    from myosuite_amd import engine as E
+    O = oracle_lib
+    cm = random_model(seed).compile()
+    try:
+        hm = E.HipModel(cm, precision=E.MM_PREC_F64_STATE)
+    except E.EngineError as exc:
+        pytest.skip(f"no fp64 kernel for this structure: refused ({str(exc)[:80]})")
+    om = O.OracleModel(cm)
+    rng = np.random.default_rng(300 + seed)
+    n = 8
+    lo, hi = cm.jnt_range[:, 0].astype(float), cm.jnt_range[:, 1].astype(float)
+    q = lo + (hi - lo) * (0.5 + 0.5 * (2 * rng.random((n, cm.nq)) - 1))
+    v = 0.5 * rng.standard_normal((n, cm.nv))
+    act = rng.random((n, cm.na)); ctrl = rng.uniform(-0.5, 1.0, (n, cm.nu)).astype(np.float32)
+    st = E.BatchState(hm, n)
+    assert st.qpos.dtype == torch.float64
+    st.qpos.copy_(torch.from_numpy(q)); st.qvel.copy_(torch.from_numpy(v))
+    if cm.na:
+        st.act.copy_(torch.from_numpy(act))
+    ds = []
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q[e]; d.qvel[:] = v[e]; d.ctrl[:] = ctrl[e]
+        if cm.na:
+            d.act[:] = act[e]
+        ds.append(d)
+    E.step(hm, st, torch.from_numpy(ctrl).cuda().contiguous(), 20)
+    for d in ds:
+        d.step(20)
+    err = np.abs(st.qpos.cpu().numpy() - np.array([d.qpos for d in ds])).max(axis=1)
+    assert err.max() < 1e-8, (seed, err)

@@ -439,7 +439,9 @@ def test_precision_modes_at_the_env_level_and_their_refusals():
     with pytest.raises(E.EngineError, match="precision"):
         E.HipModel(spec.compile(), precision=E.MM_PREC_F64)
     with pytest.raises(E.EngineError, match="precision"):
-        E.HipModel(synth.get_model("contact_toy"), lanes_per_env=16, precision=E.MM_PREC_F64)
+        E.HipModel(synth.get_model("contact_toy"), lanes_per_env=32, precision=E.MM_PREC_F64)      # (fp32 has <32,24,GEN>; the fp64 general-row kernels are 64 lanes wide)
+    hm64 = E.HipModel(synth.get_model("contact_toy"), precision=E.MM_PREC_F64)                   # not pinned: its default width moves to the family's
+    assert hm64.launch_lanes(8) == 64
     hm = E.HipModel(synth.get_model("hand"))
     with pytest.raises(E.EngineError):
         hm.set_option("precision", 7)
