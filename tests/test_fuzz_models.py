@@ -11,9 +11,10 @@ import pytest
 from myosuite_amd.model.spec import ModelSpec
 
 
-def random_model(seed: int, integrator: int = 0) -> ModelSpec:
+def random_model(seed: int, integrator: int = 0, contacts: bool = False) -> ModelSpec:
     rng = np.random.default_rng(seed)
     s = ModelSpec(f"fuzz{seed}", timestep=0.002, integrator=integrator)
+    lengths = []
     nlink = int(rng.integers(4, 10))
     names, parents = [], []
     for i in range(nlink):
@@ -32,7 +33,7 @@ def random_model(seed: int, integrator: int = 0) -> ModelSpec:
         else:
             s.add_joint(f"j{i}", f"b{i}", "hinge", range=(float(rng.uniform(-1.2, -0.3)), float(rng.uniform(0.3, 1.2))),
                         **({**kw, "frictionloss": 0.05} if (i == 2 and seed % 2 == 0) else kw))
-        names.append(f"b{i}"); parents.append(parent)
+        names.append(f"b{i}"); parents.append(parent); lengths.append(length)
         for k in range(2):
             s.add_site(f"s{i}_{k}", f"b{i}", tuple(rng.uniform(-0.03, 0.03, 2)) + (-float(rng.uniform(0.02, 0.9 * length)),))
     s.add_site("anchor", "world", (0.02, 0.01, 1.25))
@@ -67,6 +68,20 @@ def random_model(seed: int, integrator: int = 0) -> ModelSpec:
         s.add_general("servo", joint="j4", gainprm=(1.5,), biasprm=(0.0, -1.5, -0.05), ctrlrange=(-0.5, 0.5))
     if seed % 3 == 0 and nlink >= 6:
         s.add_equality_joint("j5", "j1", (0.0, 0.3, 0.1))
+    if contacts:
+        # a collision capsule along every link, a floor the hanging limbs reach, and self-collision between links that are not neighbours
+        s.add_geom("floor", "world", "plane", (0, 0, 0), pos=(0.0, 0.0, 0.88), quat=(math.cos(0.02), math.sin(0.02), 0.0, 0.0))
+        for i in range(nlink):
+            s.add_geom(f"cap{i}", f"b{i}", "capsule", (0.014, 0.4 * lengths[i]), pos=(0.0, 0.0, -0.5 * lengths[i]))
+        for i in range(1, nlink):
+            s.add_contact_pair("floor", f"cap{i}", condim=3, friction=(0.8, 0.005, 0.0001))
+        npairs = 0
+        for i in range(nlink):
+            for j in range(i + 2, nlink):
+                if parents[j] != names[i] and npairs < 6:
+                    s.add_contact_pair(f"cap{i}", f"cap{j}", condim=3 if npairs % 2 else 1, friction=(0.6, 0.005, 0.0001))
+                    npairs += 1
+        s.nconmax = 12
     return s
 
 
@@ -315,3 +330,58 @@ def test_gpu_random_contact_scenes_match_the_oracle(oracle_lib, seed):
         d.step(50)
     err = np.abs(st.qpos.cpu().numpy() - np.array([d.qpos for d in ds])).max(axis=1)
     assert np.all(np.isfinite(err)) and np.median(err[ok]) < 1e-4, (seed, np.median(err[ok]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_random_articulated_models_with_contacts_match_the_oracle(oracle_lib, seed):
+    """the generated trees again, now with a collision capsule per link, a tilted floor their limbs reach and self-collision between
+    non-neighbouring links (the structure of the self-colliding hand / the legs, in random shapes): states reached by letting the
+    ORACLE run under random excitations, then row counts and constrained accelerations of every state and 20 free-running substeps"""
+    import torch
+    from myosuite_amd import engine as E
+    O = oracle_lib
+    cm = random_model(seed, contacts=True).compile()
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    rng = np.random.default_rng(500 + seed)
+    n = 48
+    q = np.zeros((n, cm.nq)); v = np.zeros((n, cm.nv)); act = np.zeros((n, cm.na)); ctrl = rng.uniform(-0.5, 1.0, (n, cm.nu)).astype(np.float32)
+    lo, hi = cm.jnt_range[:, 0].astype(float), cm.jnt_range[:, 1].astype(float)
+    dsim = O.OracleData(om)
+    for e in range(n):
+        dsim.reset(); dsim.qpos[:] = lo + (hi - lo) * rng.random(cm.nq); dsim.qvel[:] = rng.standard_normal(cm.nv)
+        for _ in range(int(rng.integers(5, 60))):
+            dsim.ctrl[:] = ctrl[e]; dsim.step()
+        q[e] = dsim.qpos; v[e] = dsim.qvel
+        if cm.na:
+            act[e] = dsim.act
+    q32, v32, a32 = q.astype(np.float32), v.astype(np.float32), act.astype(np.float32)
+    st = E.BatchState(hm, n)
+    st.qpos.copy_(torch.from_numpy(q32)); st.qvel.copy_(torch.from_numpy(v32))
+    if cm.na:
+        st.act.copy_(torch.from_numpy(a32))
+    dv = E.Derived(hm, n, ["qacc", "nefc"])
+    c = torch.from_numpy(ctrl).cuda().contiguous()
+    E.forward(hm, st, c, dv)
+    torch.cuda.synchronize()
+    ga, gn = dv["qacc"].cpu().numpy().astype(np.float64), dv["nefc"].cpu().numpy()
+    ds, on, rel, ncon = [], np.zeros(n, int), np.zeros(n), np.zeros(n, int)
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q32[e]; d.qvel[:] = v32[e]; d.ctrl[:] = ctrl[e]
+        if cm.na:
+            d.act[:] = a32[e]
+        d.forward(); ds.append(d)
+        on[e], ncon[e] = d.nefc, d.ncon
+        rel[e] = np.abs(ga[e] - d.qacc).max() / max(1.0, np.abs(d.qacc).max())
+    flagged = np.array([d.warn != 0 for d in ds])
+    mism = (on != gn) & ~flagged
+    ok = ~mism & ~flagged
+    print(f"ARTIC seed {seed}: nv {cm.nv} pairs {cm.npair} njmax {cm.njmax} lanes {hm.launch_lanes(n)} rows median {int(np.median(on))} max {on.max()} "
+          f"states with contacts {int((ncon > 0).sum())} mismatches {int(mism.sum())} flagged {int(flagged.sum())} rel |dqacc| median {np.median(rel[ok]):.1e} max {rel[ok].max():.1e}")
+    assert (ncon > 0).sum() >= n // 6 and mism.sum() <= 2 and flagged.sum() <= n // 4
+    assert rel[ok].max() < 3e-3 and np.quantile(rel[ok], 0.9) < 3e-4, (rel[ok].max(), np.quantile(rel[ok], 0.9))
+    E.step(hm, st, c, 20)
+    for d in ds:
+        d.ctrl[:] = d.ctrl; d.step(20)
+    err = np.abs(st.qpos.cpu().numpy() - np.array([d.qpos for d in ds])).max(axis=1)
+    assert np.all(np.isfinite(err)) and np.median(err[ok]) < 5e-5, (seed, np.median(err[ok]))
