@@ -58,7 +58,42 @@ def rollout_leg(nenv=6, nsteps=20):
     return dict(qpos=qpos, qvel=qvel, act=act, obs=obs, dense=dense, model_hash=np.array(cm.hash()))
 
 
+def rollout_plane_toy(nenv=6, nsteps=160):
+    """`plane_toy` (every primitive collider: plane vs box / cylinder / ellipsoid, parallel capsules, capsule vs box = the rod over
+    the anvil): bodies dropped from random attitudes a few centimetres up (Generator seed 0), 160 substeps of falling, landing and
+    settling; positions, velocities and the contact COUNT per substep (pins multiplicities: one or two capsule-box contacts, up to
+    four plane-box / plane-cylinder contacts)."""
+    cm = synth.get_model("plane_toy")
+    om = O.OracleModel(cm)
+    rng = np.random.default_rng(0)
+    qpos = np.zeros((nsteps + 1, nenv, cm.nq)); qvel = np.zeros((nsteps + 1, nenv, cm.nv)); ncon = np.zeros((nsteps + 1, nenv), np.int32)
+    ds = []
+    for e in range(nenv):
+        d = O.OracleData(om)
+        q = cm.qpos0.astype(np.float64).copy()
+        for k in range(3):                                   # box, cylinder, ellipsoid: lifted and tumbled
+            o = 7 * k
+            q[o + 2] += rng.uniform(0.01, 0.05)
+            qq = rng.standard_normal(4) * (0.1 if e % 2 else 1.0) + np.array([1.0, 0, 0, 0]); q[o + 3:o + 7] = qq / np.linalg.norm(qq)
+        q[21] = rng.uniform(0.0, 0.02); q[22] = rng.uniform(-0.1, 0.1)                       # the bar above the rail
+        q[23] += rng.uniform(-0.04, 0.04); q[25] += rng.uniform(0.002, 0.03)                 # the rod above the anvil, slightly tilted / yawed
+        th, yw = rng.uniform(-0.05, 0.05), rng.uniform(-0.4, 0.4)
+        cy, sy, w1, z1 = np.cos(np.pi / 4 + th / 2), np.sin(np.pi / 4 + th / 2), np.cos(yw / 2), np.sin(yw / 2)
+        q[26:30] = [w1 * cy, -z1 * sy, w1 * sy, z1 * cy]
+        d.qpos[:] = q.astype(np.float32); d.qvel[:] = (0.2 * rng.standard_normal(cm.nv)).astype(np.float32)
+        d.forward()
+        ds.append(d); qpos[0, e] = d.qpos; qvel[0, e] = d.qvel; ncon[0, e] = d.ncon
+    for s in range(nsteps):
+        for e, d in enumerate(ds):
+            d.step()
+            qpos[s + 1, e] = d.qpos; qvel[s + 1, e] = d.qvel; ncon[s + 1, e] = d.ncon
+    return dict(qpos=qpos, qvel=qvel, ncon=ncon, model_hash=np.array(cm.hash()))
+
+
 if __name__ == "__main__":
+    r = rollout_plane_toy()
+    np.savez_compressed(os.path.join(OUT, "oracle_traj_plane_toy.npz"), **r)
+    print("plane_toy", r["model_hash"], "max contacts", int(r["ncon"].max()), float(np.abs(r["qpos"][-1]).max()))
     r = rollout_leg()
     np.savez_compressed(os.path.join(OUT, "oracle_traj_leg.npz"), **r)
     print("leg", r["model_hash"], float(np.abs(r["qpos"][-1]).max()))

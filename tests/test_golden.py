@@ -83,6 +83,23 @@ def test_oracle_leg_walk_trajectory_regression(oracle_lib):
         np.testing.assert_allclose(r[k], g[k], rtol=1e-8, atol=1e-10)
 
 
+def test_oracle_collider_trajectory_regression(oracle_lib):
+    """Pins the colliders (multiplicities incl. mjc_CapsuleBox's one-or-two contacts, plane-box / plane-cylinder up to four, parallel
+    capsules) and the contact solve of the checker against the committed `plane_toy` trajectory: contact COUNT per substep exactly,
+    positions to 1e-8 over 160 substeps of falling, landing and settling."""
+    import importlib.util
+    from myosuite_amd.model import synth
+    spec = importlib.util.spec_from_file_location("mgo", os.path.join(G, "make_golden_oracle.py"))
+    mgo = importlib.util.module_from_spec(spec); spec.loader.exec_module(mgo)
+    g = np.load(os.path.join(G, "oracle_traj_plane_toy.npz"))
+    assert str(g["model_hash"]) == synth.get_model("plane_toy").hash(), "plane_toy changed: regenerate tests/golden"
+    r = mgo.rollout_plane_toy()
+    np.testing.assert_array_equal(r["ncon"], g["ncon"])
+    assert int(g["ncon"].max()) >= 8 and len(np.unique(g["ncon"])) >= 5
+    for k in ("qpos", "qvel"):
+        np.testing.assert_allclose(r[k], g[k], rtol=1e-8, atol=1e-9)
+
+
 def test_registry_mirrors_reference_ids():
     from myosuite_amd.envs import registry
     ids = registry.registry_specs()
