@@ -385,3 +385,51 @@ def test_gpu_random_articulated_models_with_contacts_match_the_oracle(oracle_lib
         d.ctrl[:] = d.ctrl; d.step(20)
     err = np.abs(st.qpos.cpu().numpy() - np.array([d.qpos for d in ds])).max(axis=1)
     assert np.all(np.isfinite(err)) and np.median(err[ok]) < 5e-5, (seed, np.median(err[ok]))
+
+
+@pytest.mark.parametrize("seed,contacts,integrator", [(s_, s_ % 2 == 1, (0, 1, 3)[s_ % 3]) for s_ in range(12)])
+def test_random_models_survive_the_mjcf_round_trip(oracle_lib, seed, contacts, integrator):
+    """generated model -> MJCF text (mjcf.dump) -> importer (mjcf.load) -> compile: same dimensions and names, and the oracle steps both
+    to bit-identical states -- springs, reference angles, tendon springs / limits / wraps, dry friction, couplings, servos, link
+    capsules, contact pairs, nconmax, all three integrators through the XML.  The XML nests bodies, so a bushy tree comes back in
+    depth-first order (MuJoCo's own numbering): joints / actuators are matched by NAME, and the permuted model's trajectory agrees to
+    summation-order rounding (1e-9 after 25 steps), not to the bit; a tree that is already depth-first is bit-identical."""
+    from myosuite_amd.model import mjcf
+    O = oracle_lib
+    spec = random_model(seed, integrator=integrator, contacts=contacts)
+    cm0 = spec.compile()
+    cm1 = mjcf.load(mjcf.dump(spec)).compile()
+    if list(cm0.names["joint"]) != list(cm1.names["joint"]):
+        # muscle length ranges left to the compiler are ESTIMATED from seeded joint-space samples whose columns follow the joint
+        # order (spec.py compile(): lengthrange_samples), so a renumbered tree gets estimates that differ by ~1e-5; write the
+        # compiled ranges into the XML (MuJoCo's `lengthrange` attribute) as a saved model would carry them
+        lr = np.asarray(cm0.arrays["ACT_LENGTHRANGE"], np.float64)
+        for i, a in enumerate(spec.actuators):
+            if a.lengthrange is None and lr[i, 1] > lr[i, 0]:
+                a.lengthrange = (float(lr[i, 0]), float(lr[i, 1]))
+        cm0 = spec.compile()
+        cm1 = mjcf.load(mjcf.dump(spec)).compile()
+    for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "ntendon", "neq", "npair", "njmax", "nconmax"):
+        assert getattr(cm0, k) == getattr(cm1, k), k
+    jn0, jn1, an0, an1 = list(cm0.names["joint"]), list(cm1.names["joint"]), list(cm0.names["actuator"]), list(cm1.names["actuator"])
+    assert sorted(jn0) == sorted(jn1) and sorted(an0) == sorted(an1)
+    assert cm0.nq == cm0.njnt and cm0.nv == cm0.njnt                      # hinge / slide joints only: qpos index = joint index
+    pj = np.array([jn0.index(n) for n in jn1], int); pa = np.array([an0.index(n) for n in an1], int)
+    same_order = bool((pj == np.arange(len(pj))).all() and (pa == np.arange(len(pa))).all())
+    d0, d1 = O.OracleData(O.OracleModel(cm0)), O.OracleData(O.OracleModel(cm1))
+    rng = np.random.default_rng(seed)
+    lo, hi = cm0.jnt_range[:, 0].astype(float), cm0.jnt_range[:, 1].astype(float)
+    q = lo + (hi - lo) * rng.random(cm0.nq); v = 0.3 * rng.standard_normal(cm0.nv); act = rng.random(cm0.na); ctrl = rng.uniform(-0.5, 1, cm0.nu)
+    d0.qpos[:] = q; d0.qvel[:] = v; d0.ctrl[:] = ctrl
+    d1.qpos[:] = q[pj]; d1.qvel[:] = v[pj]; d1.ctrl[:] = ctrl[pa]
+    if cm0.na:
+        ad0, ad1 = np.asarray(cm0.arrays["ACT_ACTADR"]), np.asarray(cm1.arrays["ACT_ACTADR"])     # activation slot of each actuator (-1: none)
+        d0.act[:] = act
+        for i1, i0 in enumerate(pa):
+            assert (ad0[i0] < 0) == (ad1[i1] < 0)
+            if ad1[i1] >= 0:
+                d1.act[ad1[i1]] = act[ad0[i0]]
+    d0.step(25); d1.step(25)
+    err = np.abs(d0.qpos[pj] - d1.qpos).max()
+    assert err <= (0.0 if same_order else 1e-9), err
+    assert d0.nefc == d1.nefc and d0.ncon == d1.ncon
