@@ -163,7 +163,7 @@ class BaseV0:
             self.fat_MA = torch.zeros(n, cm.na, **f)
             self.fat_MR = torch.ones(n, cm.na, **f)
             self.fat_MF = torch.zeros(n, cm.na, **f)
-            self._fat_rng = np.random.default_rng(self.input_seed)
+            self._fat_draws = None     # random fatigue reset (fatigue.py:84-90): two [n, na] Philox draws, allocated on first use
         elif muscle_condition == "reafferentation":
             self.reaf = (cm.names["actuator"]["EIP"], cm.names["actuator"]["EPL"])
         self.init_qpos = cm.qpos0.astype(np.float32).copy()
@@ -244,9 +244,17 @@ class BaseV0:
             return
         n, na = self.num_envs, self.cm.na
         if self.fatigue_reset_random:
-            assert self.fatigue_reset_vec is None
-            nf = torch.from_numpy(self._fat_rng.random((n, na)).astype(np.float32)).to(self.device)
-            ap = torch.from_numpy(self._fat_rng.random((n, na)).astype(np.float32)).to(self.device)
+            # fatigue.py:84-90: non_fatigued, active_percentage ~ U[0,1)^na.  Drawn on the device from Philox streams 22 / 23 of
+            # (seed, GLOBAL env index, episode) -- like every other reset draw, so a shard of envs (env_index_base) reproduces its
+            # slice of the unsharded batch and two ranks with one seed never start from the same fatigue state
+            assert self.fatigue_reset_vec is None, "Cannot use 'fatigue_reset_vec' if fatigue_reset_random=True."
+            if self._fat_draws is None:
+                f = dict(dtype=torch.float32, device=self.device)
+                self._fat_draws = (torch.zeros(n, na, **f), torch.zeros(n, na, **f), torch.zeros(na, **f), torch.ones(na, **f))
+            nf, ap, lo, hi = self._fat_draws
+            seed = int(getattr(self, "_seed_u64", self.input_seed if self.input_seed is not None else 0))
+            E.env_draw(nf, lo, hi, mask, self.episode, seed, 22, env_index_base=self.env_index_base)
+            E.env_draw(ap, lo, hi, mask, self.episode, seed, 23, env_index_base=self.env_index_base)
             MA, MR, MF = nf * ap, nf * (1 - ap), 1 - nf
         else:
             # deterministic reset (to rest, or to fatigue_reset_vec): one launch, no temporaries

@@ -588,6 +588,46 @@ def test_rollout_step_other_tasks_and_sharded_streams():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env_id,kw", [
+    ("myoHandPoseRandom-v0", {}), ("myoFatiHandPoseRandom-v0", {"fatigue_reset_random": True}), ("myoHandReachRandom-v0", {}),
+    ("myoLegWalk-v0", {"reset_type": "random"}), ("myoFatiLegWalk-v0", {"fatigue_reset_random": True}), ("myoLegStandRandom-v0", {}),
+    ("myoHandReorient100-v0", {}), ("myoHandPenTwirlRandom-v0", {}), ("myoHandKeyTurnRandom-v0", {}), ("myoHandObjHoldRandom-v0", {}),
+    ("myoElbowPose1D6MExoRandom-v0", {}), ("myoSarcHandPoseRandom-v0", {}), ("myoReafHandPoseRandom-v0", {})],
+    ids=["pose", "pose-fatigue-random", "reach", "walk-random", "walk-fatigue-random", "stand", "reorient100", "pen", "keyturn", "objhold",
+         "exo-elbow", "sarc", "reaf"])
+def test_a_shard_of_envs_reproduces_its_slice_of_the_whole_batch(env_id, kw):
+    """Multi-GPU env sharding (myosuite_amd/dist.py): rank r builds `num_envs = E` envs with `env_index_base = r * E`.
+    Every reset draw (targets, poses, object sizes / types, key positions, stride coin + noise, random fatigue states) and every
+    in-kernel action draw is a Philox stream keyed on the GLOBAL env index, so the shard's observations, rewards and flags must be
+    the corresponding rows of the unsharded batch BIT FOR BIT, through several episodes of auto-resets -- for every task family, not
+    only the Pose / Reach pair the first version of this test covered."""
+    n, h = 48, 16                                         # shard = global envs 32..47
+    full = registry.make(env_id, num_envs=n, seed=11, max_episode_steps=4, **kw)
+    part = registry.make(env_id, num_envs=h, seed=11, max_episode_steps=4, env_index_base=n - h, **kw)
+    of, _ = full.reset(seed=11); op, _ = part.reset(seed=11)
+    assert torch.equal(of[n - h:], op)
+    nu = full.cm.nu
+    af = torch.empty(n, full.action_space.shape[0], device="cuda"); ap = torch.empty(h, af.shape[1], device="cuda")
+    for s in range(11):                                   # two episode boundaries
+        E.uniform(af, 5, s); E.uniform(ap, 5, s, first_index=(n - h) * af.shape[1])
+        assert torch.equal(af[n - h:], ap)
+        o1, r1, t1, u1, _ = full.step(af)
+        o2, r2, t2, u2, _ = part.step(ap)
+        assert torch.equal(o1[n - h:], o2), (s, float((o1[n - h:] - o2).abs().max()))
+        assert torch.equal(r1[n - h:], r2) and torch.equal(t1[n - h:], t2) and torch.equal(u1[n - h:], u2), s
+    assert int(full.episode.min()) >= 2 and torch.equal(full.episode[n - h:], part.episode)
+    if full.muscle_condition == "fatigue":
+        assert torch.equal(full.fat_MF[n - h:], part.fat_MF)
+        if kw.get("fatigue_reset_random"):               # and the draws differ from env to env (no two envs share a fatigue state)
+            assert len(torch.unique(full.fat_MF[:, 0])) > n // 2
+    # the fused rollout path (in-kernel action draws) on the same pair
+    full.rollout_setup(action_seed=9); part.rollout_setup(action_seed=9)
+    for s in range(9):
+        a1 = full.rollout_step(None, stream_id=s); a2 = part.rollout_step(None, stream_id=s)
+        assert all(torch.equal(x[n - h:], y) for x, y in zip(a1, a2)), s
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env_id,n,kw", [("myoLegWalk-v0", 96, {}), ("myoElbowPose1D6MRandom-v0", 256, {}), ("myoHandReorient8-v0", 64, {}),
                                          ("myoHandPoseRandom-v0", 128, {}), ("myoLegWalk-v0", 64, {"model": "leg_implicit"})],
                          ids=["leg", "elbow", "reorient", "hand", "leg_implicitfast"])
