@@ -451,8 +451,8 @@ class BaseV0:
         Returns ``(graph, action, outputs)``: fill ``action`` ([num_envs, nu], in place), call ``graph.replay()``; ``outputs`` is
         the ``(obs, reward, terminated, truncated, info)`` tuple of the captured call, whose tensors are rewritten by every
         replay.  One replay costs one launch instead of ~10, which is what bounds small models (elbow: 0.2 ms per eager step).
-        The warm-up steps advance the envs (call ``reset()`` afterwards if that matters); host-side draws (random fatigue
-        reset) are frozen into the graph."""
+        The warm-up steps advance the envs (call ``reset()`` afterwards if that matters).  Every reset draw is a device-side
+        Philox stream keyed on the device-resident episode counters, so replays keep drawing fresh values."""
         action = torch.zeros(self.num_envs, self.cm.nu, dtype=torch.float32, device=self.device)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))

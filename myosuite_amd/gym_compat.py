@@ -18,6 +18,7 @@ import importlib
 from typing import Any, Dict, List, Optional, Sequence
 
 import numpy as np
+import torch
 
 from .envs import registry
 from .envs import spaces as shim
@@ -197,6 +198,31 @@ class MyoVecEnv(_VecBase):
     @property
     def unwrapped(self):
         return self
+
+    # ---- host buffers in, host buffers out, nothing else: the boundary a CPU-side learner sees
+    def step_host(self, actions):
+        """``actions`` [n, nu] float32 on the host -> ``(obs, reward, done)`` numpy arrays on the host, at the cost of the transfers
+        and nothing more: one pinned H2D copy, the fused env-step launch (episode statistics + auto-reset inside / right behind it,
+        `BaseV0.rollout_step`), three pinned D2H copies, ONE stream synchronisation; no per-env Python objects.  ``obs`` holds the
+        first observation of the new episode for envs whose ``done`` flag (terminated | truncated) is set -- the SB3 convention
+        without ``terminal_observation``.  The returned arrays are views of pinned staging buffers, rewritten by the next call.
+        This is the path the PCIe-inclusive rate in DESIGN.md is measured on (benchmarks/host_boundary.py)."""
+        b = self.env
+        if getattr(self, "_host", None) is None:
+            if getattr(b, "_ro", None) is None:
+                b.rollout_setup()
+            pin = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._host = dict(a_dev=torch.empty(self.num_envs, b.cm.nu, dtype=torch.float32, device=b.device),
+                              a=torch.empty(self.num_envs, b.cm.nu, dtype=torch.float32, pin_memory=True),
+                              obs=pin(b.obs), rwd=pin(b.rwd), done=pin(b._ro_mask),
+                              col=list(b.rwd_dict).index("dense" if b.rwd_mode == "dense" else "sparse"))
+        h = self._host
+        h["a"].numpy()[...] = np.asarray(actions, np.float32).reshape(self.num_envs, -1)
+        h["a_dev"].copy_(h["a"], non_blocking=True)
+        obs, rwd, mask = b.rollout_step(h["a_dev"])
+        h["obs"].copy_(obs, non_blocking=True); h["rwd"].copy_(rwd, non_blocking=True); h["done"].copy_(mask, non_blocking=True)
+        torch.cuda.current_stream(b.device).synchronize()
+        return h["obs"].numpy(), h["rwd"].numpy()[:, h["col"]], h["done"].numpy().view(np.bool_)
 
     # ---- gymnasium.vector.VectorEnv flavour
     def reset5(self, *, seed=None, options=None):

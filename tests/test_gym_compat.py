@@ -154,6 +154,30 @@ def test_sb3_style_training_loop_runs_on_make_vec_env(gym_stub):
     assert o.shape == (4, 108) and term.shape == (4,) and trunc.shape == (4,)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoHandPoseRandom-v0", "myoHandReachRandom-v0", "myoFatiLegWalk-v0"])
+def test_step_host_is_the_vector_step_through_pinned_buffers(env_id):
+    """`MyoVecEnv.step_host` (numpy in / numpy out: one pinned H2D copy, the fused launch, pinned D2H copies, one sync -- the path the
+    PCIe-inclusive rate is measured on) returns exactly what the SB3-protocol `step` of a twin env returns for the same actions:
+    observations (first observation of the next episode for finished envs), scalar reward, done flags."""
+    from myosuite_amd import gym_compat as mg
+    n = 24
+    a_env = mg.MyoVecEnv(env_id, n, seed=3, max_episode_steps=5)
+    b_env = mg.MyoVecEnv(env_id, n, seed=3, max_episode_steps=5)
+    assert np.array_equal(a_env.reset(), b_env.reset())
+    rng = np.random.default_rng(1)
+    nu = a_env.action_space.shape[0]
+    ndone = 0
+    for s in range(12):
+        act = rng.uniform(-1, 1, (n, nu)).astype(np.float32)
+        o1, r1, d1 = a_env.step_host(act)
+        o2, r2, d2, _ = b_env.step(act)
+        assert o1.dtype == np.float32 and r1.shape == (n,) and d1.dtype == np.bool_
+        assert np.array_equal(d1, d2) and np.array_equal(r1, r2) and np.array_equal(o1, o2), s
+        ndone += int(d1.sum())
+    assert ndone >= 2 * n                                   # two episode boundaries went through the host path
+
+
 def _check_env(env_id):
     """The reference's own env test (tests/test_envs.py:39-128 `check_env`), line for line, against the `gym.make` door
     (gym_compat.SingleEnv): seeded construction, get_input_seed / seed / reset, a small-control step through `env.mj_model.nu`,
