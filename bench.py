@@ -475,8 +475,9 @@ def main():
 
     import torch
     from myosuite_amd import dist as D
-    from myosuite_amd import engine as E
+    from myosuite_amd import engine
 
+    engine.lib()        # load libmyosim_hip.so now: a missing extension fails here, before any process group or timing
     rank, world, local = D.init_from_env(backend="gloo" if args.oversubscribe else None)
     if args.oversubscribe:
         local = local % max(1, torch.cuda.device_count())

@@ -17,7 +17,7 @@ engine (myosuite_amd/csrc) and, for checking only, the fp64 oracle (oracle/).
 from __future__ import annotations
 
 import dataclasses
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 

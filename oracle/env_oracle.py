@@ -6,7 +6,6 @@ bench.py's cpu_baseline leg.  Each function cites the reference lines it follows
 from __future__ import annotations
 
 import collections
-import math
 
 import numpy as np
 

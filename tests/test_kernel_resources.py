@@ -4,7 +4,6 @@ bundles and their AMDGPU metadata notes read -- the instantiations the BASELINE 
 self-contact hand from 26 to 0, and the SGPR spills of the general-row kernels from 420...570 to below 260)."""
 import os
 import struct
-import subprocess
 import sys
 import tempfile
 

@@ -303,7 +303,7 @@ def test_oracle_step_path_makes_no_heap_calls_and_threads_scale(oracle_lib):
     1.5x of the 1-thread rollout's (wall-clock speed-up is NOT asserted here: this container's cores are shared with other
     tenants and a bare 4-thread spin loop is sometimes slower than 1 thread; tools/cpu_scaling.py records the real curve on the
     GPU box and bench.py's cpu_baseline reports its parallel efficiency)."""
-    import re, time
+    import re
     from myosuite_amd.model import synth
     from oracle import env_oracle as EO
     from oracle import oracle as O

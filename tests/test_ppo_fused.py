@@ -6,7 +6,6 @@ import ctypes
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 
