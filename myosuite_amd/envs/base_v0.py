@@ -190,21 +190,53 @@ class BaseV0:
         return self.state.time
 
     # ------------------------------------------------------------------ what the reference's own env test touches (tests/test_envs.py:54-128)
+    # mjModel field name -> section of the compiled model (read-only numpy copies; per-env deltas live in `state`)
+    _MJMODEL_ARRAYS = {"body_mass": "BODY_MASS", "body_pos": "BODY_POS", "body_quat": "BODY_QUAT", "body_inertia": "BODY_INERTIA",
+                       "body_parentid": "BODY_PARENT", "jnt_range": "JNT_RANGE", "jnt_type": "JNT_TYPE", "jnt_qposadr": "JNT_QPOSADR",
+                       "jnt_dofadr": "JNT_DOFADR", "jnt_bodyid": "JNT_BODYID", "jnt_stiffness": "JNT_STIFFNESS", "dof_damping": "DOF_DAMPING",
+                       "dof_armature": "DOF_ARMATURE", "dof_frictionloss": "DOF_FRICTIONLOSS", "geom_size": "GEOM_SIZE", "geom_type": "GEOM_TYPE",
+                       "geom_pos": "GEOM_POS", "geom_bodyid": "GEOM_BODYID", "site_pos": "SITE_POS", "site_bodyid": "SITE_BODYID",
+                       "tendon_lengthspring": "TENDON_LENGTHSPRING", "tendon_stiffness": "TENDON_STIFFNESS", "tendon_range": "TENDON_RANGE",
+                       "actuator_lengthrange": "ACT_LENGTHRANGE", "actuator_gainprm": "ACT_GAINPRM", "actuator_biasprm": "ACT_BIASPRM",
+                       "actuator_dynprm": "ACT_DYNPRM", "actuator_ctrlrange": "ACT_CTRLRANGE", "actuator_forcerange": "ACT_FORCERANGE",
+                       "actuator_gear": "ACT_GEAR", "actuator_acc0": "ACT_ACC0", "actuator_trnid": "ACT_TRNID", "qpos0": "QPOS0",
+                       "qpos_spring": "QPOS_SPRING"}
+
     @property
     def mj_model(self):
-        """read-only view of the compiled model with mjModel's dimension names (nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon,
-        opt.timestep): `env.mj_model.nu` as in the reference's tests / tutorials.  Not a MuJoCo object: there is none."""
+        """read-only view of the compiled model under mjModel's names: the dimensions (nq, nv, nu, na, nbody, njnt, ngeom, nsite,
+        ntendon), `opt.timestep`, the `<kind>_names` lists the reference's wrapper offers (`env.mj_model.actuator_names.index("ECRL")`,
+        agents/baseline_Reflex/ReflexCtrInterface.py:274) and the constant arrays scripts read (`body_mass`, `jnt_range`,
+        `actuator_lengthrange`, `actuator_gainprm` / `biasprm`, `tendon_lengthspring`, ...: numpy COPIES of the compiled sections --
+        writing to them changes nothing; per-env model edits go through the env's kwargs / `state.set_*_env`).  Not a MuJoCo object:
+        there is none."""
         import types
-        cm = self.cm
-        return types.SimpleNamespace(nq=cm.nq, nv=cm.nv, nu=cm.nu, na=cm.na, nbody=cm.nbody, njnt=cm.njnt, ngeom=cm.ngeom, nsite=cm.nsite,
-                                     ntendon=cm.ntendon, opt=types.SimpleNamespace(timestep=float(cm.arrays["OPT_F"][0])), names=cm.names)
+        v = getattr(self, "_mj_model_view", None)
+        if v is None:
+            cm = self.cm
+            v = types.SimpleNamespace(nq=cm.nq, nv=cm.nv, nu=cm.nu, na=cm.na, nbody=cm.nbody, njnt=cm.njnt, ngeom=cm.ngeom, nsite=cm.nsite,
+                                      ntendon=cm.ntendon, opt=types.SimpleNamespace(timestep=float(cm.arrays["OPT_F"][0])), names=cm.names)
+            for kind, d in cm.names.items():
+                setattr(v, f"{kind}_names", [n for n, _ in sorted(d.items(), key=lambda kv: kv[1])])
+            for field, sec in self._MJMODEL_ARRAYS.items():
+                if sec in cm.arrays:
+                    setattr(v, field, np.array(cm.arrays[sec]))
+            self._mj_model_view = v
+        return v
 
     @property
     def mj_data(self):
-        """view of the batched state with mjData's field names (time, qpos, qvel, act, ctrl): tensors [num_envs, ...]"""
+        """view of the batched state with mjData's field names (time, qpos, qvel, act, ctrl, qacc_warmstart): tensors [num_envs, ...],
+        plus the name-addressed getters of the reference's wrapper for single-dof joints (`get_joint_qpos(name)` / `get_joint_qvel`:
+        a [num_envs] tensor)."""
         import types
-        s = self.state
-        return types.SimpleNamespace(time=s.time, qpos=s.qpos, qvel=s.qvel, act=s.act, ctrl=self.last_ctrl, qacc_warmstart=s.qacc_warmstart)
+        s, cm = self.state, self.cm
+
+        def _jadr(name, key):
+            return int(cm.arrays[key][cm.joint_id(name)])
+        return types.SimpleNamespace(time=s.time, qpos=s.qpos, qvel=s.qvel, act=s.act, ctrl=self.last_ctrl, qacc_warmstart=s.qacc_warmstart,
+                                     get_joint_qpos=lambda name: s.qpos[:, _jadr(name, "JNT_QPOSADR")],
+                                     get_joint_qvel=lambda name: s.qvel[:, _jadr(name, "JNT_DOFADR")])
 
     def get_obs_dict(self, *sim_args, state=None):
         """the reference's `get_obs_dict(sim)` / `get_obs_dict(mj_model, mj_data)` on the env's OWN simulation: the obs_dict of the

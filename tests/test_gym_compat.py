@@ -123,6 +123,11 @@ def test_gym_make_single_env_follows_the_reference_signatures(gym_stub):
             break
     assert steps == 100 and trunc                                                             # TimeLimit(100) from the registry
     assert list(env.unwrapped.obs_dict.keys()) == ["time", "qpos", "qvel", "pose_err", "act"]
+    # name-addressed model / data access as reference scripts do it
+    mjm, mjd = ref.mj_model, ref.mj_data
+    j = mjm.joint_names[0]
+    assert torch.equal(mjd.get_joint_qpos(j), ref.state.qpos[:, 0]) and torch.equal(mjd.get_joint_qvel(j), ref.state.qvel[:, 0])
+    assert len(mjm.actuator_names) == mjm.nu == 6 and mjm.actuator_lengthrange.shape == (6, 2)
 
 
 @pytest.mark.gpu
@@ -152,6 +157,29 @@ def test_sb3_style_training_loop_runs_on_make_vec_env(gym_stub):
     o, info = venv.reset5(seed=0)
     o, r, term, trunc, info = venv.step5(np.zeros((4, 39), np.float32))
     assert o.shape == (4, 108) and term.shape == (4,) and trunc.shape == (4,)
+
+
+def test_mj_model_view_offers_the_names_and_arrays_reference_scripts_read():
+    """`env.mj_model.actuator_names.index("glmax1_r")` (agents/baseline_Reflex/ReflexCtrInterface.py:274), `env.mj_model.body_mass`,
+    `actuator_lengthrange`, `tendon_lengthspring`, `opt.timestep`: the read-only view is built from the compiled model alone (no GPU)."""
+    from myosuite_amd.envs.base_v0 import BaseV0
+    from myosuite_amd.model import synth
+
+    class Stub:
+        _MJMODEL_ARRAYS = BaseV0._MJMODEL_ARRAYS
+    for name in ("hand", "leg"):
+        st = Stub(); st.cm = cm = synth.get_model(name)
+        v = BaseV0.mj_model.fget(st)
+        assert (v.nq, v.nv, v.nu, v.na) == (cm.nq, cm.nv, cm.nu, cm.na) and v.opt.timestep == pytest.approx(cm.timestep)
+        assert len(v.actuator_names) == cm.nu and len(v.joint_names) == cm.njnt and len(v.body_names) == cm.nbody
+        for i, n in enumerate(v.actuator_names):
+            assert cm.names["actuator"][n] == i
+        assert v.body_mass.shape == (cm.nbody,) and v.actuator_lengthrange.shape == (cm.nu, 2) and v.jnt_range.shape == (cm.njnt, 2)
+        assert v.tendon_lengthspring.shape[0] == cm.ntendon and v.actuator_gainprm.shape[0] == cm.nu
+        v.body_mass[:] = 0                                   # a copy: the compiled model is untouched
+        assert float(np.asarray(cm.arrays["BODY_MASS"]).sum()) > 0
+        assert BaseV0.mj_model.fget(st) is v                 # built once
+    assert v.actuator_names.index("glmax1_r") >= 0
 
 
 @pytest.mark.gpu
