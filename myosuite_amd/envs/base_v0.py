@@ -330,6 +330,32 @@ class BaseV0:
         if "step_count" in state_dict:
             self.step_count.copy_(state_dict["step_count"])
 
+    def forward(self):
+        """`env.sim.forward()` + `get_obs()` of the reference after a state edit (env_base.py:434-459, 720-760): one forward pass of
+        the CURRENT state of every env (no stepping, no counters) refreshing `obs`, `obs_dict`, `rwd_dict`."""
+        E.reset_observation(self.hm, self.state, self._task, None)
+        self._refresh_dicts()
+
+    def get_obs(self, update_proprioception=True, update_exteroception=False):
+        """env_base.py:434-459: the observation vector of the current state (recomputed: valid after `set_env_state` or a direct
+        edit of `state.qpos` / `mj_data.qpos`)."""
+        self.forward()
+        if update_proprioception and self.proprio_keys is not None:
+            self.proprio_dict = self.get_proprioception()[2]
+        return self._obs_out()
+
+    def evaluate_success(self, paths, logger=None, successful_steps=5):
+        """env_base.py:798-824, same arithmetic: a path counts as solved when its `env_infos["solved"]` sums above
+        `successful_steps`; returns the percentage (and logs rwd_sparse / rwd_dense / success_percentage when given a logger)."""
+        num_paths = len(paths)
+        num_success = sum(1 for p in paths if np.sum(np.asarray(p["env_infos"]["solved"]) * 1.0) > successful_steps)
+        success_percentage = num_success * 100.0 / num_paths
+        if logger:
+            logger.log_kv("rwd_sparse", np.mean([np.mean(p["env_infos"]["rwd_sparse"]) for p in paths]))
+            logger.log_kv("rwd_dense", np.mean([np.sum(p["env_infos"]["rwd_dense"]) / self.horizon for p in paths]))
+            logger.log_kv("success_percentage", success_percentage)
+        return success_percentage
+
     def get_proprioception(self, obs_dict=None):
         """env_base.py:557-576: (time, proprio vector, proprio dict) over `proprio_keys`, or (None, None, None) when none are configured"""
         if self.proprio_keys is None:

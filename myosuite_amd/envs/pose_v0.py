@@ -141,8 +141,8 @@ class PoseEnvV0(BaseV0):
             ro.target = self.target_jnt_value.data_ptr(); ro.episode = self.episode.data_ptr()
             ro.reset_seed = self._seed_u64
 
-    def get_obs(self):
-        """Observation vector of the current state without stepping (mm_forward-free: Pose needs none)."""
+    def _torch_obs(self):
+        """Observation vector of the current state as torch ops on the state rows (Pose needs no forward pass)."""
         d = self.get_obs_dict()
         return torch.cat([d[k].reshape(self.num_envs, -1) for k in self._kernel_obs_keys], dim=1).to(torch.float32)
 
@@ -198,7 +198,7 @@ class PoseEnvV0(BaseV0):
                 dst = getattr(self.state, k)
                 dst.copy_(keep[k] if m is None else torch.where(m.view(-1, *([1] * (dst.dim() - 1))), keep[k], dst))
         if not simple:   # state was overwritten after the kernel wrote its observation
-            self.obs.copy_(self.get_obs()) if mask is None else self.obs.copy_(
-                torch.where(mask.bool()[:, None], self.get_obs(), self.obs))
+            self.obs.copy_(self._torch_obs()) if mask is None else self.obs.copy_(
+                torch.where(mask.bool()[:, None], self._torch_obs(), self.obs))
         self._refresh_dicts()
         return self._obs_out(), {}

@@ -620,6 +620,46 @@ def test_custom_obs_keys_are_served_from_obs_dict_like_obsdict2obsvec():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id", ["myoHandPoseRandom-v0", "myoHandReachRandom-v0", "myoLegWalk-v0", "myoHandReorient8-v0", "myoHandKeyTurnRandom-v0"])
+def test_get_obs_after_set_env_state_is_the_observation_of_that_state(env_id):
+    """env_base.py:434-459 / 720-760: `set_env_state(state)` followed by `get_obs()` gives the observation of THAT state (one forward
+    pass, no stepping, counters untouched): a second env that receives the first one's state reports the first one's observation and
+    obs_dict, and stepping both with the same action keeps them identical; `evaluate_success` counts paths like the reference."""
+    n = 8
+    a = registry.make(env_id, num_envs=n, seed=2, autoreset=False)
+    b = registry.make(env_id, num_envs=n, seed=2, autoreset=False)
+    a.reset(seed=2); b.reset(seed=2)
+    act = torch.empty(n, a.cm.nu, device="cuda")
+    for s_ in range(3):
+        E.uniform(act, 4, s_)
+        oa, *_ = a.step(act)
+    assert not torch.equal(oa, b.obs)
+    b.set_env_state(a.get_env_state())
+    steps_before = b.step_count.clone()
+    ob = b.get_obs()
+    assert torch.equal(b.step_count, steps_before)
+    if hasattr(a, "target_jnt_value") or "Reach" in env_id or "Walk" in env_id or "KeyTurn" in env_id:     # same targets (same seed, episode): identical
+        same = torch.ones(oa.shape[1], dtype=torch.bool, device="cuda")
+        if "Walk" in env_id:
+            # walk_v0.py:339-342: step() computes the observation BEFORE `self.steps += 1`, so a get_obs() afterwards sees the phase
+            # variable one step further ((steps / hip_period) % 1), in the reference as here
+            k0 = int(torch.nonzero((ob - oa).abs().max(0).values > 1e-3)[0])
+            assert torch.allclose(ob[:, k0] - oa[:, k0], torch.full((n,), 1.0 / a.hip_period, device="cuda"), atol=1e-6)
+            assert torch.equal(b.obs_dict["phase_var"][:, 0], ob[:, k0])
+            same[k0] = False
+        assert torch.allclose(ob[:, same], oa[:, same], rtol=0, atol=2e-6), float((ob - oa)[:, same].abs().max())
+        for k in a.obs_dict:
+            if k != "phase_var":
+                assert torch.allclose(b.obs_dict[k].float(), a.obs_dict[k].float(), rtol=0, atol=2e-6), k
+    E.uniform(act, 4, 9)
+    o1, r1, *_ = a.step(act); o2, r2, *_ = b.step(act)
+    assert torch.allclose(o1, o2, rtol=0, atol=5e-6) and torch.allclose(r1, r2, rtol=0, atol=5e-5)
+    paths = [{"env_infos": {"solved": np.array([0, 1, 1, 1, 1, 1, 1]), "rwd_sparse": np.zeros(7), "rwd_dense": np.ones(7)}},
+             {"env_infos": {"solved": np.array([0, 0, 0, 1, 1, 0, 0]), "rwd_sparse": np.zeros(7), "rwd_dense": np.ones(7)}}]
+    assert a.evaluate_success(paths) == 50.0
+
+
 @pytest.mark.parametrize("name", ["hand", "hand_contact"])
 def test_solver_budget_option_matches_a_model_compiled_with_it(name):
     """mm_model_set_option(m, "iterations" / "ls_iterations", n): the reference's MJX envs overwrite the loaded model's solver budget
