@@ -112,6 +112,16 @@ class SingleEnv(_EnvBase):
     def get_obs_dict(self, *sim_args, **kw):
         return self._np0(self._env.get_obs_dict())
 
+    def get_obs(self, update_proprioception=True, update_exteroception=False):      # env_base.py:434-459
+        return self._env.get_obs(update_proprioception, update_exteroception)[0].cpu().numpy()
+
+    def get_env_state(self):                                                         # env_base.py:688-718
+        return self._np0({k: v for k, v in self._env.get_env_state().items() if v is not None})
+
+    def set_env_state(self, state_dict):                                             # env_base.py:720-760
+        dev = self._env.device
+        self._env.set_env_state({k: torch.as_tensor(np.asarray(v), device=dev)[None] for k, v in state_dict.items() if v is not None})
+
     def get_reward_dict(self, obs_dict=None):
         return self._np0(self._env.get_reward_dict(self._env.obs_dict))
 

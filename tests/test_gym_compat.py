@@ -123,6 +123,15 @@ def test_gym_make_single_env_follows_the_reference_signatures(gym_stub):
             break
     assert steps == 100 and trunc                                                             # TimeLimit(100) from the registry
     assert list(env.unwrapped.obs_dict.keys()) == ["time", "qpos", "qvel", "pose_err", "act"]
+    # state save / restore through the numpy door (env_base.py:688-760): restoring and asking for the observation gives it back
+    env.reset(seed=5)
+    o_a, *_ = env.step(np.full(6, 0.3, np.float32))
+    st = env.unwrapped.get_env_state()
+    assert isinstance(st["qpos"], np.ndarray) and st["qpos"].shape == (1,)
+    o_b, *_ = env.step(np.full(6, -0.5, np.float32))
+    env.unwrapped.set_env_state(st)
+    o_c = env.unwrapped.get_obs()
+    assert o_c.shape == (9,) and o_c.dtype == np.float32 and np.allclose(o_c, o_a, atol=1e-6) and not np.allclose(o_b, o_a, atol=1e-4)
     # name-addressed model / data access as reference scripts do it
     mjm, mjd = ref.mj_model, ref.mj_data
     j = mjm.joint_names[0]
