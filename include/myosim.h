@@ -111,7 +111,7 @@ typedef struct {
   float* site_xpos;         /* [nenv][nsite][3]                               */
   float* geom_xpos;         /* [nenv][ngeom][3]                               */
   float* cvel;              /* [nenv][nbody][6] com-frame velocities (rot:lin)*/
-  float* subtree_com;       /* [nenv][nbody][3] (only tree roots are filled)  */
+  float* subtree_com;       /* [nenv][nbody][3] COM of the kinematic tree the body belongs to (the point cdof / cinert refer to): mjData.subtree_com at tree roots, the ROOT's value in every other slot */
   float* actuator_length;   /* [nenv][nu]                                     */
   float* actuator_velocity; /* [nenv][nu]                                     */
   float* actuator_force;    /* [nenv][nu]                                     */
