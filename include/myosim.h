@@ -75,7 +75,7 @@ enum { MM_STRUCT_STATE = 0, MM_STRUCT_DERIVED, MM_STRUCT_TASK, MM_STRUCT_ROLLOUT
 
 /* Simulation state of a batch, all [nenv][n] float32 device arrays. */
 typedef struct {
-  int    nenv;
+  int    nenv;            /* >= 1: every call that takes an mm_state refuses an empty batch (MM_EARG), nothing is launched */
   float* qpos;            /* [nenv][nq]                                   */
   float* qvel;            /* [nenv][nv]                                   */
   float* act;             /* [nenv][na]                                   */

@@ -1118,14 +1118,14 @@ static void fill_common(const mm_model* m, KArgs& a, const mm_state* s) {
 }
 
 extern "C" int mm_step(const mm_model* m, const mm_state* s, const float* ctrl, int nsub, void* stream) {
-  if (!m || !s || nsub < 0) return fail(MM_EARG, "mm_step: bad argument");
+  if (!m || !s || s->nenv <= 0 || nsub < 0) return fail(MM_EARG, "mm_step: bad argument");
   KArgs a; fill_common(m, a, s);
   a.ctrl = ctrl; a.mode = 0; a.t.nsubsteps = nsub; a.dbg = nullptr;
   return launch(m, a, stream);
 }
 
 extern "C" int mm_forward(const mm_model* m, const mm_state* s, const float* ctrl, const mm_derived* out, void* stream) {
-  if (!m || !s) return fail(MM_EARG, "mm_forward: bad argument");
+  if (!m || !s || s->nenv <= 0) return fail(MM_EARG, "mm_forward: bad argument");
   KArgs a; fill_common(m, a, s);
   a.ctrl = ctrl; a.mode = 1;
   if (out) { a.o = *out; a.has_derived = 1; }
@@ -1148,7 +1148,7 @@ static int sized_copy(T* dst, const T* src, size_t min_size, const char* what) {
 }
 
 static int check_task(const mm_model* m, const mm_state* s, const mm_task* t) {
-  if (!m || !s || !t) return fail(MM_EARG, "mm_env_step: bad argument");
+  if (!m || !s || s->nenv <= 0 || !t) return fail(MM_EARG, "mm_env_step: bad argument");
   if (t->task == MM_TASK_POSE && !t->target_jnt_value) return fail(MM_EARG, "pose task needs target_jnt_value");
   if (t->fwd_carry && !fwd_carry_ok(m)) return fail(MM_EUNSUPPORTED, "mm_task.fwd_carry: Euler / implicitfast, fp32, nv >= 5, every actuator with activation dynamics (MM_INFO_FWD_CARRY)");
   if (t->task == MM_TASK_REACH && (!t->tip_sites || !t->target_pos || t->ntip <= 0)) return fail(MM_EARG, "reach task needs tip_sites/target_pos");
@@ -1229,7 +1229,7 @@ extern "C" int mm_rollout_step(const mm_model* m, const mm_state* s, const mm_ta
 
 extern "C" int mm_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* qpos_src,
                         const float* qvel_src, void* stream) {
-  if (!m || !s) return fail(MM_EARG, "mm_reset: bad argument");
+  if (!m || !s || s->nenv <= 0) return fail(MM_EARG, "mm_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.qpos_src = qpos_src; r.qvel_src = qvel_src;
@@ -1242,7 +1242,7 @@ extern "C" int mm_pose_reset(const mm_model* m, const mm_state* s, const uint8_t
                              const float* qhi, const float* tlo, const float* thi, float* target, int32_t* episode,
                              int32_t* step_count, uint64_t seed, int random_qpos, float* obs, int obs_dim,
                              int obs_layout, void* stream) {
-  if (!m || !s || !tlo || !thi || !target) return fail(MM_EARG, "mm_pose_reset: bad argument");
+  if (!m || !s || s->nenv <= 0 || !tlo || !thi || !target) return fail(MM_EARG, "mm_pose_reset: bad argument");
   if (random_qpos && (!qlo || !qhi)) return fail(MM_EARG, "mm_pose_reset: random_qpos needs qlo/qhi");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
@@ -1366,7 +1366,7 @@ extern "C" int mm_env_draw(float* out, int nenv, int ncomp, const float* base, c
 extern "C" int mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* tlo, const float* thi,
                               float* target, const float* tip0, int ntip, int32_t* episode, int32_t* step_count,
                               uint64_t seed, float* obs, int obs_dim, void* stream) {
-  if (!m || !s || !tlo || !thi || !target || !tip0 || ntip <= 0) return fail(MM_EARG, "mm_reach_reset: bad argument");
+  if (!m || !s || s->nenv <= 0 || !tlo || !thi || !target || !tip0 || ntip <= 0) return fail(MM_EARG, "mm_reach_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask;
@@ -1380,7 +1380,7 @@ extern "C" int mm_reach_reset(const mm_model* m, const mm_state* s, const uint8_
 extern "C" int mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* key_a_qpos,
                              const float* key_a_qvel, const float* key_b_qpos, const float* key_b_qvel, int random,
                              int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
-  if (!m || !s || !key_a_qpos || !key_a_qvel) return fail(MM_EARG, "mm_walk_reset: bad argument");
+  if (!m || !s || s->nenv <= 0 || !key_a_qpos || !key_a_qvel) return fail(MM_EARG, "mm_walk_reset: bad argument");
   if (random && (!key_b_qpos || !key_b_qvel)) return fail(MM_EARG, "mm_walk_reset: random reset needs the second key");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
@@ -1394,7 +1394,7 @@ extern "C" int mm_walk_reset(const mm_model* m, const mm_state* s, const uint8_t
 extern "C" int mm_reorient_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
                                  const float* size_table, int ntab, float* geom_size_env, float* axis_half, float* des_rot,
                                  float tar_length, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
-  if (!m || !s || !init_qpos || !size_table || ntab <= 0 || !geom_size_env || !axis_half || !des_rot || !(tar_length > 0.f))
+  if (!m || !s || s->nenv <= 0 || !init_qpos || !size_table || ntab <= 0 || !geom_size_env || !axis_half || !des_rot || !(tar_length > 0.f))
     return fail(MM_EARG, "mm_reorient_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
@@ -1411,7 +1411,7 @@ extern "C" int mm_reorient_reset_typed(const mm_model* m, const mm_state* s, con
                                        const float* size_tables, int ntab, float* geom_size_env, int32_t* geom_type_env,
                                        float* axis_half, float* des_rot, float tar_length, int32_t* episode,
                                        int32_t* step_count, uint64_t seed, void* stream) {
-  if (!m || !s || !init_qpos || !size_tables || ntab <= 0 || !geom_size_env || !geom_type_env || !axis_half || !des_rot ||
+  if (!m || !s || s->nenv <= 0 || !init_qpos || !size_tables || ntab <= 0 || !geom_size_env || !geom_type_env || !axis_half || !des_rot ||
       !(tar_length > 0.f))
     return fail(MM_EARG, "mm_reorient_reset_typed: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
@@ -1428,7 +1428,7 @@ extern "C" int mm_reorient_reset_typed(const mm_model* m, const mm_state* s, con
 extern "C" int mm_pen_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos, float axis_half,
                             float lo0, float hi0, float lo1, float hi1, float* des_rot, float tar_length, int32_t* episode,
                             int32_t* step_count, uint64_t seed, void* stream) {
-  if (!m || !s || !init_qpos || !des_rot || !(tar_length > 0.f) || !(axis_half > 0.f))
+  if (!m || !s || s->nenv <= 0 || !init_qpos || !des_rot || !(tar_length > 0.f) || !(axis_half > 0.f))
     return fail(MM_EARG, "mm_pen_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
@@ -1444,7 +1444,7 @@ extern "C" int mm_pen_reset(const mm_model* m, const mm_state* s, const uint8_t*
 extern "C" int mm_objhold_reset(const mm_model* m, const mm_state* s, const uint8_t* mask, const float* init_qpos,
                                 const float* goal_center, float goal_half, float size_lo, float size_hi, float* goal,
                                 float* geom_size_env, int32_t* episode, int32_t* step_count, uint64_t seed, void* stream) {
-  if (!m || !s || !init_qpos || !goal_center || !goal) return fail(MM_EARG, "mm_objhold_reset: bad argument");
+  if (!m || !s || s->nenv <= 0 || !init_qpos || !goal_center || !goal) return fail(MM_EARG, "mm_objhold_reset: bad argument");
   ResetArgs r; memset(&r, 0, sizeof(r));
   r.blob = m->d_blob; r.state_f64 = m->precision == MM_PREC_F64_STATE; r.qpos0_off = m->sec[MM_SEC_QPOS0]; r.nq = m->d.nq; r.nv = m->d.nv; r.na = m->d.na;
   r.nenv = s->nenv; r.s = *s; r.mask = mask; r.episode = episode; r.step_count = step_count; r.seed = seed;

@@ -367,6 +367,8 @@ class BatchState:
     def __init__(self, model: HipModel, nenv: int):
         cm = model.cm
         dev = model.device
+        if int(nenv) < 1:
+            raise ValueError(f"BatchState needs at least one environment (got nenv = {nenv}); the C ABI refuses an empty batch with MM_EARG")
         self.model = model
         self.nenv = nenv
         model._n_states += 1

@@ -796,6 +796,29 @@ def test_ragged_and_single_env_batches(env_id, lanes):
             assert torch.equal(o, ob[:n]) and torch.equal(r, rb[:n]), (n, s)
 
 
+@pytest.mark.gpu
+def test_an_empty_batch_is_refused_everywhere(models):
+    """Edge of the batch dimension: zero environments.  The host layer refuses to build one and every C entry that takes an
+    `mm_state` returns MM_EARG for `nenv <= 0` without launching anything (a zero-block grid would be a HIP launch error)."""
+    with pytest.raises(ValueError):
+        registry.make("myoElbowPose1D6MRandom-v0", num_envs=0)
+    hm = E.HipModel(models["elbow"])
+    st = E.BatchState(hm, 4)
+    q_before = st.qpos.clone()
+    for bad in (0, -3):
+        st._c.nenv = bad
+        with pytest.raises(E.EngineError):
+            E.forward(hm, st)
+        with pytest.raises(E.EngineError):
+            E.step(hm, st, torch.zeros(4, hm.cm.nu, device="cuda"), 1)
+        with pytest.raises(E.EngineError):
+            E.reset(hm, st)
+    st._c.nenv = 4
+    E.step(hm, st, torch.zeros(4, hm.cm.nu, device="cuda"), 1)           # the handle is fine afterwards
+    torch.cuda.synchronize()
+    assert not torch.equal(st.qpos, q_before) and int(st.status.max()) == 0
+
+
 def _mujoco_fixtures():
     import glob
     return sorted(glob.glob(os.path.join(G, "mujoco_*.npz")))
