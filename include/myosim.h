@@ -83,7 +83,10 @@ typedef struct {
   float* time;            /* [nenv]                                       */
   int32_t* status;        /* [nenv] sticky bits, cleared by reset: 1 bad-state auto reset (mj_step's mj_checkPos / checkVel / checkAcc),
                                     4 the solver hit its iteration cap, 8 more constraint rows than the engine holds (surplus
-                                    rows dropped), 16 a two-wave launch lost a partner wave (a bounded wait gave up: engine bug) */
+                                    rows dropped), 16 a two-wave launch lost a partner wave (a bounded wait gave up: engine bug),
+                                    32 a NaN / Inf / > 1e10 entry in the env's control vector: ALL its controls were set to 0 for this
+                                    launch (mj_fwdActuation's mjWARN_BADCTRL); the state is not reset.  After a bad-state reset (bit 1)
+                                    the remaining substeps of the launch run on zero controls, as mj_resetData clears them */
   /* per-env model delta (the reference mutates mjModel at reset: reorient_sar_v0.py:407-409): size of ONE geom */
   const float* geom_size_env; /* [nenv][3] or NULL: replaces geom_size[geom_env_id] in collision           */
   int    geom_env_id;         /* geom id the per-env size applies to (-1 = none)                           */

@@ -929,6 +929,9 @@ static real muscle_dynamics(real ctrl, real act, const real* prm) {
 static void mmo_actuation(const mmo_model* m, mmo_data* d) {
   int nv = m->nv;
   memset(d->qfrc_actuator, 0, sizeof(real) * nv);
+  /* mj_fwdActuation: "check controls, set all to 0 if any are bad" (mjWARN_BADCTRL; bad = NaN, or beyond mjMAXVAL = 1e10) */
+  for (int a = 0; a < m->nu; a++)
+    if (!(fabs(d->ctrl[a]) < 1e10)) { memset(d->ctrl, 0, sizeof(real) * m->nu); d->warn_bad |= 4; break; }
   for (int a = 0; a < m->nu; a++) {
     real ctrl = d->ctrl[a];
     if (MI(m, ACT_CTRLLIMITED)[a]) {
@@ -1531,12 +1534,11 @@ static void mmo_rk4(const mmo_model* m, mmo_data* d) {
 
 /* mj_step: forward + integrate, with MuJoCo's bad-state auto-reset semantics */
 void mmo_step(const mmo_model* m, mmo_data* d) {
-  if (bad_state(m, d, 0)) { real c[256]; int nu = m->nu < 256 ? m->nu : 256;
-    memcpy(c, d->ctrl, sizeof(real) * nu); mmo_reset(m, d); memcpy(d->ctrl, c, sizeof(real) * nu); d->warn_bad |= 1; }
+  /* mj_checkPos / mj_checkVel, then mj_checkAcc after the forward pass: warn, mj_resetData (which clears the controls as well: a
+     caller that loops mj_step over one control vector -- Robot.step's frame_skip loop -- finishes the loop on zero input), carry on */
+  if (bad_state(m, d, 0)) { mmo_reset(m, d); memset(d->ctrl, 0, sizeof(real) * m->nu); d->warn_bad |= 1; }
   mmo_forward(m, d);
-  if (bad_state(m, d, 1)) { real c[256]; int nu = m->nu < 256 ? m->nu : 256;
-    memcpy(c, d->ctrl, sizeof(real) * nu); mmo_reset(m, d); memcpy(d->ctrl, c, sizeof(real) * nu); d->warn_bad |= 1;
-    mmo_forward(m, d); }
+  if (bad_state(m, d, 1)) { mmo_reset(m, d); memset(d->ctrl, 0, sizeof(real) * m->nu); d->warn_bad |= 1; mmo_forward(m, d); }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(real) * m->nv);
   MMO_STAGE(MMO_ST_INTEG);
   if (m->integrator == MM_INT_RK4) mmo_rk4(m, d);

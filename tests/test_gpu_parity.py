@@ -797,6 +797,62 @@ def test_ragged_and_single_env_batches(env_id, lanes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model,poison", [("hand", "nan_qvel"), ("hand", "huge_qpos"), ("elbow", "inf_qvel"), ("hand", "nan_ctrl")])
+def test_bad_state_is_reset_like_mj_step_does_and_stays_in_its_env(oracle_lib, models, model, poison):
+    """MuJoCo's mj_step checks qpos / qvel (before) and qacc (after the forward pass) for NaN / Inf / huge values, warns, calls
+    mj_resetData and carries on from the reset state (engine_forward.c mj_checkPos / mj_checkVel / mj_checkAcc; oracle mmo_step).
+    The kernel does the same per env inside the substep loop: the poisoned env ends up where the oracle's does (qpos0-based, finite,
+    zero controls from then on as mj_resetData clears them), raises status bit 1, and its neighbours -- in the same wave -- are
+    bit-identical to a batch that was never poisoned.  A bad CONTROL is mj_fwdActuation's business: all controls of that env become 0
+    (status bit 32), nothing is reset."""
+    O = oracle_lib
+    cm = models[model]
+    hm = E.HipModel(cm); om = O.OracleModel(cm)
+    n, bad = 8, 3
+    rng = np.random.default_rng(5)
+    lo, hi = cm.jnt_range[:, 0].astype(np.float64), cm.jnt_range[:, 1].astype(np.float64)
+    q = (lo + (hi - lo) * rng.random((n, cm.nq))).astype(np.float32)
+    v = (0.2 * rng.standard_normal((n, cm.nv))).astype(np.float32)
+    ctrl = rng.random((n, cm.nu)).astype(np.float32)
+    clean = E.BatchState(hm, n); dirty = E.BatchState(hm, n)
+    for st in (clean, dirty):
+        st.qpos.copy_(torch.from_numpy(q)); st.qvel.copy_(torch.from_numpy(v))
+    c_clean = torch.from_numpy(ctrl).cuda(); c_dirty = c_clean.clone()
+    if poison == "nan_qvel":
+        dirty.qvel[bad, 1] = float("nan")
+    elif poison == "inf_qvel":
+        dirty.qvel[bad, 0] = float("inf")
+    elif poison == "huge_qpos":
+        dirty.qpos[bad, 2] = 1e12
+    else:
+        c_dirty[bad, 4] = float("nan")
+    d = O.OracleData(om)
+    d.qpos[:] = dirty.qpos[bad].cpu().numpy(); d.qvel[:] = dirty.qvel[bad].cpu().numpy(); d.ctrl[:] = c_dirty[bad].cpu().numpy()
+    nsub = 5
+    E.step(hm, clean, c_clean, nsub); E.step(hm, dirty, c_dirty, nsub)
+    torch.cuda.synchronize()
+    d.step(nsub)
+    status = dirty.status.cpu().numpy()
+    others = [e for e in range(n) if e != bad]
+    assert not (status[others] & 33).any() and int(clean.status.max()) == 0
+    assert torch.equal(dirty.qpos[others], clean.qpos[others]) and torch.equal(dirty.qvel[others], clean.qvel[others])
+    assert bool(torch.isfinite(dirty.qpos).all() and torch.isfinite(dirty.qvel).all()) and np.all(np.isfinite(d.qpos))
+    if poison == "nan_ctrl":
+        # mj_fwdActuation: "check controls, set all to 0 if any are bad" (mjWARN_BADCTRL) -- no reset, the env steps on zero input
+        assert d.warn == 4 and status[bad] == 32, (d.warn, status)
+        z = O.OracleData(om); z.qpos[:] = q[bad]; z.qvel[:] = v[bad]; z.step(nsub)          # = stepping with ctrl = 0
+        assert np.array_equal(z.qpos, d.qpos)
+    else:
+        # mj_checkPos / mj_checkVel: warn, mj_resetData (state AND controls), continue from the reset state
+        assert d.warn & 1 and status[bad] & 1, (d.warn, status)
+        z = O.OracleData(om); z.step(nsub)                                                  # = qpos0, zero input, nsub substeps
+        assert np.array_equal(z.qpos, d.qpos)
+    np.testing.assert_allclose(dirty.qpos[bad].cpu().numpy(), d.qpos, atol=2e-5)
+    np.testing.assert_allclose(dirty.qvel[bad].cpu().numpy(), d.qvel, atol=2e-3)
+    assert float(dirty.time[bad]) == pytest.approx(d.time, abs=1e-7)
+
+
+@pytest.mark.gpu
 def test_an_empty_batch_is_refused_everywhere(models):
     """Edge of the batch dimension: zero environments.  The host layer refuses to build one and every C entry that takes an
     `mm_state` returns MM_EARG for `nenv <= 0` without launching anything (a zero-block grid would be a HIP launch error)."""
