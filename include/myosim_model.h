@@ -174,7 +174,7 @@ enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
      entry k of the run keeping contacts 2k, 2k+1 of the collider's order (oracle/mmo_collision.inc) */                   \
   MM_SEC(PAIR_GEOM1,       'i', 1)                                               \
   MM_SEC(PAIR_GEOM2,       'i', 1)                                               \
-  MM_SEC(PAIR_CONDIM,      'i', 1)                                               \
+  MM_SEC(PAIR_CONDIM,      'i', 1)   /* 1 | 3 | 4: pyramidal cone, 1 / 4 / 6 rows */  \
   MM_SEC(PAIR_FRICTION,    'f', 3)   /* slide, spin, roll */                     \
   MM_SEC(PAIR_MARGIN,      'f', 1)                                               \
   MM_SEC(PAIR_GAP,         'f', 1)                                               \

@@ -338,6 +338,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   d.njnt = oi[MM_OI_NJNT]; d.ngeom = oi[MM_OI_NGEOM]; d.nsite = oi[MM_OI_NSITE]; d.ntendon = oi[MM_OI_NTENDON];
   d.nwrap = oi[MM_OI_NWRAP]; d.neq = oi[MM_OI_NEQ]; d.npair = oi[MM_OI_NPAIR]; d.nM = oi[MM_OI_NM];
   d.nlevel = oi[MM_OI_NLEVEL]; d.njmax = oi[MM_OI_NJMAX]; d.nconmax = oi[MM_OI_NCONMAX]; d.ntenJ = oi[MM_OI_NTENJ];
+  d.condim4 = 0;     // set below when a pair carries condim 4
   d.iterations = oi[MM_OI_ITERATIONS]; d.ls_iterations = oi[MM_OI_LS_ITERATIONS]; d.eulerdamp = oi[MM_OI_EULERDAMP];
   d.timestep = of[MM_OF_TIMESTEP]; d.gx = of[MM_OF_GRAV_X]; d.gy = of[MM_OF_GRAV_Y]; d.gz = of[MM_OF_GRAV_Z];
   d.tolerance = of[MM_OF_TOLERANCE]; d.ls_tolerance = of[MM_OF_LS_TOLERANCE]; d.meaninertia = of[MM_OF_MEANINERTIA];
@@ -471,7 +472,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
         if (!twin) { delete m; return fail(MM_EBADBLOB, "a plane-box / plane-cylinder pair takes two consecutive entries of the PAIR_* sections"); }
       }
       if (!ok) { delete m; return fail(MM_EUNSUPPORTED, "contact pair types: plane vs sphere/capsule/ellipsoid/cylinder/box, sphere/capsule among themselves, sphere/capsule vs ellipsoid/cylinder/box (geom1 type <= geom2 type)"); }
-      if (pc[p] != 1 && pc[p] != 3) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1 or 3"); }
+      if (pc[p] == 4) m->d.condim4 = 1;
+      if (pc[p] != 1 && pc[p] != 3 && pc[p] != 4) { delete m; return fail(MM_EUNSUPPORTED, "contact condim must be 1, 3 or 4 (pyramidal cone: 1 / 4 / 6 rows; rolling friction, condim 6, is not implemented)"); }
     }
   }
   if (d.nv > 255) { delete m; return fail(MM_EUNSUPPORTED, "nv > 255"); }

@@ -69,6 +69,7 @@ struct Dims {
   int desc_words;       // words of the per-dof descendant list (4 ids each) a product M x has to walk
   int integrator;   // MM_INT_EULER | MM_INT_RK4 | MM_INT_IMPLICITFAST
   int efc_rows;     // allocated rows of the efc_J LDS table: min(lanes_per_env, njmax rounded up to 4)
+  int condim4;      // 1: some contact pair is condim 4 (torsional friction: six pyramid rows) -- the torsional pass runs
   int nconmax;      // MM_OI_NCONMAX: contacts beyond this many (in collider order) are dropped and flagged, as mjModel.nconmax
   float timestep, gx, gy, gz, tolerance, ls_tolerance, meaninertia;
   // Origin of the kernel's internal world frame (host: mean body position at qpos0, rounded to 1/64 m).  Physics is

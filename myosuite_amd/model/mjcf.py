@@ -552,6 +552,8 @@ def load(source: str, missing_include: str = "error", include_map: Optional[Dict
             a = ctx.resolve("pair", el.attrib, None)
             g1 = next(g for g in geom_info if g["name"] == a["geom1"]); g2 = next(g for g in geom_info if g["name"] == a["geom2"])
             mix = _mix(g1, g2)
+            if int(a.get("condim", mix["condim"])) not in (1, 3, 4):
+                raise MjcfError(f"<pair {a['geom1']} {a['geom2']}>: condim {a.get('condim', mix['condim'])} is not implemented (pyramidal cones with condim 1, 3, 4)")
             s.add_contact_pair(a["geom1"], a["geom2"], condim=int(a.get("condim", mix["condim"])),
                                friction=tuple(_floats(a.get("friction"), None, mix["friction"])[:3]),
                                margin=float(a.get("margin", mix["margin"])), gap=float(a.get("gap", mix["gap"])),
@@ -573,6 +575,8 @@ def load(source: str, missing_include: str = "error", include_map: Optional[Dict
                 if not (bparent.get(b1) == b2 and b2 in welded_to_world) and not (bparent.get(b2) == b1 and b1 in welded_to_world):
                     continue                                              # parent-child filter
             mix = _mix(g1, g2)
+            if mix["condim"] not in (1, 3, 4):
+                raise MjcfError(f"contact pair {g1['name']} / {g2['name']}: condim {mix['condim']} is not implemented (pyramidal cones with condim 1, 3, 4)")
             s.add_contact_pair(g1["name"], g2["name"], condim=mix["condim"], friction=tuple(mix["friction"]),
                                margin=mix["margin"], gap=mix["gap"], solref=tuple(mix["solref"]), solimp=tuple(mix["solimp"]))
 
@@ -703,6 +707,8 @@ def dry_run(source: str, include_map: Optional[Dict[str, str]] = None) -> dict:
                     ignored["visual mesh geom"] = ignored.get("visual mesh geom", 0) + 1
                 else:
                     bad(f"{gtype or 'mesh'} geom that collides (contype {ra.get('contype', '1')} / conaffinity {ra.get('conaffinity', '1')} after default classes)", w)
+            elif int(float(ra.get("condim", "3"))) not in (1, 3, 4) and not (int(float(ra.get("contype", "1"))) == 0 and int(float(ra.get("conaffinity", "1"))) == 0):
+                bad(f"colliding geom with condim {ra.get('condim')} (pyramidal cones are implemented for condim 1, 3 and 4: no rolling friction)", w)
         if t == "joint" and "default" not in [p.tag for p in parents]:
             if a.get("type") == "ball" and (a.get("limited") == "true" or "range" in a):
                 bad("limited ball joint", w)

@@ -818,8 +818,16 @@ def _make_hand_with_object(kind: str) -> ModelSpec:
     else:
         s.bodies[s._bname["target"]].quat = np.array([1.0, 0, 0, 0])            # myohand_pen.xml:44: no euler on the target
         s.add_site("target_top", "target", (0, 0, 0.065)); s.add_site("target_bottom", "target", (0, 0, -0.065))
+    # contact dimension of the object's pairs = max of the two geoms (MuJoCo): the skin is condim 3 (xml:16), the pen is condim 4
+    # (myohand_pen.xml:34: torsional friction, six pyramid rows per contact); the reorient object is authored condim 4 too
+    # (myohand_sar.xml:36) but the env sets it back to 3 at every reset (reorient_sar_v0.py:425)
     for c in caps:
-        s.add_contact_pair("obj", c, condim=3, friction=(1.0, 0.005, 0.0001))
+        s.add_contact_pair("obj", c, condim=3 if kind == "reorient" else 4, friction=(1.0, 0.005, 0.0001))
+    if kind != "reorient":
+        # six rows per contact.  60 rows still fit eight envs per CU (161 KB of LDS; 3.13 M env-steps/s at 2048 envs, as with 56); the
+        # full 64-row table costs the eighth wave (2.01 M) -- tools/gpu_pen_njmax.py.  Under random actions about one env in 2048 has a
+        # contact dropped (status bit 8) at either bound.
+        s.njmax = 60
     return s
 
 

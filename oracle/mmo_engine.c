@@ -200,7 +200,7 @@ mmo_data* mmo_data_create(const mmo_model* m) {
   d->qH = ralloc(m->nM); d->qHDiagInv = ralloc(nv);
   /* deepest nesting: mmo_rk4 (nq + nv + 5 na + 8 nv) -> forward -> mmo_solve (5 nv + 3 njmax + nv^2) or mmo_implicitfast (2 nv^2);
      mmo_collide_and_add 9 nv, mmo_tendon 6 nv, mmo_com_pos nbody */
-  d->scratch_cap = m->nq + 24 * nv + 5 * m->na + 4 * nj + 2 * nv * nv + nb + 64;
+  d->scratch_cap = m->nq + 34 * nv + 5 * m->na + 4 * nj + 2 * nv * nv + nb + 64;   /* (+ 10 nv: the torsional rows of one condim-4 contact) */
   d->scratch = ralloc(d->scratch_cap); d->scratch_top = 0;
   d->gsize_id = -1; d->gtype = -1; d->bmass_id = -1; d->bpos_id = -1;
   mmo_reset(m, d);
@@ -479,7 +479,7 @@ static void mmo_jacp(const mmo_model* m, const mmo_data* d, real* jacp, const re
 }
 
 /* full 6-D Jacobian rows: jacp (3 x nv) and jacr (3 x nv) */
-__attribute__((unused)) static void mmo_jac(const mmo_model* m, const mmo_data* d, real* jacp, real* jacr, const real* pnt, int body) {
+static void mmo_jac(const mmo_model* m, const mmo_data* d, real* jacp, real* jacr, const real* pnt, int body) {
   int nv = m->nv;
   mmo_jacp(m, d, jacp, pnt, body);
   memset(jacr, 0, sizeof(real) * 3 * nv);
@@ -931,7 +931,7 @@ static void mmo_actuation(const mmo_model* m, mmo_data* d) {
   memset(d->qfrc_actuator, 0, sizeof(real) * nv);
   /* mj_fwdActuation: "check controls, set all to 0 if any are bad" (mjWARN_BADCTRL; bad = NaN, or beyond mjMAXVAL = 1e10) */
   for (int a = 0; a < m->nu; a++)
-    if (!(fabs(d->ctrl[a]) < 1e10)) { memset(d->ctrl, 0, sizeof(real) * m->nu); d->warn_bad |= 4; break; }
+    if (!(fabs(d->ctrl[a]) < 1e10)) { memset(d->ctrl, 0, sizeof(real) * m->nu); d->warn_bad |= 32; break; }   /* (32 = the kernel's status bit; 4 is the nconmax overflow) */
   for (int a = 0; a < m->nu; a++) {
     real ctrl = d->ctrl[a];
     if (MI(m, ACT_CTRLLIMITED)[a]) {

@@ -839,7 +839,7 @@ def test_bad_state_is_reset_like_mj_step_does_and_stays_in_its_env(oracle_lib, m
     assert bool(torch.isfinite(dirty.qpos).all() and torch.isfinite(dirty.qvel).all()) and np.all(np.isfinite(d.qpos))
     if poison == "nan_ctrl":
         # mj_fwdActuation: "check controls, set all to 0 if any are bad" (mjWARN_BADCTRL) -- no reset, the env steps on zero input
-        assert d.warn == 4 and status[bad] == 32, (d.warn, status)
+        assert d.warn == 32 and status[bad] == 32, (d.warn, status)
         z = O.OracleData(om); z.qpos[:] = q[bad]; z.qvel[:] = v[bad]; z.step(nsub)          # = stepping with ctrl = 0
         assert np.array_equal(z.qpos, d.qpos)
     else:

@@ -391,19 +391,20 @@ def test_importer_takes_the_non_physical_constructs_of_a_myo_sim_style_file(orac
 
 
 def test_committed_mjcf_inventory_of_the_reference_task_files():
-    """profiles/r04_mjcf_dry_run.json (tools/mjcf_inventory.py over <reference>/myosuite/envs/myo/assets): the importer's only
-    rejections are the documented physics gaps -- mesh / height-field COLLISION geoms and inertia from meshes -- plus one file
+    """profiles/r05_mjcf_dry_run.json (tools/mjcf_inventory.py over <reference>/myosuite/envs/myo/assets): the importer's only
+    rejections are the documented physics gaps -- mesh / height-field COLLISION geoms, inertia from meshes, rolling friction (condim 6: two
+    MyoChallenge files) -- plus one file
     that is an include fragment, not a model.  Re-derived and compared when the reference checkout is present."""
     import json
     import subprocess
     import sys
-    inv = json.load(open(os.path.join(ROOT, "profiles", "r04_mjcf_dry_run.json")))
+    inv = json.load(open(os.path.join(ROOT, "profiles", "r05_mjcf_dry_run.json")))
     assert inv["files_total"] >= 20
     for f, why in inv["importer_rejections_with_includes_skipped"].items():
         assert ("collision geom of type 'mesh'" in why or "collision geom of type 'hfield'" in why or "inertia from meshes" in why
                 or "root element must be <mujoco>" in why), (f, why)
     for kind in inv["unsupported_constructs_by_number_of_files"]:
-        assert kind.startswith(("mesh geom that collides", "hfield geom that collides")), kind
+        assert kind.startswith(("mesh geom that collides", "hfield geom that collides", "colliding geom with condim 6")), kind
     if os.path.isdir("/root/reference/myosuite/envs/myo/assets"):
         now = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "mjcf_inventory.py")], text=True))
         assert now["importer_rejections_with_includes_skipped"] == inv["importer_rejections_with_includes_skipped"]

@@ -71,19 +71,22 @@ def test_constraint_stage_equals_the_dual_qp_on_limits_equalities_contacts_frict
         assert d.ncon >= 1 and d.nefc >= 14
         f = _check(d, cm, ("leg", trial)); kinds |= set(d.efc_type.tolist()); active_rows += int((np.abs(f) > 0).sum())
     # friction toy (friction-loss rows saturated and not), tendon-limit toy, contact toy, reorient (capsule-vs-convex contacts)
-    for name in ("friction_toy", "tendon_limit_toy", "contact_toy", "hand_reorient"):
+    six_row_contacts = 0
+    for name in ("friction_toy", "tendon_limit_toy", "contact_toy", "hand_reorient", "hand_pen"):      # hand_pen: condim 4, six rows per contact
         cm = synth.get_model(name); om = O.OracleModel(cm)
         hit = 0
         for trial in range(8):
             d = O.OracleData(om)
             q = cm.qpos0.astype(float).copy()
-            if name == "hand_reorient":
+            if name in ("hand_reorient", "hand_pen"):
                 q[:-6] = 0; q[0] = -1.5; q[-4] -= rng.uniform(0.012, 0.02)      # palm up, object pressed into the palm
             elif name == "contact_toy":
                 q[2] -= rng.uniform(0.0, 0.03); q[9] -= rng.uniform(0.0, 0.25)
             else:
                 q += rng.uniform(-0.6, 0.9, cm.nq)
             d.qpos[:] = q; d.qvel[:] = rng.standard_normal(cm.nv) * (0.3 if name != "friction_toy" else 2.0)
+            if name == "hand_pen":
+                d.qvel[-3:] = rng.standard_normal(3) * 20.0                     # the pen spins: the torsional rows have something to resist
             if cm.na:
                 d.act[:] = rng.random(cm.na)
             d.ctrl[:] = rng.uniform(-1, 1, cm.nu) if name == "friction_toy" else rng.random(cm.nu)
@@ -92,7 +95,10 @@ def test_constraint_stage_equals_the_dual_qp_on_limits_equalities_contacts_frict
                 continue
             hit += 1
             _check(d, cm, (name, trial)); kinds |= set(d.efc_type.tolist())
+            if name == "hand_pen":
+                six_row_contacts += int(np.sum(d.efc_type == CONTACT)) // 6; assert int(np.sum(d.efc_type == CONTACT)) == 6 * d.ncon
         assert hit >= 3, name
+    assert six_row_contacts >= 3
     assert kinds == {EQ, LIMJ, LIMT, CONTACT, FRIC}, kinds
     assert active_rows > 20
 

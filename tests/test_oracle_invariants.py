@@ -528,3 +528,43 @@ def test_pyramidal_contact_rows_closed_form(oracle_lib):
     np.testing.assert_allclose(d.efc_R[:4], R, rtol=5e-6)
     np.testing.assert_allclose(d.efc_D[:4], 1 / R, rtol=5e-6)
     np.testing.assert_allclose(d.efc_pos[:4] - d.efc_margin[:4], -pen, atol=1e-9)
+
+
+def test_condim4_contact_adds_the_torsional_pyramid_pair(oracle_lib):
+    """condim 4 (the reference's pen and reorient objects carry it: myohand_pen.xml:34, myohand_sar.xml:36): six pyramid-edge rows --
+    the four sliding edges of condim 3, then (n + mu_t r_n), (n - mu_t r_n) with r_n the relative ANGULAR velocity about the contact
+    normal and mu_t = friction[1] (a length).  Closed form on a sphere resting on a plane: the torsional rows act on the free
+    joint's rotation about z only; R of all six rows = 2 mu^2 R(first row) with mu = friction[0] (mj_makeImpedance).  And the physics:
+    a ball spinning about the vertical slows down with torsional friction, keeps spinning without (condim 3)."""
+    O = oracle_lib
+    mu, mut, pen, rad = 0.7, 0.02, 2e-4, 0.05
+
+    def ball(condim):
+        s = ModelSpec("ball", timestep=0.002)
+        s.add_geom("floor", "world", "plane", (0, 0, 0))
+        s.add_body("b", pos=(0.0, 0.0, rad - pen), mass=0.5, inertia=(5e-4, 5e-4, 5e-4)); s.add_joint("root", "b", type="free")
+        s.add_geom("g", "b", "sphere", (rad,))
+        s.add_contact_pair("floor", "g", condim=condim, friction=(mu, mut, 0.0001))
+        return s.compile()
+    cm = ball(4)
+    assert cm.njmax == 6
+    d = O.OracleData(O.OracleModel(cm)); d.qvel[:] = [0.3, -0.2, 0.0, 0.0, 0.0, 5.0]; d.forward()
+    assert d.ncon == 1 and d.nefc == 6
+    n = np.array(d.con_frame[0, 0:3]); t1 = np.array(d.con_frame[0, 3:6]); t2 = np.array(d.con_frame[0, 6:9])
+    J = np.array(d.efc_J[:6]).reshape(6, cm.nv)
+    muf, mutf = float(np.float32(mu)), float(np.float32(mut))
+    for k, dirn in enumerate((n + muf * t1, n - muf * t1, n + muf * t2, n - muf * t2, n, n)):
+        np.testing.assert_allclose(J[k, :3], dirn, atol=1e-12)
+    # rotational block: the sliding rows see the lever arm of the contact point, the torsional rows add +- mu_t n on top of it
+    np.testing.assert_allclose(J[4, 3:] - J[5, 3:], 2 * mutf * n, atol=1e-12)
+    np.testing.assert_allclose(J[4, 3:] + J[5, 3:], J[0, 3:] + J[1, 3:], atol=1e-12)          # = 2 x the normal row's rotational part
+    np.testing.assert_allclose(np.asarray(d.efc_R[:6]), d.efc_R[0], rtol=1e-12)
+    d3 = O.OracleData(O.OracleModel(ball(3))); d3.qvel[:] = d.qvel; d3.forward()
+    np.testing.assert_allclose(d.efc_R[0], d3.efc_R[0], rtol=1e-12)                            # the shared R comes from the FIRST row
+    # physics: spin about the normal decays only with the torsional pair
+    spin = {}
+    for condim in (3, 4):
+        dd = O.OracleData(O.OracleModel(ball(condim))); dd.qvel[5] = 5.0
+        dd.step(150)
+        spin[condim] = float(dd.qvel[5]); assert dd.warn == 0
+    assert spin[3] == pytest.approx(5.0, abs=1e-6) and 0.0 <= spin[4] < 4.0, spin

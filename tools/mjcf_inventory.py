@@ -2,7 +2,7 @@
 """Distance between the MJCF importer and the reference's task files: `mjcf.dry_run` over every XML under
 <reference>/myosuite/envs/myo/assets (includes into the empty simhive/myo_sim submodule are recorded, not followed).
 
-    python tools/mjcf_inventory.py [/root/reference] > profiles/r04_mjcf_dry_run.json
+    python tools/mjcf_inventory.py [/root/reference] > profiles/r05_mjcf_dry_run.json
 
 Runs where the reference checkout is present (this container); the committed JSON is what travels."""
 import json
