@@ -860,7 +860,11 @@ def make_hand_keyturn() -> ModelSpec:
 
 def make_hand_hold() -> ModelSpec:
     """myoHand + free-floating ellipsoid to hold (myosuite/envs/myo/assets/hand/myohand_hold.xml:14-23): object on a free
-    joint (nq 30 / nv 29), frictionless contacts (condim 1), a world-fixed ``goal`` site and an ``object`` site."""
+    joint (nq 30 / nv 29), frictionless contacts (condim 1), a world-fixed ``goal`` site and an ``object`` site.
+
+    The object geom is authored ``condim="1"`` (xml:19).  A generated pair's contact dimension is the MAX over its two geoms, and the
+    other one is a skin geom of the absent ``myo_sim`` tree: if those carry MuJoCo's default (3) the real contacts are frictional
+    despite the attribute -- the importer applies the max rule to whatever the real files say; this stand-in follows the attribute."""
     s, caps = _hand_palm_up_with_capsules("myohand_hold")
     OX, OZ = 0.325, 1.0 + 0.009 + 0.032
     size = (0.025, 0.036, 0.030)
