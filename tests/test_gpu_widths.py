@@ -57,6 +57,9 @@ def _env_oracle(env, e):
     if env.env_id.startswith(("myoElbowPose", "myoHandPose")):
         o = EO.PoseEnvOracle(cm, pose_thd=env.pose_thd, frame_skip=env.frame_skip)
         o.target_jnt_value = env.target_jnt_value[e].cpu().numpy().astype(np.float64)
+    elif "PenTwirl" in env.env_id:
+        o = EO.PenTwirlEnvOracle(cm, frame_skip=env.frame_skip)
+        o.des_rot = env.des_rot[e].cpu().numpy().astype(np.float64)
     elif "Reorient" in env.env_id:
         o = EO.ReorientEnvOracle(cm, frame_skip=env.frame_skip)
         o.d.set_geom_size(o.obj_g, env.geom_size[e].cpu().numpy().astype(np.float64), int(env.geom_type[e]))
@@ -451,7 +454,8 @@ def test_precision_modes_at_the_env_level_and_their_refusals():
 # 1.5e-6 -- its capsule-vs-ellipsoid / cylinder / box closest-point search stops on tolerances (and takes the midpoint of a flat
 # interval located to +-tau) on both sides, which two implementations do not hit at the same iterate
 GEN_F64 = [("myoHandPoseRandom-v0", {"model": "hand_contact"}, 1e-7), ("myoHandReorient100-v0", {}, 2e-5), ("myoLegWalk-v0", {}, 1e-7),
-           ("myoFatiLegWalk-v0", {}, 1e-6), ("myoLegWalk-v0", {"model": "leg_implicit"}, 1e-7)]
+           ("myoFatiLegWalk-v0", {}, 1e-6), ("myoLegWalk-v0", {"model": "leg_implicit"}, 1e-7),
+           ("myoHandPenTwirlRandom-v0", {}, 1e-6)]      # condim-4 contacts (six rows, up to 50 of them) against a cylinder: the torsional pass of the mm64 kernels; measured 7.1e-9
 
 
 @pytest.mark.parametrize("env_id,kw,tol", GEN_F64, ids=[c[0] + "".join("-" + str(v) for v in c[1].values()) for c in GEN_F64])
