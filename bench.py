@@ -32,6 +32,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 # implicitfast integrator) reported next to the headline line
 # the committed PMC session bench.py replays counters from (tools/prof_round.sh at the HEAD named in DESIGN.md section 5); pinned, not "the latest file"
 PMC_PROFILE = os.path.join(ROOT, "profiles", "r05d_pmc.json")
+ACCURACY_PROFILE = os.path.join(ROOT, "profiles", "r06_accuracy.json")     # tests/tools/gpu_accuracy_run.py (replayed into the line)
 REPEATS = 3                 # timed regions of --steps steps each; the line reports the median region
 EXTRA_MIN_TIMED_MS = 60.0   # an extra line times at least this much kernel work (a 1.5 ms timed region is launch-noise bound)
 # Order matters: the driver's record keeps the TAIL of the printed line, so the BASELINE.json configs 2 / 4 / 5 (elbow, reorient,
@@ -41,8 +42,7 @@ EXTRA_CONFIGS = [# the step of the reference's own GPU path: mjx_env.step = n_su
                  # (robot.py:595-607), whose outputs the Pose observation / reward do not read.  NOT the headline protocol.
                  ("myoHandPoseRandom-v0", 4096, {"do_forward": False}),
                  # precision modes (include/myosim.h): MM_PREC_F64_STATE = the same launch over real = double with fp64 state rows --
-                 # the kernels that meet "state divergence < 1e-4 rel over 1000 steps" on every env (tests/test_gpu_widths.py);
-                 # MM_PREC_MIXED = fp64 state rows + fp64 kinematics / tendons / solver / integration, fp32 CRB / RNE / muscles
+                 # the kernels that meet "state divergence < 1e-4 rel over 1000 steps" on every env (tests/test_gpu_widths.py)
                  ("myoElbowPose1D6MRandom-v0", 4096, {"precision": "f64_state"}),
                  ("myoHandPoseRandom-v0", 4096, {"precision": "f64_state"}),
                  # the one workload the reference publishes GPU numbers for (MjxHandReachRandom-v0)
@@ -75,7 +75,7 @@ def algorithmic_bytes(env, include_carry: bool = False) -> int:
         n_aux += cm.nv              # qacc_warmstart
     if include_carry and getattr(env, "_fwd_carry", None) is not None:
         n_aux += 2 * cm.nv + 1      # forward-carry row (mm_task.fwd_carry): hash + qacc + Euler's damped acceleration, read and written
-    sw = 8 if getattr(env, "precision", 0) in (2, 3) else 4      # MM_PREC_F64_STATE / MM_PREC_MIXED: the state rows are fp64
+    sw = 8 if getattr(env, "precision", 0) == 2 else 4      # MM_PREC_F64_STATE: the state rows are fp64
     return sw * 2 * (cm.nq + cm.nv + cm.na) + 4 * (cm.nu + n_task_in + 2 * n_aux + env.obs_dim + 4)
 
 
@@ -210,6 +210,7 @@ def cpu_baseline(env_id: str):
                      "liboracle.so is -O2 without contraction and is not what is timed)",
             "sample": f"{allc['envs']} envs x {allc['env_steps_each']} env-steps of {env_id} (fp64 C oracle, one thread per physical "
                       f"core = {cores} threads, {allc['seconds']:.1f} s)",
+            "sample_short": f"{allc['envs']} envs x {allc['env_steps_each']} env-steps, {cores} threads, {allc['seconds']:.1f} s",
             "single_thread": {"value": one["value"], "unit": "env-steps/s", "cores": 1,
                               "sample": f"{one['envs']} envs x {one['env_steps_each']} env-steps, one at a time on one thread ({one['seconds']:.1f} s)"},
             "parallel_efficiency": allc["value"] / (one["value"] * cores), "host": topo}
@@ -444,6 +445,81 @@ def ppo_training_lines():
     return lines
 
 
+LINE_LIMIT = 4096        # the contract line (the LAST stdout line) stays below this; everything else goes to the extras file
+
+
+def accuracy_block():
+    """north_star's accuracy target ("state divergence vs CPU mj_step < 1e-4 rel over 1000 steps") as measured by
+    tests/tools/gpu_accuracy_run.py on the GPU box (the HIP kernels against the fp64 oracle on the same action streams) and
+    committed under profiles/: REPLAYED here, not measured in this run -- bench.py's timed legs never touch the checker."""
+    try:
+        a = json.load(open(ACCURACY_PROFILE))
+        return {"replayed_from": "profiles/" + os.path.basename(ACCURACY_PROFILE), "runs": a["runs"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract keys, a compact roofline and cpu_baseline, the accuracy block and
+    an id -> env-steps/s digest of the other measured workloads.  Every other field of `full` is in the extras file / earlier lines."""
+    rf = full["roofline"]
+    c = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                              "vs_baseline", "dtype", "data")}
+    cfg = full["config"]
+    c["config"] = {k: cfg[k] for k in ("workload", "envs_per_gpu", "lanes_per_env", "parallelism", "baseline_config", "oversubscribed", "overrides") if k in cfg}
+    c["roofline"] = {"bound": rf["bound"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"], "frac": rf["frac"],
+                     "traffic": rf["traffic"], "traffic_source": rf["traffic_source"], "traffic_over_algorithmic": rf["traffic_over_algorithmic"],
+                     "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"],
+                     "bound_by": rf.get("bound_by"), "fp32_vector_peak_frac": (rf.get("flops") or {}).get("frac")}
+    cb = full.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                             "build": "fp64 C oracle (not libmujoco), gcc -O3 -march=native", "sample": cb["sample_short"],
+                             "single_thread": cb["single_thread"]["value"]}
+    acc = full.get("accuracy")
+    if acc:
+        c["accuracy"] = acc
+    if "collective" in full:
+        co = full["collective"]
+        c["collective"] = {k: co[k] for k in ("backend", "is_rccl", "world_size", "rccl_version", "gathered_rows", "expected_rows",
+                                              "bytes_per_rank", "allgather_us", "per_rank_env_steps_per_s")}
+    c["stats"] = full["stats"]
+    c["baseline_configs"] = {k: (round(v["env_steps_per_s"]) if "env_steps_per_s" in v else
+                                 (round(v["train_env_steps_per_s"]) if "train_env_steps_per_s" in v else "error"))
+                             for k, v in full.get("baseline_configs", {}).items()}
+    c["extras"] = full.get("extras_file")
+    return c
+
+
+def emit(full, extras_file):
+    """Write everything to the extras file, print it as EARLIER stdout lines (prefixed so that no reader takes them for the
+    contract line), then print the compact contract line LAST."""
+    full["extras_file"] = None
+    if extras_file:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(extras_file)), exist_ok=True)
+            with open(extras_file, "w") as f:
+                json.dump(full, f, indent=1)
+            full["extras_file"] = os.path.relpath(extras_file, ROOT)
+        except OSError:
+            pass
+    for k in ("extra_configs", "ppo_training"):
+        for row in full.get(k, []):
+            print("#extra " + json.dumps({k: row}))
+    print("#extra " + json.dumps({k: v for k, v in full.items() if k not in ("extra_configs", "ppo_training")}))
+    line = json.dumps(compact_line(full))
+    if len(line) >= LINE_LIMIT:       # never outgrow the reader again: drop the digest first, then the optional blocks
+        c = compact_line(full)
+        for k in ("baseline_configs", "accuracy", "stats", "collective"):
+            c.pop(k, None)
+            line = json.dumps(c)
+            if len(line) < LINE_LIMIT:
+                break
+    sys.stdout.flush()
+    print(line)
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,6 +538,8 @@ def main():
     ap.add_argument("--model", default=None, help="model override of the headline env (e.g. hand_contact): profile collection")
     ap.add_argument("--no-forward", action="store_true", help="do_forward=False override of the headline env: profile collection")
     ap.add_argument("--precision", default=None, help="precision override of the headline env (f64 | f64_state): profile collection")
+    ap.add_argument("--extras-file", default=os.path.join(ROOT, "gpurun_out", "bench_extras.json"),
+                    help="everything beyond the compact contract line (extra_configs, ppo_training, replayed counters, launch geometry)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: rank r runs on cuda:(r %% visible devices) and the process group is gloo, so that the N > 1 code "
                          "path (launcher respawn, barrier, max over ranks, stats gather, sharded Philox streams) can be exercised on a "
@@ -506,7 +584,7 @@ def main():
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
-        prec_name = {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64", 3: "mixed f64/f32 (fp64 state rows)"}
+        prec_name = {0: "f32", 1: "f64 (fp32 state rows)", 2: "f64"}
         out = {
             "metric": "env-steps/sec (whole node) at %d envs/GPU" % n,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -515,12 +593,13 @@ def main():
             "gpu_clocks_mhz": {"before": clocks_before, "after": clocks_after},
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": prec_name[int(getattr(env, "precision", 0))], "data": "synthetic",
-            "config": {"workload": f"{args.env}, {n} envs/GPU, random actions U[0,1) drawn in the kernel, frame_skip {env.frame_skip} + final "
-                                   f"forward + obs/reward + episode stats + auto-reset in one launch per step "
-                                   f"(synthetic model {cm.name}: nq={cm.nq} nv={cm.nv} nu={cm.nu})",
+            "config": {"workload": f"{args.env}, {n} envs/GPU, random actions, one fused launch per env-step (synthetic model {cm.name})",
+                       "workload_detail": f"random actions U[0,1) drawn in the kernel, frame_skip {env.frame_skip} + final forward + obs/reward + "
+                                          f"episode stats + auto-reset in one launch per step; nq={cm.nq} nv={cm.nv} nu={cm.nu}",
                        "envs_per_gpu": n, "lanes_per_env": env.hm.launch_lanes(n), "launches_per_step": 1 if env._ro.autoreset else "1 + the task's masked reset",
                        "parallelism": f"env-shard x{world}"},
             "roofline": roofline(env, args.env, n, kern_ms, head_ov),
+            "accuracy": accuracy_block(),
             "stats": {"mean_episode_return": float(stats[:, 0].mean()), "solved_frac": float(stats[:, 2].mean()),
                       "envs_in_stats": int(stats.shape[0]), "status_or": status_or(env.state.status)},
         }
@@ -570,9 +649,8 @@ def main():
                     extra.append({"workload": tag, "error": repr(exc)})
                     digest[workload_key(env_id, ne, ov)] = {"error": repr(exc)[:120]}
             out["extra_configs"] = extra
-        # LAST key of the line (the driver's record keeps the tail): one compact row per measured workload, BASELINE configs 2 / 4 / 5 at the end
         out["baseline_configs"] = digest
-        print(json.dumps(out))
+        emit(out, args.extras_file)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

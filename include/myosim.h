@@ -82,8 +82,10 @@ typedef struct {
   float* qacc_warmstart;  /* [nenv][nv]                                   */
   float* time;            /* [nenv]                                       */
   int32_t* status;        /* [nenv] sticky bits, cleared by reset: 1 bad-state auto reset (mj_step's mj_checkPos / checkVel / checkAcc),
-                                    4 the solver hit its iteration cap, 8 more constraint rows than the engine holds (surplus
-                                    rows dropped), 16 a two-wave launch lost a partner wave (a bounded wait gave up: engine bug),
+                                    4 the solver hit its iteration cap, 8 contacts or constraint rows were dropped: contacts beyond
+                                    mjModel.nconmax (in collider order), or a contact whose rows do not all fit njmax / the engine's 64
+                                    rows per env (MuJoCo raises mjWARN_CONTACTFULL / mjWARN_CNSTRFULL for the two; the oracle reports them
+                                    as its warn bits 4 / 2 -- tests map both onto this bit), 16 a two-wave launch lost a partner wave (a bounded wait gave up: engine bug),
                                     32 a NaN / Inf / > 1e10 entry in the env's control vector: ALL its controls were set to 0 for this
                                     launch (mj_fwdActuation's mjWARN_BADCTRL); the state is not reset.  After a bad-state reset (bit 1)
                                     the remaining substeps of the launch run on zero controls, as mj_resetData clears them */

@@ -62,7 +62,8 @@ def _compiled_model(name: str, muscle_condition: str):
 class _LazyEnvState(collections.abc.Mapping):
     """info["state"] (env_base.py:614: get_env_state() of the step that just ended): materialised on first access -- five batched
     clones per env.step are not paid by callers that never look at it.  Read it before the next step() (as the reference's dict,
-    it describes the state at the time it is taken; here that is the first access)."""
+    it describes the state at the time it is taken; here that is the first access -- or freeze(), which step() calls ahead of an
+    auto-reset so that info["state"] and info["obs_dict"] of one step describe the same state for finished envs too)."""
 
     def __init__(self, env):
         self._env, self._d = env, None
@@ -71,6 +72,11 @@ class _LazyEnvState(collections.abc.Mapping):
         if self._d is None:
             self._d = self._env.get_env_state()
         return self._d
+
+    def freeze(self):
+        """materialise now: step() calls this before an auto-reset rewrites the state rows of finished envs"""
+        self._get()
+        return self
 
     def __getitem__(self, k):
         return self._get()[k]
@@ -441,6 +447,7 @@ class BaseV0:
             # finished envs): snapshot before the masked reset rewrites self.obs
             info["final_obs"] = obs.clone()
             info["obs_dict"] = collections.OrderedDict((k, v.clone()) for k, v in self.obs_dict.items())
+            info["state"].freeze()      # get_env_state() of the step that just ended (env_base.py:614), not of the re-armed episode
             self.reset(mask=(self.done | self.truncated))
             obs = self._obs_out()
         return obs, reward, terminated, truncated, info

@@ -50,7 +50,7 @@ class MjxPoseEnv:
     def __init__(self, model: str = "hand", num_envs: int = 4096, target_jnt_range: dict = None, ctrl_dt: float = 0.02,
                  max_episode_steps: int = 100, norm_actions: bool = True, angle_reward_weight: float = 1.0,
                  ctrl_cost_weight: float = 1.0, bonus_weight: float = 4.0, pose_thd: float = 0.7,
-                 far_th: float = 4 * np.pi / 2, device=None, seed: int = 0):
+                 far_th: float = 4 * np.pi / 2, device=None, seed: int = 0, **variant_kw):
         from .envs import registry
         if target_jnt_range is None:
             target_jnt_range = registry.spec("myoHandPoseRandom-v0" if model == "hand" else "myoElbowPose1D6MRandom-v0")["kwargs"]["target_jnt_range"]
@@ -61,7 +61,7 @@ class MjxPoseEnv:
                               normalize_act=norm_actions, pose_thd=pose_thd, reset_type="random", target_type="generate",
                               frame_skip=int(round(ctrl_dt / sim_dt)),
                               weighted_reward_keys={"pose": angle_reward_weight, "act_reg": ctrl_cost_weight,
-                                                    "bonus": bonus_weight, "penalty": 1.0})
+                                                    "bonus": bonus_weight, "penalty": 1.0}, **variant_kw)
         _mjx_solver_options(self._env)
         t = self._env._task
         t.obs_layout = 1; t.act_reg_mean = 0; t.obs_dt = sim_dt; t.far_th = float(far_th)
@@ -119,10 +119,11 @@ class MjxReachEnv:
 
     def __init__(self, num_envs: int = 4096, env_id: str = "myoHandReachRandom-v0", ctrl_dt: float = 0.02,
                  max_episode_steps: int = 100, norm_actions: bool = True, reach_weight: float = 1.0, bonus_scale: float = 4.0,
-                 penalty_scale: float = 50.0, device=None, seed: int = 0):
+                 penalty_scale: float = 50.0, device=None, seed: int = 0, **variant_kw):
         from .envs import registry
         from .envs.reach_v0 import ReachEnvV0
         kw = dict(registry.spec(env_id)["kwargs"])
+        kw.update(variant_kw)
         from .model import synth
         sim_dt = synth.get_model(kw["model"]).timestep
         kw.update(normalize_act=norm_actions, frame_skip=int(round(ctrl_dt / sim_dt)),
@@ -177,6 +178,74 @@ class MjxReachEnv:
         return State(env.state, {"state": env.obs}, reward, done, metrics, info)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# muscle-condition variants of the MJX ids (envs/myo/mjx/myo_registry.py:13, 54-98)
+MJX_VARIANT_PREFIXES = ("MjxSarc", "MjxFati", "MjxReaf")
+ALLOWED_FATIGUE_OBS_KEYS = ("MA", "MR", "MF")            # fatigue_jax.py:13
+_BASE_ENVS = tuple(f"Mjx{task}{kind}-v0" for task in ("ElbowPose", "FingerPose", "HandReach") for kind in ("Fixed", "Random"))
+# register_environment_with_variants registers the base id and its `MjxFati` twin (the Sarc / Reaf twins are commented out there)
+ALL_ENVS = tuple(n for b in _BASE_ENVS for n in (b, b[:3] + "Fati" + b[3:]))
+
+
+def get_base_env_name(env_name: str) -> str:
+    """myo_registry.get_base_env_name (myo_registry.py:92-98): the id without its muscle-condition prefix."""
+    return env_name[:3] + env_name[7:] if env_name[:7] in MJX_VARIANT_PREFIXES else env_name
+
+
+class MjxFatigueEnv:
+    """Batched counterpart of ``FatigueWrapper`` (fatigue_jax.py:176-304) around an Mjx env: every action goes through
+    ``1 / (1 + exp(-5 (a - 0.5)))`` (the wrapper switches the inner env's own normalisation off and applies it itself, :232), the
+    3CC-r model turns the muscles' target loads into the active fraction MA, which is what the simulation receives as control (:241-245).
+    Here all of that is inside the fused launch (``mm_task.fatigue``; the kernel's ``compute_act`` is checked against the
+    reference's ``fatigue.py`` vectors).  The reference keeps MA / MR / MF in ``state.data.userdata``; here they are the three
+    ``[E, na]`` device tensors of ``fatigue_state(state)`` (also ``state.info["fatigue_state"]``).  ``fatigue_obs_keys`` appends
+    them to ``obs["state"]`` in the order MA, MR, MF (:280-292); ``fatigue_reset_vec`` / ``fatigue_reset_random`` as :203-209."""
+
+    def __init__(self, env, fatigue_reset_vec=None, fatigue_reset_random: bool = False, fatigue_obs_keys=()):
+        assert all(k in ALLOWED_FATIGUE_OBS_KEYS for k in fatigue_obs_keys), \
+            f"Invalid fatigue_obs_keys: {list(fatigue_obs_keys)}. Allowed keys are: {list(ALLOWED_FATIGUE_OBS_KEYS)}"
+        self.env = env
+        inner = env._env
+        assert inner.muscle_condition == "fatigue" and inner._task.fatigue == 1 and inner._task.normalize_act == 1
+        inner.fatigue_reset_vec = fatigue_reset_vec
+        inner.fatigue_reset_random = bool(fatigue_reset_random)
+        self.fatigue_obs_keys = list(fatigue_obs_keys)
+        self.num_envs, self.cm, self.max_episode_steps = env.num_envs, env.cm, env.max_episode_steps
+        self._env = inner                                  # (TrainingWrapper reaches the BaseV0 env through `_env`)
+
+    @property
+    def observation_size(self) -> int:
+        return self.env.observation_size + self.cm.na * len(self.fatigue_obs_keys)
+
+    @property
+    def action_size(self) -> int:
+        return self.env.action_size
+
+    def fatigue_state(self, state: State = None) -> Dict[str, torch.Tensor]:
+        inner = self._env
+        return {"MA": inner.fat_MA, "MR": inner.fat_MR, "MF": inner.fat_MF}
+
+    def set_fatigue_reset_random(self, fatigue_reset_random):      # fatigue_jax.py:294-295
+        self._env.fatigue_reset_random = bool(fatigue_reset_random)
+
+    def _with_fatigue(self, st: State) -> State:
+        fs = self.fatigue_state()
+        obs = st.obs
+        if self.fatigue_obs_keys and "state" in obs:
+            obs = {**obs, "state": torch.cat([obs["state"]] + [fs[k] for k in ALLOWED_FATIGUE_OBS_KEYS if k in self.fatigue_obs_keys], dim=-1)}
+        return st.replace(obs=obs, info={**st.info, "fatigue_state": fs})
+
+    def reset(self, rng: int) -> State:
+        st = self.env.reset(rng)
+        inner = self._env
+        inner._seed_u64 = int(rng) & 0xFFFFFFFFFFFFFFFF        # the random fatigue reset is keyed like the other reset draws
+        inner._fatigue_reset(None)
+        return self._with_fatigue(st)
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        return self._with_fatigue(self.env.step(state, action))
+
 # ---------------------------------------------------------------------------------------------------------------------
 # make() of myosuite/envs/myo/mjx/__init__.py:109-199 and the training wrapper of mujoco_playground / brax
 PPO_CONFIG = dict(                                   # myosuite/envs/myo/mjx/__init__.py:43-67
@@ -198,28 +267,46 @@ def get_default_config(env_name: str) -> dict:
 
 
 def make(env_name: str, config_overrides: dict = None, num_envs: int = None, device=None, seed: int = 0):
-    """``myosuite.envs.myo.mjx.make`` for the ids the reference registers there (Mjx{Elbow,Finger}Pose{Fixed,Random}-v0,
-    MjxHandReach{Fixed,Random}-v0); ``impl`` is always this engine."""
+    """``myosuite.envs.myo.mjx.make`` for the ids the reference registers there: Mjx{Elbow,Finger}Pose{Fixed,Random}-v0,
+    MjxHandReach{Fixed,Random}-v0 and the ``MjxFati`` twin of each (myo_registry.py:54-81: base env class wrapped in
+    ``FatigueWrapper``; its ``fatigue_reset_vec / fatigue_reset_random / fatigue_obs_keys`` come out of ``config_overrides``,
+    fatigue_jax.py:297-310).  ``impl`` is always this engine."""
     from .envs import registry
-    cfg = get_default_config(env_name)
-    cfg.update(config_overrides or {})
+    if env_name not in ALL_ENVS:
+        raise KeyError(f"unknown MJX env {env_name!r}. Available envs: {list(ALL_ENVS)}")
+    variant = env_name[:7] if env_name[:7] in MJX_VARIANT_PREFIXES else ""
+    base_name = get_base_env_name(env_name)
+    ov = dict(config_overrides or {})
+    fat_cfg = dict(fatigue_reset_vec=None, fatigue_reset_random=False, fatigue_obs_keys=())       # FatigueWrapper.DEFAULT_MUSCLE_CONFIG
+    vkw = {}
+    if variant == "MjxFati":
+        fat_cfg.update(ov.pop("fatigue_config", {}) or {})
+        for k in list(fat_cfg):
+            if k in ov:
+                fat_cfg[k] = ov.pop(k)
+        vkw = dict(muscle_condition="fatigue")
+    cfg = get_default_config(base_name)
+    cfg.update(ov)
+    if variant == "MjxFati":
+        cfg["norm_actions"] = True       # the wrapper disables the env's normalisation and applies the same map to every action itself
     n = int(num_envs if num_envs is not None else cfg["num_envs"])
-    fixed = "Fixed" in env_name
-    if env_name.startswith("MjxElbowPose") or env_name.startswith("MjxFingerPose"):
-        elbow = env_name.startswith("MjxElbowPose")
+    fixed = "Fixed" in base_name
+    rc = cfg["reward_config"]
+    if base_name.startswith("MjxElbowPose") or base_name.startswith("MjxFingerPose"):
+        elbow = base_name.startswith("MjxElbowPose")
         ref_id = ("myoElbowPose1D6M" if elbow else "myoFingerPose") + ("Fixed" if fixed else "Random") + "-v0"
-        rc = cfg["reward_config"]
-        return MjxPoseEnv(model="elbow" if elbow else "finger", num_envs=n, target_jnt_range=registry.spec(ref_id)["kwargs"]["target_jnt_range"],
-                          ctrl_dt=cfg["ctrl_dt"], max_episode_steps=cfg["max_episode_steps"], norm_actions=cfg["norm_actions"],
-                          angle_reward_weight=rc["angle_reward_weight"], ctrl_cost_weight=rc["ctrl_cost_weight"],
-                          bonus_weight=rc["bonus_weight"], pose_thd=rc["pose_thd"], far_th=rc["far_th"], device=device, seed=seed)
-    if env_name.startswith("MjxHandReach"):
-        rc = cfg["reward_config"]
-        return MjxReachEnv(num_envs=n, env_id="myoHandReach" + ("Fixed" if fixed else "Random") + "-v0", ctrl_dt=cfg["ctrl_dt"],
-                           max_episode_steps=cfg["max_episode_steps"], norm_actions=cfg["norm_actions"],
-                           reach_weight=rc["reach_weight"], bonus_scale=rc["bonus_scale"], penalty_scale=rc["penalty_scale"],
-                           device=device, seed=seed)
-    raise KeyError(f"unknown MJX env {env_name!r}")
+        env = MjxPoseEnv(model="elbow" if elbow else "finger", num_envs=n, target_jnt_range=registry.spec(ref_id)["kwargs"]["target_jnt_range"],
+                         ctrl_dt=cfg["ctrl_dt"], max_episode_steps=cfg["max_episode_steps"], norm_actions=cfg["norm_actions"],
+                         angle_reward_weight=rc["angle_reward_weight"], ctrl_cost_weight=rc["ctrl_cost_weight"],
+                         bonus_weight=rc["bonus_weight"], pose_thd=rc["pose_thd"], far_th=rc["far_th"], device=device, seed=seed, **vkw)
+    else:
+        env = MjxReachEnv(num_envs=n, env_id="myoHandReach" + ("Fixed" if fixed else "Random") + "-v0", ctrl_dt=cfg["ctrl_dt"],
+                          max_episode_steps=cfg["max_episode_steps"], norm_actions=cfg["norm_actions"],
+                          reach_weight=rc["reach_weight"], bonus_scale=rc["bonus_scale"], penalty_scale=rc["penalty_scale"],
+                          device=device, seed=seed, **vkw)
+    if variant == "MjxFati":
+        env = MjxFatigueEnv(env, **fat_cfg)
+    return env
 
 
 class TrainingWrapper:
@@ -246,6 +333,8 @@ class TrainingWrapper:
     truncated = property(lambda self: self._inner.truncated)
 
     def rollout_setup(self, **kw):
+        if getattr(self.env, "fatigue_obs_keys", None):
+            raise NotImplementedError("the fused rollout writes the task's observation row; fatigue_obs_keys are served by reset() / step()")
         self._inner.autoreset = True
         self._inner._task.obs_layout = 1
         return self._inner.rollout_setup(**kw)
@@ -269,4 +358,5 @@ class TrainingWrapper:
         inner.reset(mask=need)                              # masked reset launch; obs of the reset envs in the env's layout
         E.reset_observation(inner.hm, inner.state, inner._task, need.to(torch.uint8).contiguous())
         info = {**st.info, "truncation": truncation}
-        return State(st.data, {"state": inner.obs}, st.reward, done, st.metrics, info)
+        out = State(st.data, {"state": inner.obs}, st.reward, done, st.metrics, info)
+        return self.env._with_fatigue(out) if hasattr(self.env, "_with_fatigue") else out    # (fatigue_obs_keys of an MjxFati env)

@@ -7,6 +7,7 @@ this module; its step path fails loudly when the HIP library is missing.
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -44,7 +45,7 @@ def _host_cpu() -> str:
             if line.startswith("model name") and not model:
                 model = line.split(":", 1)[1].strip()
             elif line.startswith("flags") and not flags:
-                flags = str(hash(line.split(":", 1)[1].strip()) & 0xffffffff)
+                flags = hashlib.sha1(line.split(":", 1)[1].strip().encode()).hexdigest()[:8]    # stable across processes (str hash is salted)
             if model and flags:
                 break
     except OSError:
@@ -64,7 +65,14 @@ def build(force: bool = False, variant: str = None) -> str:
         force = True
     if force or not os.path.exists(path) or any(
             os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s)):
-        subprocess.check_call(["make", "-C", _HERE, "-B", _VARIANTS[v]], stdout=subprocess.DEVNULL)
+        # built under a temporary name and moved into place: a concurrent process never dlopens a half-written library
+        tmp = f".{os.getpid()}.{_VARIANTS[v]}"
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-B", _VARIANTS[v], f"OUT={tmp}"], stdout=subprocess.DEVNULL)
+            os.replace(os.path.join(_HERE, tmp), path)
+        finally:
+            if os.path.exists(os.path.join(_HERE, tmp)):
+                os.remove(os.path.join(_HERE, tmp))
         if v == "fast":
             with open(stamp, "w") as f:
                 f.write(_host_cpu())

@@ -41,6 +41,54 @@ def test_bench_defaults_are_the_baseline_workload():
     assert "cpu_baseline" in src and "barrier" in src and "max_over_ranks" in src
 
 
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline")
+
+
+def _check_compact_line(d, cpu=True):
+    """the contract line bench.py prints LAST: the driver's keys + compact `roofline` / `cpu_baseline` (VERDICT r05 #1)"""
+    for k in COMPACT_KEYS:
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    for k in ("workload", "envs_per_gpu", "lanes_per_env"):
+        assert k in d["config"], k
+    assert "model" not in d["config"] and len(d["config"]["workload"]) <= 128        # (the driver's record keeps 128 characters of it)
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_ms", "bound_by",
+              "fp32_vector_peak_frac"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["value"] > 0 and abs(d["ms_per_step"] - 1e3 * d["config"]["envs_per_gpu"] * d["n_gpus"] / d["value"]) < 1e-6 * d["ms_per_step"] + 1e-9
+    if cpu:
+        cb = d["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "build", "sample", "single_thread"):
+            assert k in cb, k
+        assert cb["kind"] == "port" and cb["value"] > 0
+
+
+def test_compact_line_of_a_full_record_is_short_and_complete():
+    """bench.compact_line over the largest full record in the tree (the round-5 default run: 27 KB) stays below 4 KB and keeps the
+    contract keys -- the size of the LAST stdout line is what the driver's reader depends on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    full["cpu_baseline"]["sample_short"] = "8192 envs x 40 env-steps, 16 threads, 5.1 s"
+    full["config"]["workload"] = full["config"]["workload"][:120]
+    full["accuracy"] = b.accuracy_block()
+    full["collective"] = {"backend": "nccl", "is_rccl": True, "world_size": 8, "rccl_version": "2.26.6", "gathered_rows": 32768, "expected_rows": 32768,
+                          "bytes_per_rank": 49152, "allgather_us": 55.2, "per_rank_env_steps_per_s": [6894156.123456] * 8, "what": "x"}
+    c = b.compact_line(full)
+    line = json.dumps(c)
+    assert len(line) < b.LINE_LIMIT == 4096, len(line)
+    _check_compact_line(c)
+    assert len(c["baseline_configs"]) >= 10 and c["collective"]["world_size"] == 8
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "MM_PREC_MIXED" not in src and "mixed" not in src.lower().replace("mixed_study", "")
+
+
 import pytest
 
 
@@ -62,11 +110,13 @@ def test_bench_n_gt_1_path_runs_oversubscribed_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0]) < 4096         # the contract line is the LAST line, and short
     d = json.loads(lines[0])
+    _check_compact_line(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "oversubscribed" in d["config"] and d["config"]["parallelism"] == "env-shard x2"
     assert d["stats"]["envs_in_stats"] == 2 * E_                      # the gather returned both shards
     assert abs(d["ms_per_step"] - 1e3 * 2 * E_ / d["value"]) < 1e-6 * d["ms_per_step"] + 1e-9
-    assert d["cpu_baseline"]["single_thread"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["cpu_baseline"]["single_thread"] > 0 and d["cpu_baseline"]["cores"] >= 1
     assert "-O3 -march=native" in d["cpu_baseline"]["build"]         # the timed CPU build is the optimised one, and says so
     # the N > 1 line is self-evidencing about its one collective
     c = d["collective"]
@@ -102,6 +152,7 @@ def test_bench_config_5_preset_runs_the_fati_leg_share_on_two_ranks():
     c = d["collective"]
     assert c["gathered_rows"] == c["expected_rows"] == 2048 and len(c["per_rank_env_steps_per_s"]) == 2
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 5336 * 1024          # 5 336 B per env-step of the fatigue leg
+    _check_compact_line(d, cpu=False)
 
 
 def _fracs(node, path=""):
@@ -118,15 +169,27 @@ def _fracs(node, path=""):
 
 
 @pytest.mark.gpu
-def test_bench_line_bookkeeping_repeats_fractions_and_replayed_counters():
-    """The default line (short): `repeats` timed regions with the median reported, no fraction above 1 anywhere (the valu-busy
+def test_bench_line_bookkeeping_repeats_fractions_and_replayed_counters(tmp_path):
+    """The default run (short): the LAST stdout line is the compact contract line (< 4 KB: the round-5 line had grown to 27 KB and the
+    driver could not read it back), everything else is in the extras file.  `repeats` timed regions with the median reported, no fraction above 1 anywhere (the valu-busy
     fraction is priced per RESIDENT wave: mm_model_launch_info), counters that were not measured in the run sit under
     roofline.profile and name the committed file they are replayed from, the GPU clocks are logged around the timed region."""
     import subprocess, sys
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+    xf = str(tmp_path / "bench_extras.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--extras-file", xf],
                          capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    last = out.stdout.rstrip().splitlines()[-1]
+    assert len(last) < 4096 and [l for l in out.stdout.splitlines() if l.startswith("{")] == [last]      # ONE parseable line, the last, short
+    c = json.loads(last)
+    _check_compact_line(c)
+    assert len(c["baseline_configs"]) >= 10 and all(isinstance(v, int) and v > 0 for v in c["baseline_configs"].values()), c["baseline_configs"]
+    assert list(c["baseline_configs"].keys())[-3:] == ["myoElbowPose1D6MRandom-v0@4096", "myoHandReorient100-v0@2048", "myoFatiLegWalk-v0@1024"]
+    assert c["roofline"]["algorithmic_bytes_per_launch"] == 1376 * 4096 and c["roofline"]["bound_by"] == "fp32-issue"
+    # everything else: the extras file (and the '#extra' lines before the contract line)
+    d = json.load(open(xf))
+    assert any(l.startswith("#extra ") for l in out.stdout.splitlines())
+    assert d["value"] == c["value"] and d["roofline"]["kernel_ms"] == c["roofline"]["kernel_ms"]
     assert d["repeats"] >= 3 and len(d["region_ms_per_step"]) == d["repeats"]
     assert sorted(d["region_ms_per_step"])[(d["repeats"] - 1) // 2] == pytest.approx(d["ms_per_step"], rel=1e-9)
     assert "gpu_clocks_mhz" in d
@@ -149,11 +212,7 @@ def test_bench_line_bookkeeping_repeats_fractions_and_replayed_counters():
     assert r["algorithmic_bytes_per_launch"] == 1376 * 4096 and r["algorithmic_bytes_per_launch_incl_carry"] == 1752 * 4096
     assert r["frac"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"], rel=1e-9)
     assert r["frac_incl_carry"] > r["frac"] and r["bound_by"] == "fp32-issue" and r["bound_by_detail"]["x_ridge"] > 10
-    # the line ENDS with the compact digest, BASELINE.json configs 2 / 4 / 5 last (the driver's record keeps the tail)
-    assert list(d.keys())[-1] == "baseline_configs"
-    assert list(d["baseline_configs"].keys())[-3:] == ["myoElbowPose1D6MRandom-v0@4096", "myoHandReorient100-v0@2048", "myoFatiLegWalk-v0@1024"]
     assert [x["key"] for x in d["extra_configs"]][-3:] == ["myoElbowPose1D6MRandom-v0@4096", "myoHandReorient100-v0@2048", "myoFatiLegWalk-v0@1024"]
-    assert len(json.dumps(d["baseline_configs"])) < 4000
     keys = {x["key"] for x in d["extra_configs"]}
     assert "myoHandReachRandom-v0@4096" in keys and "myoHandPoseRandom-v0@4096|precision=f64_state" in keys
     ppo = {x["key"]: x for x in d["ppo_training"]}
