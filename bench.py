@@ -49,6 +49,9 @@ EXTRA_CONFIGS = [# the step of the reference's own GPU path: mjx_env.step = n_su
                  ("myoHandReachRandom-v0", 4096, {}),
                  ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}),
                  ("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}),
+                 # the reorient hand under MuJoCo's default collision filter: 189 candidate pairs (every skin capsule against every other
+                 # non-adjacent one + the object against all twenty), swept in three chunks of one pair per lane (synth.make_hand_dense)
+                 ("myoHandReorient100-v0", 2048, {"model": "hand_dense"}),
                  ("myoElbowPose1D6MRandom-v0", 4096, {}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {})]
 
 

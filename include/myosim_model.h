@@ -76,6 +76,7 @@ enum { MM_CON_EQUALITY = 0, MM_CON_LIMIT_JOINT = 1, MM_CON_LIMIT_TENDON = 2,
        MM_CON_CONTACT = 3, MM_CON_FRICTION_DOF = 4 };
 
 #define MM_MINVAL 1e-15  /* MuJoCo mjMINVAL */
+#define MM_MAX_PAIRS 256 /* longest explicit contact-pair list (PAIR_* sections) the HIP engine sweeps: chunks of one pair per lane */
 
 /* ---- sections ------------------------------------------------------------ */
 #define MM_SECTIONS(MM_SEC)                                                      \

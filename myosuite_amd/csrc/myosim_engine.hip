@@ -317,7 +317,9 @@ static int check_lanes(const mm_model* m, int lanes) {
   const Dims& d = m->d;
   if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return 0;
   if (d.nbody > lanes || d.nv > lanes || d.njnt > lanes || m->nvp > lanes) return 0;
-  if (d.gen && (d.njmax > lanes || d.npair > lanes || d.neq > lanes)) return 0;   // one constraint row / pair per lane
+  // one constraint row / equality per lane; the explicit pair list is swept in chunks of `lanes` pairs (make_constraint_gen), bounded
+  // by MM_MAX_PAIRS (the pair index shares a row-descriptor word with the row kind)
+  if (d.gen && (d.njmax > lanes || d.neq > lanes || d.npair > MM_MAX_PAIRS)) return 0;
   return 1;
 }
 

@@ -891,6 +891,75 @@ def make_hand_pen() -> ModelSpec:
     return _make_hand_with_object("pen")
 
 
+def _rest_pose_segments(s: ModelSpec, names):
+    """World-frame axis segments (centre, unit axis, half length, radius) of the named capsules at qpos0 (every hand joint is a hinge
+    with ref 0: the rest pose is the body frames composed down the tree)."""
+    from .kin_np import quat_mul, quat2mat
+    nb = len(s.bodies)
+    xpos = np.zeros((nb, 3)); xquat = np.zeros((nb, 4)); xquat[0, 0] = 1.0
+    for b in range(1, nb):
+        bd = s.bodies[b]
+        xpos[b] = xpos[bd.parent] + quat2mat(xquat[bd.parent][None])[0] @ bd.pos
+        xquat[b] = quat_mul(xquat[bd.parent][None], np.asarray(bd.quat, float)[None])[0]
+    out = {}
+    for n in names:
+        g = s.geoms[s._gname[n]]
+        R = quat2mat(xquat[g["body"]][None])[0]
+        c = xpos[g["body"]] + R @ g["pos"]
+        u = (R @ quat2mat(np.asarray(g["quat"], float)[None])[0])[:, 2]
+        out[n] = (c, u, float(g["size"][1]), float(g["size"][0]))
+    return out
+
+
+def _segment_distance(c1, u1, h1, c2, u2, h2):
+    """distance between two segments c + t u, |t| <= h (clamped closest points)"""
+    d = c1 - c2
+    b = float(u1 @ u2); r1 = float(u1 @ d); r2 = float(u2 @ d)
+    den = 1.0 - b * b
+    t1 = np.clip((b * r2 - r1) / den, -h1, h1) if den > 1e-12 else 0.0
+    t2 = np.clip(r2 + b * t1, -h2, h2)
+    t1 = np.clip(b * t2 - r1, -h1, h1)
+    return float(np.linalg.norm(c1 + t1 * u1 - c2 - t2 * u2))
+
+
+def make_hand_dense() -> ModelSpec:
+    """The reorient hand under MuJoCo's DEFAULT collision filter instead of a hand-picked pair list (round 6: the pair list may be
+    longer than the wave).  `myohand_sar.xml:15-18` gives every geom of class ``reorient`` contype = conaffinity = 1, so
+    `mj_collision` tests every skin geom against every other one unless the two sit on the same body or on parent and child; the
+    real hand "self-collides" (docs/source/suite.rst:288).  Here: each of the 20 collision capsules (a capsule per metacarpal and
+    phalanx + the carpal row) against every other one that passes that filter, minus the pairs that already interpenetrate in
+    the rest pose (neighbouring segments across a joint: what a modeller's ``<exclude>`` removes, as `myo_sim`'s hand does for its
+    skin), plus the object against all twenty.  Pairs are ordered by (body1, body2) like MuJoCo's broad phase emits them.
+    Contact / row bounds are the reorient model's (nconmax 12, njmax 56: surplus contacts are dropped in pair order and
+    flagged, status bit 8, by oracle and kernel alike)."""
+    s = _make_hand_with_object("reorient")
+    s.name = "myohand_dense"
+    caps = [p["g2"] if p["g1"] == "obj" else p["g1"] for p in s.pairs]
+    seg = _rest_pose_segments(s, caps)
+    obj_pairs = {c: p for c, p in zip(caps, s.pairs)}
+    body_of = {c: s.geoms[s._gname[c]]["body"] for c in caps}
+    entries = []
+    for i, c1 in enumerate(caps):
+        for c2 in caps[i + 1:]:
+            b1, b2 = body_of[c1], body_of[c2]
+            if b1 == b2 or s.bodies[b1].parent == b2 or s.bodies[b2].parent == b1:
+                continue                                                    # mj_collision's same-body / parent-child filter
+            (x1, u1, h1, r1), (x2, u2, h2, r2) = seg[c1], seg[c2]
+            if _segment_distance(x1, u1, h1, x2, u2, h2) < r1 + r2 + 5e-4:
+                continue                                                    # <exclude>: touching in the rest pose
+            entries.append((min(b1, b2), max(b1, b2), dict(g1=c1, g2=c2)))
+    ob = s._bname["Object"]
+    for c in caps:
+        entries.append((min(body_of[c], ob), max(body_of[c], ob), None, c))
+    s.pairs = []
+    for e in sorted(entries, key=lambda e: (e[0], e[1])):
+        if e[2] is None:
+            s.pairs.append(obj_pairs[e[3]])
+        else:
+            s.add_contact_pair(e[2]["g1"], e[2]["g2"], condim=3, friction=(1.0, 0.005, 0.0001))
+    return s
+
+
 # ----------------------------------------------------------------------------- contact toy
 def make_contact_toy() -> ModelSpec:
     """Small model that exercises every contact primitive of the engine (plane-sphere, plane-capsule,
@@ -1072,6 +1141,7 @@ def builders() -> dict:
             "motorfinger": lambda: make_finger(motor=True), "torso": make_torso,
             "friction_toy": make_friction_toy, "hand_keyturn": make_hand_keyturn,
             "tendon_limit_toy": make_tendon_limit_toy, "hand_contact": lambda: make_hand(self_collision=True),
+            "hand_dense": make_hand_dense,
             "leg_implicit": lambda: make_leg(implicit=True), "torso_exo": lambda: make_torso(exosuit=True),
             "tree_star": lambda: make_tree_toy("star"), "tree_chain": lambda: make_tree_toy("chain"),
             "tree_comb": lambda: make_tree_toy("comb"), "tree_free": lambda: make_tree_toy("free"), "plane_toy": make_plane_toy}

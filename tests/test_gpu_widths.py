@@ -227,6 +227,7 @@ def _all_env_solve_scan(env_id, nenv, overrides, steps=7):
 
 
 ALL_ENV_SCANS = [("myoHandPoseRandom-v0", 4096, {"model": "hand_contact"}), ("myoHandReorient100-v0", 2048, {}), ("myoFatiLegWalk-v0", 1024, {}),
+                 ("myoHandReorient100-v0", 2048, {"model": "hand_dense"}),      # 189 candidate pairs: three chunks of the pair sweep
                  ("myoFatiLegWalk-v0", 1024, {"model": "leg_implicit"}), ("myoHandKeyTurnRandom-v0", 1024, {}),
                  # ... and the rest of the task families at 512 envs: limit rows only (sparse and dense kernels), condim-1 contacts, cylinder / box /
                  # ellipsoid objects, the 210-tendon torso, the exo elbow's carried weight, RK4-free variants of the muscle conditions
@@ -259,7 +260,8 @@ def test_every_env_of_the_contact_batches_solves_like_the_oracle(oracle_lib, env
         "row_count_mismatches": int(mism.sum()), "rel_qacc_err_median": float(q[0]), "rel_qacc_err_p99": float(q[1]), "rel_qacc_err_max": float(q[2]),
         "envs_with_rows": int((rows > 0).sum())}
     json.dump(rec, open(fn, "w"), indent=1)
-    assert status & ~1 == 0
+    # (hand_dense: a contact beyond nconmax / njmax is dropped and flagged on both sides, bit 8; the scan compares the rows that remain)
+    assert status & ~(1 | (8 if overrides.get("model") == "hand_dense" else 0)) == 0
     assert mism.sum() <= max(2, nenv // 100), int(mism.sum())
     assert q[2] < 2e-3 and q[1] < 3e-4, q
 

@@ -7,11 +7,12 @@ from myosuite_amd import engine as E
 from myosuite_amd.envs import registry
 W = {"elbow": ("myoElbowPose1D6MRandom-v0", 4096), "hand": ("myoHandPoseRandom-v0", 4096), "leg": ("myoFatiLegWalk-v0", 1024),
      "reorient": ("myoHandReorient100-v0", 2048), "contact": ("myoHandPoseRandom-v0", 4096), "legi": ("myoFatiLegWalk-v0", 1024),
+     "dense": ("myoHandReorient100-v0", 2048),       # model="hand_dense": 189 candidate pairs
      "hand64": ("myoHandPoseRandom-v0", 4096), "elbow64": ("myoElbowPose1D6MRandom-v0", 4096)}      # precision mode (fp64 state rows)
 names = [a for a in sys.argv[1:] if a in W] or ["elbow", "hand", "leg", "reorient"]
 for nm in names:
     env_id, n = W[nm]
-    env = registry.make(env_id, num_envs=n, seed=0, **({"model": "hand_contact"} if nm == "contact" else ({"model": "leg_implicit"} if nm == "legi" else
+    env = registry.make(env_id, num_envs=n, seed=0, **({"model": "hand_contact"} if nm == "contact" else {"model": "hand_dense"} if nm == "dense" else ({"model": "leg_implicit"} if nm == "legi" else
                                                                 ({"precision": "f64_state"} if nm.endswith("64") else {}))))
     env.rollout_setup(action_seed=0)
     for s in range(6): env.rollout_step(None, stream_id=s)
