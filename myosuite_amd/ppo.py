@@ -15,8 +15,9 @@ What follows brax's PPO term by term: GAE (mm_gae = compute_gae with its truncat
 0.5 * 0.5 * mse, global-norm clipping, Adam, and -- since the end of round 5 -- the entropy bonus of NormalTanhDistribution: the
 pre-squash normal's entropy PLUS the squashing log-det-Jacobian at a reparametrised sample x = mean + std e, which also feeds
 gradient into the mean (`PPOConfig.entropy_squash_term`; e is drawn once per iteration per sample, brax draws per loss call; both
-learners, torch and fused, implement it and check each other).  Deviation, stated: advantages are normalised per rank over the
-whole batch once per iteration (brax: per minibatch, per device).
+learners, torch and fused, implement it and check each other), and -- round 6 -- the advantage normalisation: per MINIBATCH and per
+device with the population standard deviation, as `compute_ppo_loss` does on the data it is handed (`PPOConfig.normalize_advantage =
+"minibatch"`; "batch" = rounds 4-5: once per iteration over the rank's whole batch).
 
 Data parallel (one process per GPU): the running observation statistics are merged over ALL ranks' rows (one small all-reduce per
 iteration: `_Norm.update(world=...)`), so the normaliser -- part of the policy and value function -- is identical on every rank; parameters and gradients live in ONE flat buffer each, so the exchange is a single
@@ -55,6 +56,7 @@ class PPOConfig:
     squash: str = "tanh"                          # "tanh": brax NormalTanhDistribution, actions in [-1, 1]; "sigmoid": excitations in [0, 1]
     unrolls: int = 1                              # unrolls of `unroll_length` per iteration (brax: batch_size * num_minibatches // num_envs)
     entropy_squash_term: bool = True              # brax NormalTanhDistribution.entropy: + log|d squash / d x| at a reparametrised sample
+    normalize_advantage: str = "minibatch"        # "minibatch": brax (inside the loss, per minibatch and device, population std) | "batch" | "none"
 
 
 def _mlp(sizes):
@@ -221,7 +223,11 @@ class OnDevicePPO:
             if not self.kern:
                 self.val_b[self.T].copy_(self._value(env.obs))
             E.gae(self.rew_b, self.term_b, self.trunc_b, self.val_b, self.adv_b, self.ret_b, cfg.discounting, cfg.gae_lambda)
-            self.nadv_b.copy_((self.adv_b - self.adv_b.mean()) / (self.adv_b.std() + 1e-8))
+            # (whole-batch form; with normalize_advantage = "minibatch" _epoch() overwrites each minibatch's entries before its gradient)
+            if cfg.normalize_advantage == "none":
+                self.nadv_b.copy_(self.adv_b)
+            else:
+                self.nadv_b.copy_((self.adv_b - self.adv_b.mean()) / (self.adv_b.std(unbiased=False) + 1e-8))
             if self.norm and self.world == 1:
                 self.norm.update(self.obs_b)       # (world > 1: iterate() merges every rank's batch, outside the graph)
             self.mean_reward.copy_(self.rew_b.mean())
@@ -279,6 +285,11 @@ class OnDevicePPO:
         perm = torch.argsort(torch.rand(B, device=self.dev))          # device-side permutation (graph safe)
         mb = B // self.cfg.num_minibatches
         for k in range(self.cfg.num_minibatches):
+            if self.cfg.normalize_advantage == "minibatch":
+                # brax compute_ppo_loss: (advantages - mean) / (std + 1e-8) over the minibatch it is handed (jnp.std: population)
+                idx = perm[k * mb:(k + 1) * mb]
+                a_ = self.adv_b.view(B).index_select(0, idx)
+                self.nadv_b.view(B).index_copy_(0, idx, (a_ - a_.mean()) / (a_.std(unbiased=False) + 1e-8))
             if self.kern:
                 self._minibatch_fused(perm[k * mb:(k + 1) * mb])
             else:

@@ -181,6 +181,37 @@ def test_fused_adam_matches_torch_clip_and_adam():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "torch"])
+def test_advantages_are_normalised_per_minibatch_like_brax(fused):
+    """brax's compute_ppo_loss normalises the advantages of the minibatch it is handed -- (A - mean) / (std + 1e-8), jnp.std = the
+    population form -- not the batch's (benchmarks/mjx_benchmark_PPO.py:50-60 trains with brax's defaults: normalize_advantage on).
+    After one pass over the batch every minibatch's slice of the normalised buffer has mean 0 and population std 1 although the
+    raw advantages of the minibatches differ; "batch" keeps the round-5 behaviour (the whole batch normalised once)."""
+    cfg = ("myoElbowPose1D6MRandom-v0", 64, (32, 32), (32, 32), "tanh", True, 4, None)
+    for mode in ("minibatch", "batch"):
+        ppo = _make(*cfg, fused=fused)
+        assert (ppo.kern is not None) == fused and ppo.cfg.normalize_advantage == "minibatch"
+        ppo.cfg.normalize_advantage = mode
+        ppo._rollout()
+        B = ppo.T * ppo.n
+        # make the minibatches differ in location and scale beyond sampling noise (the rollout's advantages are nearly homogeneous)
+        ppo.adv_b.view(B).mul_(torch.linspace(0.5, 3.0, B, device=ppo.dev)).add_(torch.linspace(-1.0, 1.0, B, device=ppo.dev))
+        torch.manual_seed(7); torch.cuda.manual_seed_all(7)
+        ppo._epoch()
+        torch.manual_seed(7); torch.cuda.manual_seed_all(7)
+        perm = torch.argsort(torch.rand(B, device=ppo.dev))
+        mb = B // ppo.cfg.num_minibatches
+        means, stds = [], []
+        for k in range(ppo.cfg.num_minibatches):
+            v = ppo.nadv_b.view(B).index_select(0, perm[k * mb:(k + 1) * mb])
+            means.append(float(v.mean())); stds.append(float(v.std(unbiased=False)))
+        if mode == "minibatch":
+            assert max(abs(m) for m in means) < 1e-5 and max(abs(s_ - 1.0) for s_ in stds) < 1e-4, (means, stds)
+        else:
+            assert max(abs(m) for m in means) > 1e-3, means          # normalised over the batch, not per minibatch
+
+
+@pytest.mark.gpu
 def test_fused_learner_rejects_networks_it_cannot_take():
     from myosuite_amd import engine as E
     with pytest.raises(E.EngineError, match="width 256"):
