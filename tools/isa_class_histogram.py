@@ -121,10 +121,12 @@ def assembly(unit):
     src = os.path.join(E.CSRC, f"myosim_{unit}.hip")
     base = os.path.basename(src)
     sched = E.SCHED_STRATEGY.get(base, E.SCHED_STRATEGY["default"])
-    out = os.path.join(tempfile.mkdtemp(prefix="isa_"), unit + ".s")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output", "-gline-tables-only"] + \
-          E.EXTRA_FLAGS + E.FILE_FLAGS.get(base, []) + ["-mllvm", f"-amdgpu-sched-strategy={sched}", "-S", "-o", out, src]
-    subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
+    out = os.path.join(tempfile.gettempdir(), f"isa_hist_{unit}.s")
+    deps = [src] + [os.path.join(E.CSRC, f) for f in os.listdir(E.CSRC) if f.endswith((".hpp", ".inc"))]
+    if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "--no-gpu-bundle-output", "-gline-tables-only"] + \
+              E.EXTRA_FLAGS + E.FILE_FLAGS.get(base, []) + ["-mllvm", f"-amdgpu-sched-strategy={sched}", "-S", "-o", out, src]
+        subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     return open(out).read().split("\n")
 
 
@@ -142,7 +144,13 @@ def main():
             files[int(m.group(1))] = m.group(3)
     start = [i for i, l in enumerate(lines) if re.match(r"^_Z\w*8k_engine\w*:", l)] + [len(lines)]
     kern = [(lines[start[i]].split(":")[0], lines[start[i]:start[i + 1]]) for i in range(len(start) - 1)]
-    names = [subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", k[0]], text=True).strip() for k in kern]
+    def demangle(n):      # _Z8k_engineILi32ELi24ELb1ELb0ELi0ELb0EEv5KArgs -> k_engine<32, 24, true, false, 0, false>
+        m = re.match(r"_Z(?:N4mm64)?8k_engineI((?:L[ib]\d+E)+)E", n)
+        if not m:
+            return n
+        a = [(("true" if v == "1" else "false") if t == "b" else v) for t, v in re.findall(r"L([ib])(\d+)E", m.group(1))]
+        return ("mm64::" if "N4mm64" in n else "") + "k_engine<" + ", ".join(a) + ">"
+    names = [demangle(k[0]) for k in kern]
     if pick.isdigit():
         ki = int(pick)
     else:
@@ -157,6 +165,7 @@ def main():
         return starts[k][1] if k >= 0 else "?"
     hist = collections.defaultdict(collections.Counter)
     cur_file, cur_line = None, None
+    last_stage = "task/io"
     for l in body:
         t = l.strip()
         m = re.match(r"\.loc\s+(\d+)\s+(\d+)", t)
@@ -167,11 +176,15 @@ def main():
         if not re.match(r"^[a-z_0-9]+(\s|$)", t):
             continue
         cls = classify(t)
+        # An instruction generated from a stage function's own lines names its stage; one generated from an inlined helper (V3 /
+        # quaternion operators, bc / gsum / dpp wrappers, the device library's expf / sincosf, hip headers) carries the helper's
+        # line, not its caller's: it inherits the stage of the last instruction ahead of it that named one (code of a stage is
+        # contiguous up to the scheduler's reordering inside a basic block).
         if cur_file and cur_file.endswith("myosim_engine_body.inc") and cur_line:
             st = stage_of(fn_of(cur_line))
-        else:
-            st = "other files (device library, hip headers)"
-        hist[st][cls] += 1
+            if st != "math/xlane helpers":
+                last_stage = st
+        hist[last_stage][cls] += 1
     order = [g[0] for g in GROUPS] + ["task/io", "math/xlane helpers", "other files (device library, hip headers)"]
     print(f"# {name}  ({unit}; static instruction counts by stage x class)")
     hdr = f"{'stage':28s}" + "".join(f"{c:>10s}" for c in CLASSES) + f"{'total':>9s}{'valu':>8s}{'fp/valu':>9s}"
