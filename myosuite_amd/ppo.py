@@ -284,12 +284,15 @@ class OnDevicePPO:
         B = self.T * self.n
         perm = torch.argsort(torch.rand(B, device=self.dev))          # device-side permutation (graph safe)
         mb = B // self.cfg.num_minibatches
+        if self.cfg.normalize_advantage == "minibatch":
+            # brax compute_ppo_loss: (advantages - mean) / (std + 1e-8) over the minibatch it is handed (jnp.std: population) -- every
+            # minibatch of this pass at once (a handful of launches per pass over the batch, not per minibatch)
+            nmb = self.cfg.num_minibatches
+            sel = perm[:nmb * mb]
+            a_ = self.adv_b.view(B).index_select(0, sel).view(nmb, mb)
+            a_ = (a_ - a_.mean(1, keepdim=True)) / (a_.std(1, unbiased=False, keepdim=True) + 1e-8)
+            self.nadv_b.view(B).index_copy_(0, sel, a_.reshape(-1))
         for k in range(self.cfg.num_minibatches):
-            if self.cfg.normalize_advantage == "minibatch":
-                # brax compute_ppo_loss: (advantages - mean) / (std + 1e-8) over the minibatch it is handed (jnp.std: population)
-                idx = perm[k * mb:(k + 1) * mb]
-                a_ = self.adv_b.view(B).index_select(0, idx)
-                self.nadv_b.view(B).index_copy_(0, idx, (a_ - a_.mean()) / (a_.std(unbiased=False) + 1e-8))
             if self.kern:
                 self._minibatch_fused(perm[k * mb:(k + 1) * mb])
             else:

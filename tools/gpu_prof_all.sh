@@ -11,9 +11,10 @@ timeout 300 bash $R/tools/prof_round.sh legimplicit1024 --env myoFatiLegWalk-v0 
 timeout 300 bash $R/tools/prof_round.sh handnofwd4096 --no-forward --steps 32 > /dev/null 2>&1 < /dev/null
 timeout 300 bash $R/tools/prof_round.sh handf64state4096 --precision f64_state --steps 32 > /dev/null 2>&1 < /dev/null
 timeout 300 bash $R/tools/prof_round.sh handreach4096 --env myoHandReachRandom-v0 --steps 32 > /dev/null 2>&1 < /dev/null
+timeout 300 bash $R/tools/prof_round.sh handdense2048 --env myoHandReorient100-v0 --envs-per-gpu 2048 --model hand_dense --steps 32 > /dev/null 2>&1 < /dev/null
 cd $R && python tools/prof_install.py $TAG hand4096:myoHandPoseRandom-v0@4096 elbow4096:myoElbowPose1D6MRandom-v0@4096 \
    fatilegwalk1024:myoFatiLegWalk-v0@1024 reorient2048:myoHandReorient100-v0@2048 \
    "handcontact4096:myoHandPoseRandom-v0@4096|model=hand_contact" "legimplicit1024:myoFatiLegWalk-v0@1024|model=leg_implicit" \
    "handnofwd4096:myoHandPoseRandom-v0@4096|do_forward=False" "handf64state4096:myoHandPoseRandom-v0@4096|precision=f64_state" \
-   "handreach4096:myoHandReachRandom-v0@4096" > gpurun_out/prof_install.log 2>&1
+   "handreach4096:myoHandReachRandom-v0@4096" "handdense2048:myoHandReorient100-v0@2048|model=hand_dense" > gpurun_out/prof_install.log 2>&1
 tail -5 gpurun_out/prof_install.log; mkdir -p gpurun_out/profiles_$TAG; cp profiles/${TAG}_* gpurun_out/profiles_$TAG/; ls gpurun_out/profiles_$TAG
