@@ -59,7 +59,11 @@ enum { MM_INFO_NQ = 0, MM_INFO_NV, MM_INFO_NU, MM_INFO_NA, MM_INFO_NBODY, MM_INF
        MM_INFO_MODEL_WORDS,     /* 32-bit words of the device model tables a block stages into LDS when they fit next to its envs */
        MM_INFO_BODY_CHAINS,     /* levels of the body-chain tree | most child chains << 4 | longest chain << 8 (0: level-by-level sweeps) */
        MM_INFO_FOLDED_RESET,    /* 1: mm_rollout.autoreset is available for the WALK / REORIENT tasks on this model (64 lanes per env, a kernel of MM_KERNELS_OBS) */
-       MM_INFO_FWD_CARRY };     /* 1: mm_task.fwd_carry is implemented for this model (see mm_task) */
+       MM_INFO_FWD_CARRY,       /* 1: mm_task.fwd_carry is implemented for this model (see mm_task) */
+       MM_INFO_TENDON_ITEMS,    /* tendon path items (site-site segments, wraps, fixed-tendon terms) the kernel sweeps per forward pass */
+       MM_INFO_TENDON_FOLDED }; /* path segments between two sites whose bodies no dof separates: constant length, summed into the tendon's
+                                   constant at mm_model_create instead of being swept (a per-env mm_state.body_pos_env on a body such a
+                                   segment spans is refused with MM_EUNSUPPORTED) */
 
 /* ABI version of this header: bumped whenever a struct below gains / loses / reorders a field, an entry point changes its
  * signature or a status / enum value is renumbered.  A caller compares MM_ABI_VERSION (what it was built against) with

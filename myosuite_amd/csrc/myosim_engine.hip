@@ -195,6 +195,9 @@ struct mm_model {
   std::vector<int32_t> desc_all, seg_tab, anc_tab;   // Aux::dof_desc / dof_seg / dof_anc, built with the dims
   int nseg = 0;                             // segments of the dof tree (SP kernels)
   int nwrapitem = 0;                        // tendon path items that wrap a geom (tangent points kept in LDS)
+  std::vector<double> ten_len0;             // per tendon: summed length of its path segments between rigidly connected bodies (folded at create)
+  std::vector<uint8_t> baked_body;          // bodies whose frame position such a folded segment spans (a per-env body_pos on one is refused)
+  int nfolded = 0;                          // path items folded into ten_len0
   int precision = MM_PREC_F32;              // MM_PREC_*: which kernel family steps this model (mm_model_set_option "precision")
 };
 
@@ -535,6 +538,31 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     }
     return out;
   };
+  // body frames of the reference configuration (joints at their reference values: the relative pose of two bodies that no dof
+  // separates does not depend on the configuration)
+  std::vector<double> ref_xp(3 * (size_t)d.nbody, 0.0), ref_xq(4 * (size_t)d.nbody, 0.0);
+  {
+    const float* bpos = (const float*)(blob + m->sec[MM_SEC_BODY_POS]);
+    const float* bquat = (const float*)(blob + m->sec[MM_SEC_BODY_QUAT]);
+    ref_xq[0] = 1.0;
+    for (int b = 1; b < d.nbody; b++) {
+      const double* pq = &ref_xq[4 * bpar[b]];
+      const double w = pq[0], x = pq[1], y = pq[2], z = pq[3];
+      const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                           2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                           2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+      for (int k = 0; k < 3; k++)
+        ref_xp[3 * b + k] = ref_xp[3 * bpar[b] + k] + R[3 * k] * bpos[3 * b] + R[3 * k + 1] * bpos[3 * b + 1] + R[3 * k + 2] * bpos[3 * b + 2];
+      const double a0 = bquat[4 * b], a1 = bquat[4 * b + 1], a2 = bquat[4 * b + 2], a3 = bquat[4 * b + 3];
+      double q[4] = {w * a0 - x * a1 - y * a2 - z * a3, w * a1 + x * a0 + y * a3 - z * a2,
+                     w * a2 - x * a3 + y * a0 + z * a1, w * a3 + x * a2 - y * a1 + z * a0};
+      const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int k = 0; k < 4; k++) ref_xq[4 * b + k] = n > 0 ? q[k] / n : (k == 0);
+    }
+  }
+  m->ten_len0.assign((size_t)std::max(d.ntendon, 1), 0.0);
+  m->baked_body.assign((size_t)std::max(d.nbody, 1), 0);
+  const float* spos = (const float*)(blob + m->sec[MM_SEC_SITE_POS]);
   // flattened path items (see Engine::tendon): wraps first, then straight segments, then fixed-tendon joint terms
   std::vector<int32_t> item_tab;
   {
@@ -557,6 +585,39 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
         }
         const int k0 = adr + j;
         if (t1 == MM_WRAP_SITE) {
+          // A straight segment between two sites whose bodies no dof separates (the same bone, or bones fixed to one another) has
+          // the same length in every pose and no Jacobian entry: it is summed into the tendon's constant here -- MyoSuite's muscle
+          // paths are mostly such via-point runs along a bone -- instead of being re-measured by a lane in every forward pass.
+          if (MM_FOLD_RIGID_SEGMENTS) {
+            int b0 = sbody[wo[k0]], b1 = sbody[wo[k0 + 1]];
+            std::vector<int> spanned;
+            bool rigid = true;
+            while (b0 != b1 && rigid) {
+              const int b = b0 > b1 ? b0 : b1;
+              if (bdofnum[b] > 0) rigid = false;
+              spanned.push_back(b);
+              if (b0 > b1) b0 = bpar[b0]; else b1 = bpar[b1];
+            }
+            if (rigid) {
+              double p[2][3];
+              for (int e = 0; e < 2; e++) {
+                const int si = wo[k0 + e], sb = sbody[si];
+                const double* q = &ref_xq[4 * sb];
+                const double w = q[0], x = q[1], y = q[2], z = q[3];
+                const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+                for (int k = 0; k < 3; k++)
+                  p[e][k] = ref_xp[3 * sb + k] + R[3 * k] * (double)spos[3 * si] + R[3 * k + 1] * (double)spos[3 * si + 1] + R[3 * k + 2] * (double)spos[3 * si + 2];
+              }
+              const double dx = p[1][0] - p[0][0], dy = p[1][1] - p[0][1], dz = p[1][2] - p[0][2];
+              m->ten_len0[t] += std::sqrt(dx * dx + dy * dy + dz * dz) * (double)inv_div;
+              for (int b : spanned) m->baked_body[b] = 1;
+              m->nfolded++;
+              j += 1;
+              continue;
+            }
+          }
           straights.push_back(Item{{t, 0, k0, wo[k0], wo[k0 + 1], 0, -1, fbits(inv_div)}});
           j += 1;
         } else {
@@ -702,6 +763,14 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
     }
     while (dev.size() % 4) dev.push_back(0u);   // 16-byte rows
     m->x.item_tab = append(packed); m->x.nitem = nit;
+    // the tendons' constant length (path segments folded at create): [ntendon] float for the fp32 kernels, then [ntendon] double
+    // (8-byte aligned) for the precision-mode kernels
+    std::vector<int32_t> l0;
+    const int nt_ = std::max(d.ntendon, 1), ntp = (nt_ + 1) & ~1;
+    for (int t = 0; t < ntp; t++) { const float f = t < d.ntendon ? (float)m->ten_len0[t] : 0.f; int32_t w; memcpy(&w, &f, 4); l0.push_back(w); }
+    for (int t = 0; t < nt_; t++) { const double v = t < d.ntendon ? m->ten_len0[t] : 0.0; int32_t w[2]; memcpy(w, &v, 8); l0.push_back(w[0]); l0.push_back(w[1]); }
+    while (dev.size() % 2) dev.push_back(0u);
+    m->x.ten_len0 = append(l0); m->x.ten_len0_f64 = m->x.ten_len0 + ntp;
   }
   {
     const int32_t* dpar = (const int32_t*)(blob + m->sec[MM_SEC_DOF_PARENTID]);
@@ -894,6 +963,8 @@ extern "C" int mm_model_info(const mm_model* m, int which) {
     case MM_INFO_BODY_CHAINS: return m->d.bchain_nlevel;
     case MM_INFO_FOLDED_RESET: return (MM_FOLD_RESET && m->lanes == 64 && !m->lanes_auto && have_obs_kernel(64, m->nvp, m->d.gen, integ_kernel(m->d.integrator))) ? 1 : 0;
     case MM_INFO_FWD_CARRY: return fwd_carry_ok(m) ? 1 : 0;
+    case MM_INFO_TENDON_ITEMS: return m->x.nitem;
+    case MM_INFO_TENDON_FOLDED: return m->nfolded;
     case MM_INFO_KERNEL_FAMILY: return m->d.gen ? 2 : ((MM_SPARSE_LDL && m->nvp >= 8 && m->d.integrator != MM_INT_IMPLICITFAST) ? 1 : 0);
   }
   return MM_EARG;
@@ -1021,6 +1092,9 @@ extern "C" int mm_model_launch_info(const mm_model* m, int nenv, int* out, int n
   return rc;
 }
 static int launch(const mm_model* m, KArgs& a, void* stream) {
+  if (a.s.body_pos_env && a.s.body_pos_env_id > 0 && a.s.body_pos_env_id < (int)m->baked_body.size() && m->baked_body[a.s.body_pos_env_id])
+    return fail(MM_EUNSUPPORTED, "mm_state.body_pos_env names a body whose frame position is part of a tendon path segment folded into the tendon's "
+                                 "constant length at mm_model_create (a segment between two bones that no dof separates)");
   const int G = pick_lanes(m, a.s.nenv);
   {   // launch on the model's device (the caller's stream must belong to it); restore the caller's current device afterwards
     int cur = -1;

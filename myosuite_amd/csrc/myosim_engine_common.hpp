@@ -97,6 +97,9 @@ struct Layout {
   int total;
 };
 
+#ifndef MM_FOLD_RIGID_SEGMENTS
+#define MM_FOLD_RIGID_SEGMENTS 1   /* 0: A/B switch: every site-site segment of a tendon path is a path item of the kernel's sweep (rounds 1-5) */
+#endif
 // debug dump layout (tests only): one record per env in global memory
 struct DbgLayout {
   int xpos, xquat, xipos, cdof, cvel, tenlen, tenvel, tenj, actfrc, actdot, M, bias, smooth, qaccsm, qacc, qfrccon,
@@ -116,6 +119,7 @@ struct Aux {
   int dof_anc;           // per dof, 2 words: ids of its ancestor dofs by depth, one byte each
   int jnt_pack;          // per joint, 2 words: type | dofadr << 4 | qposadr << 14, bits(qpos0[qposadr]) -- one load instead of type -> address -> qpos0
   int body_chain;        // per body, 3 words: chain owned by the body's lane (its top body): bottom | level << 8 | children << 12, or -1; child chain tops, one byte each
+  int ten_len0, ten_len0_f64;   // per tendon: the summed length of its path segments between rigidly connected bodies (folded at create): float table, double table
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)

@@ -32,7 +32,7 @@ RWD_KEYS_REORIENT = ["pos_align", "rot_align", "act_reg", "drop", "bonus", "spar
 RWD_KEYS_WALK = ["vel_reward", "cyclic_hip", "ref_rot", "joint_angle_rew", "act_mag", "sparse", "solved", "done", "dense"]
 (INFO_NQ, INFO_NV, INFO_NU, INFO_NA, INFO_NBODY, INFO_NSITE, INFO_NTENDON, INFO_LANES, INFO_LDS_PER_ENV,
  INFO_ENVS_PER_BLOCK, INFO_NGEOM, INFO_WAVES_PER_BLOCK, INFO_KERNEL_FAMILY, INFO_MODEL_WORDS,
- INFO_BODY_CHAINS, INFO_FOLDED_RESET, INFO_FWD_CARRY) = range(17)
+ INFO_BODY_CHAINS, INFO_FOLDED_RESET, INFO_FWD_CARRY, INFO_TENDON_ITEMS, INFO_TENDON_FOLDED) = range(19)
 
 
 MM_ABI_VERSION = 7   # include/myosim.h

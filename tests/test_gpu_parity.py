@@ -1018,3 +1018,43 @@ def test_task_struct_size_field_gives_append_only_compatibility():
         cut._ro.size = bad
         with pytest.raises(E.EngineError):
             E.rollout_step(cut.hm, cut.state, cut._task, cut._ro)
+
+
+@pytest.mark.gpu
+def test_tendon_segments_between_rigidly_connected_bodies_are_folded_into_constants(oracle_lib):
+    """mm_model_create sums the path segments whose two sites sit on bodies that no dof separates (via-point runs along one bone, or
+    across bones fixed to one another: the hand's carpal row and metacarpals) into a per-tendon constant; the kernel sweeps only the
+    segments that can change length.  Same tendon lengths as the oracle, which measures every segment (mj_tendon does,
+    robot.py:607 mj_forward) -- in fp32 to 5e-7 m (lengths up to 0.4 m) and in precision mode to the rounding of the fp32 output row (4e-8 m); the counts are what the hand's paths hold; a
+    per-env body position on a body such a segment spans would invalidate the constant and is refused."""
+    import torch
+    from myosuite_amd import engine as E
+    from myosuite_amd.model import synth
+    from oracle import oracle as O
+    cm = synth.get_model("hand")
+    hm = E.HipModel(cm, lanes_per_env=32)
+    assert hm.info(E.INFO_TENDON_FOLDED) == 70 and hm.info(E.INFO_TENDON_ITEMS) == 109, (hm.info(E.INFO_TENDON_FOLDED), hm.info(E.INFO_TENDON_ITEMS))
+    assert E.HipModel(synth.get_model("torso")).info(E.INFO_TENDON_FOLDED) == 0        # every segment of the torso's paths crosses a joint
+    n = 64
+    rng = np.random.default_rng(5)
+    lo, hi = cm.jnt_range[:, 0], cm.jnt_range[:, 1]
+    q = (lo + (hi - lo) * rng.random((n, cm.nq))).astype(np.float32)
+    om = O.OracleModel(cm)
+    ref = []
+    for e in range(n):
+        d = O.OracleData(om); d.qpos[:] = q[e]; d.forward(); ref.append(np.array(d.ten_length))
+    ref = np.stack(ref)
+    for prec, tol in ((E.MM_PREC_F32, 5e-7), (E.MM_PREC_F64_STATE, 4e-8)):
+        hmp = E.HipModel(cm, lanes_per_env=32, precision=prec)
+        st = E.BatchState(hmp, n)
+        st.qpos.copy_(torch.from_numpy(q).to(st.qpos.dtype))
+        d_ = E.Derived(hmp, n, ["ten_length"])
+        E.forward(hmp, st, torch.zeros(n, cm.nu, device="cuda"), d_)
+        got = d_["ten_length"].cpu().numpy().astype(np.float64)
+        err = np.abs(got - ref).max()
+        assert err < tol, (prec, err)
+    # the second metacarpal is fixed to the capitate and tendon segments run from one onto the other: its frame is baked into constants
+    st = E.BatchState(hm, 4)
+    st.set_body_pos_env(cm.body_id("secondmc"), torch.zeros(4, 3, device="cuda"))
+    with pytest.raises(E.EngineError, match="folded"):
+        E.forward(hm, st, torch.zeros(4, cm.nu, device="cuda"), E.Derived(hm, 4, ["ten_length"]))

@@ -361,7 +361,10 @@ def test_north_star_1000_step_divergence_gate(oracle_lib, name, lanes, nsub):
         assert run.max() < 1e-4, run.max()
     else:
         below, below_tw = int((per_env < 1e-4).sum()), int((per_env_tw < 1e-4).sum())
-        assert below >= 60 and below >= below_tw - 3, (below, below_tw, np.sort(per_env)[-8:])
+        # (64 envs: sigma of this count is 1.9 -- 59...62 across the builds of round 6 -- so this is a sanity bound at the measured
+        #  level minus one and a half sigma; the count GATE of the fp32 kernels runs on 256 envs in
+        #  test_north_star_precision_modes_strict_gate)
+        assert below >= 57 and below >= below_tw - 6, (below, below_tw, np.sort(per_env)[-8:])
         assert np.median(per_env) < 5.0 * max(np.median(per_env_tw), 5e-7), (np.median(per_env), np.median(per_env_tw))
         assert rel[-1].max() < 1e-2, rel[-1].max()
 
@@ -378,8 +381,8 @@ def test_north_star_precision_modes_strict_gate(oracle_lib, name, lanes):
                          below 1e-4 as the fp32-state twin of the oracle (rounded after every substep), every env of the
                          elbow."""
     nenv = 256
-    P64, P64S = E.MM_PREC_F64, E.MM_PREC_F64_STATE
-    rel, rel_tw, status = north_star_run(name, lanes, 10, nenv=nenv, precisions=(P64, P64S))
+    P32, P64, P64S = E.MM_PREC_F32, E.MM_PREC_F64, E.MM_PREC_F64_STATE
+    rel, rel_tw, status = north_star_run(name, lanes, 10, nenv=nenv, precisions=(P32, P64, P64S))
     per = {p: rel[p].max(axis=0) for p in rel}
     per_tw = rel_tw.max(axis=0)
     below = {p: int((per[p] < 1e-4).sum()) for p in per}
@@ -395,6 +398,7 @@ def test_north_star_precision_modes_strict_gate(oracle_lib, name, lanes):
                                  "per_env_max_over_run": per[P64S].tolist()},
                    "f64_arith_f32_state": {"envs_below_1e-4": below[P64], "max_over_envs": float(per[P64].max()), "median_env_max": float(np.median(per[P64])),
                                            "per_env_max_over_run": per[P64].tolist()},
+                   "f32": {"envs_below_1e-4": below[P32], "median_env_max": float(np.median(per[P32])), "per_env_max_over_run": per[P32].tolist()},
                    "fp32_state_twin": {"envs_below_1e-4": below_tw, "median_env_max": float(np.median(per_tw)), "per_env_max_over_run": per_tw.tolist()}}, f)
     assert status[P64] == 0 and status[P64S] == 0
     assert below[P64S] == nenv and per[P64S].max() < 1e-6, (below[P64S], np.sort(per[P64S])[-4:])
@@ -402,6 +406,18 @@ def test_north_star_precision_modes_strict_gate(oracle_lib, name, lanes):
     assert np.median(per[P64]) <= 1.5 * np.median(per_tw) + 1e-9
     if name == "elbow":
         assert below[P64] == nenv
+    # The fp32 throughput kernels on the same 256 envs: THE count gate of the fp32 path since round 6.  Which envs see a limit row
+    # switch one substep early is redrawn by any change of rounding (round 6: the order of two sums, a constant folded on the host),
+    # so the count is a binomial draw around p ~ 0.94: sigma = 3.8 of 256 -- and 1.9 of 64, which is what the 64-env test's old bound
+    # of 60 sat on (60...62 / 64 with one build, 59...60 / 64 with the next, 240 vs 239 of 256 on this sample).  Bound: the measured
+    # level (239...242 of 256; plain-fp32 CPU emulation 246, fp32-state twin 252) minus two sigma, and never more than 20 behind the twin.
+    print(f"   fp32 kernels, same {nenv} envs: {below[P32]}/{nenv} < 1e-4 (median {np.median(per[P32]):.2e})")
+    assert status[P32] == 0
+    if name == "hand":
+        assert below[P32] >= 232 and below[P32] >= below_tw - 20, (below[P32], below_tw)
+        assert np.median(per[P32]) < 5.0 * max(np.median(per_tw), 5e-7)
+    else:
+        assert below[P32] == nenv
 
 
 @pytest.mark.parametrize("env_id,n,precision", [("myoElbowPose1D6MRandom-v0", 256, "f32"), ("myoHandPoseRandom-v0", 96, "f32"),
