@@ -713,8 +713,10 @@ def test_solver_budget_option_matches_a_model_compiled_with_it(name):
         E.forward(h, st, torch.full((n, cm.nu), 0.3, device="cuda"), dv)
         torch.cuda.synchronize()
         out[key] = (dv["qacc"].cpu().numpy().astype(np.float64), dv["solver_niter"].cpu().numpy())
-    binds = name == "hand_contact"          # (limit rows alone converge in one step from a zero warm start; contact rows do not)
-    assert out["cap"][1].max() <= 1 and (out["def"][1].max() >= 2) == binds
+    binds = name == "hand_contact"          # (from MuJoCo's start limit rows alone converge in one step; contact rows do not)
+    # (the default-budget solve starts from the zero warm start -- MM_SKIP_QACCSM: an env with rows never looks at qacc_smooth -- and
+    #  may take a few steps more than MuJoCo's start rule would; the capped handle follows the rule to the letter: budget < 20)
+    assert out["cap"][1].max() <= 1 and out["def"][1].max() >= (2 if binds else 1)
     om = O.OracleModel(cm_cap); d = O.OracleData(om)
     worst = 0.0
     for e in range(n):
@@ -722,6 +724,14 @@ def test_solver_budget_option_matches_a_model_compiled_with_it(name):
         assert d.solver_niter <= 1
         worst = max(worst, float(np.abs(out["cap"][0][e] - d.qacc).max() / max(1.0, np.abs(d.qacc).max())))
     assert worst < 5e-4, worst
+    # ... and the default-budget solve, started from the (zero) warm start without a look at qacc_smooth, lands on the minimiser the
+    # oracle reaches from MuJoCo's start (strictly convex cost: the start decides the path, not the result)
+    om_def = O.OracleModel(cm); dd = O.OracleData(om_def)
+    worst_def = 0.0
+    for e in range(n):
+        dd.qpos[:] = q[e]; dd.qvel[:] = v[e]; dd.act[:] = 0; dd.ctrl[:] = 0.3; dd.qacc_warmstart[:] = 0; dd.forward()
+        worst_def = max(worst_def, float(np.abs(out["def"][0][e] - dd.qacc).max() / max(1.0, np.abs(dd.qacc).max())))
+    assert worst_def < 5e-4, worst_def
     if binds:
         assert np.abs(out["cap"][0] - out["def"][0]).max() > 1e-3 * np.abs(out["def"][0]).max()      # the budget really bound
     from myosuite_amd import mjx_api
