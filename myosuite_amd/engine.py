@@ -720,11 +720,14 @@ PROF_STAGES = ["kin", "com", "tendon", "constr", "vel", "crb", "factor", "act", 
 
 def profile_stages(fn):
     """Run fn() with in-kernel stage timers on; returns {stage: cycles} of wave 0 / block 0 (tests/tools only)."""
-    buf = torch.zeros(len(PROF_STAGES), dtype=torch.int64, device="cuda")
+    buf = torch.zeros(2 * len(PROF_STAGES), dtype=torch.int64, device="cuda")     # [main wave | helper wave of a two-wave launch]
     lib().mm_debug_set_prof(buf.data_ptr())
     try:
         fn()
         torch.cuda.synchronize()
     finally:
         lib().mm_debug_set_prof(None)
-    return dict(zip(PROF_STAGES, buf.cpu().tolist()))
+    v = buf.cpu().tolist()
+    out = dict(zip(PROF_STAGES, v[:len(PROF_STAGES)]))
+    out.update({"h_" + k: x for k, x in zip(PROF_STAGES, v[len(PROF_STAGES):]) if x})
+    return out
