@@ -641,7 +641,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   // ep_unwrapped << 20 | ep_wrapped << 21 | wrap slot << 22, bits(1/divisor or coef)]; joint word = joint id | 1 (hinge) or
   // 2 (slide) << 8 -- the kernel reads anchor / axis straight from the joint -- or dof id for ball / free dofs (via cdof).
   // jent[i] = first row | rows << 24 of the i-th entry in processing order.
-  std::vector<int32_t> jent, jrow;
+  std::vector<int32_t> jent, jrow, jent_td;     // jent_td[i] = tendon | dof << 16 of the i-th entry in processing order (the fused tendon-velocity sum)
   {
     enum { R_S = 0, R_AB = 1, R_AC = 2, R_B = 3, R_C = 4, R_A = 5, R_J = 6, R_NONE = 7 };
     struct Rec { int32_t sites, bm, wi, f2; };
@@ -699,6 +699,12 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
       }
       const int32_t jw = (direct ? j : dof) | ((direct ? (ty == MM_JNT_HINGE ? 1 : 2) : 0) << 8);
       jent.push_back((int32_t)(jrow.size() / 4) | ((int32_t)per_ent[e].size() << 24));
+      {
+        int te = 0;
+        while (te + 1 < d.ntendon && tj_adr[te + 1] <= e) te++;
+        if (te >= 65536 || dof >= 65536) { delete m; return fail(MM_EUNSUPPORTED, "tendon Jacobian beyond the engine's table limits"); }
+        jent_td.push_back(te | (dof << 16));
+      }
       for (const Rec& r : per_ent[e]) {
         if (r.wi >= 1024) { delete m; return fail(MM_EUNSUPPORTED, "more than 1024 wrapping tendon path items"); }
         const int32_t row[4] = {e | (jw << 16), r.sites, r.bm | (r.wi << 22), r.f2};
@@ -745,7 +751,7 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   }
   m->x.body_depth = append(depth); m->x.body_rootslot = append(rootslot); m->x.dof_rootslot = append(dofslot);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
-  m->x.jent = append(jent);
+  m->x.jent = append(jent); m->x.jent_td = append(jent_td);
   while (dev.size() % 4) dev.push_back(0u);   // 16-byte rows
   m->x.jrec = append(jrow);
   {

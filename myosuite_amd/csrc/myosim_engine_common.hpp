@@ -119,6 +119,7 @@ struct Aux {
   int dof_anc;           // per dof, 2 words: ids of its ancestor dofs by depth, one byte each
   int jnt_pack;          // per joint, 2 words: type | dofadr << 4 | qposadr << 14, bits(qpos0[qposadr]) -- one load instead of type -> address -> qpos0
   int body_chain;        // per body, 3 words: chain owned by the body's lane (its top body): bottom | level << 8 | children << 12, or -1; child chain tops, one byte each
+  int jent_td;           // per tendon-Jacobian entry in processing order: tendon | dof << 16 (tendon velocities summed in the entry sweep)
   int ten_len0, ten_len0_f64;   // per tendon: the summed length of its path segments between rigidly connected bodies (folded at create): float table, double table
 };
 
