@@ -751,7 +751,8 @@ extern "C" int mm_model_create(const uint32_t* blob, int nwords, mm_model** out)
   }
   m->x.body_depth = append(depth); m->x.body_rootslot = append(rootslot); m->x.dof_rootslot = append(dofslot);
   m->x.root_list = append(roots); m->x.nroot = (int)roots.size();
-  m->x.jent = append(jent); m->x.jent_td = append(jent_td);
+  m->x.jent = append(jent);
+  if (MM_FUSE_TENVEL) m->x.jent_td = append(jent_td); else m->x.jent_td = 0;      // (only the fused tendon-velocity sum reads it: no LDS words for an OFF switch)
   while (dev.size() % 4) dev.push_back(0u);   // 16-byte rows
   m->x.jrec = append(jrow);
   {

@@ -97,6 +97,13 @@ struct Layout {
   int total;
 };
 
+#ifndef MM_FUSE_TENVEL
+/* 1: tendon velocities J qvel summed entry by entry inside tendon()'s Jacobian-entry sweep (one LDS float add per entry) instead of a pass
+   of their own with one lane per tendon.  Built and measured in round 6 (same-session A/B): hand 7.93 -> 7.70 M env-steps/s, leg 2.00 ->
+   1.96 M, self-contact hand 3.65 -> 3.60 M, elbow 32.9 -> 33.4 M -- gfx950 executes a ds_add_f32 at ~3 cycles per active lane, CU-wide
+   (tools/micro/lds_atomic_bench.hip), which costs more than the per-tendon walk it replaces.  OFF. */
+#define MM_FUSE_TENVEL 0
+#endif
 #ifndef MM_FOLD_RIGID_SEGMENTS
 #define MM_FOLD_RIGID_SEGMENTS 1   /* 0: A/B switch: every site-site segment of a tendon path is a path item of the kernel's sweep (rounds 1-5) */
 #endif
@@ -119,8 +126,8 @@ struct Aux {
   int dof_anc;           // per dof, 2 words: ids of its ancestor dofs by depth, one byte each
   int jnt_pack;          // per joint, 2 words: type | dofadr << 4 | qposadr << 14, bits(qpos0[qposadr]) -- one load instead of type -> address -> qpos0
   int body_chain;        // per body, 3 words: chain owned by the body's lane (its top body): bottom | level << 8 | children << 12, or -1; child chain tops, one byte each
-  int jent_td;           // per tendon-Jacobian entry in processing order: tendon | dof << 16 (tendon velocities summed in the entry sweep)
   int ten_len0, ten_len0_f64;   // per tendon: the summed length of its path segments between rigidly connected bodies (folded at create): float table, double table
+  int jent_td;           // (MM_FUSE_TENVEL builds only) per tendon-Jacobian entry in processing order: tendon | dof << 16
 };
 
 // model constants the kernel reads through the scalar cache (appended to the device blob at KArgs::cofs, see KD / KL / KX)

@@ -60,8 +60,10 @@ EXTRA_FLAGS = os.environ.get("MYOSIM_HIPCC_FLAGS",
 #   reorient    <64,32,GEN>  1.79 M -> 1.85 M  iterative-maxocc
 #   leg walk    <64,40,GEN>  0.71 M -> 0.79 M  iterative-ilp      (iterative-maxocc: 0.71 M; iterative-minreg loses 10-25 % everywhere)
 #   implicitfast leg <64,36,GEN,2>  kernel 0.753 -> 0.724 ms  iterative-ilp   (round 3; the self-contact hand <64,24,GEN> loses 2 % with it)
-SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp",
-                  "myosim_inst_J.hip": "iterative-ilp"}   # (inst_H, the Euler leg: iterative-ilp until the stage fences went in; since then maxocc +2 %)
+SCHED_STRATEGY = {"default": "iterative-maxocc", "myosim_inst_E.hip": "iterative-ilp"}
+# (inst_H, the Euler leg: iterative-ilp until the stage fences went in; since then maxocc +2 %.  inst_J, the implicitfast units: iterative-ilp
+#  until round 6 -- with the start rule of MM_SKIP_QACCSM in, ilp spills 2 / 8 VGPRs (12 / 36 B of scratch per lane) in the 36-wide leg
+#  kernel where maxocc spills none at the same speed, 2.06 vs 2.06 M env-steps/s in one session; its SGPR spills, to VGPR lanes, go 217 -> 354)
 # Extra per-file flags.  -sink-insts-to-avoid-spills: hand pose <32,24> 5.55 -> 5.67 M; within +-1 % (mostly -) on the others.
 FILE_FLAGS = {"myosim_inst_B.hip": ["-mllvm", "-sink-insts-to-avoid-spills=1", "-mllvm", "-amdgpu-set-wave-priority=1"],   # wave priority: hand +0.6 %
               # leg <64,36,GEN>: +0.8 %.  (Incremental Newton, -DMM_NEWTON_INCR=2 -- rank-one factor modifications when <= 2 rows changed set --

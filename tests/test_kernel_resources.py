@@ -73,8 +73,11 @@ def test_shipped_bench_kernels_do_not_spill_vector_registers():
     assert int(tab[legi]["private_segment_fixed_size"]) == 0, tab[legi]
     # SGPR spills go to VGPR lanes (v_writelane / v_readlane), not to memory; the Euler leg unit sits at 275...282 since the freed VGPRs
     # changed its schedule (throughput unchanged: 1.80 M env-steps/s in the same session as 1.75 M before)
-    for name in no_spill[2:] + [reorient, legi]:
+    for name in no_spill[2:] + [reorient]:
         assert int(tab[name]["sgpr_spill_count"]) < 300, tab[name]
+    # (the implicitfast leg since round 6: scheduled for occupancy instead of ILP -- the only strategy under which it keeps every VGPR out
+    #  of scratch with MM_SKIP_QACCSM's start rule in; costs SGPR spills to VGPR lanes, 217 -> 354, and no speed: engine.py SCHED_STRATEGY)
+    assert int(tab[legi]["sgpr_spill_count"]) < 400, tab[legi]
 
 
 @pytest.mark.skipif(not (os.path.exists(E.LIB_PATH) and os.path.exists(READELF)), reason="needs the built library and llvm-readelf")
