@@ -15,12 +15,12 @@ for nm in names:
     env = registry.make(env_id, num_envs=n, seed=0, **({"model": "hand_contact"} if nm == "contact" else {"model": "hand_dense"} if nm == "dense" else ({"model": "leg_implicit"} if nm == "legi" else
                                                                 ({"precision": "f64_state"} if nm.endswith("64") else {}))))
     env.rollout_setup(action_seed=0)
-    for s in range(6): env.rollout_step(None, stream_id=s)
+    for s in range(int(os.environ.get("PERF_WARM_STEPS", "6"))): env.rollout_step(None, stream_id=s)     # (PERF_WARM_STEPS=200: the steady mix of episode phases bench.py times)
     torch.cuda.synchronize()
     K = 48
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
     t0 = time.perf_counter()
-    for s in range(K): env.rollout_step(None, stream_id=6 + s, events=evs[s])
+    for s in range(K): env.rollout_step(None, stream_id=1000 + s, events=evs[s])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     km = float(np.median([a.elapsed_time(b) for a, b in evs]))
