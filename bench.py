@@ -31,7 +31,7 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (256 CUs x 4 SIMD x 64 lanes
 # BASELINE.json configs 2, 4, 5 (+ the self-colliding hand, docs/source/suite.rst:288, and the MuJoCo-default leg on the
 # implicitfast integrator) reported next to the headline line
 # the committed PMC session bench.py replays counters from (tools/prof_round.sh at the HEAD named in DESIGN.md section 5); pinned, not "the latest file"
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r06c_pmc.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r06d_pmc.json")
 ACCURACY_PROFILE = os.path.join(ROOT, "profiles", "r06_accuracy.json")     # tests/tools/gpu_accuracy_run.py (replayed into the line)
 REPEATS = 3                 # timed regions of --steps steps each; the line reports the median region
 EXTRA_MIN_TIMED_MS = 60.0   # an extra line times at least this much kernel work (a 1.5 ms timed region is launch-noise bound)
